@@ -1,0 +1,196 @@
+/*
+ * tatt_hip.h -- C ABI of libtatt_hip.so, the MI355X (gfx950) kernels of the TATT super-resolution
+ * hot path (TSRN backbone + TP interpreter + STN/TPS sampler, forward and backward).
+ *
+ * Every entry point takes plain DEVICE pointers, sizes/strides and a hipStream_t; none allocates,
+ * synchronises or touches host memory, so a call sequence can be captured in a hipGraph.  Return
+ * value: 0 on success, otherwise a hipError_t (or 1 for an unsupported shape).  All tensors are fp32.
+ * Feature maps are token-major ("NHWC": row = (b,h,w), contiguous channel axis) unless strides say
+ * otherwise.  Scratch ("ws"/"part") sizes are stated per function.
+ *
+ * The reference (mjq11302010044/TATT) is pure PyTorch, so there is no FFI upstream; each function
+ * names the torch.nn call site it replaces (file:line in the reference).  The host-side mirror of the
+ * reference's nn.Module surface (tatt_amd/tsrn.py) is the only caller.
+ *
+ * Activation codes: 0 none, 1 relu, 2 mish (x*tanh(softplus(x)), model/tsrn.py:1056-1064), 3 tanh.
+ */
+#ifndef TATT_HIP_H
+#define TATT_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* hipStream_t;
+
+/* ---- GEMM / convolution (v_mfma_f32_32x32x2_f32, exact fp32) --------------------------------------- */
+
+/* C[z] = act(alpha * (A[z] @ B[z] + bias[z])) + beta * C[z],  A(i,r) = A[i*sam + r*sak] for r < K1 (or all r
+ * when A2 == NULL), A2[i*sa2m + (r-K1)*sa2k] otherwise; B(r,j) = B[r*sbk + j*sbn]; C[i*scm + j*scn].
+ * splitk > 1: ws >= Z*splitk*M*N floats.
+ * Replaces nn.Linear (model/tsrn.py:170; model/transformer_v2.py:455-457,788-790; model/stn_head.py:50,53),
+ * the 1x1 nn.Conv2d of GruBlock (model/tsrn.py:1071), nn.GRU input projections (model/tsrn.py:1072;
+ * model/transformer_v2.py:177) and the packed in/out projections of nn.MultiheadAttention
+ * (model/transformer_v2.py:453,786), forward and backward. */
+int tatt_gemm(const float* A, long sam, long sak, const float* A2, long sa2m, long sa2k, int K1,
+              const float* B, long sbk, long sbn, const float* bias, float* C, long scm, long scn,
+              int M, int N, int K, int Z, long bsA, long bsA2, long bsB, long bsC, long bsBias,
+              float alpha, float beta, int act, int splitk, float* ws, hipStream_t st);
+
+/* y[pixel*ldy + co] = act(conv(x, w) + bias) + beta*y; stride 1, 'same' padding; x[n*xsn + h*xsh + w*xsw + c*xsc];
+ * wpacked = [KH][KW][Cin][Cout] from tatt_repack_conv_weight.  Also computes the data gradient when given
+ * dY as x and the mode-1 packed filter.  Replaces nn.Conv2d (model/tsrn.py:597,612,877,885,1043,623;
+ * model/stn_head.py:15). */
+int tatt_conv2d_fwd(const float* x, long xsn, long xsh, long xsw, long xsc, const float* wpacked,
+                    const float* bias, float* y, long ldy, int Bn, int H, int W, int Cin, int Cout,
+                    int KH, int KW, int act, float beta, hipStream_t st);
+
+/* dw_oihw[co][ci][kh][kw] = sum_pixels x[pixel+(kh,kw)][ci] * dy[pixel*lddy + co] + beta*dw; ws >= splitk*KH*KW*Cin*Cout floats */
+int tatt_conv2d_wgrad(const float* x, long xsn, long xsh, long xsw, long xsc, const float* dy,
+                      long lddy, float* dw_oihw, int Bn, int H, int W, int Cin, int Cout, int KH,
+                      int KW, float beta, int splitk, float* ws, hipStream_t st);
+
+/* OIHW nn.Conv2d weight -> GEMM operand; mode 0: [KH][KW][Cin][Cout]; mode 1: [KH][KW][Cout][Cin], taps flipped */
+int tatt_repack_conv_weight(const float* w_oihw, float* out, int Cout, int Cin, int KH, int KW,
+                            int mode, hipStream_t st);
+
+/* ---- reductions / normalisation ------------------------------------------------------------------- */
+
+/* out[c] = scale * sum_m X[m*ld + c] + beta*out[c]  (bias gradients); ws >= ceil(M/256)*C doubles */
+int tatt_colsum(const float* X, long ld, int M, int C, float* out, float scale, float beta,
+                double* ws, hipStream_t st);
+
+/* train-mode nn.BatchNorm statistics over the M rows (model/tsrn.py:878,886,613; model/stn_head.py:19,51):
+ * mean, rstd = 1/sqrt(biased var + eps); running stats updated in place (unbiased var, momentum) when non-NULL.
+ * ws >= ceil(M/128)*2*C doubles */
+int tatt_bn_stats(const float* X, long ld, int M, int C, float eps, float momentum, float* mean,
+                  float* rstd, float* running_mean, float* running_var, double* ws, hipStream_t st);
+/* eval mode: rstd = 1/sqrt(running_var + eps) */
+int tatt_bn_rstd(const float* var, float* rstd, int C, float eps, hipStream_t st);
+/* Y = act((X - mean) * rstd * gamma + beta) */
+int tatt_bn_apply(const float* X, long ldx, float* Y, long ldy, int M, int C, const float* mean,
+                  const float* rstd, const float* gamma, const float* beta, int act, hipStream_t st);
+/* backward of tatt_bn_apply (+ batch statistics when training): dX, dgamma, dbeta; sums: 2*C floats scratch;
+ * ws >= ceil(M/128)*2*C doubles */
+int tatt_bn_bwd(const float* X, long ldx, const float* dY, long lddy, float* dX, long lddx, int M, int C,
+                const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
+                int training, float* dgamma, float* dbeta, float* sums, double* ws, hipStream_t st);
+
+/* Y = LayerNorm(A + Bres) * gamma + beta over the last axis (C <= 256), stats[M][2] = (mean, rstd).
+ * nn.LayerNorm + the residual add in front of it (model/transformer_v2.py:478-483,826-832,380-387). */
+int tatt_ln_fwd(const float* A, const float* Bres, float* Y, float* stats, int M, int C,
+                const float* gamma, const float* beta, float eps, hipStream_t st);
+/* dX = d(A+Bres); part >= ceil(M/64)*2*C floats; ws >= ceil(ceil(M/64)/256)*2*C doubles */
+int tatt_ln_bwd(const float* A, const float* Bres, const float* dY, const float* stats, float* dX, int M,
+                int C, const float* gamma, float* dgamma, float* dbeta, float* part, double* ws,
+                hipStream_t st);
+
+/* ---- element-wise ------------------------------------------------------------------------------------ */
+
+/* nn.PReLU() with one shared slope (model/tsrn.py:598,173) */
+int tatt_prelu_fwd(const float* x, float* y, const float* alpha, long n, hipStream_t st);
+/* part >= ceil(n/256) floats: per-block partial d alpha (sum with tatt_colsum(part, 1, G, 1, ...)) */
+int tatt_prelu_bwd(const float* x, const float* dy, float* dx, const float* alpha, long n, float* part,
+                   hipStream_t st);
+int tatt_act_fwd(const float* x, float* y, long n, int act, hipStream_t st);
+/* dx = dy * act'(.)  -- ref is the pre-activation, or the OUTPUT when from_output (relu/tanh only) */
+int tatt_act_bwd(const float* ref, const float* dy, float* dx, long n, int act, int from_output,
+                 hipStream_t st);
+/* y = alpha*a + beta*b (b may be NULL) */
+int tatt_axpby(const float* a, const float* b, float* y, float alpha, float beta, long n, hipStream_t st);
+/* y[m,:] = a[m,:] + b[m % period,:]  (positional embedding broadcast over the batch) */
+int tatt_add_rowbcast(const float* a, const float* b, float* y, long rows, int C, long period,
+                      hipStream_t st);
+/* nn.PixelShuffle(2) + activation on NHWC maps: out[b,2h+i,2w+j,c] = act(in[b,h,w,4c+2i+j]) (model/tsrn.py:1045-1052) */
+int tatt_pixel_shuffle_fwd(const float* in, float* out, int B, int H, int W, int C, int act,
+                           hipStream_t st);
+int tatt_pixel_shuffle_bwd(const float* in, const float* dout, float* din, int B, int H, int W, int C,
+                           int act, hipStream_t st);
+/* nn.MaxPool2d(kernel = stride = (kh,kw)) on NHWC (model/stn_head.py:36-44) */
+int tatt_maxpool_fwd(const float* in, float* out, int B, int H, int W, int C, int kh, int kw,
+                     hipStream_t st);
+int tatt_maxpool_bwd(const float* in, const float* dout, float* din, int B, int H, int W, int C, int kh,
+                     int kw, hipStream_t st);
+/* nn.Dropout(p): y = keep ? x/(1-p) : 0 with a counter-based mask keyed by (*seed, site, index); the same call
+ * with dy as x is the backward (model/transformer_v2.py:27,456,461-462,789,795-797) */
+int tatt_dropout(const float* x, float* y, long n, float p, const unsigned long long* seed, unsigned site,
+                 hipStream_t st);
+/* advance the device-resident seed word (one call per training step; graph-replay safe) */
+int tatt_bump_seed(unsigned long long* seed, hipStream_t st);
+/* dst[i0*d0+i1*d1+i2*d2+i3*d3] = src[i0*s0+...] + beta*dst  (layout changes, parameter gathers) */
+int tatt_copy4d(const float* src, float* dst, int n0, int n1, int n2, int n3, long s0, long s1, long s2,
+                long s3, long d0, long d1, long d2, long d3, float beta, hipStream_t st);
+
+/* ---- optimiser (flat buffers; step-varying scalars live in device memory => hipGraph-replayable) --------- */
+
+/* out[0] = ||g||_2 ; ws >= 1024 doubles  (torch.nn.utils.clip_grad_norm_, interfaces/super_resolution.py:1083-1084) */
+int tatt_l2norm(const float* g, long n, float* out, double* ws, hipStream_t st);
+/* p -= Adam(g * gscale * min(1, max_norm/(gnorm*gscale + 1e-6))); gnorm: device float; step: device int64, 1-based
+ * (torch.optim.Adam(lr, betas=(0.5,0.999)), interfaces/base.py:527, config/super_resolution.yaml:26-29) */
+int tatt_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
+                   float eps, const float* gnorm, float max_norm, float gscale, const long long* step,
+                   hipStream_t st);
+
+/* ---- GRU recurrences --------------------------------------------------------------------------------- */
+
+/* Bidirectional GRU recurrence, hidden 32 (nn.GRU(64,32,bidirectional), model/tsrn.py:1072) given the input
+ * projection gi[tok][192] = [fwd r,z,n | rev r,z,n]; out[tok][64] = [fwd h | rev h].
+ * token(s,t) = (s / s_in)*stride_hi + (s % s_in)*stride_lo + t*stride_t on the NHWC token grid: vertical scan
+ * (gru1): s_in=W, stride_hi=H*W, stride_lo=1, stride_t=W, T=H; horizontal (gru2): s_in=1, stride_hi=W, stride_t=1, T=W. */
+int tatt_gru32_fwd(const float* gi, const float* whh_f, const float* bhh_f, const float* whh_r,
+                   const float* bhh_r, float* out, int nseq, int T, int s_in, long stride_hi, long stride_lo,
+                   long stride_t, hipStream_t st);
+/* BPTT: writes dgi[tok][192], dgh[tok][192] (recurrent-side gate gradients) and hprev[tok][64] */
+int tatt_gru32_bwd(const float* gi, const float* out, const float* dout, const float* whh_f,
+                   const float* bhh_f, const float* whh_r, const float* bhh_r, float* dgi, float* dgh,
+                   float* hprev, int nseq, int T, int s_in, long stride_hi, long stride_lo, long stride_t,
+                   hipStream_t st);
+
+/* One time step of the query-embedding GRU (nn.GRU(64*H, 32*H, bidirectional), model/transformer_v2.py:177,218;
+ * time axis = sample axis), both directions: gi* (Wb,3*HID) incl. b_ih, whh* (3*HID,HID),
+ * hprev* (Wb,HID) or NULL for h=0, hnew* (Wb,HID), gsave* (4,Wb,HID) = r,z,n,(W_hn h+b_hn) or NULL. */
+int tatt_qgru_fwd_step(const float* gi0, const float* gi1, const float* whh0, const float* whh1,
+                       const float* bhh0, const float* bhh1, const float* hprev0, const float* hprev1,
+                       float* hnew0, float* hnew1, float* gsave0, float* gsave1, int Wb, int HID,
+                       hipStream_t st);
+/* backward step, gate part: dh = dhseq + dhcarry (dhcarry ignored when first); dgi_acc (+)= input-side gate grads;
+ * dgh = recurrent-side gate grads; dhcarry = dh*z */
+int tatt_qgru_bwd_gates(const float* dhseq0, const float* dhseq1, const float* gsave0, const float* gsave1,
+                        const float* hprev0, const float* hprev1, float* dhcarry0, float* dhcarry1,
+                        float* dgi_acc0, float* dgi_acc1, float* dgh0, float* dgh1, int Wb, int HID, int first,
+                        hipStream_t st);
+/* backward step, matmul part: dhcarry (Wb,HID) += dgh (Wb,3*HID) @ whh (3*HID,HID) */
+int tatt_qgru_bwd_mm(const float* dgh0, const float* dgh1, const float* whh0, const float* whh1,
+                     float* dhcarry0, float* dhcarry1, int Wb, int HID, hipStream_t st);
+
+/* ---- attention core ------------------------------------------------------------------------------------ */
+
+/* ctx = dropout(softmax(Q K^T)) V per head (E=64, 4 heads, S <= 32), wavg = head-mean of the dropped
+ * probabilities (may be NULL).  Q (B,Lq,64) already projected and scaled; K,V (B,S,64).
+ * Core of nn.MultiheadAttention (model/transformer_v2.py:472-474,821-824). */
+int tatt_attn_fwd(const float* Q, const float* K, const float* V, float* ctx, float* wavg, int B, int Lq,
+                  int S, float pdrop, const unsigned long long* seed, unsigned site, hipStream_t st);
+/* part >= B*ceil(Lq/64)*2*S*64 floats; dwavg may be NULL */
+int tatt_attn_bwd(const float* Q, const float* K, const float* V, const float* dctx, const float* dwavg,
+                  float* dQ, float* dK, float* dV, float* part, int B, int Lq, int S, float pdrop,
+                  const unsigned long long* seed, unsigned site, hipStream_t st);
+
+/* ---- TPS rectification ---------------------------------------------------------------------------------- */
+
+/* src[b,p,:] = repr[p,:] @ (inv @ [ctrl[b]; pad])  (model/tps_spatial_transformer.py:103-105); N ctrl points, P pixels */
+int tatt_tps_grid_fwd(const float* ctrl, const float* inv, const float* pad, const float* repr, float* src,
+                      int B, int N, int P, hipStream_t st);
+int tatt_tps_grid_bwd(const float* dsrc, const float* inv, const float* repr, float* dctrl, int B, int N,
+                      int P, hipStream_t st);
+/* out (B,H,W,C) = F.grid_sample(x, 2*clamp(src,0,1)-1) bilinear / zeros / align_corners=False
+ * (model/tps_spatial_transformer.py:107-111,11); x[b*xsn + c*xsc + h*xsh + w*xsw] */
+int tatt_grid_sample_fwd(const float* x, long xsn, long xsc, long xsh, long xsw, const float* src, float* out,
+                         int B, int C, int H, int W, hipStream_t st);
+/* gradient w.r.t. src (through the clamp); the LR image carries no gradient */
+int tatt_grid_sample_bwd(const float* x, long xsn, long xsc, long xsh, long xsw, const float* src,
+                         const float* dout, float* dsrc, int B, int C, int H, int W, hipStream_t st);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TATT_HIP_H */

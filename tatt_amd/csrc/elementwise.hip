@@ -1,0 +1,286 @@
+// Streaming element-wise kernels of the TATT hot path (all HBM-bound, lanes along the contiguous axis).
+#include "common.h"
+
+#define EW_GRID(total) dim3(cdiv((total), 256)), dim3(256)
+
+// ---- PReLU with ONE shared slope (reference nn.PReLU(): model/tsrn.py:598,173) ---------------------
+__global__ void prelu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ a,
+                                 long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v = x[i];
+    y[i] = v >= 0.f ? v : a[0] * v;
+}
+TATT_API int tatt_prelu_fwd(const float* x, float* y, const float* alpha, long n, hipStream_t st) {
+    hipLaunchKernelGGL(prelu_fwd_kernel, EW_GRID(n), 0, st, x, y, alpha, n);
+    return LAUNCH_CHECK();
+}
+// dx = dy * (x>=0 ? 1 : a);  dalpha partial[block] = sum dy*x*[x<0]
+__global__ void prelu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+                                 const float* __restrict__ a, long n, float* __restrict__ part) {
+    __shared__ float sh[4];
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    float s = 0.f;
+    if (i < n) {
+        float v = x[i], g = dy[i];
+        dx[i] = v >= 0.f ? g : a[0] * g;
+        if (v < 0.f) s = g * v;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+// part: cdiv(n,256) floats (reduce with tatt_colsum(part, 1, G, 1, dalpha, ...))
+TATT_API int tatt_prelu_bwd(const float* x, const float* dy, float* dx, const float* alpha, long n, float* part,
+                            hipStream_t st) {
+    hipLaunchKernelGGL(prelu_bwd_kernel, EW_GRID(n), 0, st, x, dy, dx, alpha, n, part);
+    return LAUNCH_CHECK();
+}
+
+// ---- generic activation forward / backward ----------------------------------------------------------
+__global__ void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n, int act) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = apply_act(x[i], act);
+}
+TATT_API int tatt_act_fwd(const float* x, float* y, long n, int act, hipStream_t st) {
+    hipLaunchKernelGGL(act_fwd_kernel, EW_GRID(n), 0, st, x, y, n, act);
+    return LAUNCH_CHECK();
+}
+// from_output: ref holds y = act(u) (valid for relu / tanh); else ref holds the pre-activation u
+__global__ void act_bwd_kernel(const float* __restrict__ ref, const float* __restrict__ dy, float* __restrict__ dx,
+                               long n, int act, int from_output) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float r = ref[i], g;
+    if (from_output) {
+        if (act == ACT_RELU) g = r > 0.f ? 1.f : 0.f;
+        else if (act == ACT_TANH) g = 1.f - r * r;
+        else g = 1.f;
+    } else g = act_grad(r, act);
+    dx[i] = dy[i] * g;
+}
+TATT_API int tatt_act_bwd(const float* ref, const float* dy, float* dx, long n, int act, int from_output,
+                          hipStream_t st) {
+    hipLaunchKernelGGL(act_bwd_kernel, EW_GRID(n), 0, st, ref, dy, dx, n, act, from_output);
+    return LAUNCH_CHECK();
+}
+
+// ---- y = alpha*a + beta*b  (b may be null) ------------------------------------------------------------
+__global__ void axpby_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y,
+                             float alpha, float beta, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v = alpha * a[i];
+    if (b) v += beta * b[i];
+    y[i] = v;
+}
+TATT_API int tatt_axpby(const float* a, const float* b, float* y, float alpha, float beta, long n, hipStream_t st) {
+    hipLaunchKernelGGL(axpby_kernel, EW_GRID(n), 0, st, a, b, y, alpha, beta, n);
+    return LAUNCH_CHECK();
+}
+// y[m, :] = a[m, :] + b[(m % period), :]   (row-broadcast add: positional / query embeddings)
+__global__ void add_rowbcast_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y,
+                                    long rows, int C, long period) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * C) return;
+    long m = i / C; int c = i % C;
+    y[i] = a[i] + b[(m % period) * C + c];
+}
+TATT_API int tatt_add_rowbcast(const float* a, const float* b, float* y, long rows, int C, long period,
+                               hipStream_t st) {
+    hipLaunchKernelGGL(add_rowbcast_kernel, EW_GRID(rows * C), 0, st, a, b, y, rows, C, period);
+    return LAUNCH_CHECK();
+}
+
+// ---- PixelShuffle(2) + activation on NHWC maps --------------------------------------------------------
+// out[b, 2h+i, 2w+j, c] = act(in[b, h, w, 4c+2i+j])    (reference nn.PixelShuffle + mish: model/tsrn.py:1045-1052)
+__global__ void pixel_shuffle_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W,
+                                         int C, int act) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // enumerates OUTPUT (b, oh, ow, c)
+    long total = (long)B * 4 * H * W * C;
+    if (idx >= total) return;
+    int c = idx % C; long r = idx / C;
+    int ow = r % (2 * W); r /= (2 * W);
+    int oh = r % (2 * H); int b = r / (2 * H);
+    int h = oh >> 1, i = oh & 1, w = ow >> 1, j = ow & 1;
+    float v = in[(((long)b * H + h) * W + w) * (4 * C) + 4 * c + 2 * i + j];
+    out[idx] = apply_act(v, act);
+}
+TATT_API int tatt_pixel_shuffle_fwd(const float* in, float* out, int B, int H, int W, int C, int act,
+                                    hipStream_t st) {
+    long total = (long)B * 4 * H * W * C;
+    hipLaunchKernelGGL(pixel_shuffle_fwd_kernel, EW_GRID(total), 0, st, in, out, B, H, W, C, act);
+    return LAUNCH_CHECK();
+}
+// din[b,h,w,4c+2i+j] = dout[b,2h+i,2w+j,c] * act'(in[...])
+__global__ void pixel_shuffle_bwd_kernel(const float* __restrict__ in, const float* __restrict__ dout,
+                                         float* __restrict__ din, int B, int H, int W, int C, int act) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // enumerates INPUT (b, h, w, ch)
+    long total = (long)B * H * W * 4 * C;
+    if (idx >= total) return;
+    int ch = idx % (4 * C); long r = idx / (4 * C);
+    int w = r % W; r /= W;
+    int h = r % H; int b = r / H;
+    int c = ch >> 2, i = (ch >> 1) & 1, j = ch & 1;
+    float g = dout[(((long)b * 2 * H + 2 * h + i) * (2 * W) + 2 * w + j) * C + c];
+    din[idx] = g * act_grad(in[idx], act);
+}
+TATT_API int tatt_pixel_shuffle_bwd(const float* in, const float* dout, float* din, int B, int H, int W, int C,
+                                    int act, hipStream_t st) {
+    long total = (long)B * H * W * 4 * C;
+    hipLaunchKernelGGL(pixel_shuffle_bwd_kernel, EW_GRID(total), 0, st, in, dout, din, B, H, W, C, act);
+    return LAUNCH_CHECK();
+}
+
+// ---- MaxPool (kh x kw, stride = kernel) on NHWC (reference nn.MaxPool2d: model/stn_head.py:36-44) -----
+__global__ void maxpool_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W, int C,
+                                   int kh, int kw) {
+    const int Ho = H / kh, Wo = W / kw;
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)B * Ho * Wo * C;
+    if (idx >= total) return;
+    int c = idx % C; long r = idx / C;
+    int ow = r % Wo; r /= Wo;
+    int oh = r % Ho; int b = r / Ho;
+    float m = -INFINITY;
+    for (int i = 0; i < kh; ++i)
+        for (int j = 0; j < kw; ++j) {
+            float v = in[(((long)b * H + oh * kh + i) * W + ow * kw + j) * C + c];
+            if (v > m) m = v;
+        }
+    out[idx] = m;
+}
+TATT_API int tatt_maxpool_fwd(const float* in, float* out, int B, int H, int W, int C, int kh, int kw,
+                              hipStream_t st) {
+    long total = (long)B * (H / kh) * (W / kw) * C;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, EW_GRID(total), 0, st, in, out, B, H, W, C, kh, kw);
+    return LAUNCH_CHECK();
+}
+// gradient goes to the FIRST maximum of each window in (i, j) scan order (strict '>' like ATen)
+__global__ void maxpool_bwd_kernel(const float* __restrict__ in, const float* __restrict__ dout,
+                                   float* __restrict__ din, int B, int H, int W, int C, int kh, int kw) {
+    const int Ho = H / kh, Wo = W / kw;
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)B * Ho * Wo * C;
+    if (idx >= total) return;
+    int c = idx % C; long r = idx / C;
+    int ow = r % Wo; r /= Wo;
+    int oh = r % Ho; int b = r / Ho;
+    float m = -INFINITY; int bi = 0, bj = 0;
+    for (int i = 0; i < kh; ++i)
+        for (int j = 0; j < kw; ++j) {
+            float v = in[(((long)b * H + oh * kh + i) * W + ow * kw + j) * C + c];
+            if (v > m) { m = v; bi = i; bj = j; }
+        }
+    float g = dout[idx];
+    for (int i = 0; i < kh; ++i)
+        for (int j = 0; j < kw; ++j)
+            din[(((long)b * H + oh * kh + i) * W + ow * kw + j) * C + c] = (i == bi && j == bj) ? g : 0.f;
+}
+TATT_API int tatt_maxpool_bwd(const float* in, const float* dout, float* din, int B, int H, int W, int C, int kh,
+                              int kw, hipStream_t st) {
+    long total = (long)B * (H / kh) * (W / kw) * C;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, EW_GRID(total), 0, st, in, dout, din, B, H, W, C, kh, kw);
+    return LAUNCH_CHECK();
+}
+
+// ---- Dropout (reference nn.Dropout(0.1): model/transformer_v2.py:27,456,461-462,789,795-797) ----------
+// y = keep ? x/(1-p) : 0, keep drawn from a counter-based hash of (seed word in device memory, site, index):
+// forward and backward regenerate the same mask; the same kernel serves both.
+__global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long n, float p,
+                               const unsigned long long* __restrict__ seed, unsigned site) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t th = dropout_thresh(p);
+    y[i] = dropout_keep(seed[0], site, (uint64_t)i, th) ? x[i] * (1.f / (1.f - p)) : 0.f;
+}
+TATT_API int tatt_dropout(const float* x, float* y, long n, float p, const unsigned long long* seed, unsigned site,
+                          hipStream_t st) {
+    hipLaunchKernelGGL(dropout_kernel, EW_GRID(n), 0, st, x, y, n, p, seed, site);
+    return LAUNCH_CHECK();
+}
+__global__ void bump_seed_kernel(unsigned long long* seed) { seed[0] += 0x632BE59BD9B4E019ull; }
+TATT_API int tatt_bump_seed(unsigned long long* seed, hipStream_t st) {
+    hipLaunchKernelGGL(bump_seed_kernel, dim3(1), dim3(1), 0, st, seed);
+    return LAUNCH_CHECK();
+}
+
+// ---- generic 4-D strided copy (layout changes: NCHW<->NHWC, parameter gathers) ------------------------
+__global__ void copy4d_kernel(const float* __restrict__ src, float* __restrict__ dst, int n0, int n1, int n2, int n3,
+                              long s0, long s1, long s2, long s3, long d0, long d1, long d2, long d3, float beta) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)n0 * n1 * n2 * n3;
+    if (idx >= total) return;
+    int i3 = idx % n3; long r = idx / n3;
+    int i2 = r % n2; r /= n2;
+    int i1 = r % n1; int i0 = r / n1;
+    float v = src[i0 * s0 + i1 * s1 + i2 * s2 + i3 * s3];
+    long o = i0 * d0 + i1 * d1 + i2 * d2 + i3 * d3;
+    dst[o] = beta != 0.f ? v + beta * dst[o] : v;
+}
+// the LAST index (n3) is the fastest-varying thread index: pick it along the contiguous axis of dst
+TATT_API int tatt_copy4d(const float* src, float* dst, int n0, int n1, int n2, int n3, long s0, long s1, long s2,
+                         long s3, long d0, long d1, long d2, long d3, float beta, hipStream_t st) {
+    long total = (long)n0 * n1 * n2 * n3;
+    hipLaunchKernelGGL(copy4d_kernel, EW_GRID(total), 0, st, src, dst, n0, n1, n2, n3, s0, s1, s2, s3, d0, d1, d2, d3,
+                       beta);
+    return LAUNCH_CHECK();
+}
+
+// ---- optimiser: global-norm clip + Adam on flat parameter/gradient buffers ----------------------------
+// (reference clip_grad_norm_(0.25) + Adam(lr, betas=(0.5,0.999)): interfaces/super_resolution.py:1083-1085,
+//  interfaces/base.py:527).  Everything that changes from step to step (norm, step count) is read from
+// DEVICE memory so that the captured hipGraph of a training step replays correctly.
+__global__ void sumsq_stage1(const float* __restrict__ g, long n, double* __restrict__ part) {
+    __shared__ double sh[4];
+    double s = 0.0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        double v = (double)g[i];
+        s += v * v;
+    }
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+__global__ void sumsq_stage2(const double* __restrict__ part, int G, float* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < G; ++i) s += part[i];
+        out[0] = (float)sqrt(s);
+    }
+}
+// out[0] = ||g||_2 ; ws >= 1024 doubles
+TATT_API int tatt_l2norm(const float* g, long n, float* out, double* ws, hipStream_t st) {
+    int G = (int)((n + 255) / 256);
+    if (G > 1024) G = 1024;
+    if (G < 1) G = 1;
+    hipLaunchKernelGGL(sumsq_stage1, dim3(G), dim3(256), 0, st, g, n, ws);
+    hipLaunchKernelGGL(sumsq_stage2, dim3(1), dim3(64), 0, st, ws, G, out);
+    return LAUNCH_CHECK();
+}
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
+                            const float* __restrict__ gnorm, float max_norm, float gscale,
+                            const long long* __restrict__ step) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double t = (double)step[0];
+    const float bc1 = (float)(1.0 - pow((double)b1, t)), bc2 = (float)(1.0 - pow((double)b2, t));
+    float coef = gscale;
+    if (max_norm > 0.f) { float c = max_norm / (gnorm[0] * gscale + 1e-6f); coef *= c < 1.f ? c : 1.f; }
+    const float gi = g[i] * coef;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    p[i] -= (lr / bc1) * mi / (sqrtf(vi) / sqrtf(bc2) + eps);
+}
+// gnorm: device float = ||g||_2 of the UNSCALED buffer; gscale: constant pre-scale (1/world_size after a sum
+// all-reduce); step: device int64 holding the 1-based step count.
+TATT_API int tatt_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
+                            float eps, const float* gnorm, float max_norm, float gscale, const long long* step,
+                            hipStream_t st) {
+    hipLaunchKernelGGL(adam_kernel, EW_GRID(n), 0, st, p, g, m, v, n, lr, b1, b2, eps, gnorm, max_norm, gscale, step);
+    return LAUNCH_CHECK();
+}

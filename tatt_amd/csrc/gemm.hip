@@ -1,0 +1,368 @@
+// fp32 MFMA GEMM / implicit-GEMM convolution for the TATT hot path (gfx950).
+//
+// One kernel template computes  C(i,j) = epilogue( sum_r A(i,r) * B(r,j) )  on v_mfma_f32_32x32x2_f32
+// (exact fp32, 64 FLOP/clk/SIMD).  A is a *virtual* matrix:
+//   AMODE 0  strided            A[i*sam + r*sak]                       (Linear layers, 1x1 convs)
+//   AMODE 2  K-concat           r < K1 ? A[...] : A2[i*sa2m+(r-K1)*sa2k] (1x1 conv over cat[res, tp_map])
+//   AMODE 3  im2col             i = output pixel, r = (kh,kw,ci)        (conv forward / data-gradient)
+//   AMODE 4  im2col transposed  i = (kh,kw,ci),   r = pixel             (conv weight-gradient)
+// B and C are strided.  Work-group tile 64x64, 4 waves (2x2) each owning one 32x32 accumulator;
+// K is consumed in chunks of 16 staged through double-buffered LDS (A stored k-major so that the
+// MFMA operand read  lane -> (row = lane&31, k = lane>>5)  is bank-conflict free).
+// Split-K (grid.y) writes raw partial tiles that tatt_splitk_reduce sums deterministically.
+#include "common.h"
+
+#define BM 64
+#define BN 64
+#define KC 16
+#define LDT 65   // padded LDS leading dimension
+
+struct GemmP {
+    const float* A; const float* A2; const float* B; const float* bias; float* C;
+    int M, N, K, K1;
+    long sam, sak, sa2m, sa2k, sbk, sbn, scm, scn;
+    long bsA, bsA2, bsB, bsC, bsBias;
+    float alpha, beta;
+    int act;
+    int splitk, chunks_per_split;
+    float* partial;
+    // conv geometry (AMODE 3/4): input addressed as X[n*xsn + h*xsh + w*xsw + c*xsc]
+    int H, W, Cin, KH, KW, pad, HW, Wshift, HWshift, Cshift;
+    long xsn, xsh, xsw, xsc;
+};
+
+__device__ __forceinline__ void decode_pixel(const GemmP& p, int pix, int& n, int& h, int& w) {
+    int hw;
+    if (p.HWshift >= 0) { n = pix >> p.HWshift; hw = pix & (p.HW - 1); }
+    else { n = pix / p.HW; hw = pix - n * p.HW; }
+    if (p.Wshift >= 0) { h = hw >> p.Wshift; w = hw & (p.W - 1); }
+    else { h = hw / p.W; w = hw - h * p.W; }
+}
+__device__ __forceinline__ void decode_kidx(const GemmP& p, int k, int& kh, int& kw, int& ci) {
+    int tap;
+    if (p.Cshift >= 0) { tap = k >> p.Cshift; ci = k & (p.Cin - 1); }
+    else { tap = k / p.Cin; ci = k - tap * p.Cin; }
+    kh = tap / p.KW; kw = tap - kh * p.KW;
+}
+
+template <int AMODE, int AK, int BK>
+__global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmP p) {
+    __shared__ float As[2][KC][LDT];
+    __shared__ float Bs[2][KC][LDT];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int z = blockIdx.z;
+    const float* A = p.A + (long)z * p.bsA;
+    const float* A2 = (AMODE == 2) ? p.A2 + (long)z * p.bsA2 : nullptr;
+    const float* B = p.B + (long)z * p.bsB;
+
+    const int nchunks = (p.K + KC - 1) / KC;
+    int c_begin = 0, c_end = nchunks;
+    if (p.splitk > 1) {
+        c_begin = blockIdx.y * p.chunks_per_split;
+        c_end = min(nchunks, c_begin + p.chunks_per_split);
+    }
+
+    // per-thread fixed decodes for the im2col modes
+    int pn[4], ph[4], pw[4];          // AMODE 3: the thread's 4 pixel rows
+    int fkh = 0, fkw = 0, fci = 0;    // AMODE 4: the thread's fixed (kh,kw,ci) row
+    bool frow_ok = false;
+    if (AMODE == 3) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int i = m0 + (t >> 4) + 16 * q;
+            if (i < p.M) decode_pixel(p, i, pn[q], ph[q], pw[q]);
+            else { pn[q] = -1; ph[q] = 0; pw[q] = 0; }
+        }
+    }
+    if (AMODE == 4) {
+        int i = m0 + (t & 63);
+        frow_ok = i < p.M;
+        if (frow_ok) decode_kidx(p, i, fkh, fkw, fci);
+    }
+
+    float ra[4], rb[4];
+    auto load_chunk = [&](int c) {
+        const int k0 = c * KC;
+        // ---- A ----
+        if (AMODE == 3) {
+            int r = k0 + (t & 15);
+            int kh = 0, kw = 0, ci = 0;
+            bool rok = r < p.K;
+            if (rok) decode_kidx(p, r, kh, kw, ci);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v = 0.f;
+                if (rok && pn[q] >= 0) {
+                    int hh = ph[q] + kh - p.pad, ww = pw[q] + kw - p.pad;
+                    if (hh >= 0 && hh < p.H && ww >= 0 && ww < p.W)
+                        v = A[pn[q] * p.xsn + hh * p.xsh + ww * p.xsw + ci * p.xsc];
+                }
+                ra[q] = v;
+            }
+        } else if (AMODE == 4) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int r = k0 + (t >> 6) + 4 * q;
+                float v = 0.f;
+                if (frow_ok && r < p.K) {
+                    int n, h, w;
+                    decode_pixel(p, r, n, h, w);
+                    int hh = h + fkh - p.pad, ww = w + fkw - p.pad;
+                    if (hh >= 0 && hh < p.H && ww >= 0 && ww < p.W)
+                        v = A[n * p.xsn + hh * p.xsh + ww * p.xsw + fci * p.xsc];
+                }
+                ra[q] = v;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int i, r;
+                if (AK) { r = k0 + (t & 15); i = m0 + (t >> 4) + 16 * q; }
+                else    { i = m0 + (t & 63); r = k0 + (t >> 6) + 4 * q; }
+                float v = 0.f;
+                if (i < p.M && r < p.K) {
+                    if (AMODE == 2 && r >= p.K1) v = A2[i * p.sa2m + (long)(r - p.K1) * p.sa2k];
+                    else v = A[i * p.sam + r * p.sak];
+                }
+                ra[q] = v;
+            }
+        }
+        // ---- B ----
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int j, r;
+            if (BK) { r = k0 + (t & 15); j = n0 + (t >> 4) + 16 * q; }
+            else    { j = n0 + (t & 63); r = k0 + (t >> 6) + 4 * q; }
+            rb[q] = (j < p.N && r < p.K) ? B[r * p.sbk + j * p.sbn] : 0.f;
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (AMODE == 3 || (AMODE != 4 && AK)) As[buf][t & 15][(t >> 4) + 16 * q] = ra[q];
+            else As[buf][(t >> 6) + 4 * q][t & 63] = ra[q];
+            if (BK) Bs[buf][t & 15][(t >> 4) + 16 * q] = rb[q];
+            else Bs[buf][(t >> 6) + 4 * q][t & 63] = rb[q];
+        }
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+    if (c_begin < c_end) {
+        load_chunk(c_begin);
+        store_chunk(0);
+        __syncthreads();
+        for (int c = c_begin; c < c_end; ++c) {
+            const int buf = (c - c_begin) & 1;
+            if (c + 1 < c_end) load_chunk(c + 1);
+            const int ar = wm * 32 + (lane & 31), bc = wn * 32 + (lane & 31), kq = lane >> 5;
+#pragma unroll
+            for (int kk = 0; kk < KC; kk += 2) {
+                float a = As[buf][kk + kq][ar];
+                float b = Bs[buf][kk + kq][bc];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            }
+            if (c + 1 < c_end) store_chunk(buf ^ 1);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: C/D layout  col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ----
+    const int j = n0 + wn * 32 + (lane & 31);
+    if (j >= p.N) return;
+    if (p.splitk > 1) {
+        float* P = p.partial + ((long)(z * p.splitk + blockIdx.y) * p.M) * p.N;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            int i = m0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+            if (i < p.M) P[(long)i * p.N + j] = acc[reg];
+        }
+        return;
+    }
+    float* C = p.C + (long)z * p.bsC;
+    const float bj = p.bias ? p.bias[(long)z * p.bsBias + j] : 0.f;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        int i = m0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        if (i < p.M) {
+            float v = apply_act(p.alpha * (acc[reg] + bj), p.act);
+            long off = i * p.scm + j * p.scn;
+            if (p.beta != 0.f) v += p.beta * C[off];
+            C[off] = v;
+        }
+    }
+}
+
+// Deterministic split-K reduction + epilogue.  remap_cin > 0: the (i,j) result of a conv
+// weight-gradient GEMM (i = (tap,ci), j = co) is scattered to the reference's OIHW layout
+// dW[co][ci][tap]  (reference nn.Conv2d weight layout, model/tsrn.py:597).
+__global__ void splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ C,
+                                     const float* __restrict__ bias, int M, int N, int S, int Z,
+                                     long scm, long scn, long bsC, long bsBias, float alpha, float beta,
+                                     int act, int remap_cin, int remap_taps) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)Z * M * N;
+    if (idx >= total) return;
+    int j = idx % N;
+    long rest = idx / N;
+    int i = rest % M;
+    int z = rest / M;
+    float s = 0.f;
+    for (int k = 0; k < S; ++k) s += partial[((long)(z * S + k) * M + i) * N + j];
+    float bj = bias ? bias[(long)z * bsBias + j] : 0.f;
+    float v = apply_act(alpha * (s + bj), act);
+    long off;
+    if (remap_cin > 0) {
+        int tap = i / remap_cin, ci = i - tap * remap_cin;
+        off = ((long)j * remap_cin + ci) * remap_taps + tap;
+    } else {
+        off = (long)z * bsC + i * scm + j * scn;
+    }
+    if (beta != 0.f) v += beta * C[off];
+    C[off] = v;
+}
+
+static int ilog2_or_neg(int v) {
+    if (v <= 0 || (v & (v - 1))) return -1;
+    int s = 0;
+    while ((1 << s) < v) ++s;
+    return s;
+}
+
+template <int AMODE>
+static int launch_gemm(const GemmP& p, int Z, bool ak, bool bk, hipStream_t st) {
+    dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), p.splitk, Z), block(256);
+    if (AMODE == 3) {
+        if (bk) hipLaunchKernelGGL((gemm_mfma_kernel<3, 1, 1>), grid, block, 0, st, p);
+        else    hipLaunchKernelGGL((gemm_mfma_kernel<3, 1, 0>), grid, block, 0, st, p);
+    } else if (AMODE == 4) {
+        if (bk) hipLaunchKernelGGL((gemm_mfma_kernel<4, 0, 1>), grid, block, 0, st, p);
+        else    hipLaunchKernelGGL((gemm_mfma_kernel<4, 0, 0>), grid, block, 0, st, p);
+    } else {
+        if (ak && bk)       hipLaunchKernelGGL((gemm_mfma_kernel<AMODE, 1, 1>), grid, block, 0, st, p);
+        else if (ak && !bk) hipLaunchKernelGGL((gemm_mfma_kernel<AMODE, 1, 0>), grid, block, 0, st, p);
+        else if (!ak && bk) hipLaunchKernelGGL((gemm_mfma_kernel<AMODE, 0, 1>), grid, block, 0, st, p);
+        else                hipLaunchKernelGGL((gemm_mfma_kernel<AMODE, 0, 0>), grid, block, 0, st, p);
+    }
+    return LAUNCH_CHECK();
+}
+
+static int finish_splitk(const GemmP& p, int Z, int remap_cin, int remap_taps, hipStream_t st) {
+    long total = (long)Z * p.M * p.N;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, p.partial, p.C, p.bias,
+                       p.M, p.N, p.splitk, Z, p.scm, p.scn, p.bsC, p.bsBias, p.alpha, p.beta, p.act,
+                       remap_cin, remap_taps);
+    return LAUNCH_CHECK();
+}
+
+static void set_split(GemmP& p, int splitk, float* ws) {
+    int nchunks = cdiv(p.K, KC);
+    if (splitk < 1) splitk = 1;
+    if (splitk > nchunks) splitk = nchunks;
+    p.chunks_per_split = cdiv(nchunks, splitk);
+    p.splitk = cdiv(nchunks, p.chunks_per_split);
+    p.partial = ws;
+    if (p.splitk > 1 && ws == nullptr) p.splitk = 1, p.chunks_per_split = nchunks;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+
+// General strided (batched) GEMM:  C = act(alpha * (A @ B + bias)) + beta * C.
+// A2/K1: optional second A source for r >= K1 (K-concatenation).  splitk > 1 needs `ws` of
+// Z*splitk*M*N floats.  Replaces nn.Linear / 1x1 nn.Conv2d / nn.GRU input projections
+// (reference model/tsrn.py:170,1071-1072; model/transformer_v2.py:455-457,788-790).
+TATT_API int tatt_gemm(const float* A, long sam, long sak, const float* A2, long sa2m, long sa2k, int K1,
+                       const float* B, long sbk, long sbn, const float* bias, float* C, long scm, long scn,
+                       int M, int N, int K, int Z, long bsA, long bsA2, long bsB, long bsC, long bsBias,
+                       float alpha, float beta, int act, int splitk, float* ws, hipStream_t st) {
+    if (M <= 0 || N <= 0 || Z <= 0) return 0;
+    GemmP p = {};
+    p.A = A; p.A2 = A2; p.B = B; p.bias = bias; p.C = C;
+    p.M = M; p.N = N; p.K = K; p.K1 = K1;
+    p.sam = sam; p.sak = sak; p.sa2m = sa2m; p.sa2k = sa2k; p.sbk = sbk; p.sbn = sbn; p.scm = scm; p.scn = scn;
+    p.bsA = bsA; p.bsA2 = bsA2; p.bsB = bsB; p.bsC = bsC; p.bsBias = bsBias;
+    p.alpha = alpha; p.beta = beta; p.act = act;
+    set_split(p, splitk, ws);
+    bool ak = (sak == 1), bk = (sbk == 1 && sbn != 1);
+    int rc = A2 ? launch_gemm<2>(p, Z, ak, bk, st) : launch_gemm<0>(p, Z, ak, bk, st);
+    if (rc) return rc;
+    if (p.splitk > 1) return finish_splitk(p, Z, 0, 0, st);
+    return 0;
+}
+
+static void fill_conv(GemmP& p, int H, int W, int Cin, int KH, int KW, long xsn, long xsh, long xsw, long xsc) {
+    p.H = H; p.W = W; p.Cin = Cin; p.KH = KH; p.KW = KW; p.pad = (KH - 1) / 2; p.HW = H * W;
+    p.Wshift = ilog2_or_neg(W); p.HWshift = ilog2_or_neg(H * W); p.Cshift = ilog2_or_neg(Cin);
+    p.xsn = xsn; p.xsh = xsh; p.xsw = xsw; p.xsc = xsc;
+}
+
+// Stride-1 'same' convolution as implicit GEMM (forward, and data-gradient when `wpacked` holds the
+// flipped/transposed filter).  x addressed with explicit strides (NCHW or NHWC), wpacked is
+// [KH][KW][Cin][Cout], output y[pixel*ldy + co] (NHWC rows).  y = act(conv + bias) + beta*y.
+// Replaces nn.Conv2d (reference model/tsrn.py:597,612,877,885,1043; model/stn_head.py:15).
+TATT_API int tatt_conv2d_fwd(const float* x, long xsn, long xsh, long xsw, long xsc, const float* wpacked,
+                             const float* bias, float* y, long ldy, int Bn, int H, int W, int Cin, int Cout,
+                             int KH, int KW, int act, float beta, hipStream_t st) {
+    GemmP p = {};
+    p.A = x; p.B = wpacked; p.bias = bias; p.C = y;
+    p.M = Bn * H * W; p.N = Cout; p.K = KH * KW * Cin;
+    p.sbk = Cout; p.sbn = 1; p.scm = ldy; p.scn = 1;
+    p.alpha = 1.f; p.beta = beta; p.act = act;
+    fill_conv(p, H, W, Cin, KH, KW, xsn, xsh, xsw, xsc);
+    set_split(p, 1, nullptr);
+    return launch_gemm<3>(p, 1, true, false, st);
+}
+
+// Convolution weight gradient: dW[co][ci][kh][kw] (OIHW, the reference parameter layout)
+//   = sum_pixels x[pixel + (kh,kw), ci] * dy[pixel, co];  dW = result + beta*dW.
+// Split over pixels (splitk) with a deterministic second-stage reduction; ws >= splitk*KH*KW*Cin*Cout floats.
+TATT_API int tatt_conv2d_wgrad(const float* x, long xsn, long xsh, long xsw, long xsc, const float* dy,
+                               long lddy, float* dw_oihw, int Bn, int H, int W, int Cin, int Cout, int KH,
+                               int KW, float beta, int splitk, float* ws, hipStream_t st) {
+    GemmP p = {};
+    p.A = x; p.B = dy; p.bias = nullptr; p.C = dw_oihw;
+    p.M = KH * KW * Cin; p.N = Cout; p.K = Bn * H * W;
+    p.sbk = lddy; p.sbn = 1; p.scm = Cout; p.scn = 1;
+    p.alpha = 1.f; p.beta = beta; p.act = ACT_NONE;
+    fill_conv(p, H, W, Cin, KH, KW, xsn, xsh, xsw, xsc);
+    set_split(p, splitk < 2 ? 2 : splitk, ws);
+    if (p.splitk < 2) { p.splitk = 2; p.chunks_per_split = cdiv(cdiv(p.K, KC), 2); }
+    int rc = launch_gemm<4>(p, 1, false, false, st);
+    if (rc) return rc;
+    return finish_splitk(p, 1, Cin, KH * KW, st);
+}
+
+// OIHW filter -> implicit-GEMM operand.  mode 0: [KH][KW][Cin][Cout] (forward);
+// mode 1: [KH][KW][Cout][Cin] spatially flipped (data-gradient: dX = conv(dY, flip(W)^T)).
+__global__ void repack_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin,
+                                     int KH, int KW, int mode) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    int total = Cout * Cin * KH * KW;
+    if (idx >= total) return;
+    // idx enumerates the OUTPUT
+    int T = KH * KW;
+    if (mode == 0) {
+        int co = idx % Cout; int r = idx / Cout; int ci = r % Cin; int tap = r / Cin;
+        out[idx] = w[((long)co * Cin + ci) * T + tap];
+    } else {
+        int ci = idx % Cin; int r = idx / Cin; int co = r % Cout; int tap = r / Cout;
+        out[idx] = w[((long)co * Cin + ci) * T + (T - 1 - tap)];
+    }
+}
+TATT_API int tatt_repack_conv_weight(const float* w_oihw, float* out, int Cout, int Cin, int KH, int KW,
+                                     int mode, hipStream_t st) {
+    int total = Cout * Cin * KH * KW;
+    hipLaunchKernelGGL(repack_weight_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w_oihw, out, Cout, Cin,
+                       KH, KW, mode);
+    return LAUNCH_CHECK();
+}

@@ -1,0 +1,340 @@
+// GRU recurrences of the TATT hot path (gfx950).
+//
+// (1) gru32_*: the 10 small bidirectional GRUs of the sequential-residual blocks (hidden 32, input 64;
+//     reference GruBlock, model/tsrn.py:1067-1084).  The input projection gi = x W_ih^T + b_ih is a
+//     GEMM done beforehand (tatt_gemm); these kernels run only the latency-bound recurrence: one
+//     32-lane group per (sequence, direction), the 96x32 recurrent matrix resident in VGPRs, h broadcast
+//     through LDS, gates in registers.  Sequences are addressed on the NHWC token grid by strides so
+//     the same kernel scans image columns (vertical, gru1) and image rows (horizontal, gru2).
+// (2) qgru_*: the query-embedding GRU (hidden 512, input 1024) whose time axis is the SAMPLE axis
+//     (reference InfoTransformer.forward, model/transformer_v2.py:201-221).  One launch
+//     per time step: h W_hh^T on v_mfma_f32_16x16x4_f32 with K split over the 4 waves of a work-group
+//     and the gate math fused in the epilogue.
+#include "common.h"
+
+struct SeqGeom {
+    int nseq, T, s_in;
+    long stride_hi, stride_lo, stride_t;   // token = (s / s_in)*stride_hi + (s % s_in)*stride_lo + t*stride_t
+};
+__device__ __forceinline__ long seq_base(const SeqGeom& g, int s) {
+    return (long)(s / g.s_in) * g.stride_hi + (long)(s % g.s_in) * g.stride_lo;
+}
+
+// ------------------------------------------------------------------------------------------------
+// small BiGRU forward.  gi: [tok][192] = [fwd r,z,n | rev r,z,n];  out: [tok][64] = [fwd h | rev h]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gru32_fwd_kernel(const float* __restrict__ gi,
+                                                        const float* __restrict__ whh_f, const float* __restrict__ bhh_f,
+                                                        const float* __restrict__ whh_r, const float* __restrict__ bhh_r,
+                                                        float* __restrict__ out, SeqGeom g) {
+    __shared__ __attribute__((aligned(16))) float hs[8][32];
+    const int t = threadIdx.x, grp = t >> 5, j = t & 31;
+    const int seq = blockIdx.x * 4 + (grp >> 1), dir = grp & 1;
+    const bool valid = seq < g.nseq;
+    const float* whh = dir ? whh_r : whh_f;
+    const float* bhh = dir ? bhh_r : bhh_f;
+    float wr[32], wz[32], wn[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        wr[k] = whh[(0 * 32 + j) * 32 + k];
+        wz[k] = whh[(1 * 32 + j) * 32 + k];
+        wn[k] = whh[(2 * 32 + j) * 32 + k];
+    }
+    const float br = bhh[j], bz = bhh[32 + j], bn = bhh[64 + j];
+    const long base = valid ? seq_base(g, seq) : 0;
+    float h = 0.f;
+    long tok = base + (long)(dir ? g.T - 1 : 0) * g.stride_t;
+    float gr = 0.f, gz = 0.f, gn = 0.f;
+    if (valid) { gr = gi[tok * 192 + dir * 96 + j]; gz = gi[tok * 192 + dir * 96 + 32 + j]; gn = gi[tok * 192 + dir * 96 + 64 + j]; }
+    for (int step = 0; step < g.T; ++step) {
+        // prefetch next step's input projection
+        float ngr = 0.f, ngz = 0.f, ngn = 0.f;
+        long ntok = tok + (dir ? -g.stride_t : g.stride_t);
+        if (valid && step + 1 < g.T) {
+            ngr = gi[ntok * 192 + dir * 96 + j]; ngz = gi[ntok * 192 + dir * 96 + 32 + j]; ngn = gi[ntok * 192 + dir * 96 + 64 + j];
+        }
+        hs[grp][j] = h;
+        __syncthreads();
+        float ar = br, az = bz, an = bn;
+        const f32x4* hv = reinterpret_cast<const f32x4*>(hs[grp]);
+#pragma unroll
+        for (int k4 = 0; k4 < 8; ++k4) {
+            f32x4 hh = hv[k4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                ar = fmaf(wr[k4 * 4 + u], hh[u], ar);
+                az = fmaf(wz[k4 * 4 + u], hh[u], az);
+                an = fmaf(wn[k4 * 4 + u], hh[u], an);
+            }
+        }
+        __syncthreads();
+        float r = sigmoid_f(gr + ar);
+        float z = sigmoid_f(gz + az);
+        float n = tanhf(gn + r * an);
+        h = (1.f - z) * n + z * h;
+        if (valid) out[tok * 64 + dir * 32 + j] = h;
+        tok = ntok; gr = ngr; gz = ngz; gn = ngn;
+    }
+}
+TATT_API int tatt_gru32_fwd(const float* gi, const float* whh_f, const float* bhh_f, const float* whh_r,
+                            const float* bhh_r, float* out, int nseq, int T, int s_in, long stride_hi, long stride_lo,
+                            long stride_t, hipStream_t st) {
+    SeqGeom g = {nseq, T, s_in, stride_hi, stride_lo, stride_t};
+    hipLaunchKernelGGL(gru32_fwd_kernel, dim3(cdiv(nseq, 4)), dim3(256), 0, st, gi, whh_f, bhh_f, whh_r, bhh_r, out, g);
+    return LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------------------------
+// small BiGRU backward (BPTT).  Recomputes the gates from gi and the stored outputs.
+// writes dgi [tok][192], dgh [tok][192] (recurrent-side gate grads: n-gate scaled by r) and
+// hprev [tok][64] (the h_{t-1} each step consumed) -- dW_hh = dgh^T hprev, dW_ih = dgi^T x, dx = dgi W_ih
+// are GEMMs issued by the host afterwards.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gru32_bwd_kernel(const float* __restrict__ gi, const float* __restrict__ out,
+                                                        const float* __restrict__ dout,
+                                                        const float* __restrict__ whh_f, const float* __restrict__ bhh_f,
+                                                        const float* __restrict__ whh_r, const float* __restrict__ bhh_r,
+                                                        float* __restrict__ dgi, float* __restrict__ dgh,
+                                                        float* __restrict__ hprev, SeqGeom g) {
+    __shared__ __attribute__((aligned(16))) float hs[8][32];
+    __shared__ __attribute__((aligned(16))) float ds[8][96];
+    const int t = threadIdx.x, grp = t >> 5, j = t & 31;
+    const int seq = blockIdx.x * 4 + (grp >> 1), dir = grp & 1;
+    const bool valid = seq < g.nseq;
+    const float* whh = dir ? whh_r : whh_f;
+    const float* bhh = dir ? bhh_r : bhh_f;
+    float wr[32], wz[32], wn[32], wt[96];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        wr[k] = whh[(0 * 32 + j) * 32 + k];
+        wz[k] = whh[(1 * 32 + j) * 32 + k];
+        wn[k] = whh[(2 * 32 + j) * 32 + k];
+    }
+#pragma unroll
+    for (int row = 0; row < 96; ++row) wt[row] = whh[row * 32 + j];
+    const float br = bhh[j], bz = bhh[32 + j], bn = bhh[64 + j];
+    const long base = valid ? seq_base(g, seq) : 0;
+    float dhc = 0.f;   // gradient carried to h_{t-1}
+    for (int step = g.T - 1; step >= 0; --step) {
+        const int ti = dir ? g.T - 1 - step : step;
+        const long tok = base + (long)ti * g.stride_t;
+        const long ptok = tok + (dir ? g.stride_t : -g.stride_t);     // token of forward-step (step-1)
+        float hp = 0.f, gr = 0.f, gz = 0.f, gn = 0.f, dh = dhc;
+        if (valid) {
+            if (step > 0) hp = out[ptok * 64 + dir * 32 + j];
+            gr = gi[tok * 192 + dir * 96 + j]; gz = gi[tok * 192 + dir * 96 + 32 + j]; gn = gi[tok * 192 + dir * 96 + 64 + j];
+            dh += dout[tok * 64 + dir * 32 + j];
+        }
+        hs[grp][j] = hp;
+        __syncthreads();
+        float ar = br, az = bz, an = bn;
+        const f32x4* hv = reinterpret_cast<const f32x4*>(hs[grp]);
+#pragma unroll
+        for (int k4 = 0; k4 < 8; ++k4) {
+            f32x4 hh = hv[k4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                ar = fmaf(wr[k4 * 4 + u], hh[u], ar);
+                az = fmaf(wz[k4 * 4 + u], hh[u], az);
+                an = fmaf(wn[k4 * 4 + u], hh[u], an);
+            }
+        }
+        const float r = sigmoid_f(gr + ar), z = sigmoid_f(gz + az), n = tanhf(gn + r * an);
+        const float dn = dh * (1.f - z);
+        const float dz = dh * (hp - n);
+        const float dnp = dn * (1.f - n * n);
+        const float drp = dnp * an * r * (1.f - r);
+        const float dzp = dz * z * (1.f - z);
+        const float dghn = dnp * r;
+        if (valid) {
+            dgi[tok * 192 + dir * 96 + j] = drp; dgi[tok * 192 + dir * 96 + 32 + j] = dzp; dgi[tok * 192 + dir * 96 + 64 + j] = dnp;
+            dgh[tok * 192 + dir * 96 + j] = drp; dgh[tok * 192 + dir * 96 + 32 + j] = dzp; dgh[tok * 192 + dir * 96 + 64 + j] = dghn;
+            hprev[tok * 64 + dir * 32 + j] = hp;
+        }
+        ds[grp][j] = drp; ds[grp][32 + j] = dzp; ds[grp][64 + j] = dghn;
+        __syncthreads();
+        float acc = dh * z;
+        const f32x4* dv = reinterpret_cast<const f32x4*>(ds[grp]);
+#pragma unroll
+        for (int k4 = 0; k4 < 24; ++k4) {
+            f32x4 dd = dv[k4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = fmaf(wt[k4 * 4 + u], dd[u], acc);
+        }
+        dhc = acc;
+        __syncthreads();
+    }
+}
+TATT_API int tatt_gru32_bwd(const float* gi, const float* out, const float* dout, const float* whh_f,
+                            const float* bhh_f, const float* whh_r, const float* bhh_r, float* dgi, float* dgh,
+                            float* hprev, int nseq, int T, int s_in, long stride_hi, long stride_lo, long stride_t,
+                            hipStream_t st) {
+    SeqGeom g = {nseq, T, s_in, stride_hi, stride_lo, stride_t};
+    hipLaunchKernelGGL(gru32_bwd_kernel, dim3(cdiv(nseq, 4)), dim3(256), 0, st, gi, out, dout, whh_f, bhh_f, whh_r, bhh_r,
+                       dgi, dgh, hprev, g);
+    return LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------------------------
+// query GRU, one time step, both directions (blockIdx.z).
+//   gi   [dir][Wb][3*HID]   time-invariant input projection (incl. b_ih)
+//   whh  [dir] -> (3*HID, HID) row-major,  bhh [dir] -> (3*HID)
+//   hprev[dir] -> (Wb, HID) or null (first step: h = 0)
+//   hnew [dir] -> (Wb, HID);  gsave[dir] -> (4, Wb, HID) = r, z, n, (W_hn h + b_hn)
+// work-group = 16 rows x 16 hidden units x 3 gates; wave w reduces k in [w*HID/4, (w+1)*HID/4).
+// MFMA 16x16x4 operand map: A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15]; each lane loads a
+// float4 along k for A and B -- the (lane>>4, element) -> k assignment is the same on both sides, which
+// is all the contraction needs.  C/D: col = lane&15, row = (lane>>4)*4 + reg.
+// ------------------------------------------------------------------------------------------------
+struct QStepP {
+    const float* gi[2]; const float* whh[2]; const float* bhh[2]; const float* hprev[2];
+    float* hnew[2]; float* gsave[2];
+    int Wb, HID;
+};
+__global__ __launch_bounds__(256) void qgru_fwd_step_kernel(QStepP p) {
+    __shared__ float red[4][3][16][17];
+    const int d = blockIdx.z;
+    const int m0 = blockIdx.x * 16, j0 = blockIdx.y * 16;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int HID = p.HID;
+    const float* hprev = p.hprev[d];
+    const float* whh = p.whh[d];
+    f32x4 acc[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (hprev) {
+        const int i = lane & 15, q = lane >> 4;
+        const int kspan = HID / 4;
+        const int kbeg = wave * kspan;
+        const int arow = min(m0 + i, p.Wb - 1);
+        for (int kb = kbeg; kb < kbeg + kspan; kb += 16) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(hprev + (long)arow * HID + kb + 4 * q);
+            f32x4 b[3];
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+                b[g] = *reinterpret_cast<const f32x4*>(whh + ((long)g * HID + j0 + i) * HID + kb + 4 * q);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[g][u], acc[g], 0, 0, 0);
+        }
+    }
+    {
+        const int col = lane & 15, rb = (lane >> 4) * 4;
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][g][rb + r][col] = acc[g][r];
+    }
+    __syncthreads();
+    const int m = t >> 4, j = t & 15;
+    if (m0 + m >= p.Wb) return;
+    float gh[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+        gh[g] = red[0][g][m][j] + red[1][g][m][j] + red[2][g][m][j] + red[3][g][m][j] + p.bhh[d][g * HID + j0 + j];
+    const long row = m0 + m;
+    const float* gi = p.gi[d] + row * 3 * HID + j0 + j;
+    const float r = sigmoid_f(gi[0] + gh[0]);
+    const float z = sigmoid_f(gi[HID] + gh[1]);
+    const float n = tanhf(gi[2 * HID] + r * gh[2]);
+    const float hp = hprev ? hprev[row * HID + j0 + j] : 0.f;
+    const float h = (1.f - z) * n + z * hp;
+    p.hnew[d][row * HID + j0 + j] = h;
+    float* gs = p.gsave[d];
+    if (gs) {
+        const long plane = (long)p.Wb * HID, o = row * HID + j0 + j;
+        gs[o] = r; gs[plane + o] = z; gs[2 * plane + o] = n; gs[3 * plane + o] = gh[2];
+    }
+}
+TATT_API int tatt_qgru_fwd_step(const float* gi0, const float* gi1, const float* whh0, const float* whh1,
+                                const float* bhh0, const float* bhh1, const float* hprev0, const float* hprev1,
+                                float* hnew0, float* hnew1, float* gsave0, float* gsave1, int Wb, int HID,
+                                hipStream_t st) {
+    if (HID % 64) return 1;
+    QStepP p = {{gi0, gi1}, {whh0, whh1}, {bhh0, bhh1}, {hprev0, hprev1}, {hnew0, hnew1}, {gsave0, gsave1}, Wb, HID};
+    hipLaunchKernelGGL(qgru_fwd_step_kernel, dim3(cdiv(Wb, 16), HID / 16, 2), dim3(256), 0, st, p);
+    return LAUNCH_CHECK();
+}
+
+// backward step part 1 (element-wise): gate gradients of one time step, both directions.
+//   dh_in  = dhseq_t + dhcarry   ->  dgi_acc += [dr', dz', dn'];  dgh_t = [dr', dz', dn'*r];  dhcarry = dh_in * z
+struct QBwdGateP {
+    const float* dhseq[2]; const float* gsave[2]; const float* hprev[2];
+    float* dhcarry[2]; float* dgi_acc[2]; float* dgh[2];
+    int Wb, HID, first;   // first: dhcarry holds garbage -> treat as zero
+};
+__global__ void qgru_bwd_gates_kernel(QBwdGateP p) {
+    const int d = blockIdx.y;
+    const long n_el = (long)p.Wb * p.HID;
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_el) return;
+    const long row = i / p.HID; const int j = i % p.HID;
+    const float* gs = p.gsave[d];
+    const float r = gs[i], z = gs[n_el + i], n = gs[2 * n_el + i], hn = gs[3 * n_el + i];
+    const float hp = p.hprev[d] ? p.hprev[d][i] : 0.f;
+    float dh = p.dhseq[d][i];
+    if (!p.first) dh += p.dhcarry[d][i];
+    const float dn = dh * (1.f - z), dz = dh * (hp - n);
+    const float dnp = dn * (1.f - n * n);
+    const float drp = dnp * hn * r * (1.f - r);
+    const float dzp = dz * z * (1.f - z);
+    const long g3 = row * 3 * p.HID + j;
+    float* acc = p.dgi_acc[d];
+    if (p.first) { acc[g3] = drp; acc[g3 + p.HID] = dzp; acc[g3 + 2 * p.HID] = dnp; }
+    else { acc[g3] += drp; acc[g3 + p.HID] += dzp; acc[g3 + 2 * p.HID] += dnp; }
+    float* dg = p.dgh[d];
+    dg[g3] = drp; dg[g3 + p.HID] = dzp; dg[g3 + 2 * p.HID] = dnp * r;
+    p.dhcarry[d][i] = dh * z;
+}
+TATT_API int tatt_qgru_bwd_gates(const float* dhseq0, const float* dhseq1, const float* gsave0, const float* gsave1,
+                                 const float* hprev0, const float* hprev1, float* dhcarry0, float* dhcarry1,
+                                 float* dgi_acc0, float* dgi_acc1, float* dgh0, float* dgh1, int Wb, int HID, int first,
+                                 hipStream_t st) {
+    QBwdGateP p = {{dhseq0, dhseq1}, {gsave0, gsave1}, {hprev0, hprev1}, {dhcarry0, dhcarry1}, {dgi_acc0, dgi_acc1},
+                   {dgh0, dgh1}, Wb, HID, first};
+    hipLaunchKernelGGL(qgru_bwd_gates_kernel, dim3(cdiv((long)Wb * HID, 256), 2), dim3(256), 0, st, p);
+    return LAUNCH_CHECK();
+}
+
+// backward step part 2:  dhcarry[d] (Wb x HID) += dgh[d] (Wb x 3HID) @ whh[d] (3HID x HID)
+struct QBwdMmP { const float* dgh[2]; const float* whh[2]; float* dhcarry[2]; int Wb, HID; };
+__global__ __launch_bounds__(256) void qgru_bwd_mm_kernel(QBwdMmP p) {
+    __shared__ float red[4][16][17];
+    const int d = blockIdx.z;
+    const int m0 = blockIdx.x * 16, j0 = blockIdx.y * 16;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int HID = p.HID, K = 3 * p.HID;
+    const float* dgh = p.dgh[d];
+    const float* whh = p.whh[d];
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int i = lane & 15, q = lane >> 4;
+    const int kspan = K / 4, kbeg = wave * kspan;
+    const int arow = min(m0 + i, p.Wb - 1);
+    for (int kb = kbeg; kb < kbeg + kspan; kb += 16) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(dgh + (long)arow * K + kb + 4 * q);
+        float b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) b[u] = whh[(long)(kb + 4 * q + u) * HID + j0 + i];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc, 0, 0, 0);
+    }
+    {
+        const int col = lane & 15, rb = (lane >> 4) * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][rb + r][col] = acc[r];
+    }
+    __syncthreads();
+    const int m = t >> 4, j = t & 15;
+    if (m0 + m >= p.Wb) return;
+    const float s = red[0][m][j] + red[1][m][j] + red[2][m][j] + red[3][m][j];
+    p.dhcarry[d][(long)(m0 + m) * HID + j0 + j] += s;
+}
+TATT_API int tatt_qgru_bwd_mm(const float* dgh0, const float* dgh1, const float* whh0, const float* whh1,
+                              float* dhcarry0, float* dhcarry1, int Wb, int HID, hipStream_t st) {
+    if ((3 * HID) % 64) return 1;
+    QBwdMmP p = {{dgh0, dgh1}, {whh0, whh1}, {dhcarry0, dhcarry1}, Wb, HID};
+    hipLaunchKernelGGL(qgru_bwd_mm_kernel, dim3(cdiv(Wb, 16), HID / 16, 2), dim3(256), 0, st, p);
+    return LAUNCH_CHECK();
+}

@@ -1,0 +1,314 @@
+// BatchNorm (train / eval, with fused activation), LayerNorm (with fused residual add) and column
+// reductions over token-major (rows x C) activations.  Memory-bound streaming kernels: rows are read
+// with lanes along the contiguous channel axis; statistics are accumulated in fp64 so that the
+// E[x^2]-E[x]^2 form is safe.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// column sums:  out[c] (+)= scale * sum_m X[m*ld + c]      (two stages, deterministic)
+// ---------------------------------------------------------------------------------------------
+#define CS_ROWS 256   // rows per block in stage 1
+
+__global__ void colsum_stage1(const float* __restrict__ X, long ld, int M, int C, double* __restrict__ part) {
+    // block handles CS_ROWS rows; thread t -> channel group; loop channels with stride blockDim
+    const int m_begin = blockIdx.x * CS_ROWS;
+    const int m_end = min(M, m_begin + CS_ROWS);
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        double s = 0.0;
+        for (int m = m_begin; m < m_end; ++m) s += (double)X[(long)m * ld + c];
+        part[(long)blockIdx.x * C + c] = s;
+    }
+}
+__global__ void colsum_stage2(const double* __restrict__ part, int G, int C, long ldp, float* __restrict__ out,
+                              float scale, float beta) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int g = 0; g < G; ++g) s += part[(long)g * ldp + c];
+    float v = (float)(s * scale);
+    out[c] = beta != 0.f ? v + beta * out[c] : v;
+}
+// ws: cdiv(M,256)*C doubles
+TATT_API int tatt_colsum(const float* X, long ld, int M, int C, float* out, float scale, float beta,
+                         double* ws, hipStream_t st) {
+    int G = cdiv(M, CS_ROWS);
+    int bt = C >= 256 ? 256 : (C >= 64 ? 64 : 64);
+    hipLaunchKernelGGL(colsum_stage1, dim3(G), dim3(bt), 0, st, X, ld, M, C, ws);
+    hipLaunchKernelGGL(colsum_stage2, dim3(cdiv(C, 64)), dim3(64), 0, st, ws, G, C, (long)C, out, scale, beta);
+    return LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm  (reference nn.BatchNorm2d / BatchNorm1d: model/tsrn.py:878,886,613; model/stn_head.py:19,51)
+// ---------------------------------------------------------------------------------------------
+// stage 1: per-block partial sums (sum, sumsq) per channel in fp64.  part[g][2][C]
+__global__ void bn_stats_stage1(const float* __restrict__ X, long ld, int M, int C, int rows_per_block,
+                                double* __restrict__ part) {
+    __shared__ double sh[2][256];
+    const int cpb = C < 256 ? C : 256;           // channels per pass (C is a power of two <= 512 here)
+    const int rpar = 256 / cpb;                  // rows handled in parallel
+    const int t = threadIdx.x;
+    const int cl = t % cpb, rl = t / cpb;
+    const int m_begin = blockIdx.x * rows_per_block;
+    const int m_end = min(M, m_begin + rows_per_block);
+    for (int c0 = 0; c0 < C; c0 += cpb) {
+        const int c = c0 + cl;
+        double s = 0.0, q = 0.0;
+        if (rl < rpar && c < C)
+            for (int m = m_begin + rl; m < m_end; m += rpar) {
+                double v = (double)X[(long)m * ld + c];
+                s += v; q += v * v;
+            }
+        sh[0][t] = s; sh[1][t] = q;
+        __syncthreads();
+        if (t < cpb && c < C) {
+            double ss = 0.0, qq = 0.0;
+            for (int r = 0; r < rpar; ++r) { ss += sh[0][r * cpb + t]; qq += sh[1][r * cpb + t]; }
+            part[((long)blockIdx.x * 2 + 0) * C + c] = ss;
+            part[((long)blockIdx.x * 2 + 1) * C + c] = qq;
+        }
+        __syncthreads();
+    }
+}
+// stage 2: mean / rstd (biased var) + running-stat update (unbiased var, momentum) -- one thread per channel
+__global__ void bn_stats_stage2(const double* __restrict__ part, int G, int C, int M, float eps, float momentum,
+                                float* __restrict__ mean, float* __restrict__ rstd,
+                                float* __restrict__ running_mean, float* __restrict__ running_var) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int g = 0; g < G; ++g) { s += part[((long)g * 2 + 0) * C + c]; q += part[((long)g * 2 + 1) * C + c]; }
+    double mu = s / M;
+    double var = q / M - mu * mu;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)mu;
+    rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        double unb = M > 1 ? var * ((double)M / (M - 1)) : var;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+    }
+}
+// ws: cdiv(M, rows_per_block)*2*C doubles
+TATT_API int tatt_bn_stats(const float* X, long ld, int M, int C, float eps, float momentum, float* mean,
+                           float* rstd, float* running_mean, float* running_var, double* ws, hipStream_t st) {
+    int rpb = 128;
+    int G = cdiv(M, rpb);
+    hipLaunchKernelGGL(bn_stats_stage1, dim3(G), dim3(256), 0, st, X, ld, M, C, rpb, ws);
+    hipLaunchKernelGGL(bn_stats_stage2, dim3(cdiv(C, 64)), dim3(64), 0, st, ws, G, C, M, eps, momentum, mean, rstd,
+                       running_mean, running_var);
+    return LAUNCH_CHECK();
+}
+// eval mode: rstd from running_var
+__global__ void bn_rstd_kernel(const float* __restrict__ var, float* __restrict__ rstd, int C, float eps) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) rstd[c] = 1.f / sqrtf(var[c] + eps);
+}
+TATT_API int tatt_bn_rstd(const float* var, float* rstd, int C, float eps, hipStream_t st) {
+    hipLaunchKernelGGL(bn_rstd_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, var, rstd, C, eps);
+    return LAUNCH_CHECK();
+}
+
+// y = act((x - mean) * rstd * gamma + beta)
+__global__ void bn_apply_kernel(const float* __restrict__ X, long ldx, float* __restrict__ Y, long ldy, int M, int C,
+                                const float* __restrict__ mean, const float* __restrict__ rstd,
+                                const float* __restrict__ gamma, const float* __restrict__ beta, int act) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)M * C;
+    if (idx >= total) return;
+    int c = idx % C;
+    long m = idx / C;
+    float u = (X[m * ldx + c] - mean[c]) * rstd[c] * gamma[c] + beta[c];
+    Y[m * ldy + c] = apply_act(u, act);
+}
+TATT_API int tatt_bn_apply(const float* X, long ldx, float* Y, long ldy, int M, int C, const float* mean,
+                           const float* rstd, const float* gamma, const float* beta, int act, hipStream_t st) {
+    long total = (long)M * C;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, X, ldx, Y, ldy, M, C, mean, rstd,
+                       gamma, beta, act);
+    return LAUNCH_CHECK();
+}
+
+// backward stage 1: per-channel partial sums of du and du*xhat, du = dy * act'(gamma*xhat+beta)
+__global__ void bn_bwd_stage1(const float* __restrict__ X, long ldx, const float* __restrict__ dY, long lddy, int M,
+                              int C, int rows_per_block, const float* __restrict__ mean,
+                              const float* __restrict__ rstd, const float* __restrict__ gamma,
+                              const float* __restrict__ beta, int act, double* __restrict__ part) {
+    __shared__ double sh[2][256];
+    const int cpb = C < 256 ? C : 256;
+    const int rpar = 256 / cpb;
+    const int t = threadIdx.x;
+    const int cl = t % cpb, rl = t / cpb;
+    const int m_begin = blockIdx.x * rows_per_block;
+    const int m_end = min(M, m_begin + rows_per_block);
+    for (int c0 = 0; c0 < C; c0 += cpb) {
+        const int c = c0 + cl;
+        double s = 0.0, q = 0.0;
+        if (rl < rpar && c < C) {
+            const float mu = mean[c], rs = rstd[c], g = gamma[c], b = beta[c];
+            for (int m = m_begin + rl; m < m_end; m += rpar) {
+                float xh = (X[(long)m * ldx + c] - mu) * rs;
+                float du = dY[(long)m * lddy + c];
+                if (act != ACT_NONE) du *= act_grad(g * xh + b, act);
+                s += (double)du; q += (double)du * xh;
+            }
+        }
+        sh[0][t] = s; sh[1][t] = q;
+        __syncthreads();
+        if (t < cpb && c < C) {
+            double ss = 0.0, qq = 0.0;
+            for (int r = 0; r < rpar; ++r) { ss += sh[0][r * cpb + t]; qq += sh[1][r * cpb + t]; }
+            part[((long)blockIdx.x * 2 + 0) * C + c] = ss;
+            part[((long)blockIdx.x * 2 + 1) * C + c] = qq;
+        }
+        __syncthreads();
+    }
+}
+__global__ void bn_bwd_stage2(const double* __restrict__ part, int G, int C, float* __restrict__ dgamma,
+                              float* __restrict__ dbeta, float* __restrict__ sums) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int g = 0; g < G; ++g) { s += part[((long)g * 2 + 0) * C + c]; q += part[((long)g * 2 + 1) * C + c]; }
+    dbeta[c] = (float)s; dgamma[c] = (float)q;
+    sums[c] = (float)s; sums[C + c] = (float)q;
+}
+// dx = gamma*rstd*(du - mean(du) - xhat*mean(du*xhat))   [training]   or   gamma*rstd*du   [eval]
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ X, long ldx, const float* __restrict__ dY, long lddy,
+                                    float* __restrict__ dX, long lddx, int M, int C,
+                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                    const float* __restrict__ gamma, const float* __restrict__ beta, int act,
+                                    const float* __restrict__ sums, int training) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)M * C;
+    if (idx >= total) return;
+    int c = idx % C;
+    long m = idx / C;
+    float rs = rstd[c], g = gamma[c];
+    float xh = (X[m * ldx + c] - mean[c]) * rs;
+    float du = dY[m * lddy + c];
+    if (act != ACT_NONE) du *= act_grad(g * xh + beta[c], act);
+    float v = du;
+    if (training) {
+        float inv = 1.f / (float)M;
+        v = du - sums[c] * inv - xh * sums[C + c] * inv;
+    }
+    dX[m * lddx + c] = g * rs * v;
+}
+// ws: cdiv(M,128)*2*C doubles; sums: 2*C floats scratch
+TATT_API int tatt_bn_bwd(const float* X, long ldx, const float* dY, long lddy, float* dX, long lddx, int M, int C,
+                         const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
+                         int training, float* dgamma, float* dbeta, float* sums, double* ws, hipStream_t st) {
+    int rpb = 128;
+    int G = cdiv(M, rpb);
+    hipLaunchKernelGGL(bn_bwd_stage1, dim3(G), dim3(256), 0, st, X, ldx, dY, lddy, M, C, rpb, mean, rstd, gamma, beta,
+                       act, ws);
+    hipLaunchKernelGGL(bn_bwd_stage2, dim3(cdiv(C, 64)), dim3(64), 0, st, ws, G, C, dgamma, dbeta, sums);
+    long total = (long)M * C;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, X, ldx, dY, lddy, dX, lddx, M, C,
+                       mean, rstd, gamma, beta, act, sums, training);
+    return LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm over the last axis with fused residual:  y = LN(a + b) * gamma + beta
+// (reference nn.LayerNorm: model/transformer_v2.py:459-460,793-795; residual adds :478-483,826-832)
+// one wave per row; lanes stride the C channels.  stats: [M][2] = (mean, rstd)
+// ---------------------------------------------------------------------------------------------
+#define LN_MAXPER 4   // supports C <= 256
+
+__global__ void ln_fwd_kernel(const float* __restrict__ A, const float* __restrict__ Bres, float* __restrict__ Y,
+                              float* __restrict__ stats, int M, int C, const float* __restrict__ gamma,
+                              const float* __restrict__ beta, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float v[LN_MAXPER];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXPER; ++k) {
+        int c = lane + 64 * k;
+        float x = 0.f;
+        if (c < C) { x = A[row * C + c]; if (Bres) x += Bres[row * C + c]; }
+        v[k] = x; s += x;
+    }
+    float mu = wave_sum(s) / C;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXPER; ++k) { int c = lane + 64 * k; if (c < C) { float d = v[k] - mu; q += d * d; } }
+    float rs = 1.f / sqrtf(wave_sum(q) / C + eps);
+#pragma unroll
+    for (int k = 0; k < LN_MAXPER; ++k) {
+        int c = lane + 64 * k;
+        if (c < C) Y[row * C + c] = (v[k] - mu) * rs * gamma[c] + beta[c];
+    }
+    if (lane == 0 && stats) { stats[row * 2] = mu; stats[row * 2 + 1] = rs; }
+}
+TATT_API int tatt_ln_fwd(const float* A, const float* Bres, float* Y, float* stats, int M, int C,
+                         const float* gamma, const float* beta, float eps, hipStream_t st) {
+    if (C > 64 * LN_MAXPER) return 1;
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, A, Bres, Y, stats, M, C, gamma, beta, eps);
+    return LAUNCH_CHECK();
+}
+
+// backward: dX (= d(a+b)) per row; per-block partial dgamma/dbeta -> part[G][2][C] (float), reduced by colsum.
+#define LN_BWD_ROWS 64   // rows per wave-loop block (4 waves x 16 rows)
+__global__ void ln_bwd_kernel(const float* __restrict__ A, const float* __restrict__ Bres,
+                              const float* __restrict__ dY, const float* __restrict__ stats, float* __restrict__ dX,
+                              int M, int C, const float* __restrict__ gamma, float* __restrict__ part) {
+    __shared__ float sh[4][2][64 * LN_MAXPER];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float dg[LN_MAXPER], db[LN_MAXPER];
+#pragma unroll
+    for (int k = 0; k < LN_MAXPER; ++k) { dg[k] = 0.f; db[k] = 0.f; }
+    const long r0 = (long)blockIdx.x * LN_BWD_ROWS;
+    for (int rr = wave; rr < LN_BWD_ROWS; rr += 4) {
+        long row = r0 + rr;
+        if (row >= M) break;
+        const float mu = stats[row * 2], rs = stats[row * 2 + 1];
+        float xh[LN_MAXPER], dxh[LN_MAXPER];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < LN_MAXPER; ++k) {
+            int c = lane + 64 * k;
+            xh[k] = 0.f; dxh[k] = 0.f;
+            if (c < C) {
+                float x = A[row * C + c]; if (Bres) x += Bres[row * C + c];
+                float dy = dY[row * C + c];
+                xh[k] = (x - mu) * rs;
+                dxh[k] = dy * gamma[c];
+                dg[k] += dy * xh[k]; db[k] += dy;
+                s1 += dxh[k]; s2 += dxh[k] * xh[k];
+            }
+        }
+        s1 = wave_sum(s1) / C; s2 = wave_sum(s2) / C;
+#pragma unroll
+        for (int k = 0; k < LN_MAXPER; ++k) {
+            int c = lane + 64 * k;
+            if (c < C) dX[row * C + c] = rs * (dxh[k] - s1 - xh[k] * s2);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < LN_MAXPER; ++k) { sh[wave][0][lane + 64 * k] = dg[k]; sh[wave][1][lane + 64 * k] = db[k]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float g = 0.f, b = 0.f;
+        for (int w = 0; w < 4; ++w) { g += sh[w][0][c]; b += sh[w][1][c]; }
+        part[((long)blockIdx.x * 2 + 0) * C + c] = g;
+        part[((long)blockIdx.x * 2 + 1) * C + c] = b;
+    }
+}
+// part: cdiv(M,64)*2*C floats;  ws: doubles for the colsum (cdiv(G,256)*2*C)
+TATT_API int tatt_ln_bwd(const float* A, const float* Bres, const float* dY, const float* stats, float* dX, int M,
+                         int C, const float* gamma, float* dgamma, float* dbeta, float* part, double* ws,
+                         hipStream_t st) {
+    if (C > 64 * LN_MAXPER) return 1;
+    int G = cdiv(M, LN_BWD_ROWS);
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(G), dim3(256), 0, st, A, Bres, dY, stats, dX, M, C, gamma, part);
+    // part viewed as (G, 2C) -> column sums give [dgamma | dbeta]
+    int G2 = cdiv(G, CS_ROWS);
+    hipLaunchKernelGGL(colsum_stage1, dim3(G2), dim3(64), 0, st, part, (long)2 * C, G, 2 * C, ws);
+    hipLaunchKernelGGL(colsum_stage2, dim3(cdiv(C, 64)), dim3(64), 0, st, ws, G2, C, (long)2 * C, dgamma, 1.f, 0.f);
+    hipLaunchKernelGGL(colsum_stage2, dim3(cdiv(C, 64)), dim3(64), 0, st, ws + C, G2, C, (long)2 * C, dbeta, 1.f, 0.f);
+    return LAUNCH_CHECK();
+}

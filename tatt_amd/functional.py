@@ -1,0 +1,509 @@
+"""Differentiable operators of the TATT hot path: each `torch.autograd.Function` runs hand-written HIP
+kernels (tatt_amd.ops -> libtatt_hip.so) in forward AND backward.  torch.autograd is only the tape.
+
+Feature maps are (B, H, W, C) contiguous tensors ("NHWC"); token matrices are their (B*H*W, C) views.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+from torch.autograd import Function
+
+from . import ops
+from .ops import ACT_NONE, ACT_RELU, ACT_MISH, ACT_TANH
+
+_SEEDS = {}
+
+
+def seed_tensor(device) -> torch.Tensor:
+    """Device-resident dropout seed word (bumped once per training step; hipGraph-replay safe)."""
+    key = str(device)
+    if key not in _SEEDS:
+        _SEEDS[key] = torch.tensor([0x1234ABCD5678EF01 & 0x7FFFFFFFFFFFFFFF], dtype=torch.int64, device=device)
+    return _SEEDS[key]
+
+
+def set_seed(device, value: int):
+    seed_tensor(device).fill_(int(value) & 0x7FFFFFFFFFFFFFFF)
+
+
+def next_dropout_step(device):
+    ops.bump_seed(seed_tensor(device))
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# --------------------------------------------------------------------------------------------------
+class Conv2dFn(Function):
+    """nn.Conv2d (stride 1, 'same') on a (B,H,W,Cin)-indexed tensor (any strides) -> (B,H,W,Cout) contiguous,
+    optional fused output activation (none / tanh)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act):
+        Cout, Cin, KH, KW = weight.shape
+        wp = ops.repack_weight(weight, 0)
+        y = ops.conv_fwd(x, wp, bias, Cout, KH, KW, act=act)
+        ctx.save_for_backward(x, weight, y if act != ACT_NONE else None)
+        ctx.act = act
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        Cout, Cin, KH, KW = weight.shape
+        dy = _c(dy)
+        if ctx.act != ACT_NONE:
+            dy = ops.act_bwd(y, dy, ctx.act, True)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wd = ops.repack_weight(weight, 1)
+            dx = ops.conv_fwd(dy, wd, None, Cin, KH, KW)
+            if not x.is_contiguous():
+                dx = dx  # gradient is returned in contiguous NHWC indexing; autograd only needs matching shape
+        if ctx.needs_input_grad[1]:
+            dw = ops.conv_wgrad(x, dy, Cout, KH, KW)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = ops.colsum(dy.reshape(-1, Cout))
+        return dx, dw, db, None
+
+
+def conv2d(x, weight, bias, act=ACT_NONE):
+    return Conv2dFn.apply(x, weight, bias, act)
+
+
+# --------------------------------------------------------------------------------------------------
+class BatchNormActFn(Function):
+    """nn.BatchNorm (train: batch statistics + running-stat update; eval: running stats) + activation."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, act):
+        C = x.shape[-1]
+        x2 = x.reshape(-1, C)
+        if training:
+            mean, rstd = ops.bn_stats(x2, eps, momentum, running_mean, running_var)
+        else:
+            mean, rstd = running_mean, ops.bn_rstd(running_var, eps)
+        y = ops.bn_apply(x2, mean, rstd, gamma, beta, act).reshape(x.shape)
+        ctx.save_for_backward(x, gamma, beta, mean, rstd)
+        ctx.act, ctx.training = act, training
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        C = x.shape[-1]
+        dx, dg, db = ops.bn_bwd(x.reshape(-1, C), _c(dy).reshape(-1, C), mean, rstd, gamma, beta, ctx.act, ctx.training)
+        return dx.reshape(x.shape), dg, db, None, None, None, None, None, None
+
+
+def batch_norm_act(x, bn, act=ACT_NONE):
+    """bn: an nn.BatchNorm{1,2}d used as parameter/buffer holder."""
+    training = bn.training
+    if training and bn.track_running_stats:
+        bn.num_batches_tracked += 1
+    return BatchNormActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.momentum, bn.eps,
+                                act)
+
+
+# --------------------------------------------------------------------------------------------------
+class LinearFn(Function):
+    """y = act(alpha*(x @ W^T + b)); optional second input concatenated along the feature axis."""
+
+    @staticmethod
+    def forward(ctx, x, xb, weight, bias, act, alpha):
+        K1 = x.shape[-1]
+        x2 = x.reshape(-1, K1)
+        xb2 = xb.reshape(-1, xb.shape[-1]) if xb is not None else None
+        y = ops.linear_fwd(x2, weight, bias, act=act, alpha=alpha, x2b=xb2)
+        ctx.save_for_backward(x, xb, weight, y if act != ACT_NONE else None)
+        ctx.act, ctx.alpha, ctx.has_bias = act, alpha, bias is not None
+        return y.reshape(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, xb, weight, y = ctx.saved_tensors
+        N, K = weight.shape
+        K1 = x.shape[-1]
+        dy2 = _c(dy).reshape(-1, N)
+        if ctx.act != ACT_NONE:
+            dy2 = ops.act_bwd(y, dy2, ctx.act, True)
+        x2 = x.reshape(-1, K1)
+        dx = dxb = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.linear_bwd_input(dy2, weight, col0=0, ncols=K1, alpha=ctx.alpha).reshape(x.shape)
+        if xb is not None and ctx.needs_input_grad[1]:
+            dxb = ops.linear_bwd_input(dy2, weight, col0=K1, ncols=K - K1, alpha=ctx.alpha).reshape(xb.shape)
+        if ctx.needs_input_grad[2]:
+            dw = ops.new(dy2, N, K)
+            ops.linear_bwd_weight(dy2, x2, alpha=ctx.alpha, out=dw, out_ld=K)
+            if xb is not None:
+                ops.linear_bwd_weight(dy2, xb.reshape(-1, K - K1), alpha=ctx.alpha, out=dw.reshape(-1)[K1:], out_ld=K)
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            db = ops.colsum(dy2, scale=ctx.alpha)
+        return dx, dxb, dw, db, None, None
+
+
+def linear(x, weight, bias=None, act=ACT_NONE, alpha=1.0, xb=None):
+    return LinearFn.apply(_c(x), None if xb is None else _c(xb), weight, bias, act, alpha)
+
+
+# --------------------------------------------------------------------------------------------------
+class BiGRU32Fn(Function):
+    """Bidirectional GRU (hidden 32) over the rows or columns of a (B,H,W,64) token grid."""
+
+    @staticmethod
+    def forward(ctx, x, wih_f, whh_f, bih_f, bhh_f, wih_r, whh_r, bih_r, bhh_r, vertical):
+        B, H, W, C = x.shape
+        x2 = x.reshape(-1, C)
+        M = x2.shape[0]
+        gi = ops.new(x, M, 192)
+        ops.linear_fwd(x2, wih_f, bih_f, out=gi[:, :96])
+        ops.linear_fwd(x2, wih_r, bih_r, out=gi[:, 96:])
+        geom = ops.seq_geom(B, H, W, vertical)
+        out = ops.gru32_fwd(gi, whh_f, bhh_f, whh_r, bhh_r, geom)
+        ctx.save_for_backward(x, gi, out, wih_f, whh_f, bhh_f, wih_r, whh_r, bhh_r)
+        ctx.geom = geom
+        return out.reshape(B, H, W, 64)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, gi, out, wih_f, whh_f, bhh_f, wih_r, whh_r, bhh_r = ctx.saved_tensors
+        C = x.shape[-1]
+        x2 = x.reshape(-1, C)
+        dgi, dgh, hprev = ops.gru32_bwd(gi, out, _c(dout).reshape(-1, 64), whh_f, bhh_f, whh_r, bhh_r, ctx.geom)
+        dx = ops.linear_bwd_input(dgi[:, :96], wih_f)
+        ops.linear_bwd_input(dgi[:, 96:], wih_r, out=dx, beta=1.0)
+        g = []
+        for d in range(2):
+            gi_d, gh_d = dgi[:, 96 * d:96 * (d + 1)], dgh[:, 96 * d:96 * (d + 1)]
+            g.append((ops.linear_bwd_weight(gi_d, x2), ops.linear_bwd_weight(gh_d, hprev[:, 32 * d:32 * (d + 1)]),
+                      ops.colsum(gi_d), ops.colsum(gh_d)))
+        (dwih_f, dwhh_f, dbih_f, dbhh_f), (dwih_r, dwhh_r, dbih_r, dbhh_r) = g
+        return dx.reshape(x.shape), dwih_f, dwhh_f, dbih_f, dbhh_f, dwih_r, dwhh_r, dbih_r, dbhh_r, None
+
+
+def bigru32(x, gru, vertical):
+    """gru: an nn.GRU(64, 32, bidirectional=True) used as parameter holder."""
+    return BiGRU32Fn.apply(_c(x), gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0,
+                           gru.weight_ih_l0_reverse, gru.weight_hh_l0_reverse, gru.bias_ih_l0_reverse,
+                           gru.bias_hh_l0_reverse, vertical)
+
+
+# --------------------------------------------------------------------------------------------------
+class AddFn(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return ops.axpby(a, b, 1.0, 1.0)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+def add(a, b):
+    return AddFn.apply(_c(a), _c(b))
+
+
+class AddRowBcastFn(Function):
+    """a (B,L,C) + b (L,C) broadcast over B; b carries no gradient (positional-encoding buffer)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        return ops.add_rowbcast(a, b, b.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, None
+
+
+class ScaleFn(Function):
+    @staticmethod
+    def forward(ctx, a, s):
+        ctx.s = s
+        return ops.axpby(a, None, s, 0.0)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.axpby(_c(dy), None, ctx.s, 0.0), None
+
+
+class MeanOf2Fn(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return ops.axpby(a, b, 0.5, 0.5)
+
+    @staticmethod
+    def backward(ctx, dy):
+        h = ops.axpby(_c(dy), None, 0.5, 0.0)
+        return h, h
+
+
+class ActFn(Function):
+    """y = act(x) for activations whose derivative is a function of the output (relu, tanh)."""
+
+    @staticmethod
+    def forward(ctx, x, act):
+        y = ops.act_fwd(x, act)
+        ctx.save_for_backward(y)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return ops.act_bwd(y, _c(dy), ctx.act, True), None
+
+
+class PReLUFn(Function):
+    @staticmethod
+    def forward(ctx, x, alpha):
+        ctx.save_for_backward(x, alpha)
+        return ops.prelu_fwd(x, alpha)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, alpha = ctx.saved_tensors
+        dx, da = ops.prelu_bwd(x, _c(dy), alpha)
+        return dx, da.reshape(alpha.shape)
+
+
+def prelu(x, alpha):
+    return PReLUFn.apply(_c(x), alpha)
+
+
+class PixelShuffleActFn(Function):
+    @staticmethod
+    def forward(ctx, x, act):
+        ctx.save_for_backward(x)
+        ctx.act = act
+        return ops.pixel_shuffle_fwd(x, act)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.pixel_shuffle_bwd(x, _c(dy), ctx.act), None
+
+
+class MaxPoolFn(Function):
+    @staticmethod
+    def forward(ctx, x, kh, kw):
+        ctx.save_for_backward(x)
+        ctx.k = (kh, kw)
+        return ops.maxpool_fwd(x, kh, kw)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.maxpool_bwd(x, _c(dy), *ctx.k), None, None
+
+
+class Permute4dFn(Function):
+    """Materialised permutation of a 4-D tensor (layout change), backward = inverse permutation."""
+
+    @staticmethod
+    def forward(ctx, x, perm):
+        ctx.perm = perm
+        return ops.to_contiguous(x.permute(*perm))
+
+    @staticmethod
+    def backward(ctx, dy):
+        inv = [0] * 4
+        for i, p in enumerate(ctx.perm):
+            inv[p] = i
+        return ops.to_contiguous(_c(dy).permute(*inv)), None
+
+
+class LayerNormFn(Function):
+    """LayerNorm(a + b) over the last axis (b optional)."""
+
+    @staticmethod
+    def forward(ctx, a, b, gamma, beta, eps):
+        C = a.shape[-1]
+        y, stats = ops.ln_fwd(a.reshape(-1, C), None if b is None else b.reshape(-1, C), gamma, beta, eps)
+        ctx.save_for_backward(a, b, stats, gamma)
+        return y.reshape(a.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, b, stats, gamma = ctx.saved_tensors
+        C = a.shape[-1]
+        dx, dg, db = ops.ln_bwd(a.reshape(-1, C), None if b is None else b.reshape(-1, C), _c(dy).reshape(-1, C), stats,
+                                gamma)
+        dx = dx.reshape(a.shape)
+        return dx, (dx if b is not None else None), dg, db, None
+
+
+def layer_norm(a, b, ln):
+    return LayerNormFn.apply(_c(a), None if b is None else _c(b), ln.weight, ln.bias, ln.eps)
+
+
+class DropoutFn(Function):
+    @staticmethod
+    def forward(ctx, x, p, site):
+        ctx.p, ctx.site = p, site
+        ctx.seed = seed_tensor(x.device)
+        return ops.dropout(x, p, ctx.seed, site)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.dropout(_c(dy), ctx.p, ctx.seed, ctx.site), None, None
+
+
+def dropout(x, p, training, site):
+    if not training or p <= 0.0:
+        return x
+    return DropoutFn.apply(_c(x), p, site)
+
+
+class AttnCoreFn(Function):
+    @staticmethod
+    def forward(ctx, Q, K, V, pdrop, site):
+        seed = seed_tensor(Q.device)
+        c, w = ops.attn_fwd(Q, K, V, pdrop, seed, site, True)
+        ctx.save_for_backward(Q, K, V)
+        ctx.pdrop, ctx.site, ctx.seed = pdrop, site, seed
+        return c, w
+
+    @staticmethod
+    def backward(ctx, dc, dw):
+        Q, K, V = ctx.saved_tensors
+        if dc is None:
+            dc = torch.zeros_like(Q)
+        dQ, dK, dV = ops.attn_bwd(Q, K, V, _c(dc), None if dw is None else _c(dw), ctx.pdrop, ctx.seed, ctx.site)
+        return dQ, dK, dV, None, None
+
+
+def multihead_attention(q_in, k_in, v_in, mha, training, site):
+    """nn.MultiheadAttention forward (batch-major tensors (B,L,E)); mha = parameter holder.
+    Returns (output (B,L,E), head-averaged attention weights (B,L,S))."""
+    E = mha.embed_dim
+    d = E // mha.num_heads
+    w, b = mha.in_proj_weight, mha.in_proj_bias
+    Q = linear(q_in, w[:E], b[:E], alpha=1.0 / math.sqrt(d))
+    K = linear(k_in, w[E:2 * E], b[E:2 * E])
+    V = linear(v_in, w[2 * E:], b[2 * E:])
+    pdrop = float(mha.dropout) if training else 0.0
+    ctx_, wts = AttnCoreFn.apply(Q, K, V, pdrop, site)
+    out = linear(ctx_, mha.out_proj.weight, mha.out_proj.bias)
+    return out, wts
+
+
+# --------------------------------------------------------------------------------------------------
+class QueryGruFn(Function):
+    """Query positional embedding: init_factor (H*W, C) -> BiGRU(C*H -> C*H/2 per direction) whose TIME axis is
+    the sample axis (reference quirk) -> (B, H, W, C)."""
+
+    @staticmethod
+    def forward(ctx, emb, wih0, whh0, bih0, bhh0, wih1, whh1, bih1, bhh1, B, H, W):
+        C = emb.shape[1]
+        HID = whh0.shape[1]
+        IN = wih0.shape[1]
+        assert IN == H * C and 2 * HID == H * C
+        dev = emb
+        # x[w, h*C + c] = emb[h*W + w, c]
+        x = ops.new(dev, W, IN)
+        ops.copy4d(emb, x, (1, W, H, C), (0, C, W * C, 1), (0, IN, C, 1))
+        gi = [ops.linear_fwd(x, wih0, bih0), ops.linear_fwd(x, wih1, bih1)]       # (W, 3*HID) each
+        hseq = ops.new(dev, 2, B, W, HID)
+        gsave = ops.new(dev, 2, B, 4, W, HID)
+        for s in range(B):
+            t0, t1 = s, B - 1 - s
+            hp0 = hseq[0, t0 - 1] if s > 0 else None
+            hp1 = hseq[1, t1 + 1] if s > 0 else None
+            ops.call("tatt_qgru_fwd_step", ops.P(gi[0]), ops.P(gi[1]), ops.P(whh0), ops.P(whh1), ops.P(bhh0),
+                     ops.P(bhh1), ops.P(hp0), ops.P(hp1), ops.P(hseq[0, t0]), ops.P(hseq[1, t1]),
+                     ops.P(gsave[0, t0]), ops.P(gsave[1, t1]), W, HID, ops.stream())
+        # q[n, h, w, c] = hseq[d][n][w][(h % (H/2))*C + c], d = h // (H/2)
+        q = ops.new(dev, B, H, W, C)
+        Hh = H // 2
+        for d in range(2):
+            ops.copy4d(hseq[d], q[:, d * Hh:], (B, W, Hh, C), (W * HID, HID, C, 1), (H * W * C, C, W * C, 1))
+        ctx.save_for_backward(emb, x, wih0, whh0, wih1, whh1, hseq, gsave)
+        ctx.dims = (B, H, W, C, HID, IN)
+        return q
+
+    @staticmethod
+    def backward(ctx, dq):
+        emb, x, wih0, whh0, wih1, whh1, hseq, gsave = ctx.saved_tensors
+        B, H, W, C, HID, IN = ctx.dims
+        dq = _c(dq)
+        dev = emb
+        Hh = H // 2
+        dhseq = ops.new(dev, 2, B, W, HID)
+        for d in range(2):
+            ops.copy4d(dq[:, d * Hh:], dhseq[d], (B, W, Hh, C), (H * W * C, C, W * C, 1), (W * HID, HID, C, 1))
+        dgh = ops.new(dev, 2, B, W, 3 * HID)
+        dgi_acc = ops.new(dev, 2, W, 3 * HID)
+        dhc = ops.new(dev, 2, W, HID)
+        for s in range(B):
+            t0, t1 = B - 1 - s, s            # reverse of the forward order in each direction
+            hp0 = hseq[0, t0 - 1] if t0 > 0 else None
+            hp1 = hseq[1, t1 + 1] if t1 < B - 1 else None
+            ops.call("tatt_qgru_bwd_gates", ops.P(dhseq[0, t0]), ops.P(dhseq[1, t1]), ops.P(gsave[0, t0]),
+                     ops.P(gsave[1, t1]), ops.P(hp0), ops.P(hp1), ops.P(dhc[0]), ops.P(dhc[1]), ops.P(dgi_acc[0]),
+                     ops.P(dgi_acc[1]), ops.P(dgh[0, t0]), ops.P(dgh[1, t1]), W, HID, int(s == 0), ops.stream())
+            if s < B - 1:
+                ops.call("tatt_qgru_bwd_mm", ops.P(dgh[0, t0]), ops.P(dgh[1, t1]), ops.P(whh0), ops.P(whh1),
+                         ops.P(dhc[0]), ops.P(dhc[1]), W, HID, ops.stream())
+        grads = []
+        dx = ops.new(dev, W, IN)
+        for d, (wih, whh) in enumerate(((wih0, whh0), (wih1, whh1))):
+            g2 = dgh[d].reshape(B * W, 3 * HID)
+            # dW_hh = sum_t dgh_t^T h_{t-1}: skip the step whose h_prev is the zero initial state
+            if B > 1:
+                if d == 0:
+                    dwhh = ops.linear_bwd_weight(g2[W:], hseq[0].reshape(B * W, HID)[:-W])
+                else:
+                    dwhh = ops.linear_bwd_weight(g2[:-W], hseq[1].reshape(B * W, HID)[W:])
+            else:
+                dwhh = torch.zeros_like(whh)
+            dbhh = ops.colsum(g2)
+            dwih = ops.linear_bwd_weight(dgi_acc[d], x)
+            dbih = ops.colsum(dgi_acc[d])
+            ops.linear_bwd_input(dgi_acc[d], wih, out=dx, beta=0.0 if d == 0 else 1.0)
+            grads.append((dwih, dwhh, dbih, dbhh))
+        demb = torch.empty_like(emb)
+        ops.copy4d(dx, demb, (1, W, H, C), (0, IN, C, 1), (0, C, W * C, 1))
+        (a0, b0, c0, d0), (a1, b1, c1, d1) = grads
+        return demb, a0, b0, c0, d0, a1, b1, c1, d1, None, None, None
+
+
+def query_embedding(emb, gru, B, H, W):
+    return QueryGruFn.apply(emb, gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0,
+                            gru.weight_ih_l0_reverse, gru.weight_hh_l0_reverse, gru.bias_ih_l0_reverse,
+                            gru.bias_hh_l0_reverse, B, H, W)
+
+
+# --------------------------------------------------------------------------------------------------
+class TpsGridFn(Function):
+    @staticmethod
+    def forward(ctx, ctrl, inv, pad, repr_):
+        ctx.save_for_backward(inv, repr_)
+        ctx.N = ctrl.shape[1]
+        return ops.tps_grid_fwd(ctrl, inv, pad, repr_)
+
+    @staticmethod
+    def backward(ctx, dsrc):
+        inv, repr_ = ctx.saved_tensors
+        return ops.tps_grid_bwd(_c(dsrc), inv, repr_, ctx.N), None, None, None
+
+
+class GridSampleFn(Function):
+    """x (B,C,H,W) any strides (no gradient), src (B,H*W,2) in [0,1] coordinates -> (B,H,W,C)."""
+
+    @staticmethod
+    def forward(ctx, x, src):
+        ctx.save_for_backward(x, src)
+        return ops.grid_sample_fwd(x, src)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, src = ctx.saved_tensors
+        if ctx.needs_input_grad[0]:
+            raise RuntimeError("tatt_amd: gradient w.r.t. the LR image through the TPS sampler is not on the path")
+        return None, ops.grid_sample_bwd(x, src, _c(dout))

@@ -1,0 +1,379 @@
+"""Raw (non-autograd) launchers of the libtatt_hip.so kernels on torch CUDA(HIP) tensors.
+
+torch is used here only as device-memory / stream plumbing: every function marshals `data_ptr()`s,
+sizes and strides into the C ABI declared in include/tatt_hip.h and launches on torch's current HIP
+stream (so the calls are hipGraph-capturable).  There is no CPU fallback: a non-HIP tensor raises.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from ._lib import LIB
+
+ACT_NONE, ACT_RELU, ACT_MISH, ACT_TANH = 0, 1, 2, 3
+_vp = ctypes.c_void_p
+
+
+def _check_dev(t: torch.Tensor):
+    if not t.is_cuda:
+        raise RuntimeError("tatt_amd kernels need tensors on an AMD GPU (HIP device); got %s. "
+                           "There is no CPU fallback in the product path." % t.device)
+    if t.dtype != torch.float32:
+        raise RuntimeError("tatt_amd kernels are fp32; got %s" % t.dtype)
+
+
+def P(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    return _vp(t.data_ptr())
+
+
+def stream():
+    return _vp(torch.cuda.current_stream().cuda_stream)
+
+
+def call(name: str, *args):
+    rc = getattr(LIB, name)(*args)
+    if rc != 0:
+        raise RuntimeError("%s failed with code %d" % (name, rc))
+
+
+def cdiv(a, b):
+    return (a + b - 1) // b
+
+
+def new(ref: torch.Tensor, *shape, dtype=torch.float32):
+    return torch.empty(shape, device=ref.device, dtype=dtype)
+
+
+# --------------------------------------------------------------------------------------------------
+# GEMM family
+# --------------------------------------------------------------------------------------------------
+def gemm(A, sam, sak, B, sbk, sbn, C, scm, scn, M, N, K, *, A2=None, sa2m=0, sa2k=0, K1=0, bias=None,
+         Z=1, bsA=0, bsA2=0, bsB=0, bsC=0, bsBias=0, alpha=1.0, beta=0.0, act=ACT_NONE, splitk=1):
+    """C = act(alpha*(A@B + bias)) + beta*C with explicit element strides (see tatt_gemm)."""
+    _check_dev(C)
+    ws = None
+    if splitk > 1:
+        nchunks = cdiv(K, 16)
+        splitk = max(1, min(splitk, nchunks))
+        if splitk > 1:
+            ws = new(C, Z * splitk * M * N)
+    call("tatt_gemm", P(A), sam, sak, P(A2), sa2m, sa2k, K1, P(B), sbk, sbn, P(bias), P(C), scm, scn,
+         M, N, K, Z, bsA, bsA2, bsB, bsC, bsBias, alpha, beta, act, splitk, P(ws), stream())
+    return C
+
+
+def _auto_split(M_out, N_out, Kred):
+    tiles = cdiv(M_out, 64) * cdiv(N_out, 64)
+    nchunks = cdiv(Kred, 16)
+    want = max(1, 512 // tiles)
+    return max(1, min(want, nchunks // 8 if nchunks >= 16 else 1))
+
+
+def linear_fwd(x2, W, b=None, *, act=ACT_NONE, alpha=1.0, x2b=None, out=None):
+    """y (M,N) = act(alpha*(x2 @ W^T + b)).  x2 (M,K) row-major (last stride 1); W (N,K) contiguous.
+    x2b: optional second source for the K-columns beyond x2.shape[1] (K-concatenation)."""
+    _check_dev(x2)
+    M, K1 = x2.shape
+    N, K = W.shape
+    y = out if out is not None else new(x2, M, N)
+    if x2b is None:
+        assert K1 == K
+        gemm(x2, x2.stride(0), x2.stride(1), W, 1, K, y, y.stride(0), 1, M, N, K, bias=b, alpha=alpha, act=act)
+    else:
+        assert K1 + x2b.shape[1] == K
+        gemm(x2, x2.stride(0), x2.stride(1), W, 1, K, y, y.stride(0), 1, M, N, K, A2=x2b, sa2m=x2b.stride(0),
+             sa2k=x2b.stride(1), K1=K1, bias=b, alpha=alpha, act=act)
+    return y
+
+
+def linear_bwd_input(dy, W, *, col0=0, ncols=None, alpha=1.0, out=None, beta=0.0):
+    """dx (M,ncols) = alpha * dy (M,N) @ W[:, col0:col0+ncols]   (W (N,K) contiguous)."""
+    M, N = dy.shape
+    K = W.shape[1]
+    ncols = K if ncols is None else ncols
+    dx = out if out is not None else new(dy, M, ncols)
+    Wv = W.reshape(-1)[col0:] if col0 else W
+    gemm(dy, dy.stride(0), dy.stride(1), Wv, K, 1, dx, dx.stride(0), 1, M, ncols, N, alpha=alpha, beta=beta)
+    return dx
+
+
+def linear_bwd_weight(dy, x2, *, alpha=1.0, out=None, out_ld=None, beta=0.0):
+    """dW (N,K) = alpha * dy^T (N,M) @ x2 (M,K); reduction over the M tokens (split-K, deterministic)."""
+    M, N = dy.shape
+    K = x2.shape[1]
+    dW = out if out is not None else new(dy, N, K)
+    ld = out_ld if out_ld is not None else dW.stride(0)
+    gemm(dy, dy.stride(1), dy.stride(0), x2, x2.stride(0), x2.stride(1), dW, ld, 1, N, K, M, alpha=alpha, beta=beta,
+         splitk=_auto_split(N, K, M))
+    return dW
+
+
+def colsum(x2, *, out=None, scale=1.0, beta=0.0):
+    """out[c] = scale * sum_m x2[m, c]  (+ beta*out)."""
+    _check_dev(x2)
+    M, C = x2.shape
+    out = out if out is not None else new(x2, C)
+    ws = new(x2, cdiv(M, 256) * C, dtype=torch.float64)
+    call("tatt_colsum", P(x2), x2.stride(0), M, C, P(out), scale, beta, P(ws), stream())
+    return out
+
+
+# --------------------------------------------------------------------------------------------------
+# convolution (x given as a (B,H,W,C)-indexed tensor with arbitrary strides)
+# --------------------------------------------------------------------------------------------------
+def repack_weight(w_oihw, mode):
+    Cout, Cin, KH, KW = w_oihw.shape
+    out = new(w_oihw, KH * KW * Cin * Cout)
+    call("tatt_repack_conv_weight", P(w_oihw), P(out), Cout, Cin, KH, KW, mode, stream())
+    return out
+
+
+def conv_fwd(x_bhwc, wpacked, bias, Cout, KH, KW, *, act=ACT_NONE, out=None, beta=0.0):
+    _check_dev(x_bhwc)
+    B, H, W, Cin = x_bhwc.shape
+    sn, sh, sw, sc = x_bhwc.stride()
+    y = out if out is not None else new(x_bhwc, B, H, W, Cout)
+    call("tatt_conv2d_fwd", P(x_bhwc), sn, sh, sw, sc, P(wpacked), P(bias), P(y), Cout, B, H, W, Cin, Cout, KH, KW,
+         act, beta, stream())
+    return y
+
+
+def conv_wgrad(x_bhwc, dy_bhwc, Cout, KH, KW):
+    B, H, W, Cin = x_bhwc.shape
+    sn, sh, sw, sc = x_bhwc.stride()
+    dw = new(x_bhwc, Cout, Cin, KH, KW)
+    Mo, Kred = KH * KW * Cin, B * H * W
+    splitk = max(2, _auto_split(Mo, Cout, Kred))
+    ws = new(x_bhwc, (splitk + 1) * Mo * Cout)
+    call("tatt_conv2d_wgrad", P(x_bhwc), sn, sh, sw, sc, P(dy_bhwc), Cout, P(dw), B, H, W, Cin, Cout, KH, KW, 0.0,
+         splitk, P(ws), stream())
+    return dw
+
+
+# --------------------------------------------------------------------------------------------------
+# normalisation
+# --------------------------------------------------------------------------------------------------
+def bn_stats(x2, eps, momentum, running_mean, running_var):
+    M, C = x2.shape
+    mean, rstd = new(x2, C), new(x2, C)
+    ws = new(x2, cdiv(M, 128) * 2 * C, dtype=torch.float64)
+    call("tatt_bn_stats", P(x2), x2.stride(0), M, C, eps, momentum, P(mean), P(rstd), P(running_mean), P(running_var),
+         P(ws), stream())
+    return mean, rstd
+
+
+def bn_rstd(var, eps):
+    rstd = torch.empty_like(var)
+    call("tatt_bn_rstd", P(var), P(rstd), var.numel(), eps, stream())
+    return rstd
+
+
+def bn_apply(x2, mean, rstd, gamma, beta, act, out=None):
+    M, C = x2.shape
+    y = out if out is not None else new(x2, M, C)
+    call("tatt_bn_apply", P(x2), x2.stride(0), P(y), y.stride(0), M, C, P(mean), P(rstd), P(gamma), P(beta), act, stream())
+    return y
+
+
+def bn_bwd(x2, dy2, mean, rstd, gamma, beta, act, training):
+    M, C = x2.shape
+    dx = new(x2, M, C)
+    dgamma, dbeta, sums = new(x2, C), new(x2, C), new(x2, 2 * C)
+    ws = new(x2, cdiv(M, 128) * 2 * C, dtype=torch.float64)
+    call("tatt_bn_bwd", P(x2), x2.stride(0), P(dy2), dy2.stride(0), P(dx), C, M, C, P(mean), P(rstd), P(gamma), P(beta),
+         act, int(training), P(dgamma), P(dbeta), P(sums), P(ws), stream())
+    return dx, dgamma, dbeta
+
+
+def ln_fwd(a2, b2, gamma, beta, eps=1e-5):
+    M, C = a2.shape
+    y, stats = new(a2, M, C), new(a2, M, 2)
+    call("tatt_ln_fwd", P(a2), P(b2), P(y), P(stats), M, C, P(gamma), P(beta), eps, stream())
+    return y, stats
+
+
+def ln_bwd(a2, b2, dy2, stats, gamma):
+    M, C = a2.shape
+    dx, dgamma, dbeta = new(a2, M, C), new(a2, C), new(a2, C)
+    G = cdiv(M, 64)
+    part = new(a2, G * 2 * C)
+    ws = new(a2, cdiv(G, 256) * 2 * C, dtype=torch.float64)
+    call("tatt_ln_bwd", P(a2), P(b2), P(dy2), P(stats), P(dx), M, C, P(gamma), P(dgamma), P(dbeta), P(part), P(ws),
+         stream())
+    return dx, dgamma, dbeta
+
+
+# --------------------------------------------------------------------------------------------------
+# element-wise
+# --------------------------------------------------------------------------------------------------
+def prelu_fwd(x, alpha):
+    _check_dev(x)
+    y = torch.empty_like(x)
+    call("tatt_prelu_fwd", P(x), P(y), P(alpha), x.numel(), stream())
+    return y
+
+
+def prelu_bwd(x, dy, alpha):
+    dx = torch.empty_like(x)
+    G = cdiv(x.numel(), 256)
+    part = new(x, G, 1)
+    call("tatt_prelu_bwd", P(x), P(dy), P(dx), P(alpha), x.numel(), P(part), stream())
+    return dx, colsum(part)
+
+
+def act_fwd(x, act):
+    y = torch.empty_like(x)
+    call("tatt_act_fwd", P(x), P(y), x.numel(), act, stream())
+    return y
+
+
+def act_bwd(ref, dy, act, from_output):
+    dx = torch.empty_like(dy)
+    call("tatt_act_bwd", P(ref), P(dy), P(dx), dy.numel(), act, int(from_output), stream())
+    return dx
+
+
+def axpby(a, b, alpha=1.0, beta=1.0):
+    _check_dev(a)
+    y = torch.empty_like(a)
+    call("tatt_axpby", P(a), P(b), P(y), alpha, beta, a.numel(), stream())
+    return y
+
+
+def add_rowbcast(a2, b2, period):
+    y = torch.empty_like(a2)
+    rows = a2.numel() // a2.shape[-1]
+    call("tatt_add_rowbcast", P(a2), P(b2), P(y), rows, a2.shape[-1], period, stream())
+    return y
+
+
+def pixel_shuffle_fwd(x, act):
+    B, H, W, C4 = x.shape
+    y = new(x, B, 2 * H, 2 * W, C4 // 4)
+    call("tatt_pixel_shuffle_fwd", P(x), P(y), B, H, W, C4 // 4, act, stream())
+    return y
+
+
+def pixel_shuffle_bwd(x, dout, act):
+    B, H, W, C4 = x.shape
+    dx = torch.empty_like(x)
+    call("tatt_pixel_shuffle_bwd", P(x), P(dout), P(dx), B, H, W, C4 // 4, act, stream())
+    return dx
+
+
+def maxpool_fwd(x, kh, kw):
+    B, H, W, C = x.shape
+    y = new(x, B, H // kh, W // kw, C)
+    call("tatt_maxpool_fwd", P(x), P(y), B, H, W, C, kh, kw, stream())
+    return y
+
+
+def maxpool_bwd(x, dout, kh, kw):
+    B, H, W, C = x.shape
+    dx = torch.empty_like(x)
+    call("tatt_maxpool_bwd", P(x), P(dout), P(dx), B, H, W, C, kh, kw, stream())
+    return dx
+
+
+def dropout(x, p, seed, site):
+    y = torch.empty_like(x)
+    call("tatt_dropout", P(x), P(y), x.numel(), p, P(seed), site, stream())
+    return y
+
+
+def bump_seed(seed):
+    call("tatt_bump_seed", P(seed), stream())
+
+
+def copy4d(src, dst, sizes, sstr, dstr, beta=0.0):
+    n = list(sizes)
+    call("tatt_copy4d", P(src), P(dst), n[0], n[1], n[2], n[3], sstr[0], sstr[1], sstr[2], sstr[3], dstr[0], dstr[1],
+         dstr[2], dstr[3], beta, stream())
+    return dst
+
+
+def to_contiguous(x4):
+    """Materialise a 4-D strided view as a contiguous tensor (e.g. NCHW input viewed as NHWC)."""
+    _check_dev(x4)
+    out = new(x4, *x4.shape)
+    copy4d(x4, out, x4.shape, x4.stride(), out.stride())
+    return out
+
+
+# --------------------------------------------------------------------------------------------------
+# GRU / attention / TPS
+# --------------------------------------------------------------------------------------------------
+def seq_geom(B, H, W, vertical):
+    """(nseq, T, s_in, stride_hi, stride_lo, stride_t) on the (B,H,W) token grid."""
+    if vertical:
+        return B * W, H, W, H * W, 1, W
+    return B * H, W, 1, W, 0, 1
+
+
+def gru32_fwd(gi, whh_f, bhh_f, whh_r, bhh_r, geom):
+    out = new(gi, gi.shape[0], 64)
+    call("tatt_gru32_fwd", P(gi), P(whh_f), P(bhh_f), P(whh_r), P(bhh_r), P(out), *geom, stream())
+    return out
+
+
+def gru32_bwd(gi, out, dout, whh_f, bhh_f, whh_r, bhh_r, geom):
+    dgi, dgh, hprev = torch.empty_like(gi), torch.empty_like(gi), torch.empty_like(out)
+    call("tatt_gru32_bwd", P(gi), P(out), P(dout), P(whh_f), P(bhh_f), P(whh_r), P(bhh_r), P(dgi), P(dgh), P(hprev),
+         *geom, stream())
+    return dgi, dgh, hprev
+
+
+def attn_fwd(Q, K, V, pdrop, seed, site, need_weights=True):
+    B, Lq, E = Q.shape
+    S = K.shape[1]
+    assert E == 64
+    ctx = torch.empty_like(Q)
+    wavg = new(Q, B, Lq, S) if need_weights else None
+    call("tatt_attn_fwd", P(Q), P(K), P(V), P(ctx), P(wavg), B, Lq, S, pdrop, P(seed), site, stream())
+    return ctx, wavg
+
+
+def attn_bwd(Q, K, V, dctx, dwavg, pdrop, seed, site):
+    B, Lq, E = Q.shape
+    S = K.shape[1]
+    dQ, dK, dV = torch.empty_like(Q), torch.empty_like(K), torch.empty_like(V)
+    part = new(Q, B * cdiv(Lq, 64) * 2 * S * 64)
+    call("tatt_attn_bwd", P(Q), P(K), P(V), P(dctx), P(dwavg), P(dQ), P(dK), P(dV), P(part), B, Lq, S, pdrop, P(seed),
+         site, stream())
+    return dQ, dK, dV
+
+
+def tps_grid_fwd(ctrl, inv, pad, repr_):
+    B, N, _ = ctrl.shape
+    Pn = repr_.shape[0]
+    src = new(ctrl, B, Pn, 2)
+    call("tatt_tps_grid_fwd", P(ctrl), P(inv), P(pad), P(repr_), P(src), B, N, Pn, stream())
+    return src
+
+
+def tps_grid_bwd(dsrc, inv, repr_, N):
+    B, Pn, _ = dsrc.shape
+    dctrl = new(dsrc, B, N, 2)
+    call("tatt_tps_grid_bwd", P(dsrc), P(inv), P(repr_), P(dctrl), B, N, Pn, stream())
+    return dctrl
+
+
+def grid_sample_fwd(x_nchw, src):
+    B, C, H, W = x_nchw.shape
+    sn, sc, sh, sw = x_nchw.stride()
+    out = new(x_nchw, B, H, W, C)
+    call("tatt_grid_sample_fwd", P(x_nchw), sn, sc, sh, sw, P(src), P(out), B, C, H, W, stream())
+    return out
+
+
+def grid_sample_bwd(x_nchw, src, dout):
+    B, C, H, W = x_nchw.shape
+    sn, sc, sh, sw = x_nchw.stride()
+    dsrc = torch.empty_like(src)
+    call("tatt_grid_sample_bwd", P(x_nchw), sn, sc, sh, sw, P(src), P(dout), P(dsrc), B, C, H, W, stream())
+    return dsrc

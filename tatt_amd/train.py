@@ -1,0 +1,139 @@
+"""Training-step harness for the TATT hot path: loss, global-norm clip, Adam, data parallelism.
+
+Mirrors the reference's hot loop (interfaces/super_resolution.py:873-894,1072-1085):
+    sr = model(lr, text_prior); loss = ImageLoss(sr, hr).mean()*100; zero_grad; backward;
+    clip_grad_norm_(0.25); Adam(1e-3, betas=(0.5, 0.999)).step()
+and replaces torch.nn.DataParallel (interfaces/base.py:386-396) by one process per GPU with an RCCL
+all-reduce of ONE flat gradient buffer over xGMI (`torch.distributed`, backend "nccl" = RCCL on ROCm).
+
+* Parameters, gradients and Adam moments live in flat fp32 buffers (7.6 M elements = 30.4 MB each); the module's
+  nn.Parameters are views into the flat parameter buffer, their `.grad`s views into the flat gradient buffer.
+* Clip + Adam are two HIP kernels (tatt_l2norm, tatt_adam_step) whose step-varying scalars live in device
+  memory, so a whole step (forward, loss, backward, optimiser) can be captured once as a hipGraph and replayed.
+* ImageLoss itself (harness, not a kernel target) is a handful of torch element-wise ops on
+  the (B,4,2H,2W) images.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import functional as Fh
+from . import ops
+from .dp import FlatParams, broadcast_model, allreduce_grads
+
+
+def gradient_map(x):
+    """GradientPriorLoss.gradient_map (reference loss/image_loss.py:50-58)."""
+    h, w = x.shape[-2:]
+    r = F.pad(x, (0, 1, 0, 0))[:, :, :, 1:]
+    l = F.pad(x, (1, 0, 0, 0))[:, :, :, :w]
+    t = F.pad(x, (0, 0, 1, 0))[:, :, :h, :]
+    b = F.pad(x, (0, 0, 0, 1))[:, :, 1:, :]
+    return torch.sqrt(((r - l) * 0.5) ** 2 + ((t - b) * 0.5) ** 2 + 1e-6)
+
+
+def image_loss(sr, hr, weights=(1.0, 1e-4)):
+    """ImageLoss(gradient=True, loss_weight=[1, 1e-4]).forward (reference loss/image_loss.py:19-34): per-sample."""
+    mse = ((sr - hr) ** 2).mean((1, 2, 3))
+    gp = (gradient_map(sr[:, :3]) - gradient_map(hr[:, :3])).abs().mean((1, 2, 3))
+    return weights[0] * mse + weights[1] * gp
+
+
+class Trainer:
+    """One training step per `step()` call; optional whole-step hipGraph; optional data parallelism."""
+
+    def __init__(self, model, lr=1e-3, betas=(0.5, 0.999), eps=1e-8, clip=0.25, use_graph=False, warmup_eager=2,
+                 process_group=None, broadcast_init=True):
+        self.model = model
+        self.lr, self.betas, self.eps, self.clip = lr, betas, eps, clip
+        self.pg = process_group
+        self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        self.flat = FlatParams(model)
+        self.params = self.flat.params
+        self.n = self.flat.n
+        dev = self.flat.p.device
+        self.dev = dev
+        self.flat_p, self.flat_g = self.flat.p, self.flat.g
+        self.flat_m = torch.zeros(self.n, device=dev)
+        self.flat_v = torch.zeros(self.n, device=dev)
+        if self.world > 1 and broadcast_init:
+            broadcast_model(self.flat, model, process_group)
+        self.gnorm = torch.zeros(1, device=dev)
+        self.step_count = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.norm_ws = torch.empty(1024, dtype=torch.float64, device=dev)
+        self.use_graph = use_graph
+        self.warmup_eager = warmup_eager
+        self._graphs = None
+        self._static = None
+        self._nsteps = 0
+        self.last_loss = None
+
+    # -- pieces ----------------------------------------------------------------------------------
+    def _fwd_bwd(self, x, tp, hr):
+        self.flat_g.zero_()
+        out = self.model(x, tp) if tp is not None else self.model(x)
+        sr = out[0] if isinstance(out, tuple) else out
+        loss = image_loss(sr, hr).mean() * 100.0
+        loss.backward()
+        return loss.detach()
+
+    def _optim(self):
+        self.step_count += 1
+        ops.call("tatt_l2norm", ops.P(self.flat_g), self.n, ops.P(self.gnorm), ops.P(self.norm_ws), ops.stream())
+        ops.call("tatt_adam_step", ops.P(self.flat_p), ops.P(self.flat_g), ops.P(self.flat_m), ops.P(self.flat_v),
+                 self.n, self.lr, self.betas[0], self.betas[1], self.eps, ops.P(self.gnorm), self.clip,
+                 1.0 / self.world, ops.P(self.step_count), ops.stream())
+        Fh.next_dropout_step(self.dev)
+
+    def _allreduce(self):
+        if self.world > 1:
+            allreduce_grads(self.flat, self.pg)       # sum; the 1/world factor is folded into tatt_adam_step
+
+    @property
+    def last_grad_norm(self):
+        """||g||_2 of the (rank-averaged) gradient before clipping."""
+        return self.gnorm / self.world
+
+    # -- public ----------------------------------------------------------------------------------
+    def step(self, x, tp, hr):
+        """x (B,4,H,W), tp (B,37,1,26) or None (TSRN), hr (B,4,2H,2W), all on this rank's GPU.  Returns the loss
+        tensor (device scalar, no host sync)."""
+        self._nsteps += 1
+        if not self.use_graph or self._nsteps <= self.warmup_eager:
+            loss = self._fwd_bwd(x, tp, hr)
+            self._allreduce()
+            self._optim()
+            self.last_loss = loss
+            return loss
+        if self._graphs is None:
+            self._capture(x, tp, hr)
+        sx, stp, shr = self._static
+        sx.copy_(x)
+        shr.copy_(hr)
+        if stp is not None:
+            stp.copy_(tp)
+        g1, g2 = self._graphs
+        g1.replay()
+        if g2 is not None:
+            self._allreduce()
+            g2.replay()
+        return self.last_loss
+
+    def _capture(self, x, tp, hr):
+        self._static = (x.clone(), None if tp is None else tp.clone(), hr.clone())
+        sx, stp, shr = self._static
+        torch.cuda.synchronize()
+        g1 = torch.cuda.CUDAGraph()
+        g2 = None
+        with torch.cuda.graph(g1):
+            self.last_loss = self._fwd_bwd(sx, stp, shr)
+            if self.world == 1:
+                self._optim()
+        if self.world > 1:
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2):
+                self._optim()
+        self._graphs = (g1, g2)

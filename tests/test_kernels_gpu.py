@@ -1,0 +1,306 @@
+"""Per-kernel parity: each HIP operator (through the C ABI, forward and backward) against the CPU oracle /
+plain fp32 torch on the same seeded inputs.  Tolerances are fp32 round-off class (rtol 2e-4 / atol 2e-5 on
+values, 5e-4 on gradients)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import tatt_oracle as O
+from tests.util import compare_fn, check_close
+
+pytestmark = pytest.mark.gpu
+
+
+def R(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return torch.randn(*shape, generator=g) * scale
+
+
+# ------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(100, 70, 37), (256, 64, 64), (64, 192, 128), (33, 5, 300)])
+def test_gemm_nt_bias_act(dev, M, N, K):
+    from tatt_amd import ops
+    A, W, b = R(M, K), R(N, K, seed=1), R(N, seed=2)
+    for act, alpha in ((0, 1.0), (1, 0.5)):
+        y = ops.linear_fwd(A.to(dev), W.to(dev), b.to(dev), act=act, alpha=alpha)
+        ref = alpha * (A @ W.t() + b)
+        ref = torch.relu(ref) if act == 1 else ref
+        check_close("gemm_nt", y, ref)
+
+
+def test_gemm_concat_beta_splitk(dev):
+    from tatt_amd import ops
+    M = 300
+    A1, A2, W, b = R(M, 64), R(M, 64, seed=1), R(64, 128, seed=2), R(64, seed=3)
+    y = ops.linear_fwd(A1.to(dev), W.to(dev), b.to(dev), x2b=A2.to(dev))
+    check_close("concat", y, torch.cat([A1, A2], 1) @ W.t() + b)
+    dy = R(M, 64, seed=4)
+    dx = ops.linear_bwd_input(dy.to(dev), W.to(dev), col0=64, ncols=64)
+    check_close("bwd_input_cols", dx, dy @ W[:, 64:])
+    acc = R(M, 64, seed=5).to(dev)
+    ref = acc.cpu() + dy @ W[:, :64]
+    ops.linear_bwd_input(dy.to(dev), W.to(dev), col0=0, ncols=64, out=acc, beta=1.0)
+    check_close("beta", acc, ref)
+    big = R(5000, 96, seed=6), R(5000, 40, seed=7)
+    dW = ops.linear_bwd_weight(big[0].to(dev), big[1].to(dev))
+    check_close("bwd_weight_splitk", dW, big[0].t() @ big[1], rtol=5e-4, atol=2e-4)
+
+
+def test_gemm_batched_strided(dev):
+    from tatt_amd import ops
+    Z, M, N, K = 3, 50, 40, 24
+    A, B = R(Z, M, K), R(Z, K, N, seed=1)
+    C = torch.zeros(Z, M, N, device=dev)
+    ops.gemm(A.to(dev), K, 1, B.to(dev), N, 1, C, N, 1, M, N, K, Z=Z, bsA=M * K, bsB=K * N, bsC=M * N)
+    check_close("batched", C, A @ B)
+
+
+def test_linear_fn_autograd(dev):
+    from tatt_amd import functional as Fh
+    x, xb, W, b = R(2, 50, 64), R(2, 50, 64, seed=1), R(32, 128, seed=2, scale=0.2), R(32, seed=3)
+    compare_fn("linear_cat_relu",
+               lambda x, xb, W, b: Fh.linear(x, W, b, act=1, alpha=0.7, xb=xb),
+               lambda x, xb, W, b: torch.relu(0.7 * (torch.cat([x, xb], -1) @ W.t() + b)),
+               [x, xb, W, b], dev)
+
+
+# ------------------------------------------------------------------------------------------- conv
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k", [(2, 16, 64, 64, 64, 3), (1, 16, 64, 64, 256, 3), (2, 16, 64, 4, 64, 9),
+                                             (1, 32, 128, 64, 4, 9), (3, 8, 32, 32, 64, 3), (2, 1, 2, 256, 256, 3),
+                                             (2, 5, 7, 4, 32, 3)])
+def test_conv2d_fn(dev, B, H, W, Cin, Cout, k):
+    from tatt_amd import functional as Fh
+    x = R(B, Cin, H, W)
+    w = R(Cout, Cin, k, k, seed=1, scale=1.0 / math.sqrt(Cin * k * k))
+    b = R(Cout, seed=2)
+    compare_fn("conv%dx%d_%d_%d" % (k, k, Cin, Cout),
+               lambda x, w, b: Fh.conv2d(x.permute(0, 2, 3, 1), w, b).permute(0, 3, 1, 2),
+               lambda x, w, b: F.conv2d(x, w, b, padding=k // 2), [x, w, b], dev, grtol=1e-3)
+
+
+def test_conv_tanh_epilogue(dev):
+    from tatt_amd import functional as Fh
+    x, w, b = R(1, 8, 8, 16), R(4, 16, 3, 3, seed=1, scale=0.2), R(4, seed=2)
+    compare_fn("conv_tanh", lambda x, w, b: Fh.conv2d(x.permute(0, 2, 3, 1), w, b, 3).permute(0, 3, 1, 2),
+               lambda x, w, b: torch.tanh(F.conv2d(x, w, b, padding=1)), [x, w, b], dev)
+
+
+# ------------------------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("act", [0, 1, 2])
+@pytest.mark.parametrize("C,M", [(64, 2048), (512, 6), (32, 300)])
+def test_batchnorm_act(dev, training, act, C, M):
+    from tatt_amd import functional as Fh
+    x = R(M, C) * 1.5 + 0.3
+    g, b = 1 + 0.1 * R(C, seed=1), 0.1 * R(C, seed=2)
+    rm, rv = 0.1 * R(C, seed=3), 1 + 0.3 * torch.rand(C)
+    bn = torch.nn.BatchNorm1d(C)
+    bn.train(training)
+    actf = {0: lambda t: t, 1: torch.relu, 2: O.mish}[act]
+
+    def ref(x, g, b):
+        sd = {"bn.weight": g, "bn.bias": b, "bn.running_mean": rm, "bn.running_var": rv,
+              "bn.num_batches_tracked": torch.tensor(0)}
+        ns = {}
+        y = actf(O.batch_norm(x, sd, "bn", training, new_stats=ns))
+        ref.ns = ns
+        return y
+
+    def hip(x, g, b):
+        bn_d = torch.nn.BatchNorm1d(C).to(dev)
+        bn_d.train(training)
+        with torch.no_grad():
+            bn_d.running_mean.copy_(rm); bn_d.running_var.copy_(rv)
+        bn_d.weight, bn_d.bias = torch.nn.Parameter(g), torch.nn.Parameter(b)
+        y = Fh.BatchNormActFn.apply(x, g, b, bn_d.running_mean, bn_d.running_var, training, 0.1, 1e-5, act)
+        hip.bn = bn_d
+        return y
+
+    compare_fn("bn", hip, ref, [x, g, b], dev, grtol=1e-3)
+    if training:
+        check_close("running_mean", hip.bn.running_mean, ref.ns["bn.running_mean"])
+        check_close("running_var", hip.bn.running_var, ref.ns["bn.running_var"])
+
+
+def test_layernorm(dev):
+    from tatt_amd import functional as Fh
+    a, b, g, be = R(3, 100, 64), R(3, 100, 64, seed=1), 1 + 0.1 * R(64, seed=2), 0.1 * R(64, seed=3)
+    ln = torch.nn.LayerNorm(64)
+    compare_fn("ln_res", lambda a, b, g, be: Fh.LayerNormFn.apply(a, b, g, be, 1e-5),
+               lambda a, b, g, be: O.layer_norm(a + b, g, be), [a, b, g, be], dev)
+    compare_fn("ln", lambda a, g, be: Fh.LayerNormFn.apply(a, None, g, be, 1e-5),
+               lambda a, g, be: O.layer_norm(a, g, be), [a, g, be], dev)
+
+
+# ------------------------------------------------------------------------------------------- element-wise
+def test_prelu_pixelshuffle_maxpool_tanh(dev):
+    from tatt_amd import functional as Fh
+    x, al = R(2, 16, 64, 8), torch.tensor([0.25])
+    compare_fn("prelu", Fh.prelu, O.prelu, [x, al], dev)
+    x = R(2, 4, 6, 32)
+    compare_fn("pixel_shuffle_mish", lambda x: Fh.PixelShuffleActFn.apply(x, 2),
+               lambda x: O.mish(O.pixel_shuffle2(x.permute(0, 3, 1, 2))).permute(0, 2, 3, 1), [x], dev)
+    x = R(2, 8, 16, 12)
+    for kh, kw in ((2, 2), (1, 2)):
+        compare_fn("maxpool", lambda x: Fh.MaxPoolFn.apply(x, kh, kw),
+                   lambda x: F.max_pool2d(x.permute(0, 3, 1, 2), (kh, kw)).permute(0, 2, 3, 1), [x], dev)
+    compare_fn("tanh", lambda x: Fh.ActFn.apply(x, 3), torch.tanh, [x], dev)
+    a, b = R(5, 7, 3, 2), R(5, 7, 3, 2, seed=1)
+    compare_fn("add", Fh.add, lambda a, b: a + b, [a, b], dev)
+    compare_fn("mean2", Fh.MeanOf2Fn.apply, lambda a, b: 0.5 * (a + b), [a, b], dev)
+    compare_fn("permute", lambda a: Fh.Permute4dFn.apply(a, (0, 3, 1, 2)), lambda a: a.permute(0, 3, 1, 2), [a], dev)
+
+
+def test_dropout_mask_consistency(dev):
+    from tatt_amd import functional as Fh
+    Fh.set_seed(dev, 42)
+    x = torch.ones(1 << 16, device=dev, requires_grad=True)
+    y = Fh.dropout(x, 0.1, True, 7)
+    keep = (y != 0).float()
+    frac = float(keep.mean())
+    assert abs(frac - 0.9) < 0.01, frac
+    assert torch.allclose(y[y != 0], torch.full_like(y[y != 0], 1 / 0.9))
+    y.sum().backward()
+    assert torch.equal((x.grad != 0).float(), keep)           # backward regenerates the same mask
+    y2 = Fh.dropout(x, 0.1, True, 8)
+    assert not torch.equal((y2 != 0), (y != 0))              # a different site draws a different mask
+    Fh.next_dropout_step(dev)
+    y3 = Fh.dropout(x, 0.1, True, 7)
+    assert not torch.equal((y3 != 0), (y != 0))              # a new step draws a different mask
+    assert Fh.dropout(x, 0.1, False, 7) is x
+
+
+# ------------------------------------------------------------------------------------------- GRUs
+def _gru_sd(seed):
+    g = torch.nn.GRU(64, 32, bidirectional=True, batch_first=True)
+    torch.manual_seed(seed)
+    for p in g.parameters():
+        torch.nn.init.uniform_(p, -0.3, 0.3)
+    return g
+
+
+@pytest.mark.parametrize("vertical", [True, False])
+@pytest.mark.parametrize("B,H,W", [(2, 16, 64), (3, 5, 7)])
+def test_bigru32(dev, vertical, B, H, W):
+    from tatt_amd import functional as Fh
+    g = _gru_sd(3)
+    names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0", "weight_ih_l0_reverse",
+             "weight_hh_l0_reverse", "bias_ih_l0_reverse", "bias_hh_l0_reverse"]
+    params = [getattr(g, n).detach() for n in names]
+    x = R(B, H, W, 64)
+
+    def ref(x, *ps):
+        sd = {"g." + n: p for n, p in zip(names, ps)}
+        if vertical:      # sequences along H for every (b, w)
+            y = O.bigru(x.permute(0, 2, 1, 3).reshape(B * W, H, 64), sd, "g")
+            return y.reshape(B, W, H, 64).permute(0, 2, 1, 3)
+        return O.bigru(x.reshape(B * H, W, 64), sd, "g").reshape(B, H, W, 64)
+
+    compare_fn("bigru32", lambda x, *ps: Fh.BiGRU32Fn.apply(x, *ps, vertical), ref, [x] + params, dev, grtol=1e-3)
+
+
+@pytest.mark.parametrize("B", [1, 2, 5])
+def test_query_gru(dev, B):
+    from tatt_amd import functional as Fh
+    H, W, C = 4, 8, 64                       # GRU(256 -> 2 x 128)
+    g = torch.nn.GRU(C * H, C * H // 2, bidirectional=True, batch_first=True)
+    torch.manual_seed(5)
+    for p in g.parameters():
+        torch.nn.init.uniform_(p, -0.08, 0.08)
+    names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0", "weight_ih_l0_reverse",
+             "weight_hh_l0_reverse", "bias_ih_l0_reverse", "bias_hh_l0_reverse"]
+    params = [getattr(g, n).detach() for n in names]
+    emb = R(H * W, C)
+
+    def ref(emb, *ps):
+        sd = {"ig.transformer.gru_encoding." + n: p for n, p in zip(names, ps)}
+        sd["ig.init_factor.weight"] = emb
+        return O.query_embedding(sd, "ig", B, H, W).reshape(B, H, W, C)
+
+    compare_fn("query_gru", lambda emb, *ps: Fh.QueryGruFn.apply(emb, *ps, B, H, W), ref, [emb] + params, dev,
+               grtol=1e-3)
+
+
+# ------------------------------------------------------------------------------------------- attention
+@pytest.mark.parametrize("Lq,S", [(1024, 26), (26, 26), (70, 5)])
+def test_mha(dev, Lq, S):
+    from tatt_amd import functional as Fh
+    B, E = 2, 64
+    mha = torch.nn.MultiheadAttention(E, 4, dropout=0.1)
+    torch.manual_seed(1)
+    torch.nn.init.uniform_(mha.in_proj_bias, -0.2, 0.2)
+    torch.nn.init.uniform_(mha.out_proj.bias, -0.2, 0.2)
+    ps = [mha.in_proj_weight.detach(), mha.in_proj_bias.detach(), mha.out_proj.weight.detach(),
+          mha.out_proj.bias.detach()]
+    q, k, v = R(B, Lq, E), R(B, S, E, seed=1), R(B, S, E, seed=2)
+
+    def ref(q, k, v, w, b, ow, ob):
+        sd = {"m.in_proj_weight": w, "m.in_proj_bias": b, "m.out_proj.weight": ow, "m.out_proj.bias": ob}
+        return O.mha(q, k, v, sd, "m", 4)
+
+    def hip(q, k, v, w, b, ow, ob):
+        m = torch.nn.MultiheadAttention(E, 4, dropout=0.1).to(dev)
+        m.in_proj_weight, m.in_proj_bias = torch.nn.Parameter(w), torch.nn.Parameter(b)
+        m.out_proj.weight, m.out_proj.bias = torch.nn.Parameter(ow), torch.nn.Parameter(ob)
+        hip.m = m
+        return Fh.multihead_attention(q, k, v, m, False, 0)
+
+    cin = [q, k, v] + ps
+    # parameters are re-wrapped inside hip(): compare input grads here, parameter grads below
+    compare_fn("mha", hip, ref, cin, dev, grad_mask=[True, True, True, False, False, False, False])
+    # parameter gradients
+    cs = [t.clone().requires_grad_(True) for t in ps]
+    o, w_ = ref(q, k, v, *cs)
+    (o.sum() + (w_ * R(*w_.shape, seed=9)).sum()).backward()
+    m = hip.m
+    for p in m.parameters():
+        p.grad = None
+    o2, w2 = Fh.multihead_attention(q.to(dev), k.to(dev), v.to(dev), m, False, 0)
+    (o2.sum() + (w2 * R(*w_.shape, seed=9).to(dev)).sum()).backward()
+    for got, want, n in zip([m.in_proj_weight, m.in_proj_bias, m.out_proj.weight, m.out_proj.bias], cs,
+                            ["in_w", "in_b", "out_w", "out_b"]):
+        check_close("mha.grad." + n, got.grad, want.grad, rtol=1e-3, atol=1e-4 * float(want.grad.abs().max()))
+
+
+def test_attn_dropout_fwd_bwd_consistent(dev):
+    """With attention dropout on, backward must see the same mask: check d/dV of sum(ctx) == sum of dropped probs."""
+    from tatt_amd import functional as Fh
+    Fh.set_seed(dev, 7)
+    B, Lq, S = 1, 64, 26
+    Q, K = R(B, Lq, 64).to(dev), R(B, S, 64, seed=1).to(dev)
+    V = R(B, S, 64, seed=2).to(dev).requires_grad_(True)
+    ctx, w = Fh.AttnCoreFn.apply(Q, K, V, 0.1, 11)
+    ctx.sum().backward()
+    # d sum(ctx) / dV[s, h*16+i] = sum_q P_dropped[h, q, s]; head-mean weights w = mean_h P_dropped
+    got = V.grad.reshape(S, 4, 16).mean(2).sum(1) / 4          # mean over heads of column sums
+    check_close("attn_dropout", got, w[0].sum(0), rtol=1e-4, atol=1e-4)
+    zeros = float((w == 0).float().mean())
+    assert zeros < 0.01          # head-averaged weights are rarely exactly zero; but mask must have hit some heads
+    assert abs(float(w.sum()) / Lq - 1.0) < 0.1
+
+
+# ------------------------------------------------------------------------------------------- TPS
+def test_tps_golden_and_grad(dev):
+    from tatt_amd import functional as Fh
+    from tatt_amd.tsrn import TPSSpatialTransformer
+    z = np.load("tests/golden/tps.npz")
+    tps = TPSSpatialTransformer((16, 64), 20, (0.05, 0.05))
+    x, ctrl = torch.from_numpy(z["x"]), torch.from_numpy(z["ctrl"])
+    sd = {"t." + k: v for k, v in tps.state_dict().items()}
+
+    def ref(x, ctrl):
+        y, src = O.tps_transform(x, ctrl, sd, "t")
+        return y.permute(0, 2, 3, 1), src
+
+    def hip(x, ctrl):
+        t = tps.to(dev)
+        src = Fh.TpsGridFn.apply(ctrl, t.inverse_kernel, t.padding_matrix, t.target_coordinate_repr)
+        return Fh.GridSampleFn.apply(x, src), src
+
+    compare_fn("tps", hip, ref, [x, ctrl], dev, grad_mask=[False, True], rtol=1e-3, atol=1e-4, grtol=2e-3, gatol=2e-3)
+    y, src = hip(x.to(dev), ctrl.to(dev))
+    check_close("tps.golden.y", y.permute(0, 3, 1, 2), torch.from_numpy(z["y"]), rtol=1e-3, atol=2e-4)
+    check_close("tps.golden.src", src, torch.from_numpy(z["src"]), rtol=1e-4, atol=1e-5)

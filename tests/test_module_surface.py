@@ -1,0 +1,94 @@
+"""CPU: host logic -- the drop-in nn.Module surface and the C ABI."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.fixtures import summarize
+
+STD = dict(scale_factor=2, width=128, height=32, STN=True, mask=True, srb_nums=5, hidden_units=32)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("name,cls,nkeys", [("kat", "TSRN_TL_TRANS", 304), ("kat_tsrn", "TSRN", 239)])
+def test_state_dict_keys_and_default_init_match_reference(name, cls, nkeys):
+    """Same keys, shapes and -- under torch.manual_seed(1234) -- the same initial values as the reference module
+    (fingerprints captured from the reference import by tools/gen_golden.py)."""
+    import tatt_amd
+    z = np.load("tests/golden/%s.npz" % name)
+    torch.manual_seed(1234)
+    sd = getattr(tatt_amd, cls)(**STD).state_dict()
+    assert list(sd.keys()) == z["sd_keys"].tolist()
+    assert len(sd) == nkeys
+    for k, ref in zip(sd, z["sd_summary"]):
+        assert np.abs(summarize(sd[k].float()) - ref).max() < 1e-6, k
+
+
+def test_param_count_and_shapes():
+    import tatt_amd
+    m = tatt_amd.TSRN_TL_TRANS(**STD)
+    assert sum(p.numel() for p in m.parameters()) == 7608334
+    sd = m.state_dict()
+    assert tuple(sd["block1.0.weight"].shape) == (64, 4, 9, 9)
+    assert tuple(sd["block2.gru1.conv1.weight"].shape) == (64, 128, 1, 1)
+    assert tuple(sd["infoGen.transformer.gru_encoding.weight_ih_l0"].shape) == (1536, 1024)
+    assert tuple(sd["block8.0.conv.weight"].shape) == (256, 64, 3, 3)
+    assert tuple(sd["tps.target_coordinate_repr"].shape) == (1024, 23)
+    big = tatt_amd.TSRN_TL_TRANS(scale_factor=2, width=256, height=64, STN=False)
+    assert sum(p.numel() for p in big.parameters()) == 20111814
+
+
+def test_load_state_dict_roundtrip_and_modes():
+    import tatt_amd
+    a, b = tatt_amd.TSRN_TL_TRANS(**STD), tatt_amd.TSRN_TL_TRANS(**STD)
+    b.load_state_dict(a.state_dict(), strict=True)
+    for (k1, v1), (k2, v2) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+    a.train(); assert a.training and a.block2.bn1.training
+    a.eval(); assert not a.block2.bn1.training
+    for p in a.parameters():
+        p.requires_grad = False
+
+
+def test_product_path_has_no_cpu_fallback():
+    import tatt_amd
+    m = tatt_amd.TSRN_TL_TRANS(**STD).eval()
+    with pytest.raises(RuntimeError, match="GPU"):
+        m(torch.rand(1, 4, 16, 64), torch.rand(1, 37, 1, 26))
+    with pytest.raises(RuntimeError):
+        tatt_amd.TSRN(**STD).eval()(torch.rand(1, 4, 16, 64))
+
+
+def test_product_does_not_import_oracle():
+    for root, _, files in os.walk(os.path.join(ROOT, "tatt_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from tatt_amd._lib import LIB, LIB_PATH, parse_header
+    protos = parse_header()
+    assert len(protos) >= 37
+    dll = ctypes.CDLL(LIB_PATH)
+    for name in protos:
+        assert hasattr(dll, name), name
+    LIB.load()
+    # every TATT_API definition in the sources is declared in the header
+    defined = set()
+    for f in os.listdir(os.path.join(ROOT, "tatt_amd", "csrc")):
+        if f.endswith(".hip"):
+            defined |= set(re.findall(r"TATT_API\s+int\s+(\w+)", open(os.path.join(ROOT, "tatt_amd", "csrc", f)).read()))
+    assert defined == set(protos), defined ^ set(protos)
+
+
+def test_image_loss_matches_oracle():
+    from oracle import tatt_oracle as O
+    from tatt_amd.train import image_loss
+    g = torch.Generator().manual_seed(0)
+    sr, hr = torch.rand(3, 4, 32, 128, generator=g) * 2 - 1, torch.rand(3, 4, 32, 128, generator=g)
+    assert torch.allclose(image_loss(sr, hr), O.image_loss(sr, hr), atol=1e-7)

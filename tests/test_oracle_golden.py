@@ -1,0 +1,94 @@
+"""CPU: the oracle (oracle/tatt_oracle.py) against the golden vectors generated from the real reference
+(tools/gen_golden.py).  This is what pins the oracle; the GPU parity tests then compare the HIP path with it."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import tatt_oracle as O
+from oracle.fixtures import randomize_state_dict, summarize
+from tests.util import max_err, rel_err
+
+STD = dict(scale_factor=2, width=128, height=32, STN=True, mask=True, srb_nums=5, hidden_units=32)
+
+
+def product_sd(cls="TSRN_TL_TRANS", randomize=True, **kw):
+    """Seed-1234 state_dict from the product module's constructor (bit-identical to the reference's init,
+    see test_module_surface.py) -- so no 30 MB weight file has to be committed."""
+    import tatt_amd
+    torch.manual_seed(1234)
+    sd = getattr(tatt_amd, cls)(**(kw or STD)).state_dict()
+    return randomize_state_dict(sd) if randomize else sd
+
+
+def test_known_answer_vector():
+    z = np.load("tests/golden/kat.npz")
+    sd = product_sd(randomize=False)
+    with torch.no_grad():
+        o = O.generator_forward(sd, torch.from_numpy(z["x"]), torch.from_numpy(z["tp"]), training=False)
+    assert abs(float(o["sr"].double().sum()) - 168.209915) < 1e-3
+    assert max_err(o["sr"], torch.from_numpy(z["sr"])) < 5e-6
+    assert max_err(o["pr_weights"], torch.from_numpy(z["pr_weights"])) < 1e-6
+
+
+@pytest.mark.parametrize("name,cls,tatt,kw", [
+    ("tatt_eval_b2", "TSRN_TL_TRANS", True, STD), ("tsrn_eval_b2", "TSRN", False, STD),
+    ("large_tile", "TSRN_TL_TRANS", True, dict(scale_factor=2, width=256, height=64, STN=False, mask=True,
+                                               srb_nums=5, hidden_units=32))])
+def test_eval_forward(name, cls, tatt, kw):
+    z = np.load("tests/golden/%s.npz" % name)
+    sd = product_sd(cls, **kw)
+    with torch.no_grad():
+        o = O.generator_forward(sd, torch.from_numpy(z["x"]), torch.from_numpy(z["tp"]) if tatt else None,
+                                training=False, tatt=tatt, stn=kw["STN"])
+    assert max_err(o["sr"], torch.from_numpy(z["sr"])) < 5e-6
+    assert max_err(o["block1"][:, :8], torch.from_numpy(z["block1"])) < 1e-5
+    assert max_err(o["block7"][:, :8], torch.from_numpy(z["block7"])) < 1e-5
+    if tatt:
+        assert max_err(o["pr_weights"], torch.from_numpy(z["pr_weights"])) < 1e-6
+
+
+@pytest.mark.parametrize("name,cls,tatt", [("tatt_train_b4", "TSRN_TL_TRANS", True), ("tsrn_train_b3", "TSRN", False)])
+def test_train_step(name, cls, tatt):
+    z = np.load("tests/golden/%s.npz" % name)
+    sd = product_sd(cls)
+    x, hr = torch.from_numpy(z["x"]), torch.from_numpy(z["hr"])
+    tp = torch.from_numpy(z["tp"]) if tatt else None
+    loss, grads, sd1, _, out, total = O.train_step(sd, x, tp, hr, tatt=tatt, stn=True)
+    assert abs(float(loss) - float(z["loss"])) < 1e-4 * float(z["loss"])
+    assert max_err(out["sr"], torch.from_numpy(z["sr"])) < 3e-4          # conditioning: see tests/golden/REPORT.txt
+    assert abs(float(total) - float(z["gnorm"])) < 1e-3 * float(z["gnorm"])
+    assert sorted(k for k, g in grads.items() if g is None) == sorted(z["none_keys"].tolist())
+    noise = set(z["noise_keys"].tolist())
+    for k, ref in zip(z["grad_keys"].tolist(), z["grad_summary"]):
+        if k in noise:
+            continue
+        got = summarize(grads[k])
+        assert abs(got[0] - ref[0]) < 1e-2 * ref[0] + 1e-7, (k, got[0], ref[0])
+    for key in z.files:
+        if key.startswith("g:"):
+            assert rel_err(grads[key[2:]], torch.from_numpy(z[key])) < 1e-2, key
+    for k, ref in zip(z["w1_keys"].tolist(), z["w1_summary"]):
+        if k in noise:
+            continue
+        got = summarize(sd1[k].float())
+        assert abs(got[0] - ref[0]) < 1e-3 * abs(ref[0]) + 1e-5, k          # post-Adam weight norms
+
+
+def test_query_gru_batch_axis_quirk():
+    z = np.load("tests/golden/qgru.npz")
+    sd = product_sd(scale_factor=2, width=128, height=32, STN=False)
+    for B in (1, 2, 4):
+        q = O.query_embedding(sd, "infoGen", B, 16, 64)
+        assert max_err(q[:, ::37], torch.from_numpy(z["q%d" % B])) < 1e-5
+    # the quirk itself: a sample's embedding depends on its index in the batch and on B
+    q4 = O.query_embedding(sd, "infoGen", 4, 16, 64)
+    assert max_err(q4[0], q4[1]) > 1e-4
+
+
+def test_tps_out_of_range_control_points():
+    z = np.load("tests/golden/tps.npz")
+    sd = product_sd()
+    y, src = O.tps_transform(torch.from_numpy(z["x"]), torch.from_numpy(z["ctrl"]), sd, "tps")
+    assert float(src.min()) < 0 and float(src.max()) > 1            # the clamp is exercised
+    assert max_err(y, torch.from_numpy(z["y"])) < 1e-5
+    assert max_err(src, torch.from_numpy(z["src"])) < 1e-5

@@ -1,0 +1,57 @@
+import numpy as np
+import torch
+
+
+def to_dev(t, dev, grad=False):
+    return t.detach().clone().to(dev).requires_grad_(grad)
+
+
+def rel_err(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-12))
+
+
+def max_err(a, b):
+    return float((a.detach().double().cpu() - b.detach().double().cpu()).abs().max())
+
+
+def check_close(name, got, ref, rtol=2e-4, atol=2e-5):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    bad = err > tol
+    if bool(bad.any()):
+        i = int(torch.argmax(err - tol))
+        raise AssertionError("%s: %d/%d elements off; worst |d|=%.3e (got %.6g ref %.6g), rel-norm err %.3e" % (
+            name, int(bad.sum()), bad.numel(), float(err.reshape(-1)[i]), float(got.reshape(-1)[i]),
+            float(ref.reshape(-1)[i]), rel_err(got, ref)))
+
+
+def compare_fn(name, hip_fn, ref_fn, inputs, dev, grad_mask=None, rtol=2e-4, atol=2e-5, grtol=5e-4, gatol=5e-5):
+    """Run hip_fn on GPU copies and ref_fn on CPU copies of `inputs` (list of tensors / None); compare
+    outputs (tuple or tensor) and gradients of a random linear functional of the outputs."""
+    grad_mask = grad_mask if grad_mask is not None else [t is not None and t.is_floating_point() for t in inputs]
+    cin = [None if t is None else t.detach().clone().requires_grad_(bool(g)) for t, g in zip(inputs, grad_mask)]
+    gin = [None if t is None else t.detach().clone().to(dev).requires_grad_(bool(g)) for t, g in zip(inputs, grad_mask)]
+    ro = ref_fn(*cin)
+    go = hip_fn(*gin)
+    ro = ro if isinstance(ro, (tuple, list)) else (ro,)
+    go = go if isinstance(go, (tuple, list)) else (go,)
+    assert len(ro) == len(go)
+    gen = torch.Generator().manual_seed(123)
+    lr = lg = 0.0
+    for k, (r, g) in enumerate(zip(ro, go)):
+        check_close("%s.out%d" % (name, k), g, r, rtol, atol)
+        w = torch.randn(r.shape, generator=gen)
+        lr = lr + (r * w).sum()
+        lg = lg + (g * w.to(dev)).sum()
+    if any(grad_mask):
+        lr.backward()
+        lg.backward()
+        for k, (c, g, m) in enumerate(zip(cin, gin, grad_mask)):
+            if m:
+                assert g.grad is not None, "%s: no grad for input %d" % (name, k)
+                check_close("%s.grad%d" % (name, k), g.grad, c.grad, grtol, gatol * max(1.0, float(c.grad.abs().max())))
