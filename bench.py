@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Headline benchmark: LR images/s of a full TATT training step (forward + ImageLoss + backward + clip 0.25 + Adam,
+dropout ON, STN ON) on synthetic 16x64 -> 32x128 batches, B = 48 per GPU, fp32 (BASELINE.json configs[1]/[2]).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.  `value` is the whole-job aggregate (weak scaling: 48 images per GPU per step).
+Extra objects: `roofline` (the dominant kernel -- the fp32-MFMA implicit-GEMM 3x3 convolution -- timed live with HIP
+events on the launch stream after the timed region) and `cpu_baseline` (the CPU oracle timed on this host's cores,
+N=1 only, a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+FLOP_PER_IMAGE_FWD_BWD = 7.613e9     # SURVEY.md 8d (FlopCounterMode on the reference graph, 16x64, STN on)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=48, help="LR images per GPU per step")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=48)
+    ap.add_argument("--arch", default="tatt", choices=["tatt", "tsrn"])
+    return ap.parse_args()
+
+
+def make_batch(B, rank, dev):
+    g = torch.Generator().manual_seed(rank)                         # rank r draws data seed r
+    x = torch.rand(B, 4, 16, 64, generator=g)
+    x[:, 3] = (x[:, 3] > 0.5).float()                               # binarised mask channel (dataset/dataset.py:1312-1317)
+    hr = torch.rand(B, 4, 32, 128, generator=g)
+    tp = torch.softmax(torch.randn(B, 37, 1, 26, generator=g), 1)
+    return x.to(dev), tp.to(dev), hr.to(dev)
+
+
+def time_dominant_kernel(dev, B):
+    """Average duration of the dominant kernel (implicit-GEMM 3x3 conv, 64->64 channels, B x 16 x 64 pixels) measured with
+    HIP events on the stream it is launched on.  Algorithmic FLOPs per launch = 2 * pixels * (3*3*64) * 64."""
+    from tatt_amd import ops
+    x = torch.randn(B, 16, 64, 64, device=dev)
+    w = torch.randn(64, 64, 3, 3, device=dev) * 0.05
+    b = torch.zeros(64, device=dev)
+    wp = ops.repack_weight(w, 0)
+    y = torch.empty(B, 16, 64, 64, device=dev)
+    for _ in range(5):
+        ops.conv_fwd(x, wp, b, 64, 3, 3, out=y)
+    n = 50
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(n):
+        ops.conv_fwd(x, wp, b, 64, 3, 3, out=y)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    flops = 2.0 * B * 16 * 64 * 576 * 64
+    return ms, flops
+
+
+def cpu_baseline(arch, B):
+    """The CPU oracle (validated against the reference, tests/golden/REPORT.txt) timed on this host: ONE full training
+    step (fwd + loss + bwd + clip + Adam, dropout on) on the same synthetic workload."""
+    from oracle import tatt_oracle as O
+    import tatt_amd
+    torch.manual_seed(1234)
+    cls = tatt_amd.TSRN_TL_TRANS if arch == "tatt" else tatt_amd.TSRN
+    sd = cls(scale_factor=2, width=128, height=32, STN=True, mask=True, srb_nums=5, hidden_units=32).state_dict()
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(0)
+    x, hr = torch.rand(B, 4, 16, 64, generator=g), torch.rand(B, 4, 32, 128, generator=g)
+    tp = torch.softmax(torch.randn(B, 37, 1, 26, generator=g), 1) if arch == "tatt" else None
+    O.train_step(sd, x[:2], None if tp is None else tp[:2], hr[:2], tatt=arch == "tatt", stn=True, drop_on=True)   # warm-up
+    t0 = time.time()
+    O.train_step(sd, x, tp, hr, tatt=arch == "tatt", stn=True, drop_on=True)
+    dt = time.time() - t0
+    return {"value": round(B / dt, 3), "unit": "LR images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "1 full train step (fwd+loss+bwd+clip+Adam, dropout on) of the CPU oracle at B=%d, fp32, "
+                      "%.1f s; the reference itself measured 3.6 img/s on 8 vCPU (BASELINE.md)" % (B, dt)}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    pg = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+        pg = torch.distributed.group.WORLD
+
+    import tatt_amd
+    from tatt_amd.train import Trainer
+    from __graft_entry__ import build
+    build()
+
+    torch.manual_seed(1234)
+    kw = dict(scale_factor=2, width=128, height=32, STN=True, mask=True, srb_nums=5, hidden_units=32)
+    model = (tatt_amd.TSRN_TL_TRANS if a.arch == "tatt" else tatt_amd.TSRN)(**kw).to(dev).train()
+    use_graph = (not a.no_graph) and a.warmup >= 3
+    tr = Trainer(model, use_graph=use_graph, warmup_eager=2, process_group=pg)
+    x, tp, hr = make_batch(a.batch, rank, dev)
+    if a.arch != "tatt":
+        tp = None
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    graph_ok = use_graph
+    try:
+        for _ in range(a.warmup):
+            tr.step(x, tp, hr)
+        barrier()
+    except Exception as e:                      # graph capture unsupported -> eager
+        if not use_graph:
+            raise
+        print("[bench] hipGraph capture failed (%s); falling back to eager launches" % e, file=sys.stderr)
+        graph_ok = False
+        torch.cuda.synchronize()
+        tr = Trainer(model, use_graph=False, process_group=pg, broadcast_init=False)
+        for _ in range(a.warmup):
+            tr.step(x, tp, hr)
+        barrier()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = tr.step(x, tp, hr)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t)
+    loss_v = float(loss)
+    assert loss_v == loss_v, "loss is NaN"
+
+    if rank == 0:
+        ms = dt / a.steps * 1e3
+        ips = a.batch * world * a.steps / dt
+        kms, kflops = time_dominant_kernel(dev, a.batch)
+        ach = kflops / (kms * 1e-3) / 1e12
+        out = {
+            "metric": "LR images/s (train fwd+bwd+clip+Adam) at 16x64->32x128",
+            "value": round(ips, 2), "unit": "LR images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "fp32", "data": "synthetic",
+            "config": {"workload": "TATT (TSRN_TL_TRANS, STN on, dropout on) train step, batch %d/GPU, 16x64 LR -> 32x128 SR, "
+                                   "ImageLoss + clip 0.25 + Adam(1e-3,(0.5,0.999))" % a.batch if a.arch == "tatt" else
+                       "TSRN train step, batch %d/GPU" % a.batch,
+                       "global_batch": a.batch * world, "parallelism": "dp%d" % world,
+                       "launch": "hipGraph replay" if graph_ok else "eager", "final_loss": round(loss_v, 5),
+                       "whole_step_tflops": round(ips * FLOP_PER_IMAGE_FWD_BWD / 1e12, 2)},
+            "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                         "kernel": "gemm_mfma_kernel<3,1,0> (implicit-GEMM conv 3x3, 64->64 ch, %d x16x64 px)" % a.batch,
+                         "kernel_ms": round(kms, 4), "flops_per_launch": kflops},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.arch, a.cpu_batch)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

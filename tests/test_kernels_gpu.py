@@ -83,7 +83,7 @@ def test_conv2d_fn(dev, B, H, W, Cin, Cout, k):
 
 def test_conv_tanh_epilogue(dev):
     from tatt_amd import functional as Fh
-    x, w, b = R(1, 8, 8, 16), R(4, 16, 3, 3, seed=1, scale=0.2), R(4, seed=2)
+    x, w, b = R(1, 16, 8, 8), R(4, 16, 3, 3, seed=1, scale=0.2), R(4, seed=2)
     compare_fn("conv_tanh", lambda x, w, b: Fh.conv2d(x.permute(0, 2, 3, 1), w, b, 3).permute(0, 3, 1, 2),
                lambda x, w, b: torch.tanh(F.conv2d(x, w, b, padding=1)), [x, w, b], dev)
 

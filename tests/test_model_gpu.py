@@ -91,8 +91,12 @@ def _train_case(dev, cls, tatt, B, golden):
     assert max_err(sr, o_out["sr"]) < 3e-4, max_err(sr, o_out["sr"])
     assert abs(float(loss) - float(o_loss)) < 1e-4 * abs(float(o_loss))
     worst = ("", 0.0)
+    noise = set(z["noise_keys"].tolist())     # gradients that are mathematically zero (conv bias feeding a BatchNorm)
     for k, p in m.named_parameters():
         og = o_grads[k]
+        if k in noise:
+            assert float(p.grad.abs().max()) < 1e-4, k
+            continue
         if og is None:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
             continue
@@ -101,12 +105,12 @@ def _train_case(dev, cls, tatt, B, golden):
         r = float((p.grad.cpu() - og).norm() / (og.norm() + 1e-6 * og.numel() ** 0.5))
         if r > worst[1]:
             worst = (k, r)
+    print("worst relative gradient error vs oracle: %s %.3e" % worst)
     assert worst[1] < 1e-2, worst
     # ---- against the reference-generated golden vector ----
     assert max_err(sr, torch.from_numpy(z["sr"])) < 3e-4
     assert abs(float(loss) - float(z["loss"])) < 1e-4 * abs(float(z["loss"]))
     gsum = dict(zip(list(z["grad_keys"]), z["grad_summary"]))
-    noise = set(z["noise_keys"].tolist())
     params = dict(m.named_parameters())
     for k, ref in gsum.items():
         if k in noise:
