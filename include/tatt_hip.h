@@ -56,13 +56,13 @@ int tatt_repack_conv_weight(const float* w_oihw, float* out, int Cout, int Cin, 
 
 /* ---- reductions / normalisation ------------------------------------------------------------------- */
 
-/* out[c] = scale * sum_m X[m*ld + c] + beta*out[c]  (bias gradients); ws >= ceil(M/256)*C doubles */
+/* out[c] = scale * sum_m X[m*ld + c] + beta*out[c]  (bias gradients); ws >= 128*C doubles */
 int tatt_colsum(const float* X, long ld, int M, int C, float* out, float scale, float beta,
                 double* ws, hipStream_t st);
 
 /* train-mode nn.BatchNorm statistics over the M rows (model/tsrn.py:878,886,613; model/stn_head.py:19,51):
  * mean, rstd = 1/sqrt(biased var + eps); running stats updated in place (unbiased var, momentum) when non-NULL.
- * ws >= ceil(M/128)*2*C doubles */
+ * ws >= 128*2*C doubles */
 int tatt_bn_stats(const float* X, long ld, int M, int C, float eps, float momentum, float* mean,
                   float* rstd, float* running_mean, float* running_var, double* ws, hipStream_t st);
 /* eval mode: rstd = 1/sqrt(running_var + eps) */
@@ -71,7 +71,7 @@ int tatt_bn_rstd(const float* var, float* rstd, int C, float eps, hipStream_t st
 int tatt_bn_apply(const float* X, long ldx, float* Y, long ldy, int M, int C, const float* mean,
                   const float* rstd, const float* gamma, const float* beta, int act, hipStream_t st);
 /* backward of tatt_bn_apply (+ batch statistics when training): dX, dgamma, dbeta; sums: 2*C floats scratch;
- * ws >= ceil(M/128)*2*C doubles */
+ * ws >= 128*2*C doubles */
 int tatt_bn_bwd(const float* X, long ldx, const float* dY, long lddy, float* dX, long lddx, int M, int C,
                 const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
                 int training, float* dgamma, float* dbeta, float* sums, double* ws, hipStream_t st);
@@ -80,7 +80,7 @@ int tatt_bn_bwd(const float* X, long ldx, const float* dY, long lddy, float* dX,
  * nn.LayerNorm + the residual add in front of it (model/transformer_v2.py:478-483,826-832,380-387). */
 int tatt_ln_fwd(const float* A, const float* Bres, float* Y, float* stats, int M, int C,
                 const float* gamma, const float* beta, float eps, hipStream_t st);
-/* dX = d(A+Bres); part >= ceil(M/64)*2*C floats; ws >= ceil(ceil(M/64)/256)*2*C doubles */
+/* dX = d(A+Bres); part >= ceil(M/64)*2*C floats; ws >= 128*2*C doubles */
 int tatt_ln_bwd(const float* A, const float* Bres, const float* dY, const float* stats, float* dX, int M,
                 int C, const float* gamma, float* dgamma, float* dbeta, float* part, double* ws,
                 hipStream_t st);

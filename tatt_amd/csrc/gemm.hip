@@ -215,8 +215,15 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, float* _
     long rest = idx / N;
     int i = rest % M;
     int z = rest / M;
-    float s = 0.f;
-    for (int k = 0; k < S; ++k) s += partial[((long)(z * S + k) * M + i) * N + j];
+    const float* pp = partial + ((long)z * S * M + i) * N + j;
+    const long step = (long)M * N;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 4 <= S; k += 4) {
+        s0 += pp[(long)k * step]; s1 += pp[(long)(k + 1) * step]; s2 += pp[(long)(k + 2) * step]; s3 += pp[(long)(k + 3) * step];
+    }
+    for (; k < S; ++k) s0 += pp[(long)k * step];
+    float s = (s0 + s1) + (s2 + s3);
     float bj = bias ? bias[(long)z * bsBias + j] : 0.f;
     float v = apply_act(alpha * (s + bj), act);
     long off;

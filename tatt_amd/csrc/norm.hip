@@ -7,34 +7,53 @@
 // ---------------------------------------------------------------------------------------------
 // column sums:  out[c] (+)= scale * sum_m X[m*ld + c]      (two stages, deterministic)
 // ---------------------------------------------------------------------------------------------
-#define CS_ROWS 256   // rows per block in stage 1
+#define CS_MAXG 128   // stage-1 blocks (partials per column)
 
-__global__ void colsum_stage1(const float* __restrict__ X, long ld, int M, int C, double* __restrict__ part) {
-    // block handles CS_ROWS rows; thread t -> channel group; loop channels with stride blockDim
-    const int m_begin = blockIdx.x * CS_ROWS;
-    const int m_end = min(M, m_begin + CS_ROWS);
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        double s = 0.0;
-        for (int m = m_begin; m < m_end; ++m) s += (double)X[(long)m * ld + c];
-        part[(long)blockIdx.x * C + c] = s;
+// stage 1: block g sums rows [g*rpb, (g+1)*rpb); thread = (channel lane tx = t&63, row lane ty = t>>6)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_stage1(const T* __restrict__ X, long ld, int M, int C, int rpb,
+                                                     double* __restrict__ part) {
+    __shared__ double sh[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int m_begin = blockIdx.x * rpb;
+    const int m_end = min(M, m_begin + rpb);
+    for (int c0 = 0; c0 < C; c0 += 64) {
+        const int c = c0 + tx;
+        double s0 = 0.0, s1 = 0.0;
+        if (c < C) {
+            int m = m_begin + ty;
+            for (; m + 4 < m_end; m += 8) { s0 += (double)X[(long)m * ld + c]; s1 += (double)X[(long)(m + 4) * ld + c]; }
+            if (m < m_end) s0 += (double)X[(long)m * ld + c];
+        }
+        sh[ty][tx] = s0 + s1;
+        __syncthreads();
+        if (ty == 0 && c < C) part[(long)blockIdx.x * C + c] = (sh[0][tx] + sh[1][tx]) + (sh[2][tx] + sh[3][tx]);
+        __syncthreads();
     }
 }
-__global__ void colsum_stage2(const double* __restrict__ part, int G, int C, long ldp, float* __restrict__ out,
-                              float scale, float beta) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// stage 2: out[c] = scale * sum_g part[g*ldp + c] (+ beta*out[c]); block = 64 columns x 4 g-lanes
+__global__ __launch_bounds__(256) void colsum_stage2(const double* __restrict__ part, int G, int C, long ldp,
+                                                     float* __restrict__ out, float scale, float beta) {
+    __shared__ double sh[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
     double s = 0.0;
-    for (int g = 0; g < G; ++g) s += part[(long)g * ldp + c];
-    float v = (float)(s * scale);
-    out[c] = beta != 0.f ? v + beta * out[c] : v;
+    if (c < C) for (int g = ty; g < G; g += 4) s += part[(long)g * ldp + c];
+    sh[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        float v = (float)(((sh[0][tx] + sh[1][tx]) + (sh[2][tx] + sh[3][tx])) * scale);
+        out[c] = beta != 0.f ? v + beta * out[c] : v;
+    }
 }
-// ws: cdiv(M,256)*C doubles
+static inline int cs_groups(int M) { int g = cdiv(M, 64); return g > CS_MAXG ? CS_MAXG : (g < 1 ? 1 : g); }
+// ws: min(ceil(M/64),128)*C doubles
 TATT_API int tatt_colsum(const float* X, long ld, int M, int C, float* out, float scale, float beta,
                          double* ws, hipStream_t st) {
-    int G = cdiv(M, CS_ROWS);
-    int bt = C >= 256 ? 256 : (C >= 64 ? 64 : 64);
-    hipLaunchKernelGGL(colsum_stage1, dim3(G), dim3(bt), 0, st, X, ld, M, C, ws);
-    hipLaunchKernelGGL(colsum_stage2, dim3(cdiv(C, 64)), dim3(64), 0, st, ws, G, C, (long)C, out, scale, beta);
+    int G = cs_groups(M);
+    int rpb = cdiv(M, G);
+    hipLaunchKernelGGL((colsum_stage1<float>), dim3(G), dim3(256), 0, st, X, ld, M, C, rpb, ws);
+    hipLaunchKernelGGL(colsum_stage2, dim3(cdiv(C, 64)), dim3(256), 0, st, ws, G, C, (long)C, out, scale, beta);
     return LAUNCH_CHECK();
 }
 
@@ -74,10 +93,16 @@ __global__ void bn_stats_stage1(const float* __restrict__ X, long ld, int M, int
 __global__ void bn_stats_stage2(const double* __restrict__ part, int G, int C, int M, float eps, float momentum,
                                 float* __restrict__ mean, float* __restrict__ rstd,
                                 float* __restrict__ running_mean, float* __restrict__ running_var) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    __shared__ double sh[2][4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
     double s = 0.0, q = 0.0;
-    for (int g = 0; g < G; ++g) { s += part[((long)g * 2 + 0) * C + c]; q += part[((long)g * 2 + 1) * C + c]; }
+    if (c < C) for (int g = ty; g < G; g += 4) { s += part[((long)g * 2 + 0) * C + c]; q += part[((long)g * 2 + 1) * C + c]; }
+    sh[0][ty][tx] = s; sh[1][ty][tx] = q;
+    __syncthreads();
+    if (ty != 0 || c >= C) return;
+    s = (sh[0][0][tx] + sh[0][1][tx]) + (sh[0][2][tx] + sh[0][3][tx]);
+    q = (sh[1][0][tx] + sh[1][1][tx]) + (sh[1][2][tx] + sh[1][3][tx]);
     double mu = s / M;
     double var = q / M - mu * mu;
     if (var < 0.0) var = 0.0;
@@ -92,10 +117,10 @@ __global__ void bn_stats_stage2(const double* __restrict__ part, int G, int C, i
 // ws: cdiv(M, rows_per_block)*2*C doubles
 TATT_API int tatt_bn_stats(const float* X, long ld, int M, int C, float eps, float momentum, float* mean,
                            float* rstd, float* running_mean, float* running_var, double* ws, hipStream_t st) {
-    int rpb = 128;
-    int G = cdiv(M, rpb);
+    int G = cs_groups(M);
+    int rpb = cdiv(M, G);
     hipLaunchKernelGGL(bn_stats_stage1, dim3(G), dim3(256), 0, st, X, ld, M, C, rpb, ws);
-    hipLaunchKernelGGL(bn_stats_stage2, dim3(cdiv(C, 64)), dim3(64), 0, st, ws, G, C, M, eps, momentum, mean, rstd,
+    hipLaunchKernelGGL(bn_stats_stage2, dim3(cdiv(C, 64)), dim3(256), 0, st, ws, G, C, M, eps, momentum, mean, rstd,
                        running_mean, running_var);
     return LAUNCH_CHECK();
 }
@@ -166,10 +191,16 @@ __global__ void bn_bwd_stage1(const float* __restrict__ X, long ldx, const float
 }
 __global__ void bn_bwd_stage2(const double* __restrict__ part, int G, int C, float* __restrict__ dgamma,
                               float* __restrict__ dbeta, float* __restrict__ sums) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    __shared__ double sh[2][4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
     double s = 0.0, q = 0.0;
-    for (int g = 0; g < G; ++g) { s += part[((long)g * 2 + 0) * C + c]; q += part[((long)g * 2 + 1) * C + c]; }
+    if (c < C) for (int g = ty; g < G; g += 4) { s += part[((long)g * 2 + 0) * C + c]; q += part[((long)g * 2 + 1) * C + c]; }
+    sh[0][ty][tx] = s; sh[1][ty][tx] = q;
+    __syncthreads();
+    if (ty != 0 || c >= C) return;
+    s = (sh[0][0][tx] + sh[0][1][tx]) + (sh[0][2][tx] + sh[0][3][tx]);
+    q = (sh[1][0][tx] + sh[1][1][tx]) + (sh[1][2][tx] + sh[1][3][tx]);
     dbeta[c] = (float)s; dgamma[c] = (float)q;
     sums[c] = (float)s; sums[C + c] = (float)q;
 }
@@ -199,11 +230,11 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ X, long ldx, const
 TATT_API int tatt_bn_bwd(const float* X, long ldx, const float* dY, long lddy, float* dX, long lddx, int M, int C,
                          const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
                          int training, float* dgamma, float* dbeta, float* sums, double* ws, hipStream_t st) {
-    int rpb = 128;
-    int G = cdiv(M, rpb);
+    int G = cs_groups(M);
+    int rpb = cdiv(M, G);
     hipLaunchKernelGGL(bn_bwd_stage1, dim3(G), dim3(256), 0, st, X, ldx, dY, lddy, M, C, rpb, mean, rstd, gamma, beta,
                        act, ws);
-    hipLaunchKernelGGL(bn_bwd_stage2, dim3(cdiv(C, 64)), dim3(64), 0, st, ws, G, C, dgamma, dbeta, sums);
+    hipLaunchKernelGGL(bn_bwd_stage2, dim3(cdiv(C, 64)), dim3(256), 0, st, ws, G, C, dgamma, dbeta, sums);
     long total = (long)M * C;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, X, ldx, dY, lddy, dX, lddx, M, C,
                        mean, rstd, gamma, beta, act, sums, training);
@@ -306,9 +337,10 @@ TATT_API int tatt_ln_bwd(const float* A, const float* Bres, const float* dY, con
     int G = cdiv(M, LN_BWD_ROWS);
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(G), dim3(256), 0, st, A, Bres, dY, stats, dX, M, C, gamma, part);
     // part viewed as (G, 2C) -> column sums give [dgamma | dbeta]
-    int G2 = cdiv(G, CS_ROWS);
-    hipLaunchKernelGGL(colsum_stage1, dim3(G2), dim3(64), 0, st, part, (long)2 * C, G, 2 * C, ws);
-    hipLaunchKernelGGL(colsum_stage2, dim3(cdiv(C, 64)), dim3(64), 0, st, ws, G2, C, (long)2 * C, dgamma, 1.f, 0.f);
-    hipLaunchKernelGGL(colsum_stage2, dim3(cdiv(C, 64)), dim3(64), 0, st, ws + C, G2, C, (long)2 * C, dbeta, 1.f, 0.f);
+    int G2 = cs_groups(G);
+    int rpb = cdiv(G, G2);
+    hipLaunchKernelGGL((colsum_stage1<float>), dim3(G2), dim3(256), 0, st, part, (long)2 * C, G, 2 * C, rpb, ws);
+    hipLaunchKernelGGL(colsum_stage2, dim3(cdiv(C, 64)), dim3(256), 0, st, ws, G2, C, (long)2 * C, dgamma, 1.f, 0.f);
+    hipLaunchKernelGGL(colsum_stage2, dim3(cdiv(C, 64)), dim3(256), 0, st, ws + C, G2, C, (long)2 * C, dbeta, 1.f, 0.f);
     return LAUNCH_CHECK();
 }

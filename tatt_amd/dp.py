@@ -36,6 +36,10 @@ class FlatParams:
     def zero_grad(self):
         self.g.zero_()
 
+    def grad_view(self, p):
+        off, k = self.offsets[id(p)]
+        return self.g[off:off + k].view_as(p)
+
 
 def broadcast_model(flat: FlatParams, model: torch.nn.Module, group=None, src: int = 0):
     """Ranks start from rank `src`'s weights and buffers (DataParallel re-replicates every forward instead)."""

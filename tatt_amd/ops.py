@@ -118,7 +118,7 @@ def colsum(x2, *, out=None, scale=1.0, beta=0.0):
     _check_dev(x2)
     M, C = x2.shape
     out = out if out is not None else new(x2, C)
-    ws = new(x2, cdiv(M, 256) * C, dtype=torch.float64)
+    ws = new(x2, 128 * C, dtype=torch.float64)
     call("tatt_colsum", P(x2), x2.stride(0), M, C, P(out), scale, beta, P(ws), stream())
     return out
 
@@ -161,7 +161,7 @@ def conv_wgrad(x_bhwc, dy_bhwc, Cout, KH, KW):
 def bn_stats(x2, eps, momentum, running_mean, running_var):
     M, C = x2.shape
     mean, rstd = new(x2, C), new(x2, C)
-    ws = new(x2, cdiv(M, 128) * 2 * C, dtype=torch.float64)
+    ws = new(x2, 128 * 2 * C, dtype=torch.float64)
     call("tatt_bn_stats", P(x2), x2.stride(0), M, C, eps, momentum, P(mean), P(rstd), P(running_mean), P(running_var),
          P(ws), stream())
     return mean, rstd
@@ -184,7 +184,7 @@ def bn_bwd(x2, dy2, mean, rstd, gamma, beta, act, training):
     M, C = x2.shape
     dx = new(x2, M, C)
     dgamma, dbeta, sums = new(x2, C), new(x2, C), new(x2, 2 * C)
-    ws = new(x2, cdiv(M, 128) * 2 * C, dtype=torch.float64)
+    ws = new(x2, 128 * 2 * C, dtype=torch.float64)
     call("tatt_bn_bwd", P(x2), x2.stride(0), P(dy2), dy2.stride(0), P(dx), C, M, C, P(mean), P(rstd), P(gamma), P(beta),
          act, int(training), P(dgamma), P(dbeta), P(sums), P(ws), stream())
     return dx, dgamma, dbeta
@@ -202,7 +202,7 @@ def ln_bwd(a2, b2, dy2, stats, gamma):
     dx, dgamma, dbeta = new(a2, M, C), new(a2, C), new(a2, C)
     G = cdiv(M, 64)
     part = new(a2, G * 2 * C)
-    ws = new(a2, cdiv(G, 256) * 2 * C, dtype=torch.float64)
+    ws = new(a2, 128 * 2 * C, dtype=torch.float64)
     call("tatt_ln_bwd", P(a2), P(b2), P(dy2), P(stats), P(dx), M, C, P(gamma), P(dgamma), P(dbeta), P(part), P(ws),
          stream())
     return dx, dgamma, dbeta
