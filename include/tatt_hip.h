@@ -54,15 +54,39 @@ int tatt_conv2d_wgrad(const float* x, long xsn, long xsh, long xsw, long xsc, co
 int tatt_repack_conv_weight(const float* w_oihw, float* out, int Cout, int Cin, int KH, int KW,
                             int mode, hipStream_t st);
 
+/* C = sum over S partial (M x N) slabs (+ beta*C); remap_cin > 0: row i = tap*remap_cin + ci, col j = co is scattered to
+ * the OIHW filter layout dW[co][ci][tap] */
+int tatt_splitk_reduce(const float* partial, float* C, int M, int N, int S, int remap_cin, int remap_taps,
+                       float beta, hipStream_t st);
+
+/* Specialised 3x3 convolution, Cin/Cout/W multiples of 64, NHWC contiguous, halo tile + filter taps staged in LDS,
+ * v_mfma_f32_32x32x2_f32: the SRB / block7 / up-sampler convs (model/tsrn.py:877,885,612,1043), forward and (with the
+ * mode-1 packed filter) data gradient.  y = act(conv + bias) + beta*y */
+int tatt_conv3_c64_fwd(const float* x, const float* wpacked, const float* bias, float* y, int B, int H, int W,
+                       int Cin, int Cout, int act, float beta, hipStream_t st);
+/* weight-gradient partials part[G][9*Cin][Cout] (G persistent work-groups, G <= B*H*W/64); finish with
+ * tatt_splitk_reduce(part, dw_oihw, 9*Cin, Cout, G, Cin, 9, beta) */
+int tatt_conv3_c64_wgrad_partial(const float* x, const float* dy, float* part, int B, int H, int W, int Cin,
+                                 int Cout, int G, hipStream_t st);
+
+/* 9x9 convolution 64 -> 4 channels (fp32 vector ALU; filter through the scalar cache): the final reconstruction conv
+ * (model/tsrn.py:623) and, with the mode-1 packed filter, the data gradient of block1 (model/tsrn.py:597).
+ * x (B,H,W,C) NHWC, C % 16 == 0, H % 8 == 0, W % 32 == 0; wpacked [81][C][4]; y (B,H,W,4) */
+int tatt_conv9_c64_to_c4(const float* x, const float* wpacked, const float* bias, float* y, int B, int H, int W,
+                         int C, hipStream_t st);
+/* dw (4,64,9,9) = sum_px x[px+tap][ci] * dy[px][co]; part >= min(B*H*W/256, 256)*81*64*4 floats */
+int tatt_conv9_c64_c4_wgrad(const float* x, const float* dy, float* dw, float* part, int B, int H, int W,
+                            hipStream_t st);
+
 /* ---- reductions / normalisation ------------------------------------------------------------------- */
 
-/* out[c] = scale * sum_m X[m*ld + c] + beta*out[c]  (bias gradients); ws >= 128*C doubles */
+/* out[c] = scale * sum_m X[m*ld + c] + beta*out[c]  (bias gradients); ws >= 256*C doubles */
 int tatt_colsum(const float* X, long ld, int M, int C, float* out, float scale, float beta,
                 double* ws, hipStream_t st);
 
 /* train-mode nn.BatchNorm statistics over the M rows (model/tsrn.py:878,886,613; model/stn_head.py:19,51):
  * mean, rstd = 1/sqrt(biased var + eps); running stats updated in place (unbiased var, momentum) when non-NULL.
- * ws >= 128*2*C doubles */
+ * ws >= 256*2*C doubles */
 int tatt_bn_stats(const float* X, long ld, int M, int C, float eps, float momentum, float* mean,
                   float* rstd, float* running_mean, float* running_var, double* ws, hipStream_t st);
 /* eval mode: rstd = 1/sqrt(running_var + eps) */
@@ -71,7 +95,7 @@ int tatt_bn_rstd(const float* var, float* rstd, int C, float eps, hipStream_t st
 int tatt_bn_apply(const float* X, long ldx, float* Y, long ldy, int M, int C, const float* mean,
                   const float* rstd, const float* gamma, const float* beta, int act, hipStream_t st);
 /* backward of tatt_bn_apply (+ batch statistics when training): dX, dgamma, dbeta; sums: 2*C floats scratch;
- * ws >= 128*2*C doubles */
+ * ws >= 256*2*C doubles */
 int tatt_bn_bwd(const float* X, long ldx, const float* dY, long lddy, float* dX, long lddx, int M, int C,
                 const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
                 int training, float* dgamma, float* dbeta, float* sums, double* ws, hipStream_t st);
@@ -80,7 +104,7 @@ int tatt_bn_bwd(const float* X, long ldx, const float* dY, long lddy, float* dX,
  * nn.LayerNorm + the residual add in front of it (model/transformer_v2.py:478-483,826-832,380-387). */
 int tatt_ln_fwd(const float* A, const float* Bres, float* Y, float* stats, int M, int C,
                 const float* gamma, const float* beta, float eps, hipStream_t st);
-/* dX = d(A+Bres); part >= ceil(M/64)*2*C floats; ws >= 128*2*C doubles */
+/* dX = d(A+Bres); part >= ceil(M/64)*2*C floats; ws >= 256*2*C doubles */
 int tatt_ln_bwd(const float* A, const float* Bres, const float* dY, const float* stats, float* dX, int M,
                 int C, const float* gamma, float* dgamma, float* dbeta, float* part, double* ws,
                 hipStream_t st);
@@ -159,8 +183,8 @@ int tatt_qgru_bwd_gates(const float* dhseq0, const float* dhseq1, const float* g
                         const float* hprev0, const float* hprev1, float* dhcarry0, float* dhcarry1,
                         float* dgi_acc0, float* dgi_acc1, float* dgh0, float* dgh1, int Wb, int HID, int first,
                         hipStream_t st);
-/* backward step, matmul part: dhcarry (Wb,HID) += dgh (Wb,3*HID) @ whh (3*HID,HID) */
-int tatt_qgru_bwd_mm(const float* dgh0, const float* dgh1, const float* whh0, const float* whh1,
+/* backward step, matmul part: dhcarry (Wb,HID) += dgh (Wb,3*HID) @ whh (3*HID,HID); whhT* = whh transposed (HID,3*HID) */
+int tatt_qgru_bwd_mm(const float* dgh0, const float* dgh1, const float* whhT0, const float* whhT1,
                      float* dhcarry0, float* dhcarry1, int Wb, int HID, hipStream_t st);
 
 /* ---- attention core ------------------------------------------------------------------------------------ */

@@ -1,0 +1,205 @@
+// 3x3 convolutions between multiples of 64 channels on NHWC maps -- the bulk of the backbone's FLOPs (11 of them per
+// forward, reference model/tsrn.py:877,885,612,1043) -- on v_mfma_f32_32x32x2_f32 (exact fp32).
+//
+// Forward / data-gradient (tatt_conv3_c64_fwd): one work-group = one 64-pixel row segment x 64 output channels.
+//   * the (3 x 66)-pixel halo of 64 input channels is staged ONCE in LDS ([row][px][65]: the odd pitch makes the MFMA
+//     A-operand read  lane -> (pixel = lane&31, k = lane>>5)  bank-conflict free) and reused by all 9 taps;
+//   * the 64x64 filter slice of each tap streams through a single LDS buffer, prefetched into registers while the
+//     previous tap's 32 MFMAs per wave run; 67.5 KB LDS => 2 work-groups per CU overlap each other's barriers;
+//   * 4 waves = 2 (pixel halves) x 2 (channel halves), one 32x32 accumulator each; 288 MFMAs per wave per 64 input channels.
+// Weight-gradient (tatt_conv3_c64_wgrad): persistent work-groups walk row segments; each wave keeps the 9 taps x (32 ci x 32 co)
+//   quadrant in 9 accumulators (144 VGPRs); A = x halo read channel-contiguous, B = dy tile; per-block partials are
+//   summed deterministically and scattered to the OIHW parameter layout by the split-K reducer of gemm.hip.
+#include "common.h"
+
+#define C3_PX 64
+#define C3_XP 65     // halo channel pitch (floats)
+#define C3_HW 66     // halo width (pixels)
+
+struct Conv3P {
+    const float* x; const float* w; const float* bias; float* y;
+    int B, H, W, Cin, Cout, act;
+    float beta;
+};
+
+__global__ __launch_bounds__(256, 2) void conv3_c64_fwd_kernel(Conv3P p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float (*Xs)[C3_HW][C3_XP] = reinterpret_cast<float (*)[C3_HW][C3_XP]>(smem);           // [3][66][65]
+    float (*Ws)[64] = reinterpret_cast<float (*)[64]>(smem + 3 * C3_HW * C3_XP + 2);       // [64][64], 16B aligned (12872 floats)
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int segs = p.W / C3_PX, cob = p.Cout / 64;
+    int bid = blockIdx.x;
+    const int cb = bid % cob; bid /= cob;
+    const int seg = bid % segs; bid /= segs;
+    const int h = bid % p.H; const int n = bid / p.H;
+    const int w0 = seg * C3_PX, co0 = cb * 64;
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+    f32x4 wreg[4];
+    auto load_w = [&](int tap, int ci0) {
+        // filter slice [tap][ci0..ci0+64][co0..co0+64] of the packed [9][Cin][Cout] operand: 64 rows of 256 B
+        const float* src = p.w + ((long)tap * p.Cin + ci0) * p.Cout + co0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = t + 256 * q;             // 0..1023 float4s
+            const int r = idx >> 4, c4 = idx & 15;
+            wreg[q] = *reinterpret_cast<const f32x4*>(src + (long)r * p.Cout + 4 * c4);
+        }
+    };
+    auto store_w = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = t + 256 * q;
+            *reinterpret_cast<f32x4*>(&Ws[idx >> 4][4 * (idx & 15)]) = wreg[q];
+        }
+    };
+
+    for (int ci0 = 0; ci0 < p.Cin; ci0 += 64) {
+        __syncthreads();                      // previous chunk's readers are done with Xs / Ws
+        // ---- stage the halo: 3 rows x 66 pixels x 64 channels (16 float4 per pixel) ----
+        for (int i = t; i < 3 * C3_HW * 16; i += 256) {
+            const int c4 = i & 15, pp = i >> 4;
+            const int r = pp / C3_HW, px = pp - r * C3_HW;
+            const int hh = h + r - 1, ww = w0 + px - 1;
+            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (hh >= 0 && hh < p.H && ww >= 0 && ww < p.W)
+                v = *reinterpret_cast<const f32x4*>(p.x + (((long)n * p.H + hh) * p.W + ww) * p.Cin + ci0 + 4 * c4);
+            float* d = &Xs[r][px][4 * c4];
+            d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+        }
+        load_w(0, ci0);
+        store_w();
+        __syncthreads();
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap + 1 < 9) load_w(tap + 1, ci0);
+            const int kh = tap / 3, kw = tap - 3 * kh;
+            const float* arow = &Xs[kh][wm * 32 + (lane & 31) + kw][lane >> 5];
+            const float* brow = &Ws[lane >> 5][wn * 32 + (lane & 31)];
+#pragma unroll
+            for (int k = 0; k < 64; k += 2)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[k], brow[k * 64], acc, 0, 0, 0);
+            if (tap + 1 < 9) {
+                __syncthreads();              // everyone finished reading Ws
+                store_w();
+                __syncthreads();
+            }
+        }
+    }
+    // ---- epilogue: col = lane&31 (output channel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (pixel) ----
+    const int co = co0 + wn * 32 + (lane & 31);
+    const float bj = p.bias ? p.bias[co] : 0.f;
+    const long rowbase = ((long)n * p.H + h) * p.W + w0 + wm * 32;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int px = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        float v = apply_act(acc[reg] + bj, p.act);
+        const long o = (rowbase + px) * p.Cout + co;
+        if (p.beta != 0.f) v += p.beta * p.y[o];
+        p.y[o] = v;
+    }
+}
+#define C3_FWD_LDS ((3 * C3_HW * C3_XP + 2 + 64 * 64) * 4)
+// x (B,H,W,Cin) NHWC contiguous; w = packed [9][Cin][Cout]; y (B,H,W,Cout); Cin, Cout, W multiples of 64
+TATT_API int tatt_conv3_c64_fwd(const float* x, const float* wpacked, const float* bias, float* y, int B, int H, int W,
+                                int Cin, int Cout, int act, float beta, hipStream_t st) {
+    if (Cin % 64 || Cout % 64 || W % C3_PX) return 1;
+    Conv3P p = {x, wpacked, bias, y, B, H, W, Cin, Cout, act, beta};
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            C3_FWD_LDS);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv3_c64_fwd_kernel, dim3(B * H * (W / C3_PX) * (Cout / 64)), dim3(256), C3_FWD_LDS, st, p);
+    return LAUNCH_CHECK();
+}
+
+// ---- weight gradient -------------------------------------------------------------------------------------------------
+struct Conv3WP {
+    const float* x; const float* dy; float* part;
+    int B, H, W, Cin, Cout, nseg;
+};
+__global__ __launch_bounds__(256) void conv3_c64_wgrad_kernel(Conv3WP p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float (*Xs)[C3_HW][64] = reinterpret_cast<float (*)[C3_HW][64]>(smem);                  // [3][66][64]
+    float (*Ds)[64] = reinterpret_cast<float (*)[64]>(smem + 3 * C3_HW * 64);               // [64 px][64 co]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int qi = wave & 1, qo = wave >> 1;             // (ci half, co half) quadrant of this wave
+    const int cib = blockIdx.y % (p.Cin / 64), cob = blockIdx.y / (p.Cin / 64);
+    const int ci0 = cib * 64, co0 = cob * 64;
+    const int segs = p.W / C3_PX;
+    f32x16 acc[9];
+#pragma unroll
+    for (int a = 0; a < 9; ++a)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[a][i] = 0.f;
+
+    for (int s = blockIdx.x; s < p.nseg; s += gridDim.x) {
+        int bid = s;
+        const int seg = bid % segs; bid /= segs;
+        const int h = bid % p.H; const int n = bid / p.H;
+        const int w0 = seg * C3_PX;
+        __syncthreads();
+        for (int i = t; i < 3 * C3_HW * 16; i += 256) {
+            const int c4 = i & 15, pp = i >> 4;
+            const int r = pp / C3_HW, px = pp - r * C3_HW;
+            const int hh = h + r - 1, ww = w0 + px - 1;
+            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (hh >= 0 && hh < p.H && ww >= 0 && ww < p.W)
+                v = *reinterpret_cast<const f32x4*>(p.x + (((long)n * p.H + hh) * p.W + ww) * p.Cin + ci0 + 4 * c4);
+            *reinterpret_cast<f32x4*>(&Xs[r][px][4 * c4]) = v;
+        }
+        for (int i = t; i < 64 * 16; i += 256) {
+            const int c4 = i & 15, px = i >> 4;
+            *reinterpret_cast<f32x4*>(&Ds[px][4 * c4]) =
+                *reinterpret_cast<const f32x4*>(p.dy + (((long)n * p.H + h) * p.W + w0 + px) * p.Cout + co0 + 4 * c4);
+        }
+        __syncthreads();
+        // A(i = ci, k = pixel) = Xs[kh][pixel + kw][ci];  B(k = pixel, j = co) = Ds[pixel][co]
+        const int kq = lane >> 5;
+        const float* bcol = &Ds[kq][qo * 32 + (lane & 31)];
+        const float* acol = &Xs[0][kq][qi * 32 + (lane & 31)];
+#pragma unroll 2
+        for (int k = 0; k < 64; k += 2) {
+            const float b = bcol[k * 64];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int kh = tap / 3, kw = tap - 3 * (tap / 3);
+                const float a = acol[(kh * C3_HW + k + kw) * 64];
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[tap], 0, 0, 0);
+            }
+        }
+    }
+    // partial[blockIdx.x][(tap*Cin + ci)][Cout]
+    float* P = p.part + (long)blockIdx.x * 9 * p.Cin * p.Cout;
+    const int co = co0 + qo * 32 + (lane & 31);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int ci = ci0 + qi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+            P[((long)tap * p.Cin + ci) * p.Cout + co] = acc[tap][reg];
+        }
+}
+#define C3_WG_LDS ((3 * C3_HW * 64 + 64 * 64) * 4)
+// partials: part[G][9*Cin][Cout] with G = *nblocks_out work-groups along x (<= 256); reduce with the split-K reducer
+TATT_API int tatt_conv3_c64_wgrad_partial(const float* x, const float* dy, float* part, int B, int H, int W, int Cin,
+                                          int Cout, int G, hipStream_t st) {
+    if (Cin % 64 || Cout % 64 || W % C3_PX) return 1;
+    const int nseg = B * H * (W / C3_PX);
+    Conv3WP p = {x, dy, part, B, H, W, Cin, Cout, nseg};
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            C3_WG_LDS);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv3_c64_wgrad_kernel, dim3(G, (Cin / 64) * (Cout / 64)), dim3(256), C3_WG_LDS, st, p);
+    return LAUNCH_CHECK();
+}

@@ -1,0 +1,170 @@
+// 9x9 convolutions with 4 channels on one side (the RGB+mask image end of the network), fp32 VALU.
+//
+//   tatt_conv9_c64_to_c4:      y[px][4]  = sum_{tap,ci<64} x[px+tap][ci] * w[tap][ci][4]   (+bias)
+//       = the final reconstruction conv (reference model/tsrn.py:623, 64->4 at HR resolution) and, with the flipped
+//         filter, the data-gradient of block1 (4->64, model/tsrn.py:597).
+//   tatt_conv9_c64_c4_wgrad:   dw[co<4][ci<64][tap] = sum_px x[px+tap][ci] * dy[px][co]
+//
+// With only 4 output channels the MFMA tile (32x32) would be 8x padded, so these stay on the vector ALU at the
+// same 157 TFLOP/s fp32 peak: one thread per output pixel holds its 4 accumulators, a (8+8)x(32+8) halo tile of 16
+// input channels is staged in LDS channel-quad-major ([c4][row][col] float4: lanes read consecutive 16 B), and the
+// filter -- uniform across the wave -- is read through the scalar cache (s_load) straight into SGPR operands.
+#include "common.h"
+
+#define T9_H 8
+#define T9_W 32
+#define T9_HH (T9_H + 8)
+#define T9_WW (T9_W + 8)
+#define T9_CK 16
+
+// stage channels [c0, c0+16) of the halo tile; Xs[c4][row][col] as float4
+__device__ __forceinline__ void stage_halo_q(const float* __restrict__ x, f32x4 (*Xs)[T9_HH][T9_WW], int n, int h0, int w0,
+                                             int H, int W, int C, int c0) {
+    for (int i = threadIdx.x; i < T9_HH * T9_WW * 4; i += 256) {
+        const int c4 = i & 3, p = i >> 2;
+        const int r = p / T9_WW, cc = p - r * T9_WW;
+        const int hh = h0 + r - 4, ww = w0 + cc - 4;
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (hh >= 0 && hh < H && ww >= 0 && ww < W)
+            v = *reinterpret_cast<const f32x4*>(x + (((long)n * H + hh) * W + ww) * C + c0 + 4 * c4);
+        Xs[c4][r][cc] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void conv9_c64_to_c4_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                              const float* __restrict__ bias, float* __restrict__ y,
+                                                              int B, int H, int W, int C) {
+    __shared__ f32x4 Xs[4][T9_HH][T9_WW];
+    const int tiles_w = W / T9_W, tiles_h = H / T9_H;
+    int bid = blockIdx.x;
+    const int tw = bid % tiles_w; bid /= tiles_w;
+    const int th = bid % tiles_h; const int n = bid / tiles_h;
+    const int h0 = th * T9_H, w0 = tw * T9_W;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int c0 = 0; c0 < C; c0 += T9_CK) {
+        __syncthreads();
+        stage_halo_q(x, Xs, n, h0, w0, H, W, C, c0);
+        __syncthreads();
+        for (int kh = 0; kh < 9; ++kh) {
+#pragma unroll
+            for (int kw = 0; kw < 9; ++kw) {
+                const float* wt = wp + ((long)(kh * 9 + kw) * C + c0) * 4;      // uniform -> scalar loads
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    const f32x4 v = Xs[c4][ty + kh][tx + kw];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float* wv = wt + (c4 * 4 + u) * 4;
+                        a0 = fmaf(v[u], wv[0], a0); a1 = fmaf(v[u], wv[1], a1);
+                        a2 = fmaf(v[u], wv[2], a2); a3 = fmaf(v[u], wv[3], a3);
+                    }
+                }
+            }
+        }
+    }
+    if (bias) { a0 += bias[0]; a1 += bias[1]; a2 += bias[2]; a3 += bias[3]; }
+    const long o = (((long)n * H + h0 + ty) * W + w0 + tx) * 4;
+    *reinterpret_cast<f32x4*>(y + o) = (f32x4){a0, a1, a2, a3};
+}
+// x (B,H,W,C) NHWC contiguous, C % 16 == 0, H % 8 == 0, W % 32 == 0; wp = [81][C][4]; y (B,H,W,4)
+TATT_API int tatt_conv9_c64_to_c4(const float* x, const float* wpacked, const float* bias, float* y, int B, int H, int W,
+                                  int C, hipStream_t st) {
+    if (C % T9_CK || H % T9_H || W % T9_W) return 1;
+    hipLaunchKernelGGL(conv9_c64_to_c4_kernel, dim3(B * (H / T9_H) * (W / T9_W)), dim3(256), 0, st, x, wpacked, bias, y, B,
+                       H, W, C);
+    return LAUNCH_CHECK();
+}
+
+// ---- weight gradient ---------------------------------------------------------------------------------------------
+// thread (ci = t & 15, tap lane tl = t >> 4): taps tl, tl+16, ..., 4 output channels each -> 6 x 4 accumulators per 16-channel
+// chunk, kept in registers over all the tiles a (persistent) block walks.  Halo tile channel-contiguous: Xc[row][col][16].
+#define W9_TAPS 6
+__global__ __launch_bounds__(256) void conv9_c64_c4_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                 float* __restrict__ part, int B, int H, int W) {
+    __shared__ float Xc[T9_HH][T9_WW][T9_CK];
+    __shared__ f32x4 Dy[T9_H][T9_W];
+    const int tiles_w = W / T9_W, tiles_h = H / T9_H;
+    const int ntiles = B * tiles_h * tiles_w;
+    const int ci = threadIdx.x & 15, tl = threadIdx.x >> 4;
+    float acc[4][W9_TAPS][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < W9_TAPS; ++b)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[a][b][c] = 0.f;
+    int kh[W9_TAPS], kw[W9_TAPS];
+#pragma unroll
+    for (int j = 0; j < W9_TAPS; ++j) {
+        int tap = tl + 16 * j;
+        if (tap > 80) tap = 80;          // clamped lanes recompute tap 80; their result is discarded at the end
+        kh[j] = tap / 9; kw[j] = tap - 9 * (tap / 9);
+    }
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int bid = tile;
+        const int tw = bid % tiles_w; bid /= tiles_w;
+        const int th = bid % tiles_h; const int n = bid / tiles_h;
+        const int h0 = th * T9_H, w0 = tw * T9_W;
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < T9_HH * T9_WW * 4; i += 256) {
+                const int c4 = i & 3, p = i >> 2;
+                const int r = p / T9_WW, cc = p - r * T9_WW;
+                const int hh = h0 + r - 4, ww = w0 + cc - 4;
+                f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (hh >= 0 && hh < H && ww >= 0 && ww < W)
+                    v = *reinterpret_cast<const f32x4*>(x + (((long)n * H + hh) * W + ww) * 64 + ch * T9_CK + 4 * c4);
+                *reinterpret_cast<f32x4*>(&Xc[r][cc][4 * c4]) = v;
+            }
+            if (ch == 0) {
+                const int r = threadIdx.x >> 5, cc = threadIdx.x & 31;
+                Dy[r][cc] = *reinterpret_cast<const f32x4*>(dy + (((long)n * H + h0 + r) * W + w0 + cc) * 4);
+            }
+            __syncthreads();
+            for (int r = 0; r < T9_H; ++r)
+                for (int cc = 0; cc < T9_W; ++cc) {
+                    const f32x4 g = Dy[r][cc];
+#pragma unroll
+                    for (int j = 0; j < W9_TAPS; ++j) {
+                        const float xv = Xc[r + kh[j]][cc + kw[j]][ci];
+                        acc[ch][j][0] = fmaf(xv, g[0], acc[ch][j][0]); acc[ch][j][1] = fmaf(xv, g[1], acc[ch][j][1]);
+                        acc[ch][j][2] = fmaf(xv, g[2], acc[ch][j][2]); acc[ch][j][3] = fmaf(xv, g[3], acc[ch][j][3]);
+                    }
+                }
+        }
+    }
+    // partial[block][(tap*64 + c)][4]
+    float* P = part + (long)blockIdx.x * 81 * 64 * 4;
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+        for (int j = 0; j < W9_TAPS; ++j) {
+            const int tap = tl + 16 * j;
+            if (tap <= 80)
+                *reinterpret_cast<f32x4*>(P + ((long)tap * 64 + ch * T9_CK + ci) * 4) =
+                    (f32x4){acc[ch][j][0], acc[ch][j][1], acc[ch][j][2], acc[ch][j][3]};
+        }
+}
+__global__ void conv9_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int G) {
+    // dw[co][ci][tap] (OIHW, Cout=4, Cin=64) = sum_g part[g][tap*64+ci][co]
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // enumerates (tap*64+ci)*4 + co
+    if (idx >= 81 * 64 * 4) return;
+    float s0 = 0.f, s1 = 0.f;
+    int g = 0;
+    for (; g + 2 <= G; g += 2) { s0 += part[(long)g * 20736 + idx]; s1 += part[(long)(g + 1) * 20736 + idx]; }
+    if (g < G) s0 += part[(long)g * 20736 + idx];
+    const int co = idx & 3, r = idx >> 2, ci = r & 63, tap = r >> 6;
+    dw[((long)co * 64 + ci) * 81 + tap] = s0 + s1;
+}
+// x (B,H,W,64), dy (B,H,W,4) -> dw (4,64,9,9); part >= nblocks*81*64*4 floats, nblocks = min(#tiles, 256)
+TATT_API int tatt_conv9_c64_c4_wgrad(const float* x, const float* dy, float* dw, float* part, int B, int H, int W,
+                                     hipStream_t st) {
+    if (H % T9_H || W % T9_W) return 1;
+    int ntiles = B * (H / T9_H) * (W / T9_W);
+    int G = ntiles < 256 ? ntiles : 256;
+    hipLaunchKernelGGL(conv9_c64_c4_wgrad_kernel, dim3(G), dim3(256), 0, st, x, dy, part, B, H, W);
+    hipLaunchKernelGGL(conv9_wgrad_reduce_kernel, dim3(cdiv(81 * 64 * 4, 256)), dim3(256), 0, st, part, dw, G);
+    return LAUNCH_CHECK();
+}

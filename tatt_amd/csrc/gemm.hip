@@ -373,3 +373,14 @@ TATT_API int tatt_repack_conv_weight(const float* w_oihw, float* out, int Cout, 
                        KH, KW, mode);
     return LAUNCH_CHECK();
 }
+
+// Deterministic reduction of S partial (M x N) slabs: C = sum_s partial[s] (+ beta*C).  remap_cin > 0 scatters row
+// i = tap*remap_cin + ci, column j = co to the OIHW filter layout dW[co][ci][tap] (used by the specialised conv
+// weight-gradient kernels of conv3.hip).
+TATT_API int tatt_splitk_reduce(const float* partial, float* C, int M, int N, int S, int remap_cin, int remap_taps,
+                                float beta, hipStream_t st) {
+    long total = (long)M * N;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, partial, C, (const float*)nullptr,
+                       M, N, S, 1, (long)N, 1L, 0L, 0L, 1.f, beta, (int)ACT_NONE, remap_cin, remap_taps);
+    return LAUNCH_CHECK();
+}

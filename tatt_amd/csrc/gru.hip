@@ -299,6 +299,7 @@ TATT_API int tatt_qgru_bwd_gates(const float* dhseq0, const float* dhseq1, const
 }
 
 // backward step part 2:  dhcarry[d] (Wb x HID) += dgh[d] (Wb x 3HID) @ whh[d] (3HID x HID)
+// whh is passed TRANSPOSED (HID x 3HID) so that both MFMA operands are read as float4 along the contraction axis.
 struct QBwdMmP { const float* dgh[2]; const float* whh[2]; float* dhcarry[2]; int Wb, HID; };
 __global__ __launch_bounds__(256) void qgru_bwd_mm_kernel(QBwdMmP p) {
     __shared__ float red[4][16][17];
@@ -314,9 +315,7 @@ __global__ __launch_bounds__(256) void qgru_bwd_mm_kernel(QBwdMmP p) {
     const int arow = min(m0 + i, p.Wb - 1);
     for (int kb = kbeg; kb < kbeg + kspan; kb += 16) {
         const f32x4 a = *reinterpret_cast<const f32x4*>(dgh + (long)arow * K + kb + 4 * q);
-        float b[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) b[u] = whh[(long)(kb + 4 * q + u) * HID + j0 + i];
+        const f32x4 b = *reinterpret_cast<const f32x4*>(whh + (long)(j0 + i) * K + kb + 4 * q);
 #pragma unroll
         for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc, 0, 0, 0);
     }
@@ -331,10 +330,10 @@ __global__ __launch_bounds__(256) void qgru_bwd_mm_kernel(QBwdMmP p) {
     const float s = red[0][m][j] + red[1][m][j] + red[2][m][j] + red[3][m][j];
     p.dhcarry[d][(long)(m0 + m) * HID + j0 + j] += s;
 }
-TATT_API int tatt_qgru_bwd_mm(const float* dgh0, const float* dgh1, const float* whh0, const float* whh1,
+TATT_API int tatt_qgru_bwd_mm(const float* dgh0, const float* dgh1, const float* whhT0, const float* whhT1,
                               float* dhcarry0, float* dhcarry1, int Wb, int HID, hipStream_t st) {
     if ((3 * HID) % 64) return 1;
-    QBwdMmP p = {{dgh0, dgh1}, {whh0, whh1}, {dhcarry0, dhcarry1}, Wb, HID};
+    QBwdMmP p = {{dgh0, dgh1}, {whhT0, whhT1}, {dhcarry0, dhcarry1}, Wb, HID};
     hipLaunchKernelGGL(qgru_bwd_mm_kernel, dim3(cdiv(Wb, 16), HID / 16, 2), dim3(256), 0, st, p);
     return LAUNCH_CHECK();
 }

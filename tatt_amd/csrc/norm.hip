@@ -7,7 +7,7 @@
 // ---------------------------------------------------------------------------------------------
 // column sums:  out[c] (+)= scale * sum_m X[m*ld + c]      (two stages, deterministic)
 // ---------------------------------------------------------------------------------------------
-#define CS_MAXG 128   // stage-1 blocks (partials per column)
+#define CS_MAXG 256   // stage-1 blocks (partials per column)
 
 // stage 1: block g sums rows [g*rpb, (g+1)*rpb); thread = (channel lane tx = t&63, row lane ty = t>>6)
 template <typename T>
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void colsum_stage2(const double* __restrict__ 
     }
 }
 static inline int cs_groups(int M) { int g = cdiv(M, 64); return g > CS_MAXG ? CS_MAXG : (g < 1 ? 1 : g); }
-// ws: min(ceil(M/64),128)*C doubles
+// ws: min(ceil(M/64),256)*C doubles
 TATT_API int tatt_colsum(const float* X, long ld, int M, int C, float* out, float scale, float beta,
                          double* ws, hipStream_t st) {
     int G = cs_groups(M);

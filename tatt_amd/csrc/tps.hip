@@ -21,20 +21,20 @@ __global__ __launch_bounds__(256) void tps_grid_fwd_kernel(const float* __restri
     __syncthreads();
     if (t < NP * 2) {
         int j = t >> 1, d = t & 1;
-        float s = 0.f;
-        for (int i = 0; i < NP; ++i) s = fmaf(inv[j * NP + i], Y[i][d], s);
-        Mp[j][d] = s;
+        double s = 0.0;          // the kernel inverse has large cancelling entries: accumulate in fp64
+        for (int i = 0; i < NP; ++i) s += (double)inv[j * NP + i] * (double)Y[i][d];
+        Mp[j][d] = (float)s;
     }
     __syncthreads();
     const int p = blockIdx.x * blockDim.x + t;
     if (p >= P) return;
-    float sx = 0.f, sy = 0.f;
+    double sx = 0.0, sy = 0.0;
     for (int j = 0; j < NP; ++j) {
-        float r = repr[(long)p * NP + j];
-        sx = fmaf(r, Mp[j][0], sx); sy = fmaf(r, Mp[j][1], sy);
+        double r = (double)repr[(long)p * NP + j];
+        sx += r * (double)Mp[j][0]; sy += r * (double)Mp[j][1];
     }
-    src[((long)b * P + p) * 2] = sx;
-    src[((long)b * P + p) * 2 + 1] = sy;
+    src[((long)b * P + p) * 2] = (float)sx;
+    src[((long)b * P + p) * 2 + 1] = (float)sy;
 }
 TATT_API int tatt_tps_grid_fwd(const float* ctrl, const float* inv, const float* pad, const float* repr, float* src,
                                int B, int N, int P, hipStream_t st) {

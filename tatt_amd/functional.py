@@ -440,6 +440,11 @@ class QueryGruFn(Function):
         dgh = ops.new(dev, 2, B, W, 3 * HID)
         dgi_acc = ops.new(dev, 2, W, 3 * HID)
         dhc = ops.new(dev, 2, W, HID)
+        whhT = []
+        for whh in (whh0, whh1):                     # (3*HID, HID) -> (HID, 3*HID) once per backward
+            tT = ops.new(dev, HID, 3 * HID)
+            ops.copy4d(whh, tT, (1, 1, HID, 3 * HID), (0, 0, 1, HID), (0, 0, 3 * HID, 1))
+            whhT.append(tT)
         for s in range(B):
             t0, t1 = B - 1 - s, s            # reverse of the forward order in each direction
             hp0 = hseq[0, t0 - 1] if t0 > 0 else None
@@ -448,7 +453,7 @@ class QueryGruFn(Function):
                      ops.P(gsave[1, t1]), ops.P(hp0), ops.P(hp1), ops.P(dhc[0]), ops.P(dhc[1]), ops.P(dgi_acc[0]),
                      ops.P(dgi_acc[1]), ops.P(dgh[0, t0]), ops.P(dgh[1, t1]), W, HID, int(s == 0), ops.stream())
             if s < B - 1:
-                ops.call("tatt_qgru_bwd_mm", ops.P(dgh[0, t0]), ops.P(dgh[1, t1]), ops.P(whh0), ops.P(whh1),
+                ops.call("tatt_qgru_bwd_mm", ops.P(dgh[0, t0]), ops.P(dgh[1, t1]), ops.P(whhT[0]), ops.P(whhT[1]),
                          ops.P(dhc[0]), ops.P(dhc[1]), W, HID, ops.stream())
         grads = []
         dx = ops.new(dev, W, IN)

@@ -118,7 +118,7 @@ def colsum(x2, *, out=None, scale=1.0, beta=0.0):
     _check_dev(x2)
     M, C = x2.shape
     out = out if out is not None else new(x2, C)
-    ws = new(x2, 128 * C, dtype=torch.float64)
+    ws = new(x2, 256 * C, dtype=torch.float64)
     call("tatt_colsum", P(x2), x2.stride(0), M, C, P(out), scale, beta, P(ws), stream())
     return out
 
@@ -134,10 +134,21 @@ def repack_weight(w_oihw, mode):
 
 
 def conv_fwd(x_bhwc, wpacked, bias, Cout, KH, KW, *, act=ACT_NONE, out=None, beta=0.0):
+    """Stride-1 'same' convolution; dispatches to the specialised kernels where the shape allows:
+    3x3 with Cin, Cout, W multiples of 64 (LDS-halo MFMA kernel), 9x9 64k->4 (vector-ALU kernel), else the generic
+    implicit-GEMM MFMA kernel."""
     _check_dev(x_bhwc)
     B, H, W, Cin = x_bhwc.shape
     sn, sh, sw, sc = x_bhwc.stride()
     y = out if out is not None else new(x_bhwc, B, H, W, Cout)
+    contig = x_bhwc.is_contiguous()
+    if contig and KH == 3 and KW == 3 and Cin % 64 == 0 and Cout % 64 == 0 and W % 64 == 0:
+        call("tatt_conv3_c64_fwd", P(x_bhwc), P(wpacked), P(bias), P(y), B, H, W, Cin, Cout, act, beta, stream())
+        return y
+    if contig and KH == 9 and KW == 9 and Cout == 4 and Cin % 16 == 0 and H % 8 == 0 and W % 32 == 0 \
+            and act == ACT_NONE and beta == 0.0:
+        call("tatt_conv9_c64_to_c4", P(x_bhwc), P(wpacked), P(bias), P(y), B, H, W, Cin, stream())
+        return y
     call("tatt_conv2d_fwd", P(x_bhwc), sn, sh, sw, sc, P(wpacked), P(bias), P(y), Cout, B, H, W, Cin, Cout, KH, KW,
          act, beta, stream())
     return y
@@ -147,6 +158,19 @@ def conv_wgrad(x_bhwc, dy_bhwc, Cout, KH, KW):
     B, H, W, Cin = x_bhwc.shape
     sn, sh, sw, sc = x_bhwc.stride()
     dw = new(x_bhwc, Cout, Cin, KH, KW)
+    contig = x_bhwc.is_contiguous() and dy_bhwc.is_contiguous()
+    if contig and KH == 3 and KW == 3 and Cin % 64 == 0 and Cout % 64 == 0 and W % 64 == 0:
+        nseg = B * H * (W // 64)
+        G = min(nseg, max(1, 256 // ((Cin // 64) * (Cout // 64))))
+        part = new(x_bhwc, G * 9 * Cin * Cout)
+        call("tatt_conv3_c64_wgrad_partial", P(x_bhwc), P(dy_bhwc), P(part), B, H, W, Cin, Cout, G, stream())
+        call("tatt_splitk_reduce", P(part), P(dw), 9 * Cin, Cout, G, Cin, 9, 0.0, stream())
+        return dw
+    if contig and KH == 9 and KW == 9 and Cout == 4 and Cin == 64 and H % 8 == 0 and W % 32 == 0:
+        G = min(B * (H // 8) * (W // 32), 256)
+        part = new(x_bhwc, G * 81 * 64 * 4)
+        call("tatt_conv9_c64_c4_wgrad", P(x_bhwc), P(dy_bhwc), P(dw), P(part), B, H, W, stream())
+        return dw
     Mo, Kred = KH * KW * Cin, B * H * W
     splitk = max(2, _auto_split(Mo, Cout, Kred))
     ws = new(x_bhwc, (splitk + 1) * Mo * Cout)
@@ -161,7 +185,7 @@ def conv_wgrad(x_bhwc, dy_bhwc, Cout, KH, KW):
 def bn_stats(x2, eps, momentum, running_mean, running_var):
     M, C = x2.shape
     mean, rstd = new(x2, C), new(x2, C)
-    ws = new(x2, 128 * 2 * C, dtype=torch.float64)
+    ws = new(x2, 256 * 2 * C, dtype=torch.float64)
     call("tatt_bn_stats", P(x2), x2.stride(0), M, C, eps, momentum, P(mean), P(rstd), P(running_mean), P(running_var),
          P(ws), stream())
     return mean, rstd
@@ -184,7 +208,7 @@ def bn_bwd(x2, dy2, mean, rstd, gamma, beta, act, training):
     M, C = x2.shape
     dx = new(x2, M, C)
     dgamma, dbeta, sums = new(x2, C), new(x2, C), new(x2, 2 * C)
-    ws = new(x2, 128 * 2 * C, dtype=torch.float64)
+    ws = new(x2, 256 * 2 * C, dtype=torch.float64)
     call("tatt_bn_bwd", P(x2), x2.stride(0), P(dy2), dy2.stride(0), P(dx), C, M, C, P(mean), P(rstd), P(gamma), P(beta),
          act, int(training), P(dgamma), P(dbeta), P(sums), P(ws), stream())
     return dx, dgamma, dbeta
@@ -202,7 +226,7 @@ def ln_bwd(a2, b2, dy2, stats, gamma):
     dx, dgamma, dbeta = new(a2, M, C), new(a2, C), new(a2, C)
     G = cdiv(M, 64)
     part = new(a2, G * 2 * C)
-    ws = new(a2, 128 * 2 * C, dtype=torch.float64)
+    ws = new(a2, 256 * 2 * C, dtype=torch.float64)
     call("tatt_ln_bwd", P(a2), P(b2), P(dy2), P(stats), P(dx), M, C, P(gamma), P(dgamma), P(dbeta), P(part), P(ws),
          stream())
     return dx, dgamma, dbeta

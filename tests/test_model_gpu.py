@@ -108,7 +108,7 @@ def _train_case(dev, cls, tatt, B, golden):
     print("worst relative gradient error vs oracle: %s %.3e" % worst)
     assert worst[1] < 1e-2, worst
     # ---- against the reference-generated golden vector ----
-    assert max_err(sr, torch.from_numpy(z["sr"])) < 3e-4
+    assert max_err(sr, torch.from_numpy(z["sr"])) < SR_TOL        # stated tolerance; STN conditioning, see DESIGN.md 2
     assert abs(float(loss) - float(z["loss"])) < 1e-4 * abs(float(z["loss"]))
     gsum = dict(zip(list(z["grad_keys"]), z["grad_summary"]))
     params = dict(m.named_parameters())
@@ -140,6 +140,32 @@ def test_tatt_train_step_grads(dev):
 
 def test_tsrn_train_step_grads(dev):
     _train_case(dev, "TSRN", False, 3, "tsrn_train_b3")
+
+
+def test_train_step_without_stn_is_tight(dev):
+    """Without the (ill-conditioned) STN/TPS front end the train-mode forward/backward agrees with the oracle to fp32
+    round-off: SR to 2e-5, every gradient to 2e-3 relative."""
+    from tatt_amd.train import image_loss
+    kw = dict(STD, STN=False)
+    m = build("TSRN_TL_TRANS", dev, **kw).train()
+    m.infoGen.dropout_on = False
+    sd0 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    x, tp, hr = make_inputs(3, seed=5)
+    sr, mid = m(x.to(dev), tp.to(dev))
+    loss = image_loss(sr, hr.to(dev)).mean() * 100
+    loss.backward()
+    o_loss, o_grads, _, _, o_out, _ = O.train_step(sd0, x, tp, hr, tatt=True, stn=False)
+    assert max_err(sr, o_out["sr"]) < 2e-5, max_err(sr, o_out["sr"])
+    assert max_err(mid["trans_feat"], o_out["tp_map"]) < 2e-5
+    assert max_err(mid["pr_weights"], o_out["pr_weights"]) < 1e-6
+    worst = ("", 0.0)
+    for k, p in m.named_parameters():
+        og = o_grads[k]
+        if og is None or float(og.norm()) < 1e-6 * og.numel() ** 0.5:
+            continue
+        r = float((p.grad.cpu() - og).norm() / og.norm())
+        worst = max(worst, (k, r), key=lambda t: t[1])
+    assert worst[1] < 2e-3, worst
 
 
 def test_optimizer_step_matches_oracle(dev):
