@@ -39,11 +39,12 @@ int tatt_gemm(const float* A, long sam, long sak, const float* A2, long sa2m, lo
 
 /* y[pixel*ldy + co] = act(conv(x, w) + bias) + beta*y; stride 1, 'same' padding; x[n*xsn + h*xsh + w*xsw + c*xsc];
  * wpacked = [KH][KW][Cin][Cout] from tatt_repack_conv_weight.  Also computes the data gradient when given
- * dY as x and the mode-1 packed filter.  Replaces nn.Conv2d (model/tsrn.py:597,612,877,885,1043,623;
+ * dY as x and the mode-1 packed filter.  splitk > 1 (ws >= splitk*Bn*H*W*Cout floats) for small-M / deep-K shapes.
+ * Replaces nn.Conv2d (model/tsrn.py:597,612,877,885,1043,623;
  * model/stn_head.py:15). */
 int tatt_conv2d_fwd(const float* x, long xsn, long xsh, long xsw, long xsc, const float* wpacked,
                     const float* bias, float* y, long ldy, int Bn, int H, int W, int Cin, int Cout,
-                    int KH, int KW, int act, float beta, hipStream_t st);
+                    int KH, int KW, int act, float beta, int splitk, float* ws, hipStream_t st);
 
 /* dw_oihw[co][ci][kh][kw] = sum_pixels x[pixel+(kh,kw)][ci] * dy[pixel*lddy + co] + beta*dw; ws >= splitk*KH*KW*Cin*Cout floats */
 int tatt_conv2d_wgrad(const float* x, long xsn, long xsh, long xsw, long xsc, const float* dy,

@@ -71,3 +71,26 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+
+// ---- latency-tolerant strided sums ------------------------------------------------------------------------------
+// The reduction kernels run at low occupancy, so a naive `for (...) s += p[i*stride]` serialises on load latency
+// (~1 us per dependent L2 round trip).  U independent loads are issued per trip instead.
+template <typename T, int U>
+__device__ __forceinline__ double sum_strided(const T* __restrict__ p, int n, long stride) {
+    double acc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc[u] = 0.0;
+    int i = 0;
+    for (; i + U <= n; i += U) {
+        T v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = p[(long)(i + u) * stride];
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] += (double)v[u];
+    }
+    for (; i < n; ++i) acc[0] += (double)p[(long)i * stride];
+    double s = 0.0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) s += acc[u];
+    return s;
+}

@@ -204,26 +204,37 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmP p) {
 // Deterministic split-K reduction + epilogue.  remap_cin > 0: the (i,j) result of a conv
 // weight-gradient GEMM (i = (tap,ci), j = co) is scattered to the reference's OIHW layout
 // dW[co][ci][tap]  (reference nn.Conv2d weight layout, model/tsrn.py:597).
-__global__ void splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ C,
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ C,
                                      const float* __restrict__ bias, int M, int N, int S, int Z,
                                      long scm, long scn, long bsC, long bsBias, float alpha, float beta,
                                      int act, int remap_cin, int remap_taps) {
-    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    long total = (long)Z * M * N;
-    if (idx >= total) return;
-    int j = idx % N;
-    long rest = idx / N;
-    int i = rest % M;
-    int z = rest / M;
-    const float* pp = partial + ((long)z * S * M + i) * N + j;
-    const long step = (long)M * N;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int k = 0;
-    for (; k + 4 <= S; k += 4) {
-        s0 += pp[(long)k * step]; s1 += pp[(long)(k + 1) * step]; s2 += pp[(long)(k + 2) * step]; s3 += pp[(long)(k + 3) * step];
+    __shared__ float sh[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;       // 64 outputs x 4 slab lanes per block
+    const long idx = (long)blockIdx.x * 64 + tx;
+    const long total = (long)Z * M * N;
+    const bool ok = idx < total;
+    int j = 0, i = 0, z = 0;
+    float s = 0.f;
+    if (ok) {
+        j = idx % N;
+        long rest = idx / N;
+        i = rest % M;
+        z = rest / M;
+        const long step = (long)M * N;
+        const float* pp = partial + ((long)z * S * M + i) * N + j;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int k = ty;
+        for (; k + 12 < S; k += 16) {
+            float v0 = pp[(long)k * step], v1 = pp[(long)(k + 4) * step], v2 = pp[(long)(k + 8) * step], v3 = pp[(long)(k + 12) * step];
+            a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+        }
+        for (; k < S; k += 4) a0 += pp[(long)k * step];
+        s = (a0 + a1) + (a2 + a3);
     }
-    for (; k < S; ++k) s0 += pp[(long)k * step];
-    float s = (s0 + s1) + (s2 + s3);
+    sh[ty][tx] = s;
+    __syncthreads();
+    if (ty != 0 || !ok) return;
+    s = (sh[0][tx] + sh[1][tx]) + (sh[2][tx] + sh[3][tx]);
     float bj = bias ? bias[(long)z * bsBias + j] : 0.f;
     float v = apply_act(alpha * (s + bj), act);
     long off;
@@ -264,7 +275,7 @@ static int launch_gemm(const GemmP& p, int Z, bool ak, bool bk, hipStream_t st) 
 
 static int finish_splitk(const GemmP& p, int Z, int remap_cin, int remap_taps, hipStream_t st) {
     long total = (long)Z * p.M * p.N;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, p.partial, p.C, p.bias,
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(total, 64)), dim3(256), 0, st, p.partial, p.C, p.bias,
                        p.M, p.N, p.splitk, Z, p.scm, p.scn, p.bsC, p.bsBias, p.alpha, p.beta, p.act,
                        remap_cin, remap_taps);
     return LAUNCH_CHECK();
@@ -319,15 +330,18 @@ static void fill_conv(GemmP& p, int H, int W, int Cin, int KH, int KW, long xsn,
 // Replaces nn.Conv2d (reference model/tsrn.py:597,612,877,885,1043; model/stn_head.py:15).
 TATT_API int tatt_conv2d_fwd(const float* x, long xsn, long xsh, long xsw, long xsc, const float* wpacked,
                              const float* bias, float* y, long ldy, int Bn, int H, int W, int Cin, int Cout,
-                             int KH, int KW, int act, float beta, hipStream_t st) {
+                             int KH, int KW, int act, float beta, int splitk, float* ws, hipStream_t st) {
     GemmP p = {};
     p.A = x; p.B = wpacked; p.bias = bias; p.C = y;
     p.M = Bn * H * W; p.N = Cout; p.K = KH * KW * Cin;
     p.sbk = Cout; p.sbn = 1; p.scm = ldy; p.scn = 1;
     p.alpha = 1.f; p.beta = beta; p.act = act;
     fill_conv(p, H, W, Cin, KH, KW, xsn, xsh, xsw, xsc);
-    set_split(p, 1, nullptr);
-    return launch_gemm<3>(p, 1, true, false, st);
+    set_split(p, splitk, ws);        // split-K (ws >= splitk*Bn*H*W*Cout floats) spreads small-M / deep-K convs (STN tail) over the CUs
+    int rc = launch_gemm<3>(p, 1, true, false, st);
+    if (rc) return rc;
+    if (p.splitk > 1) return finish_splitk(p, 1, 0, 0, st);
+    return 0;
 }
 
 // Convolution weight gradient: dW[co][ci][kh][kw] (OIHW, the reference parameter layout)
@@ -380,7 +394,7 @@ TATT_API int tatt_repack_conv_weight(const float* w_oihw, float* out, int Cout, 
 TATT_API int tatt_splitk_reduce(const float* partial, float* C, int M, int N, int S, int remap_cin, int remap_taps,
                                 float beta, hipStream_t st) {
     long total = (long)M * N;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, partial, C, (const float*)nullptr,
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(total, 64)), dim3(256), 0, st, partial, C, (const float*)nullptr,
                        M, N, S, 1, (long)N, 1L, 0L, 0L, 1.f, beta, (int)ACT_NONE, remap_cin, remap_taps);
     return LAUNCH_CHECK();
 }

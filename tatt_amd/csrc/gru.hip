@@ -115,16 +115,25 @@ __global__ __launch_bounds__(256) void gru32_bwd_kernel(const float* __restrict_
     const float br = bhh[j], bz = bhh[32 + j], bn = bhh[64 + j];
     const long base = valid ? seq_base(g, seq) : 0;
     float dhc = 0.f;   // gradient carried to h_{t-1}
-    for (int step = g.T - 1; step >= 0; --step) {
+    // software prefetch: the loads of step s-1 (h_{t-2}, gi, dout) do not depend on step s's arithmetic
+    auto fetch = [&](int step, float& hp, float& gr, float& gz, float& gn, float& go) {
+        hp = gr = gz = gn = go = 0.f;
+        if (!valid || step < 0) return;
         const int ti = dir ? g.T - 1 - step : step;
         const long tok = base + (long)ti * g.stride_t;
         const long ptok = tok + (dir ? g.stride_t : -g.stride_t);     // token of forward-step (step-1)
-        float hp = 0.f, gr = 0.f, gz = 0.f, gn = 0.f, dh = dhc;
-        if (valid) {
-            if (step > 0) hp = out[ptok * 64 + dir * 32 + j];
-            gr = gi[tok * 192 + dir * 96 + j]; gz = gi[tok * 192 + dir * 96 + 32 + j]; gn = gi[tok * 192 + dir * 96 + 64 + j];
-            dh += dout[tok * 64 + dir * 32 + j];
-        }
+        if (step > 0) hp = out[ptok * 64 + dir * 32 + j];
+        gr = gi[tok * 192 + dir * 96 + j]; gz = gi[tok * 192 + dir * 96 + 32 + j]; gn = gi[tok * 192 + dir * 96 + 64 + j];
+        go = dout[tok * 64 + dir * 32 + j];
+    };
+    float n_hp, n_gr, n_gz, n_gn, n_go;
+    fetch(g.T - 1, n_hp, n_gr, n_gz, n_gn, n_go);
+    for (int step = g.T - 1; step >= 0; --step) {
+        const int ti = dir ? g.T - 1 - step : step;
+        const long tok = base + (long)ti * g.stride_t;
+        const float hp = n_hp, gr = n_gr, gz = n_gz, gn = n_gn;
+        const float dh = dhc + n_go;
+        fetch(step - 1, n_hp, n_gr, n_gz, n_gn, n_go);
         hs[grp][j] = hp;
         __syncthreads();
         float ar = br, az = bz, an = bn;

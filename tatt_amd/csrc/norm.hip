@@ -19,13 +19,10 @@ __global__ __launch_bounds__(256) void colsum_stage1(const T* __restrict__ X, lo
     const int m_end = min(M, m_begin + rpb);
     for (int c0 = 0; c0 < C; c0 += 64) {
         const int c = c0 + tx;
-        double s0 = 0.0, s1 = 0.0;
-        if (c < C) {
-            int m = m_begin + ty;
-            for (; m + 4 < m_end; m += 8) { s0 += (double)X[(long)m * ld + c]; s1 += (double)X[(long)(m + 4) * ld + c]; }
-            if (m < m_end) s0 += (double)X[(long)m * ld + c];
-        }
-        sh[ty][tx] = s0 + s1;
+        double s0 = 0.0;
+        if (c < C && m_begin + ty < m_end)
+            s0 = sum_strided<T, 8>(X + (long)(m_begin + ty) * ld + c, (m_end - m_begin - ty + 3) / 4, 4 * ld);
+        sh[ty][tx] = s0;
         __syncthreads();
         if (ty == 0 && c < C) part[(long)blockIdx.x * C + c] = (sh[0][tx] + sh[1][tx]) + (sh[2][tx] + sh[3][tx]);
         __syncthreads();
@@ -38,7 +35,7 @@ __global__ __launch_bounds__(256) void colsum_stage2(const double* __restrict__ 
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + tx;
     double s = 0.0;
-    if (c < C) for (int g = ty; g < G; g += 4) s += part[(long)g * ldp + c];
+    if (c < C && ty < G) s = sum_strided<double, 8>(part + (long)ty * ldp + c, (G - ty + 3) / 4, 4 * ldp);
     sh[ty][tx] = s;
     __syncthreads();
     if (ty == 0 && c < C) {
@@ -73,11 +70,16 @@ __global__ void bn_stats_stage1(const float* __restrict__ X, long ld, int M, int
     for (int c0 = 0; c0 < C; c0 += cpb) {
         const int c = c0 + cl;
         double s = 0.0, q = 0.0;
-        if (rl < rpar && c < C)
-            for (int m = m_begin + rl; m < m_end; m += rpar) {
-                double v = (double)X[(long)m * ld + c];
-                s += v; q += v * v;
+        if (rl < rpar && c < C) {
+            int m = m_begin + rl;
+            for (; m + 3 * rpar < m_end; m += 4 * rpar) {
+                float v0 = X[(long)m * ld + c], v1 = X[(long)(m + rpar) * ld + c];
+                float v2 = X[(long)(m + 2 * rpar) * ld + c], v3 = X[(long)(m + 3 * rpar) * ld + c];
+                s += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+                q += ((double)v0 * v0 + (double)v1 * v1) + ((double)v2 * v2 + (double)v3 * v3);
             }
+            for (; m < m_end; m += rpar) { double v = (double)X[(long)m * ld + c]; s += v; q += v * v; }
+        }
         sh[0][t] = s; sh[1][t] = q;
         __syncthreads();
         if (t < cpb && c < C) {
@@ -97,7 +99,10 @@ __global__ void bn_stats_stage2(const double* __restrict__ part, int G, int C, i
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + tx;
     double s = 0.0, q = 0.0;
-    if (c < C) for (int g = ty; g < G; g += 4) { s += part[((long)g * 2 + 0) * C + c]; q += part[((long)g * 2 + 1) * C + c]; }
+    if (c < C && ty < G) {
+        s = sum_strided<double, 8>(part + ((long)ty * 2 + 0) * C + c, (G - ty + 3) / 4, (long)8 * C);
+        q = sum_strided<double, 8>(part + ((long)ty * 2 + 1) * C + c, (G - ty + 3) / 4, (long)8 * C);
+    }
     sh[0][ty][tx] = s; sh[1][ty][tx] = q;
     __syncthreads();
     if (ty != 0 || c >= C) return;
@@ -171,7 +176,20 @@ __global__ void bn_bwd_stage1(const float* __restrict__ X, long ldx, const float
         double s = 0.0, q = 0.0;
         if (rl < rpar && c < C) {
             const float mu = mean[c], rs = rstd[c], g = gamma[c], b = beta[c];
-            for (int m = m_begin + rl; m < m_end; m += rpar) {
+            int m = m_begin + rl;
+            for (; m + 3 * rpar < m_end; m += 4 * rpar) {
+                float xv[4], dv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { xv[u] = X[(long)(m + u * rpar) * ldx + c]; dv[u] = dY[(long)(m + u * rpar) * lddy + c]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float xh = (xv[u] - mu) * rs;
+                    float du = dv[u];
+                    if (act != ACT_NONE) du *= act_grad(g * xh + b, act);
+                    s += (double)du; q += (double)du * xh;
+                }
+            }
+            for (; m < m_end; m += rpar) {
                 float xh = (X[(long)m * ldx + c] - mu) * rs;
                 float du = dY[(long)m * lddy + c];
                 if (act != ACT_NONE) du *= act_grad(g * xh + b, act);
@@ -195,7 +213,10 @@ __global__ void bn_bwd_stage2(const double* __restrict__ part, int G, int C, flo
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + tx;
     double s = 0.0, q = 0.0;
-    if (c < C) for (int g = ty; g < G; g += 4) { s += part[((long)g * 2 + 0) * C + c]; q += part[((long)g * 2 + 1) * C + c]; }
+    if (c < C && ty < G) {
+        s = sum_strided<double, 8>(part + ((long)ty * 2 + 0) * C + c, (G - ty + 3) / 4, (long)8 * C);
+        q = sum_strided<double, 8>(part + ((long)ty * 2 + 1) * C + c, (G - ty + 3) / 4, (long)8 * C);
+    }
     sh[0][ty][tx] = s; sh[1][ty][tx] = q;
     __syncthreads();
     if (ty != 0 || c >= C) return;

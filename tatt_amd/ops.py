@@ -70,7 +70,7 @@ def gemm(A, sam, sak, B, sbk, sbn, C, scm, scn, M, N, K, *, A2=None, sa2m=0, sa2
 def _auto_split(M_out, N_out, Kred):
     tiles = cdiv(M_out, 64) * cdiv(N_out, 64)
     nchunks = cdiv(Kred, 16)
-    want = max(1, 512 // tiles)
+    want = max(1, min(128, 512 // tiles))
     return max(1, min(want, nchunks // 8 if nchunks >= 16 else 1))
 
 
@@ -149,8 +149,15 @@ def conv_fwd(x_bhwc, wpacked, bias, Cout, KH, KW, *, act=ACT_NONE, out=None, bet
             and act == ACT_NONE and beta == 0.0:
         call("tatt_conv9_c64_to_c4", P(x_bhwc), P(wpacked), P(bias), P(y), B, H, W, Cin, stream())
         return y
+    M, K = B * H * W, KH * KW * Cin
+    tiles, nchunks = cdiv(M, 64) * cdiv(Cout, 64), cdiv(K, 16)
+    splitk, ws = 1, None
+    if tiles < 128 and nchunks >= 32:
+        splitk = max(1, min(256 // tiles, nchunks // 8))
+        if splitk > 1:
+            ws = new(x_bhwc, splitk * M * Cout)
     call("tatt_conv2d_fwd", P(x_bhwc), sn, sh, sw, sc, P(wpacked), P(bias), P(y), Cout, B, H, W, Cin, Cout, KH, KW,
-         act, beta, stream())
+         act, beta, splitk, P(ws), stream())
     return y
 
 

@@ -55,3 +55,33 @@ def compare_fn(name, hip_fn, ref_fn, inputs, dev, grad_mask=None, rtol=2e-4, ato
             if m:
                 assert g.grad is not None, "%s: no grad for input %d" % (name, k)
                 check_close("%s.grad%d" % (name, k), g.grad, c.grad, grtol, gatol * max(1.0, float(c.grad.abs().max())))
+
+
+import re
+
+# conv biases that feed a BatchNorm (train mode): their gradient is mathematically zero -- whatever an implementation
+# returns is round-off noise (and Adam's first step turns that noise into +-lr).  Compared as "both negligible".
+STRUCTURAL_ZERO_GRAD = re.compile(r"^(block[2-6]\.conv[12]\.bias|block7\.0\.bias|stn_head\.stn_convnet\.\d+\.0\.bias|"
+                                  r"stn_head\.stn_fc1\.0\.bias)$")
+
+
+def compare_param_grads(named_params, oracle_grads, rtol, rtol_stn=None):
+    """-> (worst key, worst relative error); asserts structure (None grads, structural zeros)."""
+    scale = max(float(g.abs().max()) for g in oracle_grads.values() if g is not None)
+    worst = ("", 0.0)
+    for k, p in named_params:
+        og = oracle_grads[k]
+        if og is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        assert p.grad is not None, k
+        pg = p.grad.detach().cpu()
+        if STRUCTURAL_ZERO_GRAD.match(k):
+            assert float(pg.abs().max()) < 1e-4 * scale and float(og.abs().max()) < 1e-4 * scale, k
+            continue
+        r = float((pg - og).norm() / (og.norm() + 1e-7 * scale * og.numel() ** 0.5))
+        lim = rtol_stn if (rtol_stn is not None and k.startswith("stn_head")) else rtol
+        assert r < lim, (k, r, lim)
+        if r > worst[1]:
+            worst = (k, r)
+    return worst
