@@ -12,7 +12,7 @@ __global__ __launch_bounds__(256) void tps_grid_fwd_kernel(const float* __restri
                                                            const float* __restrict__ pad, const float* __restrict__ repr,
                                                            float* __restrict__ src, int N, int P) {
     __shared__ float Y[TPS_MAXNP][2];
-    __shared__ float Mp[TPS_MAXNP][2];
+    __shared__ double Mp[TPS_MAXNP][2];
     const int NP = N + 3, b = blockIdx.y, t = threadIdx.x;
     if (t < NP * 2) {
         int i = t >> 1, d = t & 1;
@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void tps_grid_fwd_kernel(const float* __restri
         int j = t >> 1, d = t & 1;
         double s = 0.0;          // the kernel inverse has large cancelling entries: accumulate in fp64
         for (int i = 0; i < NP; ++i) s += (double)inv[j * NP + i] * (double)Y[i][d];
-        Mp[j][d] = (float)s;
+        Mp[j][d] = s;
     }
     __syncthreads();
     const int p = blockIdx.x * blockDim.x + t;
@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void tps_grid_fwd_kernel(const float* __restri
     double sx = 0.0, sy = 0.0;
     for (int j = 0; j < NP; ++j) {
         double r = (double)repr[(long)p * NP + j];
-        sx += r * (double)Mp[j][0]; sy += r * (double)Mp[j][1];
+        sx += r * Mp[j][0]; sy += r * Mp[j][1];
     }
     src[((long)b * P + p) * 2] = (float)sx;
     src[((long)b * P + p) * 2 + 1] = (float)sy;

@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""GPU-box micro-benchmark of the individual hot kernels at the benchmark shapes (B=48, 16x64 LR), timed with HIP events on
+the launch stream.  Prints one line per kernel: average microseconds, achieved TFLOP/s or GB/s.  `--only name` restricts to
+one kernel (for rocprofv3 --pmc runs)."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tatt_amd import ops  # noqa: E402
+from tatt_amd.build import build  # noqa: E402
+
+build(verbose=False)
+ap = argparse.ArgumentParser()
+ap.add_argument("--only", default="")
+ap.add_argument("--iters", type=int, default=30)
+ap.add_argument("--batch", type=int, default=48)
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+B = a.batch
+
+
+def timeit(name, fn, flops=0.0, bytes_=0.0, iters=None):
+    if a.only and a.only != name:
+        return
+    iters = iters or a.iters
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / iters * 1e3
+    extra = ""
+    if flops:
+        extra += "  %7.1f TFLOP/s" % (flops / us / 1e6)
+    if bytes_:
+        extra += "  %7.1f GB/s" % (bytes_ / us / 1e3)
+    print("%-28s %9.1f us%s" % (name, us, extra), flush=True)
+
+
+R = lambda *s: torch.randn(*s, device=dev)  # noqa: E731
+M = B * 1024
+
+# ---- convolutions ----
+x64 = R(B, 16, 64, 64)
+w33 = R(64, 64, 3, 3) * 0.05
+b64 = R(64)
+wp = ops.repack_weight(w33, 0)
+y64 = torch.empty_like(x64)
+f33 = 2.0 * M * 576 * 64
+timeit("conv3_fwd_64_64", lambda: ops.conv_fwd(x64, wp, b64, 64, 3, 3, out=y64), f33)
+timeit("conv3_wgrad_64_64", lambda: ops.conv_wgrad(x64, y64, 64, 3, 3), f33)
+xs = x64.permute(0, 3, 1, 2).contiguous().permute(0, 2, 3, 1)       # strided view -> generic implicit-GEMM kernel
+timeit("conv3_generic_64_64", lambda: ops.conv_fwd(xs, wp, b64, 64, 3, 3, out=y64), f33)
+w256 = R(256, 64, 3, 3) * 0.05
+wp256 = ops.repack_weight(w256, 0)
+y256 = torch.empty(B, 16, 64, 256, device=dev)
+timeit("conv3_fwd_64_256", lambda: ops.conv_fwd(x64, wp256, None, 256, 3, 3, out=y256), 4 * f33)
+wd256 = ops.repack_weight(w256, 1)
+timeit("conv3_dgrad_256_64", lambda: ops.conv_fwd(y256, wd256, None, 64, 3, 3, out=y64), 4 * f33)
+timeit("conv3_wgrad_64_256", lambda: ops.conv_wgrad(x64, y256, 256, 3, 3), 4 * f33)
+xhr = R(B, 32, 128, 64)
+w99 = R(4, 64, 9, 9) * 0.02
+wp99 = ops.repack_weight(w99, 0)
+yhr = torch.empty(B, 32, 128, 4, device=dev)
+f99 = 2.0 * B * 4096 * 5184 * 4
+timeit("conv9_fwd_64_4_hr", lambda: ops.conv_fwd(xhr, wp99, None, 4, 9, 9, out=yhr), f99)
+timeit("conv9_wgrad_64_4_hr", lambda: ops.conv_wgrad(xhr, yhr, 4, 9, 9), f99)
+wd99 = ops.repack_weight(w99, 1)       # [81][4][64]: dgrad 4 -> 64 (generic kernel)
+timeit("conv9_dgrad_4_64_hr", lambda: ops.conv_fwd(yhr, wd99, None, 64, 9, 9, out=xhr), f99)
+x4 = R(B, 16, 64, 4)
+w1 = R(64, 4, 9, 9) * 0.05
+wp1 = ops.repack_weight(w1, 0)
+timeit("conv9_fwd_4_64_lr", lambda: ops.conv_fwd(x4, wp1, b64, 64, 9, 9, out=y64), 2.0 * M * 324 * 64)
+timeit("conv9_wgrad_4_64_lr", lambda: ops.conv_wgrad(x4, y64, 64, 9, 9), 2.0 * M * 324 * 64)
+
+# ---- token GEMMs (M = B*1024 tokens) ----
+t64, t128, t192 = R(M, 64), R(M, 64), R(M, 192)
+W64, W192, W128 = R(64, 64), R(192, 64), R(64, 128)
+o64, o192 = torch.empty(M, 64, device=dev), torch.empty(M, 192, device=dev)
+timeit("linear_fwd_64_64", lambda: ops.linear_fwd(t64, W64, b64, out=o64), 2.0 * M * 64 * 64, M * 128 * 4)
+timeit("linear_fwd_64_96x2", lambda: ops.linear_fwd(t64, W192, None, out=o192), 2.0 * M * 64 * 192, M * 256 * 4)
+timeit("linear_fwd_cat128_64", lambda: ops.linear_fwd(t64, W128, b64, x2b=t128, out=o64), 2.0 * M * 128 * 64, M * 192 * 4)
+timeit("linear_bwd_input_192_64", lambda: ops.linear_bwd_input(t192, W192, out=o64), 2.0 * M * 192 * 64, M * 256 * 4)
+timeit("linear_bwd_weight_64x64", lambda: ops.linear_bwd_weight(t64, t128), 2.0 * M * 64 * 64, M * 128 * 4)
+timeit("linear_bwd_weight_192x64", lambda: ops.linear_bwd_weight(t192, t64), 2.0 * M * 192 * 64, M * 256 * 4)
+timeit("colsum_64", lambda: ops.colsum(t64), 0, M * 64 * 4)
+timeit("colsum_192", lambda: ops.colsum(t192), 0, M * 192 * 4)
+
+# ---- norms / element-wise ----
+g64 = torch.ones(64, device=dev)
+rm, rv = torch.zeros(64, device=dev), torch.ones(64, device=dev)
+timeit("bn_stats", lambda: ops.bn_stats(t64, 1e-5, 0.1, rm, rv), 0, M * 64 * 4)
+mean, rstd = ops.bn_stats(t64, 1e-5, 0.1, rm, rv)
+timeit("bn_apply_mish", lambda: ops.bn_apply(t64, mean, rstd, g64, b64, 2, out=o64), 0, M * 128 * 4)
+timeit("bn_bwd_mish", lambda: ops.bn_bwd(t64, t128, mean, rstd, g64, b64, 2, True), 0, M * 64 * 4 * 5)
+timeit("ln_fwd", lambda: ops.ln_fwd(t64, t128, g64, b64), 0, M * 64 * 4 * 3)
+_, st = ops.ln_fwd(t64, t128, g64, b64)
+timeit("ln_bwd", lambda: ops.ln_bwd(t64, t128, o64, st, g64), 0, M * 64 * 4 * 4)
+
+# ---- GRU recurrences ----
+gi = R(M, 192)
+whh, bhh = R(96, 32) * 0.2, R(96) * 0.1
+for vert in (True, False):
+    geom = ops.seq_geom(B, 16, 64, vert)
+    nm = "v" if vert else "h"
+    timeit("gru32_fwd_" + nm, lambda: ops.gru32_fwd(gi, whh, bhh, whh, bhh, geom), 0, M * 256 * 4)
+    out = ops.gru32_fwd(gi, whh, bhh, whh, bhh, geom)
+    timeit("gru32_bwd_" + nm, lambda: ops.gru32_bwd(gi, out, t64, whh, bhh, whh, bhh, geom), 0, M * (192 * 3 + 64 * 3) * 4)
+
+# ---- attention core ----
+seed = torch.zeros(1, dtype=torch.int64, device=dev)
+Q, K, V = R(B, 1024, 64), R(B, 26, 64), R(B, 26, 64)
+timeit("attn_fwd", lambda: ops.attn_fwd(Q, K, V, 0.1, seed, 1), 2.0 * B * 1024 * 26 * 64 * 2, M * 64 * 4 * 2)
+timeit("attn_bwd", lambda: ops.attn_bwd(Q, K, V, Q, None, 0.1, seed, 1), 2.0 * B * 1024 * 26 * 64 * 5, M * 64 * 4 * 3)
