@@ -195,6 +195,79 @@ def bigru32(x, gru, vertical):
 
 
 # --------------------------------------------------------------------------------------------------
+class GruBlockFn(Function):
+    """reference GruBlock (model/tsrn.py:1067-1084) as ONE operator: 1x1 conv (optionally over cat[x, xb]) -> BiGRU(64 -> 2x32)
+    along image columns (vertical) or rows.
+
+    The 1x1 conv has no non-linearity before the GRU's input projection, so the two linear maps are composed on the fly:
+        gi = W_ih (W_c x + b_c) + b_ih = (W_ih W_c) x + (W_ih b_c + b_ih)
+    (a 192 x K matrix product of a few kFLOP) and the token matrix is streamed ONCE per direction of the pass instead of three
+    times: forward = 1 GEMM + recurrence; backward = recurrence + 1 GEMM for dx (+1 for the concatenated half) + 2 split-K
+    GEMMs for the weight gradients; the gradients of W_ih, W_c, b_c follow from the composed ones by tiny products."""
+
+    @staticmethod
+    def forward(ctx, x, xb, conv_w, conv_b, wih_f, whh_f, bih_f, bhh_f, wih_r, whh_r, bih_r, bhh_r, vertical):
+        B, H, W, K1 = x.shape
+        Wc = conv_w.reshape(conv_w.shape[0], -1)                 # (64, K)
+        K = Wc.shape[1]
+        x2 = x.reshape(-1, K1)
+        xb2 = xb.reshape(-1, K - K1) if xb is not None else None
+        Wp = ops.new(x, 192, K)                                  # composed projection  [W_ih_f; W_ih_r] @ W_c
+        bp = ops.new(x, 192)
+        for d, (wih, bih) in enumerate(((wih_f, bih_f), (wih_r, bih_r))):
+            ops.gemm(wih, 64, 1, Wc, K, 1, Wp[96 * d:], K, 1, 96, K, 64)
+            ops.gemm(conv_b, 0, 1, wih, 1, 64, bp[96 * d:], 0, 1, 1, 96, 64, bias=bih)
+        gi = ops.linear_fwd(x2, Wp, bp, x2b=xb2)
+        geom = ops.seq_geom(B, H, W, vertical)
+        out = ops.gru32_fwd(gi, whh_f, bhh_f, whh_r, bhh_r, geom)
+        ctx.save_for_backward(x, xb, Wc, Wp, gi, out, wih_f, whh_f, bhh_f, wih_r, whh_r, bhh_r)
+        ctx.geom = geom
+        ctx.wshape = conv_w.shape
+        return out.reshape(B, H, W, 64)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, xb, Wc, Wp, gi, out, wih_f, whh_f, bhh_f, wih_r, whh_r, bhh_r = ctx.saved_tensors
+        K1 = x.shape[-1]
+        K = Wc.shape[1]
+        x2 = x.reshape(-1, K1)
+        dgi, dgh, hprev = ops.gru32_bwd(gi, out, _c(dout).reshape(-1, 64), whh_f, bhh_f, whh_r, bhh_r, ctx.geom)
+        dbp = ops.colsum(dgi)                                     # (192) = [db_ih_f | db_ih_r]
+        dbhh = ops.colsum(dgh)
+        dWp = ops.new(dgi, 192, K)
+        ops.linear_bwd_weight(dgi, x2, out=dWp, out_ld=K)
+        dx = ops.linear_bwd_input(dgi, Wp, col0=0, ncols=K1).reshape(x.shape) if ctx.needs_input_grad[0] else None
+        dxb = None
+        if xb is not None:
+            ops.linear_bwd_weight(dgi, xb.reshape(-1, K - K1), out=dWp.reshape(-1)[K1:], out_ld=K)
+            if ctx.needs_input_grad[1]:
+                dxb = ops.linear_bwd_input(dgi, Wp, col0=K1, ncols=K - K1).reshape(xb.shape)
+        dWhh = ops.linear_bwd_weight(dgh, hprev)                  # (192, 64): diagonal blocks are the two directions
+        dWc = ops.new(dgi, 64, K)
+        dbc = ops.new(dgi, 64)
+        gr = []
+        for d, wih in enumerate((wih_f, wih_r)):
+            dWp_d = dWp[96 * d:96 * (d + 1)]
+            dwih = ops.new(dgi, 96, 64)
+            ops.gemm(dWp_d, K, 1, Wc, 1, K, dwih, 64, 1, 96, 64, K)                       # dW_ih = dW' W_c^T
+            ops.gemm(wih, 1, 64, dWp_d, K, 1, dWc, K, 1, 64, K, 96, beta=float(d))       # dW_c += W_ih^T dW'
+            ops.gemm(dbp[96 * d:], 0, 1, wih, 64, 1, dbc, 0, 1, 1, 64, 96, beta=float(d))  # db_c += W_ih^T db'
+            gr.append((dwih, dWhh[96 * d:96 * (d + 1), 32 * d:32 * (d + 1)].contiguous(), dbp[96 * d:96 * (d + 1)],
+                       dbhh[96 * d:96 * (d + 1)]))
+        (a0, b0, c0, d0), (a1, b1, c1, d1) = gr
+        return dx, dxb, dWc.reshape(ctx.wshape), dbc, a0, b0, c0, d0, a1, b1, c1, d1, None
+
+
+def gru_block(x, blk, vertical, xb=None):
+    """blk: a GruBlock parameter holder (conv1 = 1x1 nn.Conv2d, gru = nn.GRU(64, 32, bidirectional))."""
+    g = blk.gru
+    return GruBlockFn.apply(_c(x), None if xb is None else _c(xb), blk.conv1.weight, blk.conv1.bias,
+                            g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0,
+                            g.weight_ih_l0_reverse, g.weight_hh_l0_reverse, g.bias_ih_l0_reverse, g.bias_hh_l0_reverse,
+                            vertical)
+
+
+# --------------------------------------------------------------------------------------------------
 class AddFn(Function):
     @staticmethod
     def forward(ctx, a, b):

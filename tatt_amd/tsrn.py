@@ -274,9 +274,7 @@ def _tps_forward(x_nchw, ctrl, tps: TPSSpatialTransformer):
 def _gru_block(x, blk: GruBlock, vertical, x_cat=None):
     """GruBlock.forward (model/tsrn.py:1075-1084) on NHWC; `vertical` scans image columns (the reference feeds
     gru1 the H/W-transposed map, :907), x_cat = second half of the channel concat (tp_map)."""
-    w = blk.conv1.weight.reshape(blk.conv1.weight.shape[0], -1)
-    y = Fh.linear(x, w, blk.conv1.bias, xb=x_cat)
-    return Fh.bigru32(y, blk.gru, vertical)
+    return Fh.gru_block(x, blk, vertical, xb=x_cat)
 
 
 def _srb(x, tp_map, blk: RecurrentResidualBlock):

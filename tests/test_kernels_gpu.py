@@ -223,6 +223,46 @@ def test_bigru32(dev, vertical, B, H, W):
     compare_fn("bigru32", lambda x, *ps: Fh.BiGRU32Fn.apply(x, *ps, vertical), ref, [x] + params, dev, grtol=1e-3)
 
 
+@pytest.mark.parametrize("vertical,cat", [(True, True), (False, False)])
+def test_gru_block_fused(dev, vertical, cat):
+    """GruBlock = 1x1 conv (over cat[x, tp_map] for gru1) + BiGRU, as the single fused operator."""
+    from tatt_amd import functional as Fh
+    from tatt_amd.tsrn import GruBlock
+    B, H, W = 2, 16, 64
+    torch.manual_seed(11)
+    blk = GruBlock(128 if cat else 64, 64)
+    names = [n for n, _ in blk.named_parameters()]
+    params = [p.detach() for _, p in blk.named_parameters()]
+    x, xb = R(B, H, W, 64), (R(B, H, W, 64, seed=1) if cat else None)
+
+    def ref(x, xb, *ps):
+        sd = {"b." + n: p for n, p in zip(names, ps)}
+        inp = torch.cat([x, xb], -1) if xb is not None else x
+        inp = inp.permute(0, 3, 1, 2)                        # NCHW
+        if vertical:
+            return O.gru_block(inp.transpose(-1, -2), sd, "b").transpose(-1, -2).permute(0, 2, 3, 1)
+        return O.gru_block(inp, sd, "b").permute(0, 2, 3, 1)
+
+    def hip(x, xb, *ps):
+        b2 = GruBlock(128 if cat else 64, 64).to(dev)
+        for (n, _), p in zip(list(b2.named_parameters()), ps):
+            mod, leaf = n.rsplit(".", 1)
+            setattr(b2.get_submodule(mod), leaf, torch.nn.Parameter(p))
+        hip.blk = b2
+        return Fh.gru_block(x, b2, vertical, xb=xb)
+
+    compare_fn("gru_block", hip, ref, [x, xb] + params, dev,
+               grad_mask=[True, cat] + [False] * len(params), grtol=1e-3)
+    # parameter gradients
+    cs = [p.clone().requires_grad_(True) for p in params]
+    wgt = R(B, H, W, 64, seed=5)
+    (ref(x, xb, *cs) * wgt).sum().backward()
+    b2 = hip.blk
+    (Fh.gru_block(x.to(dev), b2, vertical, xb=None if xb is None else xb.to(dev)) * wgt.to(dev)).sum().backward()
+    for (n, p), c in zip(b2.named_parameters(), cs):
+        check_close("gru_block.grad." + n, p.grad, c.grad, rtol=2e-3, atol=2e-4 * float(c.grad.abs().max()))
+
+
 @pytest.mark.parametrize("B", [1, 2, 5])
 def test_query_gru(dev, B):
     from tatt_amd import functional as Fh
