@@ -24,6 +24,9 @@ __device__ __forceinline__ float mish_grad_f(float x) {
     return t + x * (1.f - t * t) * sg;
 }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
+// fast gate functions for the latency-bound GRU recurrences: v_exp_f32 + v_rcp_f32 (abs. error ~1e-7, i.e. fp32 round-off class)
+__device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float tanh_fast(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_MISH = 2, ACT_TANH = 3 };
 

