@@ -114,8 +114,8 @@ TATT_API int tatt_attn_fwd(const float* Q, const float* K, const float* V, float
     return LAUNCH_CHECK();
 }
 
-// backward: recomputes P; dQ per (query, head); dK/dV reduced over the block's queries (cross-lane + LDS)
-// and written as per-block partials part[b][blk][2][S][64], summed deterministically by attn_bwd_reduce.
+// backward: recomputes P; dQ per (query, head); dK/dV reduced over the block's 64 queries on the matrix cores
+// (v_mfma_f32_16x16x4_f32) and written as per-block partials part[b][blk][2][S][64], summed deterministically by attn_bwd_reduce.
 struct AttnBwdP {
     const float* Q; const float* K; const float* V; const float* dctx; const float* dwavg;   // dwavg may be null
     float* dQ; float* part;
@@ -125,16 +125,15 @@ struct AttnBwdP {
 __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdP a) {
     __shared__ __attribute__((aligned(16))) float Ks[AT_SMAX][AT_E];
     __shared__ __attribute__((aligned(16))) float Vs[AT_SMAX][AT_E];
-    // per-wave slabs: every (s, head, i) entry is produced exactly once per wave (after the cross-lane
-    // reduction over its 16 queries), so plain stores suffice and the 4-wave sum below is order-fixed.
-    __shared__ float dKs[4][AT_SMAX][AT_E];
-    __shared__ float dVs[4][AT_SMAX][AT_E];
+    // per head: [query][key] matrix (dropped probabilities, then score gradients) = the A operand of the dV / dK MFMAs
+    __shared__ float PS[AT_H][AT_QPB][AT_SMAX + 1];
     const int b = blockIdx.y;
-    const int wave = threadIdx.x >> 6;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     attn_load_kv(a.K, a.V, b, a.S, Ks, Vs);
     __syncthreads();
-    const int head = threadIdx.x & 3;
-    const int qi = blockIdx.x * AT_QPB + (threadIdx.x >> 2);
+    const int head = threadIdx.x & 3, ql = threadIdx.x >> 2;
+    const int q0 = blockIdx.x * AT_QPB;
+    const int qi = q0 + ql;
     const bool valid = qi < a.Lq;
     const int qc = valid ? qi : a.Lq - 1;
     const long rowoff = ((long)b * a.Lq + qc) * AT_E + head * AT_D;
@@ -157,22 +156,16 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdP a) {
     float dot = 0.f;
 #pragma unroll
     for (int s = 0; s < AT_SMAX; ++s) {
-        float d = 0.f;
+        float d = 0.f, pd = 0.f;
         if (s < a.S) {
 #pragma unroll
             for (int i = 0; i < AT_D; ++i) d = fmaf(g[i], Vs[s][head * AT_D + i], d);
             if (a.dwavg && valid) d += 0.25f * a.dwavg[((long)b * a.Lq + qi) * a.S + s];
             const bool keep = !drop || dropout_keep(sd, a.site, base + s, th);
-            const float pd = keep ? p[s] * sc : 0.f;       // dropped probability (what multiplied V)
-            // dV[s][:] += pd * g   (reduce over the 16 queries of this wave that share the head)
-#pragma unroll
-            for (int i = 0; i < AT_D; ++i) {
-                float v = pd * g[i];
-                v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
-                if ((threadIdx.x & 63) < 4) dVs[wave][s][head * AT_D + i] = v;
-            }
-            d = keep ? d * sc : 0.f;                         // gradient w.r.t. the un-dropped probability
+            pd = keep ? p[s] * sc : 0.f;                 // dropped probability (what multiplied V)
+            d = keep ? d * sc : 0.f;                     // gradient w.r.t. the un-dropped probability
         }
+        PS[head][ql][s] = pd;
         dp[s] = d;
         dot = fmaf(p[s], d, dot);
     }
@@ -180,28 +173,51 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdP a) {
 #pragma unroll
     for (int i = 0; i < AT_D; ++i) dq[i] = 0.f;
 #pragma unroll
-    for (int s = 0; s < AT_SMAX; ++s)
+    for (int s = 0; s < AT_SMAX; ++s) {
+        const float dsc = (valid && s < a.S) ? p[s] * (dp[s] - dot) : 0.f;
+        dp[s] = dsc;                                     // now holds the score gradient
         if (s < a.S) {
-            const float dsc = valid ? p[s] * (dp[s] - dot) : 0.f;
 #pragma unroll
-            for (int i = 0; i < AT_D; ++i) {
-                dq[i] = fmaf(dsc, Ks[s][head * AT_D + i], dq[i]);
-                float v = dsc * q[i];
-                v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
-                if ((threadIdx.x & 63) < 4) dKs[wave][s][head * AT_D + i] = v;
-            }
+            for (int i = 0; i < AT_D; ++i) dq[i] = fmaf(dsc, Ks[s][head * AT_D + i], dq[i]);
         }
+    }
     if (valid) {
 #pragma unroll
         for (int i4 = 0; i4 < 4; ++i4)
             *reinterpret_cast<f32x4*>(a.dQ + rowoff + 4 * i4) = (f32x4){dq[4 * i4], dq[4 * i4 + 1], dq[4 * i4 + 2], dq[4 * i4 + 3]};
     }
     __syncthreads();
+    // ---- dV[s][i] = sum_q Pd[q][s] g[q][i],  dK[s][i] = sum_q dS[q][s] Q[q][i]: per head (= wave) a (32 x 64) x (64 x 16)
+    //      product on v_mfma_f32_16x16x4_f32.  A[i = key (lane&15)][k = query (lane>>4)] from PS, B[k = query][j = lane&15]
+    //      straight from global (dctx / Q rows were just read: L2 hits).  C: col = lane&15, row = (lane>>4)*4 + reg.
     float* P = a.part + ((long)b * a.nblk + blockIdx.x) * 2 * a.S * AT_E;
-    for (int i = threadIdx.x; i < a.S * AT_E; i += blockDim.x) {
-        const int s = i / AT_E, e = i % AT_E;
-        P[i] = (dKs[0][s][e] + dKs[1][s][e]) + (dKs[2][s][e] + dKs[3][s][e]);
-        P[a.S * AT_E + i] = (dVs[0][s][e] + dVs[1][s][e]) + (dVs[2][s][e] + dVs[3][s][e]);
+    const int w = wave;                                   // head handled by this wave
+    const int col = lane & 15, kq = lane >> 4;
+    for (int pass = 0; pass < 2; ++pass) {
+        const float* Bsrc = pass == 0 ? a.dctx : a.Q;
+        f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll 4
+        for (int k0 = 0; k0 < AT_QPB; k0 += 4) {
+            const int qq = q0 + k0 + kq;
+            const float bv = qq < a.Lq ? Bsrc[((long)b * a.Lq + qq) * AT_E + w * AT_D + col] : 0.f;
+            const float a0 = PS[w][k0 + kq][col], a1 = PS[w][k0 + kq][16 + col];
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bv, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv, acc1, 0, 0, 0);
+        }
+        // pass 0 -> dV (second half of the partial record), pass 1 -> dK (first half)
+        float* dst = P + (pass == 0 ? a.S * AT_E : 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int s0 = kq * 4 + r, s1 = 16 + kq * 4 + r;
+            if (s0 < a.S) dst[s0 * AT_E + w * AT_D + col] = acc0[r];
+            if (s1 < a.S) dst[s1 * AT_E + w * AT_D + col] = acc1[r];
+        }
+        if (pass == 0) {
+            __syncthreads();                               // every wave has consumed the probabilities
+#pragma unroll
+            for (int s = 0; s < AT_SMAX; ++s) PS[head][ql][s] = dp[s];
+            __syncthreads();
+        }
     }
 }
 __global__ void attn_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ dK, float* __restrict__ dV,

@@ -203,9 +203,32 @@ __global__ __launch_bounds__(256) void conv3_c64_fwd_v2_kernel(Conv3P p) {
             const int kh = tap / 3, kw = tap - 3 * kh;
             const float* arow = Xs + (kh * C3_HW + wm * 32 + (lane & 31) + kw) * C3_XP + (lane >> 5);
             const float* brow = WsB + wbuf * 4096 + (lane >> 5) * 64 + wn * 32 + (lane & 31);
-#pragma unroll
-            for (int k = 0; k < 64; k += 2)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[k], brow[k * 64], acc, 0, 0, 0);
+            // 32 dependent MFMAs in 4 groups of 8.  The LDS operand reads of group g+1 are pinned (sched_barrier) in front of the
+            // MFMAs of group g, so they complete under 512 cycles of matrix work; left alone, the scheduler sinks every read pair
+            // right in front of its MFMA and exposes the LDS latency 16 times per tap (measured: MFMA pipe 45 % busy).
+            float ra[4][8], rb[4][8];
+#define C3_LOADG(g)                                                                                   \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                            \
+                ra[g][j] = arow[(g) * 16 + 2 * j]; rb[g][j] = brow[((g) * 16 + 2 * j) * 64]; }
+#define C3_MFMAG(g)                                                                                   \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j)                                              \
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[g][j], rb[g][j], acc, 0, 0, 0);
+            C3_LOADG(0)
+            __builtin_amdgcn_sched_barrier(0);
+            C3_LOADG(1)
+            __builtin_amdgcn_sched_barrier(0);
+            C3_MFMAG(0)
+            __builtin_amdgcn_sched_barrier(0);
+            C3_LOADG(2)
+            __builtin_amdgcn_sched_barrier(0);
+            C3_MFMAG(1)
+            __builtin_amdgcn_sched_barrier(0);
+            C3_LOADG(3)
+            __builtin_amdgcn_sched_barrier(0);
+            C3_MFMAG(2)
+            __builtin_amdgcn_sched_barrier(0);
+            C3_MFMAG(3)
+            __builtin_amdgcn_sched_barrier(0);
             // ---- publish the prefetched data ----
             if (more_w) store_w(WsB + (wbuf ^ 1) * 4096);
             if (has_next) {
@@ -308,15 +331,24 @@ __global__ __launch_bounds__(256) void conv3_c64_wgrad_kernel(Conv3WP p) {
         const int kq = lane >> 5;
         const float* bcol = &Ds[kq][qo * 32 + (lane & 31)];
         const float* acol = &Xs[0][kq][qi * 32 + (lane & 31)];
-#pragma unroll 2
-        for (int k = 0; k < 64; k += 2) {
-            const float b = bcol[k * 64];
+        // 32 k-steps (pixel pairs) x 9 independent accumulators; operands of step k+1 are read (pinned by sched_barrier)
+        // before the 9 MFMAs of step k issue, so the LDS latency hides under 576 cycles of matrix work.
+        float wa[2][9], wb[2];
+#define C3W_LOAD(buf, k)                                                                   \
+        wb[buf] = bcol[(k) * 64];                                                          \
+        _Pragma("unroll") for (int tap = 0; tap < 9; ++tap)                                 \
+            wa[buf][tap] = acol[((tap / 3) * C3_HW + (k) + (tap - 3 * (tap / 3))) * 64];
+        C3W_LOAD(0, 0)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int kh = tap / 3, kw = tap - 3 * (tap / 3);
-                const float a = acol[(kh * C3_HW + k + kw) * 64];
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[tap], 0, 0, 0);
-            }
+        for (int k = 0; k < 64; k += 2) {
+            const int cur = (k >> 1) & 1;
+            if (k + 2 < 64) { C3W_LOAD(cur ^ 1, k + 2) }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[cur][tap], wb[cur], acc[tap], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     // partial[blockIdx.x][(tap*Cin + ci)][Cout]
