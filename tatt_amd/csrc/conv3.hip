@@ -259,6 +259,149 @@ __global__ __launch_bounds__(256) void conv3_c64_fwd_v2_kernel(Conv3P p) {
     }
 }
 
+// ---- v3: v2 with 8 waves per work-group: the input channels of a tap are split between two groups of 4 waves (two waves
+// per SIMD), so the per-tap bookkeeping of one wave (address math, LDS publishes, barrier skew: ~1.3k cycles, which a lone
+// wave per SIMD cannot overlap with its own dependent MFMA chain) runs under the other wave's MFMAs.  The two partial sums
+// are combined through LDS in the epilogue.
+#define C3_V3_LDS (C3_V2_LDS + 16 * 256 * 4)
+__global__ __launch_bounds__(512) void conv3_c64_fwd_v3_kernel(Conv3P p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* XsB = smem;                                   // [2][3][66][65]
+    float* WsB = smem + 2 * C3_HALO_PITCH;               // [2][64][64]
+    float* Red = WsB + 2 * 4096;                         // [16][256] partial accumulators of the second channel half
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int half = wave >> 2, wm = wave & 1, wn = (wave >> 1) & 1;
+    const int segs = p.W / C3_PX, cob = p.Cout / 64, nch = p.Cin / 64;
+    const int ntiles = p.B * p.H * segs * cob;
+    const int G = gridDim.x;
+
+    auto decode = [&](int tile, int& n, int& h, int& w0, int& co0) {
+        int bid = tile;
+        const int cb = bid % cob; bid /= cob;
+        const int seg = bid % segs; bid /= segs;
+        h = bid % p.H; n = bid / p.H;
+        w0 = seg * C3_PX; co0 = cb * 64;
+    };
+    // one float4 of the halo of (tile, chunk): idx in [0, 3168)
+    auto halo_load = [&](int n, int h, int w0, int ci0, int idx) -> f32x4 {
+        const int c4 = idx & 15, pp = idx >> 4;
+        const int r = pp / C3_HW, px = pp - r * C3_HW;
+        const int hh = h + r - 1, ww = w0 + px - 1;
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (hh >= 0 && hh < p.H && ww >= 0 && ww < p.W)
+            v = *reinterpret_cast<const f32x4*>(p.x + (((long)n * p.H + hh) * p.W + ww) * p.Cin + ci0 + 4 * c4);
+        return v;
+    };
+    auto halo_store = [&](float* Xs, int idx, f32x4 v) {
+        const int c4 = idx & 15, pp = idx >> 4;
+        float* d = Xs + pp * C3_XP + 4 * c4;
+        d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+    };
+    f32x4 wreg[2];
+    auto load_w = [&](int tap, int ci0, int co0) {
+        const float* src = p.w + ((long)tap * p.Cin + ci0) * p.Cout + co0;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int idx = t + 512 * q;
+            wreg[q] = *reinterpret_cast<const f32x4*>(src + (long)(idx >> 4) * p.Cout + 4 * (idx & 15));
+        }
+    };
+    auto store_w = [&](float* Ws) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int idx = t + 512 * q;
+            *reinterpret_cast<f32x4*>(Ws + (idx >> 4) * 64 + 4 * (idx & 15)) = wreg[q];
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    int n, h, w0, co0;
+    decode(tile, n, h, w0, co0);
+    // ---- prologue: first halo + first filter slice ----
+    for (int i = t; i < 9 * C3_SLICE; i += 512) halo_store(XsB, i, halo_load(n, h, w0, 0, i));
+    load_w(0, 0, co0);
+    store_w(WsB);
+    __syncthreads();
+
+    int xbuf = 0, wbuf = 0, ch = 0;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    while (true) {
+        // next work item
+        int ntile = tile, nchk = ch + 1;
+        if (nchk == nch) { nchk = 0; ntile = tile + G; }
+        const bool has_next = ntile < ntiles;
+        int nn = n, nh = h, nw0 = w0, nco0 = co0;
+        if (has_next && nchk == 0) decode(ntile, nn, nh, nw0, nco0);
+        const float* Xs = XsB + xbuf * C3_HALO_PITCH;
+        float* XsN = XsB + (xbuf ^ 1) * C3_HALO_PITCH;
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            // ---- issue the loads that the MFMAs below will hide ----
+            const bool more_w = tap < 8 || has_next;
+            if (tap < 8) load_w(tap + 1, ch * 64, co0);
+            else if (has_next) load_w(0, nchk * 64, nco0);
+            f32x4 h0 = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int i0 = tap * C3_SLICE + t;
+            const bool hload = has_next && t < C3_SLICE;
+            if (hload) h0 = halo_load(nn, nh, nw0, nchk * 64, i0);
+            // ---- 32 MFMAs: A = halo (pixel, channel pair), B = filter slice (channel pair, output channel) ----
+            const int kh = tap / 3, kw = tap - 3 * kh;
+            const float* arow = Xs + (kh * C3_HW + wm * 32 + (lane & 31) + kw) * C3_XP + half * 32 + (lane >> 5);
+            const float* brow = WsB + wbuf * 4096 + (half * 32 + (lane >> 5)) * 64 + wn * 32 + (lane & 31);
+            // 32 dependent MFMAs in 4 groups of 8.  The LDS operand reads of group g+1 are pinned (sched_barrier) in front of the
+            // MFMAs of group g, so they complete under 512 cycles of matrix work; left alone, the scheduler sinks every read pair
+            // right in front of its MFMA and exposes the LDS latency 16 times per tap (measured: MFMA pipe 45 % busy).
+            float ra[2][8], rb[2][8];
+            C3_LOADG(0)
+            __builtin_amdgcn_sched_barrier(0);
+            C3_LOADG(1)
+            __builtin_amdgcn_sched_barrier(0);
+            C3_MFMAG(0)
+            __builtin_amdgcn_sched_barrier(0);
+            C3_MFMAG(1)
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- publish the prefetched data ----
+            if (more_w) store_w(WsB + (wbuf ^ 1) * 4096);
+            if (hload) halo_store(XsN, i0, h0);
+            __syncthreads();
+            wbuf ^= 1;
+        }
+        if (ch == nch - 1) {
+            // ---- combine the two channel halves through LDS ----
+            if (half == 1) {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) { Red[reg * 256 + (t & 255)] = acc[reg]; acc[reg] = 0.f; }
+            }
+            __syncthreads();
+            if (half == 0) {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) acc[reg] += Red[reg * 256 + t];
+            }
+        }
+        if (ch == nch - 1 && half == 0) {
+            // ---- epilogue: col = lane&31 (output channel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (pixel) ----
+            const int co = co0 + wn * 32 + (lane & 31);
+            const float bj = p.bias ? p.bias[co] : 0.f;
+            const long rowbase = ((long)n * p.H + h) * p.W + w0 + wm * 32;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int px = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                float v = apply_act(acc[reg] + bj, p.act);
+                const long o = (rowbase + px) * p.Cout + co;
+                if (p.beta != 0.f) v += p.beta * p.y[o];
+                p.y[o] = v;
+                acc[reg] = 0.f;
+            }
+        }
+        if (!has_next) break;
+        tile = ntile; ch = nchk; n = nn; h = nh; w0 = nw0; co0 = nco0;
+        xbuf ^= 1;
+    }
+}
+
 #define C3_FWD_LDS ((3 * C3_HW * C3_XP + 2 + 64 * 64) * 4)
 // x (B,H,W,Cin) NHWC contiguous; w = packed [9][Cin][Cout]; y (B,H,W,Cout); Cin, Cout, W multiples of 64
 TATT_API int tatt_conv3_c64_fwd(const float* x, const float* wpacked, const float* bias, float* y, int B, int H, int W,
@@ -266,22 +409,27 @@ TATT_API int tatt_conv3_c64_fwd(const float* x, const float* wpacked, const floa
     if (Cin % 64 || Cout % 64 || W % C3_PX) return 1;
     Conv3P p = {x, wpacked, bias, y, B, H, W, Cin, Cout, act, beta};
     static bool attr_set = false;
-    static int variant = 2;
+    static int variant = 3;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             C3_FWD_LDS);
         hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_fwd_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             C3_V2_LDS);
-        const char* e = getenv("TATT_CONV3_VARIANT");       // 1 = one tile per work-group (A/B testing), 2 = persistent pipelined
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_fwd_v3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            C3_V3_LDS);
+        const char* e = getenv("TATT_CONV3_VARIANT");       // 1 = one tile per work-group, 2 = persistent pipelined (4 waves), 3 = persistent, 8 waves (default)
         if (e) variant = atoi(e);
         attr_set = true;
     }
     const int ntiles = B * H * (W / C3_PX) * (Cout / 64);
     if (variant == 1) {
         hipLaunchKernelGGL(conv3_c64_fwd_kernel, dim3(ntiles), dim3(256), C3_FWD_LDS, st, p);
-    } else {
+    } else if (variant == 2) {
         const int G = ntiles < 256 ? ntiles : 256;
         hipLaunchKernelGGL(conv3_c64_fwd_v2_kernel, dim3(G), dim3(256), C3_V2_LDS, st, p);
+    } else {
+        const int G = ntiles < 256 ? ntiles : 256;
+        hipLaunchKernelGGL(conv3_c64_fwd_v3_kernel, dim3(G), dim3(512), C3_V3_LDS, st, p);
     }
     return LAUNCH_CHECK();
 }

@@ -45,10 +45,15 @@ __device__ __forceinline__ void decode_kidx(const GemmP& p, int k, int& kh, int&
     kh = tap / p.KW; kw = tap - kh * p.KW;
 }
 
-template <int AMODE, int AK, int BK>
+template <int AMODE, int AK, int BK, int KCT>
 __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmP p) {
-    __shared__ float As[2][KC][LDT];
-    __shared__ float Bs[2][KC][LDT];
+    // KCT = K-chunk: 16 (im2col modes, short K) or 64 (token GEMMs: whole 256-B rows per wave load, 4x fewer exposed
+    // global-load round trips per tile)
+    constexpr int NP = KCT / 4;          // elements per thread per operand per chunk
+    constexpr int KL = KCT;              // lanes along k when an operand is k-contiguous
+    constexpr int RP = 256 / KCT;        // rows covered per pass in that case
+    __shared__ float As[2][KCT][LDT];
+    __shared__ float Bs[2][KCT][LDT];
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
@@ -61,7 +66,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmP p) {
     const float* A2 = (AMODE == 2) ? p.A2 + (long)z * p.bsA2 : nullptr;
     const float* B = p.B + (long)z * p.bsB;
 
-    const int nchunks = (p.K + KC - 1) / KC;
+    const int nchunks = (p.K + KCT - 1) / KCT;
     int c_begin = 0, c_end = nchunks;
     if (p.splitk > 1) {
         c_begin = blockIdx.y * p.chunks_per_split;
@@ -86,9 +91,9 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmP p) {
         if (frow_ok) decode_kidx(p, i, fkh, fkw, fci);
     }
 
-    float ra[4], rb[4];
+    float ra[NP], rb[NP];
     auto load_chunk = [&](int c) {
-        const int k0 = c * KC;
+        const int k0 = c * KCT;
         // ---- A ----
         if (AMODE == 3) {
             int r = k0 + (t & 15);
@@ -121,9 +126,9 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmP p) {
             }
         } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < NP; ++q) {
                 int i, r;
-                if (AK) { r = k0 + (t & 15); i = m0 + (t >> 4) + 16 * q; }
+                if (AK) { r = k0 + (t & (KL - 1)); i = m0 + t / KL + RP * q; }
                 else    { i = m0 + (t & 63); r = k0 + (t >> 6) + 4 * q; }
                 float v = 0.f;
                 if (i < p.M && r < p.K) {
@@ -135,19 +140,19 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmP p) {
         }
         // ---- B ----
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NP; ++q) {
             int j, r;
-            if (BK) { r = k0 + (t & 15); j = n0 + (t >> 4) + 16 * q; }
+            if (BK) { r = k0 + (t & (KL - 1)); j = n0 + t / KL + RP * q; }
             else    { j = n0 + (t & 63); r = k0 + (t >> 6) + 4 * q; }
             rb[q] = (j < p.N && r < p.K) ? B[r * p.sbk + j * p.sbn] : 0.f;
         }
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (AMODE == 3 || (AMODE != 4 && AK)) As[buf][t & 15][(t >> 4) + 16 * q] = ra[q];
+        for (int q = 0; q < NP; ++q) {
+            if (AMODE == 3 || (AMODE != 4 && AK)) As[buf][t & (KL - 1)][t / KL + RP * q] = ra[q];
             else As[buf][(t >> 6) + 4 * q][t & 63] = ra[q];
-            if (BK) Bs[buf][t & 15][(t >> 4) + 16 * q] = rb[q];
+            if (BK) Bs[buf][t & (KL - 1)][t / KL + RP * q] = rb[q];
             else Bs[buf][(t >> 6) + 4 * q][t & 63] = rb[q];
         }
     };
@@ -165,7 +170,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmP p) {
             if (c + 1 < c_end) load_chunk(c + 1);
             const int ar = wm * 32 + (lane & 31), bc = wn * 32 + (lane & 31), kq = lane >> 5;
 #pragma unroll
-            for (int kk = 0; kk < KC; kk += 2) {
+            for (int kk = 0; kk < KCT; kk += 2) {
                 float a = As[buf][kk + kq][ar];
                 float b = Bs[buf][kk + kq][bc];
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
@@ -255,20 +260,20 @@ static int ilog2_or_neg(int v) {
     return s;
 }
 
-template <int AMODE>
+template <int AMODE, int KCT>
 static int launch_gemm(const GemmP& p, int Z, bool ak, bool bk, hipStream_t st) {
     dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), p.splitk, Z), block(256);
     if (AMODE == 3) {
-        if (bk) hipLaunchKernelGGL((gemm_mfma_kernel<3, 1, 1>), grid, block, 0, st, p);
-        else    hipLaunchKernelGGL((gemm_mfma_kernel<3, 1, 0>), grid, block, 0, st, p);
+        if (bk) hipLaunchKernelGGL((gemm_mfma_kernel<3, 1, 1, 16>), grid, block, 0, st, p);
+        else    hipLaunchKernelGGL((gemm_mfma_kernel<3, 1, 0, 16>), grid, block, 0, st, p);
     } else if (AMODE == 4) {
-        if (bk) hipLaunchKernelGGL((gemm_mfma_kernel<4, 0, 1>), grid, block, 0, st, p);
-        else    hipLaunchKernelGGL((gemm_mfma_kernel<4, 0, 0>), grid, block, 0, st, p);
+        if (bk) hipLaunchKernelGGL((gemm_mfma_kernel<4, 0, 1, 16>), grid, block, 0, st, p);
+        else    hipLaunchKernelGGL((gemm_mfma_kernel<4, 0, 0, 16>), grid, block, 0, st, p);
     } else {
-        if (ak && bk)       hipLaunchKernelGGL((gemm_mfma_kernel<AMODE, 1, 1>), grid, block, 0, st, p);
-        else if (ak && !bk) hipLaunchKernelGGL((gemm_mfma_kernel<AMODE, 1, 0>), grid, block, 0, st, p);
-        else if (!ak && bk) hipLaunchKernelGGL((gemm_mfma_kernel<AMODE, 0, 1>), grid, block, 0, st, p);
-        else                hipLaunchKernelGGL((gemm_mfma_kernel<AMODE, 0, 0>), grid, block, 0, st, p);
+        if (ak && bk)       hipLaunchKernelGGL((gemm_mfma_kernel<AMODE, 1, 1, KCT>), grid, block, 0, st, p);
+        else if (ak && !bk) hipLaunchKernelGGL((gemm_mfma_kernel<AMODE, 1, 0, KCT>), grid, block, 0, st, p);
+        else if (!ak && bk) hipLaunchKernelGGL((gemm_mfma_kernel<AMODE, 0, 1, KCT>), grid, block, 0, st, p);
+        else                hipLaunchKernelGGL((gemm_mfma_kernel<AMODE, 0, 0, KCT>), grid, block, 0, st, p);
     }
     return LAUNCH_CHECK();
 }
@@ -281,8 +286,8 @@ static int finish_splitk(const GemmP& p, int Z, int remap_cin, int remap_taps, h
     return LAUNCH_CHECK();
 }
 
-static void set_split(GemmP& p, int splitk, float* ws) {
-    int nchunks = cdiv(p.K, KC);
+static void set_split(GemmP& p, int splitk, float* ws, int kc = KC) {
+    int nchunks = cdiv(p.K, kc);
     if (splitk < 1) splitk = 1;
     if (splitk > nchunks) splitk = nchunks;
     p.chunks_per_split = cdiv(nchunks, splitk);
@@ -310,9 +315,12 @@ TATT_API int tatt_gemm(const float* A, long sam, long sak, const float* A2, long
     p.sam = sam; p.sak = sak; p.sa2m = sa2m; p.sa2k = sa2k; p.sbk = sbk; p.sbn = sbn; p.scm = scm; p.scn = scn;
     p.bsA = bsA; p.bsA2 = bsA2; p.bsB = bsB; p.bsC = bsC; p.bsBias = bsBias;
     p.alpha = alpha; p.beta = beta; p.act = act;
-    set_split(p, splitk, ws);
+    const bool big = K >= 64 && (!A2 || K1 % 64 == 0);      // 64-deep chunks for the token GEMMs
+    set_split(p, splitk, ws, big ? 64 : KC);
     bool ak = (sak == 1), bk = (sbk == 1 && sbn != 1);
-    int rc = A2 ? launch_gemm<2>(p, Z, ak, bk, st) : launch_gemm<0>(p, Z, ak, bk, st);
+    int rc;
+    if (big) rc = A2 ? launch_gemm<2, 64>(p, Z, ak, bk, st) : launch_gemm<0, 64>(p, Z, ak, bk, st);
+    else     rc = A2 ? launch_gemm<2, 16>(p, Z, ak, bk, st) : launch_gemm<0, 16>(p, Z, ak, bk, st);
     if (rc) return rc;
     if (p.splitk > 1) return finish_splitk(p, Z, 0, 0, st);
     return 0;
@@ -338,7 +346,7 @@ TATT_API int tatt_conv2d_fwd(const float* x, long xsn, long xsh, long xsw, long 
     p.alpha = 1.f; p.beta = beta; p.act = act;
     fill_conv(p, H, W, Cin, KH, KW, xsn, xsh, xsw, xsc);
     set_split(p, splitk, ws);        // split-K (ws >= splitk*Bn*H*W*Cout floats) spreads small-M / deep-K convs (STN tail) over the CUs
-    int rc = launch_gemm<3>(p, 1, true, false, st);
+    int rc = launch_gemm<3, 16>(p, 1, true, false, st);
     if (rc) return rc;
     if (p.splitk > 1) return finish_splitk(p, 1, 0, 0, st);
     return 0;
@@ -358,7 +366,7 @@ TATT_API int tatt_conv2d_wgrad(const float* x, long xsn, long xsh, long xsw, lon
     fill_conv(p, H, W, Cin, KH, KW, xsn, xsh, xsw, xsc);
     set_split(p, splitk < 2 ? 2 : splitk, ws);
     if (p.splitk < 2) { p.splitk = 2; p.chunks_per_split = cdiv(cdiv(p.K, KC), 2); }
-    int rc = launch_gemm<4>(p, 1, false, false, st);
+    int rc = launch_gemm<4, 16>(p, 1, false, false, st);
     if (rc) return rc;
     return finish_splitk(p, 1, Cin, KH * KW, st);
 }
