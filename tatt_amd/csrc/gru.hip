@@ -162,15 +162,16 @@ __global__ __launch_bounds__(256) void gru32_bwd_kernel(const float* __restrict_
         }
         ds[grp][j] = drp; ds[grp][32 + j] = dzp; ds[grp][64 + j] = dghn;
         __syncthreads();
-        float acc = dh * z;
+        // 96-term dot product split over 4 accumulators (a single dependent FMA chain would cost ~96 x 8 cycles per step)
+        float c0 = dh * z, c1 = 0.f, c2 = 0.f, c3 = 0.f;
         const f32x4* dv = reinterpret_cast<const f32x4*>(ds[grp]);
 #pragma unroll
         for (int k4 = 0; k4 < 24; ++k4) {
             f32x4 dd = dv[k4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) acc = fmaf(wt[k4 * 4 + u], dd[u], acc);
+            c0 = fmaf(wt[k4 * 4 + 0], dd[0], c0); c1 = fmaf(wt[k4 * 4 + 1], dd[1], c1);
+            c2 = fmaf(wt[k4 * 4 + 2], dd[2], c2); c3 = fmaf(wt[k4 * 4 + 3], dd[3], c3);
         }
-        dhc = acc;
+        dhc = (c0 + c1) + (c2 + c3);
         __syncthreads();
     }
 }
@@ -344,5 +345,81 @@ TATT_API int tatt_qgru_bwd_mm(const float* dgh0, const float* dgh1, const float*
     if ((3 * HID) % 64) return 1;
     QBwdMmP p = {{dgh0, dgh1}, {whhT0, whhT1}, {dhcarry0, dhcarry1}, Wb, HID};
     hipLaunchKernelGGL(qgru_bwd_mm_kernel, dim3(cdiv(Wb, 16), HID / 16, 2), dim3(256), 0, st, p);
+    return LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------------------------
+// GruBlock glue (reference GruBlock = 1x1 conv + BiGRU, model/tsrn.py:1067-1084): the 1x1 conv W_c (64 x K), b_c and the
+// GRU input projections W_ih (2 x 96 x 64), b_ih are composed into ONE projection  W' = W_ih W_c (192 x K),
+// b' = W_ih b_c + b_ih  applied to the token matrix by a single GEMM; `tail` maps the gradients of the composed
+// projection back to the reference's parameters.  A few hundred kFLOP each: one small launch instead of 4 / 6 GEMM launches.
+// ------------------------------------------------------------------------------------------------
+__global__ void gru_compose_kernel(const float* __restrict__ wih_f, const float* __restrict__ wih_r,
+                                   const float* __restrict__ bih_f, const float* __restrict__ bih_r,
+                                   const float* __restrict__ Wc, const float* __restrict__ bc, float* __restrict__ Wp,
+                                   float* __restrict__ bp, int K) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 192 * (K + 1)) return;
+    const int row = idx / (K + 1), col = idx - row * (K + 1);
+    const float* w = (row < 96 ? wih_f : wih_r) + (row % 96) * 64;
+    float s0 = 0.f, s1 = 0.f;
+    if (col < K) {
+        for (int c = 0; c < 64; c += 2) { s0 = fmaf(w[c], Wc[c * K + col], s0); s1 = fmaf(w[c + 1], Wc[(c + 1) * K + col], s1); }
+        Wp[row * K + col] = s0 + s1;
+    } else {
+        for (int c = 0; c < 64; c += 2) { s0 = fmaf(w[c], bc[c], s0); s1 = fmaf(w[c + 1], bc[c + 1], s1); }
+        bp[row] = s0 + s1 + (row < 96 ? bih_f : bih_r)[row % 96];
+    }
+}
+TATT_API int tatt_gru_compose(const float* wih_f, const float* wih_r, const float* bih_f, const float* bih_r,
+                              const float* Wc, const float* bc, float* Wp, float* bp, int K, hipStream_t st) {
+    hipLaunchKernelGGL(gru_compose_kernel, dim3(cdiv(192 * (K + 1), 256)), dim3(256), 0, st, wih_f, wih_r, bih_f, bih_r, Wc,
+                       bc, Wp, bp, K);
+    return LAUNCH_CHECK();
+}
+// dW_ih_d (96x64) = dW'_d W_c^T + db'_d b_c^T ;  dW_c (64xK) = sum_d W_ih_d^T dW'_d ;  db_c (64) = sum_d W_ih_d^T db'_d
+__global__ void gru_tail_kernel(const float* __restrict__ dWp, const float* __restrict__ dbp,
+                                const float* __restrict__ Wc, const float* __restrict__ bc,
+                                const float* __restrict__ wih_f, const float* __restrict__ wih_r,
+                                float* __restrict__ dwih_f, float* __restrict__ dwih_r, float* __restrict__ dWc,
+                                float* __restrict__ dbc, int K) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < 2 * 96 * 64) {
+        const int d = idx / 6144, r = (idx % 6144) / 64, c = idx & 63;
+        const float* a = dWp + (long)(96 * d + r) * K;
+        const float* b = Wc + (long)c * K;
+        float s0 = dbp[96 * d + r] * bc[c], s1 = 0.f;
+        for (int k = 0; k < K; k += 2) { s0 = fmaf(a[k], b[k], s0); s1 = fmaf(a[k + 1], b[k + 1], s1); }
+        (d ? dwih_r : dwih_f)[r * 64 + c] = s0 + s1;
+        return;
+    }
+    idx -= 2 * 96 * 64;
+    if (idx < 64 * K) {
+        const int c = idx / K, k = idx - c * K;
+        float s0 = 0.f, s1 = 0.f;
+        for (int row = 0; row < 96; ++row) {
+            s0 = fmaf(wih_f[row * 64 + c], dWp[(long)row * K + k], s0);
+            s1 = fmaf(wih_r[row * 64 + c], dWp[(long)(96 + row) * K + k], s1);
+        }
+        dWc[idx] = s0 + s1;
+        return;
+    }
+    idx -= 64 * K;
+    if (idx < 64) {
+        float s0 = 0.f, s1 = 0.f;
+        for (int row = 0; row < 96; ++row) {
+            s0 = fmaf(wih_f[row * 64 + idx], dbp[row], s0);
+            s1 = fmaf(wih_r[row * 64 + idx], dbp[96 + row], s1);
+        }
+        dbc[idx] = s0 + s1;
+    }
+}
+TATT_API int tatt_gru_tail(const float* dWp, const float* dbp, const float* Wc, const float* bc, const float* wih_f,
+                           const float* wih_r, float* dwih_f, float* dwih_r, float* dWc, float* dbc, int K,
+                           hipStream_t st) {
+    if (K % 2) return 1;
+    const int total = 2 * 96 * 64 + 64 * K + 64;
+    hipLaunchKernelGGL(gru_tail_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, dWp, dbp, Wc, bc, wih_f, wih_r, dwih_f,
+                       dwih_r, dWc, dbc, K);
     return LAUNCH_CHECK();
 }

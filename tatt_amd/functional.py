@@ -138,12 +138,14 @@ class LinearFn(Function):
             dx = ops.linear_bwd_input(dy2, weight, col0=0, ncols=K1, alpha=ctx.alpha).reshape(x.shape)
         if xb is not None and ctx.needs_input_grad[1]:
             dxb = ops.linear_bwd_input(dy2, weight, col0=K1, ncols=K - K1, alpha=ctx.alpha).reshape(xb.shape)
+        want_db = ctx.has_bias and ctx.needs_input_grad[3]
         if ctx.needs_input_grad[2]:
             dw = ops.new(dy2, N, K)
-            ops.linear_bwd_weight(dy2, x2, alpha=ctx.alpha, out=dw, out_ld=K)
+            db = ops.new(dy2, N) if want_db else None             # bias gradient rides along with the weight-gradient GEMM
+            ops.linear_bwd_weight(dy2, x2, alpha=ctx.alpha, out=dw, out_ld=K, rowsum=db)
             if xb is not None:
                 ops.linear_bwd_weight(dy2, xb.reshape(-1, K - K1), alpha=ctx.alpha, out=dw.reshape(-1)[K1:], out_ld=K)
-        if ctx.has_bias and ctx.needs_input_grad[3]:
+        elif want_db:
             db = ops.colsum(dy2, scale=ctx.alpha)
         return dx, dxb, dw, db, None, None
 
@@ -214,9 +216,8 @@ class GruBlockFn(Function):
         xb2 = xb.reshape(-1, K - K1) if xb is not None else None
         Wp = ops.new(x, 192, K)                                  # composed projection  [W_ih_f; W_ih_r] @ W_c
         bp = ops.new(x, 192)
-        for d, (wih, bih) in enumerate(((wih_f, bih_f), (wih_r, bih_r))):
-            ops.gemm(wih, 64, 1, Wc, K, 1, Wp[96 * d:], K, 1, 96, K, 64)
-            ops.gemm(conv_b, 0, 1, wih, 1, 64, bp[96 * d:], 0, 1, 1, 96, 64, bias=bih)
+        ops.call("tatt_gru_compose", ops.P(wih_f), ops.P(wih_r), ops.P(bih_f), ops.P(bih_r), ops.P(Wc), ops.P(conv_b),
+                 ops.P(Wp), ops.P(bp), K, ops.stream())
         gi = ops.linear_fwd(x2, Wp, bp, x2b=xb2)
         geom = ops.seq_geom(B, H, W, vertical)
         out = ops.gru32_fwd(gi, whh_f, bhh_f, whh_r, bhh_r, geom)
@@ -232,31 +233,24 @@ class GruBlockFn(Function):
         K = Wc.shape[1]
         x2 = x.reshape(-1, K1)
         dgi, dgh, hprev = ops.gru32_bwd(gi, out, _c(dout).reshape(-1, 64), whh_f, bhh_f, whh_r, bhh_r, ctx.geom)
-        dbp = ops.colsum(dgi)                                     # (192) = [db_ih_f | db_ih_r]
-        dbhh = ops.colsum(dgh)
+        # weight-gradient GEMMs over the tokens; the bias gradients (column sums of dgi / dgh) ride along as a virtual ones column
+        dbp, dbhh = ops.new(dgi, 192), ops.new(dgi, 192)
         dWp = ops.new(dgi, 192, K)
-        ops.linear_bwd_weight(dgi, x2, out=dWp, out_ld=K)
+        ops.linear_bwd_weight(dgi, x2, out=dWp, out_ld=K, rowsum=dbp)
         dx = ops.linear_bwd_input(dgi, Wp, col0=0, ncols=K1).reshape(x.shape) if ctx.needs_input_grad[0] else None
         dxb = None
         if xb is not None:
             ops.linear_bwd_weight(dgi, xb.reshape(-1, K - K1), out=dWp.reshape(-1)[K1:], out_ld=K)
             if ctx.needs_input_grad[1]:
                 dxb = ops.linear_bwd_input(dgi, Wp, col0=K1, ncols=K - K1).reshape(xb.shape)
-        dWhh = ops.linear_bwd_weight(dgh, hprev)                  # (192, 64): diagonal blocks are the two directions
-        dWc = ops.new(dgi, 64, K)
-        dbc = ops.new(dgi, 64)
-        gr = []
-        for d, wih in enumerate((wih_f, wih_r)):
-            dWp_d = dWp[96 * d:96 * (d + 1)]
-            dwih = ops.new(dgi, 96, 64)
-            ops.gemm(dWp_d, K, 1, Wc, 1, K, dwih, 64, 1, 96, 64, K)                       # dW_ih = dW' W_c^T ...
-            ops.gemm(dbp[96 * d:], 1, 1, conv_b, 1, 1, dwih, 64, 1, 96, 64, 1, beta=1.0)  # ... + db' b_c^T
-            ops.gemm(wih, 1, 64, dWp_d, K, 1, dWc, K, 1, 64, K, 96, beta=float(d))       # dW_c += W_ih^T dW'
-            ops.gemm(dbp[96 * d:], 0, 1, wih, 64, 1, dbc, 0, 1, 1, 64, 96, beta=float(d))  # db_c += W_ih^T db'
-            gr.append((dwih, dWhh[96 * d:96 * (d + 1), 32 * d:32 * (d + 1)].contiguous(), dbp[96 * d:96 * (d + 1)],
-                       dbhh[96 * d:96 * (d + 1)]))
-        (a0, b0, c0, d0), (a1, b1, c1, d1) = gr
-        return dx, dxb, dWc.reshape(ctx.wshape), dbc, a0, b0, c0, d0, a1, b1, c1, d1, None
+        dWhh = ops.linear_bwd_weight(dgh, hprev, rowsum=dbhh)     # (192, 64): diagonal blocks are the two directions
+        dwih_f, dwih_r = ops.new(dgi, 96, 64), ops.new(dgi, 96, 64)
+        dWc, dbc = ops.new(dgi, 64, K), ops.new(dgi, 64)
+        ops.call("tatt_gru_tail", ops.P(dWp), ops.P(dbp), ops.P(Wc), ops.P(conv_b), ops.P(wih_f), ops.P(wih_r),
+                 ops.P(dwih_f), ops.P(dwih_r), ops.P(dWc), ops.P(dbc), K, ops.stream())
+        return (dx, dxb, dWc.reshape(ctx.wshape), dbc,
+                dwih_f, dWhh[:96, :32].contiguous(), dbp[:96], dbhh[:96],
+                dwih_r, dWhh[96:, 32:].contiguous(), dbp[96:], dbhh[96:], None)
 
 
 def gru_block(x, blk, vertical, xb=None):

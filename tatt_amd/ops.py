@@ -53,7 +53,7 @@ def new(ref: torch.Tensor, *shape, dtype=torch.float32):
 # GEMM family
 # --------------------------------------------------------------------------------------------------
 def gemm(A, sam, sak, B, sbk, sbn, C, scm, scn, M, N, K, *, A2=None, sa2m=0, sa2k=0, K1=0, bias=None,
-         Z=1, bsA=0, bsA2=0, bsB=0, bsC=0, bsBias=0, alpha=1.0, beta=0.0, act=ACT_NONE, splitk=1):
+         Z=1, bsA=0, bsA2=0, bsB=0, bsC=0, bsBias=0, alpha=1.0, beta=0.0, act=ACT_NONE, splitk=1, rowsum=None):
     """C = act(alpha*(A@B + bias)) + beta*C with explicit element strides (see tatt_gemm)."""
     _check_dev(C)
     ws = None
@@ -63,7 +63,7 @@ def gemm(A, sam, sak, B, sbk, sbn, C, scm, scn, M, N, K, *, A2=None, sa2m=0, sa2
         if splitk > 1:
             ws = new(C, Z * splitk * M * N)
     call("tatt_gemm", P(A), sam, sak, P(A2), sa2m, sa2k, K1, P(B), sbk, sbn, P(bias), P(C), scm, scn,
-         M, N, K, Z, bsA, bsA2, bsB, bsC, bsBias, alpha, beta, act, splitk, P(ws), stream())
+         M, N, K, Z, bsA, bsA2, bsB, bsC, bsBias, alpha, beta, act, splitk, P(ws), P(rowsum), stream())
     return C
 
 
@@ -102,14 +102,16 @@ def linear_bwd_input(dy, W, *, col0=0, ncols=None, alpha=1.0, out=None, beta=0.0
     return dx
 
 
-def linear_bwd_weight(dy, x2, *, alpha=1.0, out=None, out_ld=None, beta=0.0):
-    """dW (N,K) = alpha * dy^T (N,M) @ x2 (M,K); reduction over the M tokens (split-K, deterministic)."""
+def linear_bwd_weight(dy, x2, *, alpha=1.0, out=None, out_ld=None, beta=0.0, rowsum=None):
+    """dW (N,K) = alpha * dy^T (N,M) @ x2 (M,K); reduction over the M tokens (split-K, deterministic).
+    rowsum: optional (N,) tensor that receives alpha * dy.sum(0) -- the bias gradient -- from the same pass."""
     M, N = dy.shape
     K = x2.shape[1]
     dW = out if out is not None else new(dy, N, K)
     ld = out_ld if out_ld is not None else dW.stride(0)
-    gemm(dy, dy.stride(1), dy.stride(0), x2, x2.stride(0), x2.stride(1), dW, ld, 1, N, K, M, alpha=alpha, beta=beta,
-         splitk=_auto_split(N, K, M))
+    Kv = K + 1 if rowsum is not None else K
+    gemm(dy, dy.stride(1), dy.stride(0), x2, x2.stride(0), x2.stride(1), dW, ld, 1, N, Kv, M, alpha=alpha, beta=beta,
+         splitk=_auto_split(N, Kv, M), rowsum=rowsum)
     return dW
 
 
