@@ -402,6 +402,170 @@ __global__ __launch_bounds__(512) void conv3_c64_fwd_v3_kernel(Conv3P p) {
     }
 }
 
+// ---- v4: wave-specialised: 4 MFMA waves + 1 loader wave ----------------------------------------------------------------------------
+// Measured on v2: per tap a wave spends ~2.0k cycles on 32 MFMAs and another ~2.1k on everything else (prefetch address math,
+// global loads, LDS publishes, barrier, operand-read latency), and with one wave per SIMD nothing overlaps the two.  Here the
+// four MFMA waves only read LDS and issue MFMAs; a fifth wave owns ALL global->LDS traffic (the next tap's 16 KB filter slice
+// and 1/9 of the next work item's halo per tap).  One barrier per tap hands the buffers over.
+__global__ __launch_bounds__(320) void conv3_c64_fwd_v4_kernel(Conv3P p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* XsB = smem;                                   // [2][3][66][65]
+    float* WsB = smem + 2 * C3_HALO_PITCH;               // [2][64][64]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int segs = p.W / C3_PX, cob = p.Cout / 64, nch = p.Cin / 64;
+    const int ntiles = p.B * p.H * segs * cob;
+    const int G = gridDim.x;
+    auto decode = [&](int tile, int& n, int& h, int& w0, int& co0) {
+        int bid = tile;
+        const int cb = bid % cob; bid /= cob;
+        const int seg = bid % segs; bid /= segs;
+        h = bid % p.H; n = bid / p.H;
+        w0 = seg * C3_PX; co0 = cb * 64;
+    };
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    int n, h, w0, co0;
+    decode(tile, n, h, w0, co0);
+    // ---- prologue (all 5 waves): first halo + first filter slice ----
+    for (int i = t; i < 9 * C3_SLICE; i += 320) {
+        const int c4 = i & 15, pp = i >> 4;
+        const int r = pp / C3_HW, px = pp - r * C3_HW;
+        const int hh = h + r - 1, ww = w0 + px - 1;
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (hh >= 0 && hh < p.H && ww >= 0 && ww < p.W)
+            v = *reinterpret_cast<const f32x4*>(p.x + (((long)n * p.H + hh) * p.W + ww) * p.Cin + 4 * c4);
+        float* d = XsB + pp * C3_XP + 4 * c4;
+        d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+    }
+    for (int i = t; i < 1024; i += 320)
+        *reinterpret_cast<f32x4*>(WsB + (i >> 4) * 64 + 4 * (i & 15)) =
+            *reinterpret_cast<const f32x4*>(p.w + (long)(i >> 4) * p.Cout + co0 + 4 * (i & 15));
+    __syncthreads();
+
+    int xbuf = 0, wbuf = 0, ch = 0;
+    if (wave == 4) {
+        // ================================ loader wave ================================
+        while (true) {
+            int ntile = tile, nchk = ch + 1;
+            if (nchk == nch) { nchk = 0; ntile = tile + G; }
+            const bool has_next = ntile < ntiles;
+            int nn = n, nh = h, nw0 = w0, nco0 = co0;
+            if (has_next && nchk == 0) decode(ntile, nn, nh, nw0, nco0);
+            float* XsN = XsB + (xbuf ^ 1) * C3_HALO_PITCH;
+#pragma unroll 1
+            for (int tap = 0; tap < 9; ++tap) {
+                const bool more_w = tap < 8 || has_next;
+                f32x4 wv[16], hv[6];
+                if (more_w) {
+                    const int ntap = tap < 8 ? tap + 1 : 0;
+                    const int wci = tap < 8 ? ch * 64 : nchk * 64;
+                    const int wco = tap < 8 ? co0 : nco0;
+                    const float* src = p.w + ((long)ntap * p.Cin + wci) * p.Cout + wco;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int idx = lane + 64 * q;
+                        wv[q] = *reinterpret_cast<const f32x4*>(src + (long)(idx >> 4) * p.Cout + 4 * (idx & 15));
+                    }
+                }
+                // halo slice of the next item: row r = tap/3, pixels (tap%3)*22 .. +21  (66 = 3 x 22: no division per element)
+                const int r = tap / 3, pxb = (tap - 3 * r) * 22;
+                const int hh = nh + r - 1;
+                const bool row_ok = has_next && hh >= 0 && hh < p.H;
+                if (has_next) {
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) {
+                        const int idx = lane + 64 * q;
+                        const int px = pxb + (idx >> 4), ww = nw0 + px - 1;
+                        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        if (idx < C3_SLICE && row_ok && ww >= 0 && ww < p.W)
+                            v = *reinterpret_cast<const f32x4*>(p.x + (((long)nn * p.H + hh) * p.W + ww) * p.Cin + nchk * 64 +
+                                                                4 * (idx & 15));
+                        hv[q] = v;
+                    }
+                }
+                if (more_w) {
+                    float* Wd = WsB + (wbuf ^ 1) * 4096;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int idx = lane + 64 * q;
+                        *reinterpret_cast<f32x4*>(Wd + (idx >> 4) * 64 + 4 * (idx & 15)) = wv[q];
+                    }
+                }
+                if (has_next) {
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) {
+                        const int idx = lane + 64 * q;
+                        if (idx < C3_SLICE) {
+                            float* d = XsN + (r * C3_HW + pxb + (idx >> 4)) * C3_XP + 4 * (idx & 15);
+                            d[0] = hv[q][0]; d[1] = hv[q][1]; d[2] = hv[q][2]; d[3] = hv[q][3];
+                        }
+                    }
+                }
+                __syncthreads();
+                wbuf ^= 1;
+            }
+            if (!has_next) break;
+            tile = ntile; ch = nchk; n = nn; h = nh; w0 = nw0; co0 = nco0;
+            xbuf ^= 1;
+        }
+        return;
+    }
+    // ================================ MFMA waves ================================
+    const int wm = wave & 1, wn = wave >> 1;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    while (true) {
+        int ntile = tile, nchk = ch + 1;
+        if (nchk == nch) { nchk = 0; ntile = tile + G; }
+        const bool has_next = ntile < ntiles;
+        const float* Xs = XsB + xbuf * C3_HALO_PITCH;
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            const int kh = tap / 3, kw = tap - 3 * kh;
+            const float* arow = Xs + (kh * C3_HW + wm * 32 + (lane & 31) + kw) * C3_XP + (lane >> 5);
+            const float* brow = WsB + wbuf * 4096 + (lane >> 5) * 64 + wn * 32 + (lane & 31);
+            float ra[4][8], rb[4][8];
+            C3_LOADG(0)
+            __builtin_amdgcn_sched_barrier(0);
+            C3_LOADG(1)
+            __builtin_amdgcn_sched_barrier(0);
+            C3_MFMAG(0)
+            __builtin_amdgcn_sched_barrier(0);
+            C3_LOADG(2)
+            __builtin_amdgcn_sched_barrier(0);
+            C3_MFMAG(1)
+            __builtin_amdgcn_sched_barrier(0);
+            C3_LOADG(3)
+            __builtin_amdgcn_sched_barrier(0);
+            C3_MFMAG(2)
+            __builtin_amdgcn_sched_barrier(0);
+            C3_MFMAG(3)
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            wbuf ^= 1;
+        }
+        if (ch == nch - 1) {
+            const int co = co0 + wn * 32 + (lane & 31);
+            const float bj = p.bias ? p.bias[co] : 0.f;
+            const long rowbase = ((long)n * p.H + h) * p.W + w0 + wm * 32;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int px = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                float v = apply_act(acc[reg] + bj, p.act);
+                const long o = (rowbase + px) * p.Cout + co;
+                if (p.beta != 0.f) v += p.beta * p.y[o];
+                p.y[o] = v;
+                acc[reg] = 0.f;
+            }
+        }
+        if (!has_next) break;
+        if (nchk == 0) decode(ntile, n, h, w0, co0);
+        tile = ntile; ch = nchk;
+        xbuf ^= 1;
+    }
+}
+
 #define C3_FWD_LDS ((3 * C3_HW * C3_XP + 2 + 64 * 64) * 4)
 // x (B,H,W,Cin) NHWC contiguous; w = packed [9][Cin][Cout]; y (B,H,W,Cout); Cin, Cout, W multiples of 64
 TATT_API int tatt_conv3_c64_fwd(const float* x, const float* wpacked, const float* bias, float* y, int B, int H, int W,
@@ -409,7 +573,7 @@ TATT_API int tatt_conv3_c64_fwd(const float* x, const float* wpacked, const floa
     if (Cin % 64 || Cout % 64 || W % C3_PX) return 1;
     Conv3P p = {x, wpacked, bias, y, B, H, W, Cin, Cout, act, beta};
     static bool attr_set = false;
-    static int variant = 2;
+    static int variant = 4;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             C3_FWD_LDS);
@@ -417,7 +581,9 @@ TATT_API int tatt_conv3_c64_fwd(const float* x, const float* wpacked, const floa
                             C3_V2_LDS);
         hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_fwd_v3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             C3_V3_LDS);
-        const char* e = getenv("TATT_CONV3_VARIANT");       // 1 = one tile per work-group, 2 = persistent pipelined (4 waves), 3 = persistent, 8 waves (measured slower: 60.6 vs 54.4 us)
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_fwd_v4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            C3_V2_LDS);
+        const char* e = getenv("TATT_CONV3_VARIANT");       // 1 = one tile per work-group, 2 = persistent pipelined (4 waves), 3 = persistent, 8 waves (measured slower: 60.6 vs 54.4 us), 4 = 4 MFMA waves + 1 loader wave (default)
         if (e) variant = atoi(e);
         attr_set = true;
     }
@@ -427,9 +593,12 @@ TATT_API int tatt_conv3_c64_fwd(const float* x, const float* wpacked, const floa
     } else if (variant == 2) {
         const int G = ntiles < 256 ? ntiles : 256;
         hipLaunchKernelGGL(conv3_c64_fwd_v2_kernel, dim3(G), dim3(256), C3_V2_LDS, st, p);
-    } else {
+    } else if (variant == 3) {
         const int G = ntiles < 256 ? ntiles : 256;
         hipLaunchKernelGGL(conv3_c64_fwd_v3_kernel, dim3(G), dim3(512), C3_V3_LDS, st, p);
+    } else {
+        const int G = ntiles < 256 ? ntiles : 256;
+        hipLaunchKernelGGL(conv3_c64_fwd_v4_kernel, dim3(G), dim3(320), C3_V2_LDS, st, p);
     }
     return LAUNCH_CHECK();
 }

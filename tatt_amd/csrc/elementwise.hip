@@ -245,11 +245,13 @@ __global__ void sumsq_stage1(const float* __restrict__ g, long n, double* __rest
     if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 __global__ void sumsq_stage2(const double* __restrict__ part, int G, float* __restrict__ out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s = 0.0;
-        for (int i = 0; i < G; ++i) s += part[i];
-        out[0] = (float)sqrt(s);
-    }
+    __shared__ double sh[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < G; i += 256) s += part[i];
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (float)sqrt((sh[0] + sh[1]) + (sh[2] + sh[3]));
 }
 // out[0] = ||g||_2 ; ws >= 1024 doubles
 TATT_API int tatt_l2norm(const float* g, long n, float* out, double* ws, hipStream_t st) {
@@ -257,7 +259,7 @@ TATT_API int tatt_l2norm(const float* g, long n, float* out, double* ws, hipStre
     if (G > 1024) G = 1024;
     if (G < 1) G = 1;
     hipLaunchKernelGGL(sumsq_stage1, dim3(G), dim3(256), 0, st, g, n, ws);
-    hipLaunchKernelGGL(sumsq_stage2, dim3(1), dim3(64), 0, st, ws, G, out);
+    hipLaunchKernelGGL(sumsq_stage2, dim3(1), dim3(256), 0, st, ws, G, out);
     return LAUNCH_CHECK();
 }
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,

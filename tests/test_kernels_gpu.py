@@ -370,8 +370,12 @@ def test_tps_golden_and_grad(dev):
     y, src = hip(x.to(dev), ctrl.to(dev))
     check_close("tps.golden.src", src, torch.from_numpy(z["src"]), rtol=1e-5, atol=5e-5)
     check_close("tps.golden.y", y.permute(0, 3, 1, 2), torch.from_numpy(z["y"]), rtol=1e-3, atol=2e-3)
-    # on a smooth image the same coordinates give a tight match
+    # on a smooth image (horizontal ramp) the same coordinates give a tight match -- away from the top/bottom border, where
+    # the zero padding makes the output as sensitive to the y coordinate as white noise (d out / d cy = 16 * value)
     xs = torch.linspace(0, 1, 64).reshape(1, 1, 1, 64).expand(3, 4, 16, 64).contiguous()
-    ys, _ = O.tps_transform(xs, ctrl, sd, "t")
+    ys, srcs = O.tps_transform(xs, ctrl, sd, "t")
     yh, _ = hip(xs.to(dev), ctrl.to(dev))
-    check_close("tps.smooth", yh.permute(0, 3, 1, 2), ys, rtol=1e-4, atol=2e-5)
+    inner = ((srcs[..., 1] > 0.06) & (srcs[..., 1] < 0.94)).reshape(3, 1, 16, 64).expand(3, 4, 16, 64)
+    d = (yh.permute(0, 3, 1, 2).cpu() - ys).abs()
+    assert float(d[inner].max()) < 1e-4, float(d[inner].max())
+    assert float(d.max()) < 2e-3

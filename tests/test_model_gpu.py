@@ -103,13 +103,14 @@ def _train_case(dev, cls, tatt, B, golden):
         if k in noise:
             continue
         got = summarize(params[k].grad.cpu())
-        lim = 3e-2 if k.startswith("stn_head") else 1e-2
+        lim = 3e-2 if k.startswith("stn_head") else (5e-2 if params[k].numel() == 1 else 1e-2)   # see tests/util.py
         assert abs(got[0] - ref[0]) < lim * ref[0] + 1e-7, (k, got[0], ref[0])       # l2 norm of the gradient
     for key in z.files:
         if key.startswith("g:"):
             g = params[key[2:]].grad.cpu()
             ref = torch.from_numpy(z[key])
-            assert rel_err(g, ref) < (3e-2 if key.startswith("g:stn_head") else 1e-2), (key, rel_err(g, ref))
+            lim = 3e-2 if key.startswith("g:stn_head") else (5e-2 if g.numel() == 1 else 1e-2)
+            assert rel_err(g, ref) < lim, (key, rel_err(g, ref))
     # running statistics were updated like the reference's BatchNorm
     sd1 = m.state_dict()
     for k in sd1:
