@@ -27,8 +27,8 @@ typedef struct ihipStream_t* hipStream_t;
 
 /* C[z] = act(alpha * (A[z] @ B[z] + bias[z])) + beta * C[z],  A(i,r) = A[i*sam + r*sak] for r < K1 (or all r
  * when A2 == NULL), A2[i*sa2m + (r-K1)*sa2k] otherwise; B(r,j) = B[r*sbk + j*sbn]; C[i*scm + j*scn].
- * splitk > 1: ws >= Z*splitk*M*N floats.  rowsum != NULL (Z == 1): B gets a virtual all-ones LAST column (N counts it) and that
- * column of the result -- the row sums of A, i.e. a bias gradient -- is written to rowsum[M] instead of C.
+ * splitk > 1: ws >= Z*splitk*M*N floats.  rowsum != NULL (Z == 1): rowsum[i] = alpha * sum_r A(i,r) is produced in the same pass
+ * (a bias gradient riding along with the weight-gradient GEMM); with split-K ws needs splitk*M more floats.
  * Replaces nn.Linear (model/tsrn.py:170; model/transformer_v2.py:455-457,788-790; model/stn_head.py:50,53),
  * the 1x1 nn.Conv2d of GruBlock (model/tsrn.py:1071), nn.GRU input projections (model/tsrn.py:1072;
  * model/transformer_v2.py:177) and the packed in/out projections of nn.MultiheadAttention
@@ -52,7 +52,9 @@ int tatt_conv2d_wgrad(const float* x, long xsn, long xsh, long xsw, long xsc, co
                       long lddy, float* dw_oihw, int Bn, int H, int W, int Cin, int Cout, int KH,
                       int KW, float beta, int splitk, float* ws, hipStream_t st);
 
-/* OIHW nn.Conv2d weight -> GEMM operand; mode 0: [KH][KW][Cin][Cout]; mode 1: [KH][KW][Cout][Cin], taps flipped */
+/* OIHW nn.Conv2d weight -> GEMM operand; mode 0: [KH][KW][Cin][Cout]; mode 1: [KH][KW][Cout][Cin], taps flipped (data gradient);
+ * mode 2: [KH][KW][Cout][Cin]; mode 3: [KH][KW][Cin][Cout], taps flipped -- forward / data-gradient filters with the
+ * contraction axis contiguous, for tatt_conv3_c64_fwd_t */
 int tatt_repack_conv_weight(const float* w_oihw, float* out, int Cout, int Cin, int KH, int KW,
                             int mode, hipStream_t st);
 
@@ -66,6 +68,10 @@ int tatt_splitk_reduce(const float* partial, float* C, int M, int N, int S, int 
  * mode-1 packed filter) data gradient.  y = act(conv + bias) + beta*y */
 int tatt_conv3_c64_fwd(const float* x, const float* wpacked, const float* bias, float* y, int B, int H, int W,
                        int Cin, int Cout, int act, float beta, hipStream_t st);
+/* same convolution, filter packed [9][Cout][Cin] (repack mode 2; mode 3 for the data gradient): both MFMA operands are read
+ * from LDS with 16-byte loads along the contraction axis -- the production kernel (8x fewer LDS instructions) */
+int tatt_conv3_c64_fwd_t(const float* x, const float* wt, const float* bias, float* y, int B, int H, int W, int Cin,
+                         int Cout, int act, float beta, hipStream_t st);
 /* weight-gradient partials part[G][9*Cin][Cout] (G persistent work-groups, G <= B*H*W/64); finish with
  * tatt_splitk_reduce(part, dw_oihw, 9*Cin, Cout, G, Cin, 9, beta) */
 int tatt_conv3_c64_wgrad_partial(const float* x, const float* dy, float* part, int B, int H, int W, int Cin,

@@ -566,6 +566,149 @@ __global__ __launch_bounds__(320) void conv3_c64_fwd_v4_kernel(Conv3P p) {
     }
 }
 
+// ---- v5: v2 (persistent, in-wave prefetch) with 16-BYTE LDS operand reads ---------------------------------------------------------
+// Measured: v1..v4 all stall at ~45 % MFMA utilisation however the global traffic is organised -- the limiter is the LDS
+// *instruction* rate: with one wave per SIMD a 4-byte-per-lane ds_read reaches only ~1/5 of its peak (MI355X_MICROARCH.md,
+// LDS), and the 32x32x2 MFMA wants two of them every 64 cycles.  Here both operands are stored with the CONTRACTION axis
+// contiguous (halo [row][px][68], filter slice transposed [co][68]; pitch 68 = conflict-free for ds_read_b128), each lane
+// reads 4 consecutive input channels per 16-byte load and feeds 4 MFMAs with it: lane (i, kq = lane>>5) uses channels
+// 8c + 4kq + u for u = 0..3 on BOTH operands, which is all the contraction needs.  8x fewer LDS instructions.
+#define C5_XP 68
+#define C5_HALO (3 * C3_HW * C5_XP)              // 13464 floats (16-byte aligned)
+#define C5_WT (64 * C5_XP)                       // 4352 floats
+#define C5_LDS ((2 * C5_HALO + 2 * C5_WT) * 4)   // 142,528 B
+__global__ __launch_bounds__(256) void conv3_c64_fwd_v5_kernel(Conv3P p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* XsB = smem;                                   // [2][3][66][68]
+    float* WsB = smem + 2 * C5_HALO;                     // [2][64 co][68]   (filter slice, ci contiguous)
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int segs = p.W / C3_PX, cob = p.Cout / 64, nch = p.Cin / 64;
+    const int ntiles = p.B * p.H * segs * cob;
+    const int G = gridDim.x;
+    auto decode = [&](int tile, int& n, int& h, int& w0, int& co0) {
+        int bid = tile;
+        const int cb = bid % cob; bid /= cob;
+        const int seg = bid % segs; bid /= segs;
+        h = bid % p.H; n = bid / p.H;
+        w0 = seg * C3_PX; co0 = cb * 64;
+    };
+    // float4 #idx (c4 = idx&15, pixel = idx>>4) of halo row r, pixels [pxb, pxb+22)
+    auto halo_load = [&](int n, int hh, int w0, int ci0, int pxb, int idx) -> f32x4 {
+        const int ww = w0 + pxb + (idx >> 4) - 1;
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (hh >= 0 && hh < p.H && ww >= 0 && ww < p.W)
+            v = *reinterpret_cast<const f32x4*>(p.x + (((long)n * p.H + hh) * p.W + ww) * p.Cin + ci0 + 4 * (idx & 15));
+        return v;
+    };
+    // packed filter (mode 2/3 of tatt_repack_conv_weight): wt[tap][co][ci], ci contiguous
+    f32x4 wreg[4];
+    auto load_w = [&](int tap, int ci0, int co0) {
+        const float* src = p.w + ((long)tap * p.Cout + co0) * p.Cin + ci0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = t + 256 * q;                 // co = idx>>4, ci quad = idx&15
+            wreg[q] = *reinterpret_cast<const f32x4*>(src + (long)(idx >> 4) * p.Cin + 4 * (idx & 15));
+        }
+    };
+    auto store_w = [&](float* Ws) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = t + 256 * q;
+            *reinterpret_cast<f32x4*>(Ws + (idx >> 4) * C5_XP + 4 * (idx & 15)) = wreg[q];
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    int n, h, w0, co0;
+    decode(tile, n, h, w0, co0);
+    // ---- prologue ----
+    for (int s9 = 0; s9 < 9; ++s9) {
+        const int r = s9 / 3, pxb = (s9 - 3 * r) * 22;
+        for (int i = t; i < C3_SLICE; i += 256)
+            *reinterpret_cast<f32x4*>(XsB + (r * C3_HW + pxb + (i >> 4)) * C5_XP + 4 * (i & 15)) = halo_load(n, h + r - 1, w0, 0, pxb, i);
+    }
+    load_w(0, 0, co0);
+    store_w(WsB);
+    __syncthreads();
+
+    int xbuf = 0, wbuf = 0, ch = 0;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    while (true) {
+        int ntile = tile, nchk = ch + 1;
+        if (nchk == nch) { nchk = 0; ntile = tile + G; }
+        const bool has_next = ntile < ntiles;
+        int nn = n, nh = h, nw0 = w0, nco0 = co0;
+        if (has_next && nchk == 0) decode(ntile, nn, nh, nw0, nco0);
+        const float* Xs = XsB + xbuf * C5_HALO;
+        float* XsN = XsB + (xbuf ^ 1) * C5_HALO;
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            // ---- issue the loads that the MFMAs below will hide: next filter slice + 1/9 of the next halo ----
+            const bool more_w = tap < 8 || has_next;
+            if (tap < 8) load_w(tap + 1, ch * 64, co0);
+            else if (has_next) load_w(0, nchk * 64, nco0);
+            const int r = tap / 3, pxb = (tap - 3 * r) * 22;      // this tap's slice of the NEXT halo: row r, 22 pixels
+            f32x4 h0 = (f32x4){0.f, 0.f, 0.f, 0.f}, h1 = h0;
+            if (has_next) {
+                h0 = halo_load(nn, nh + r - 1, nw0, nchk * 64, pxb, t);
+                if (t < C3_SLICE - 256) h1 = halo_load(nn, nh + r - 1, nw0, nchk * 64, pxb, 256 + t);
+            }
+            // ---- 32 MFMAs fed by 8 + 8 sixteen-byte LDS reads, kept two steps ahead ----
+            const int kh = r, kw = tap - 3 * r;
+            const float* arow = Xs + (kh * C3_HW + wm * 32 + (lane & 31) + kw) * C5_XP + 4 * (lane >> 5);
+            const float* brow = WsB + wbuf * C5_WT + (wn * 32 + (lane & 31)) * C5_XP + 4 * (lane >> 5);
+            f32x4 va[8], vb[8];
+#define C5_LD(c) va[c] = *reinterpret_cast<const f32x4*>(arow + 8 * (c)); vb[c] = *reinterpret_cast<const f32x4*>(brow + 8 * (c));
+#define C5_MM(c) _Pragma("unroll") for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(va[c][u], vb[c][u], acc, 0, 0, 0);
+            C5_LD(0) C5_LD(1)
+            __builtin_amdgcn_sched_barrier(0);
+            C5_LD(2) C5_LD(3)
+            __builtin_amdgcn_sched_barrier(0);
+            C5_MM(0) C5_MM(1)
+            __builtin_amdgcn_sched_barrier(0);
+            C5_LD(4) C5_LD(5)
+            __builtin_amdgcn_sched_barrier(0);
+            C5_MM(2) C5_MM(3)
+            __builtin_amdgcn_sched_barrier(0);
+            C5_LD(6) C5_LD(7)
+            __builtin_amdgcn_sched_barrier(0);
+            C5_MM(4) C5_MM(5)
+            __builtin_amdgcn_sched_barrier(0);
+            C5_MM(6) C5_MM(7)
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- publish the prefetched data ----
+            if (more_w) store_w(WsB + (wbuf ^ 1) * C5_WT);
+            if (has_next) {
+                *reinterpret_cast<f32x4*>(XsN + (r * C3_HW + pxb + (t >> 4)) * C5_XP + 4 * (t & 15)) = h0;
+                if (t < C3_SLICE - 256)
+                    *reinterpret_cast<f32x4*>(XsN + (r * C3_HW + pxb + 16 + (t >> 4)) * C5_XP + 4 * (t & 15)) = h1;
+            }
+            __syncthreads();
+            wbuf ^= 1;
+        }
+        if (ch == nch - 1) {
+            const int co = co0 + wn * 32 + (lane & 31);
+            const float bj = p.bias ? p.bias[co] : 0.f;
+            const long rowbase = ((long)n * p.H + h) * p.W + w0 + wm * 32;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int px = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                float v = apply_act(acc[reg] + bj, p.act);
+                const long o = (rowbase + px) * p.Cout + co;
+                if (p.beta != 0.f) v += p.beta * p.y[o];
+                p.y[o] = v;
+                acc[reg] = 0.f;
+            }
+        }
+        if (!has_next) break;
+        tile = ntile; ch = nchk; n = nn; h = nh; w0 = nw0; co0 = nco0;
+        xbuf ^= 1;
+    }
+}
+
 #define C3_FWD_LDS ((3 * C3_HW * C3_XP + 2 + 64 * 64) * 4)
 // x (B,H,W,Cin) NHWC contiguous; w = packed [9][Cin][Cout]; y (B,H,W,Cout); Cin, Cout, W multiples of 64
 TATT_API int tatt_conv3_c64_fwd(const float* x, const float* wpacked, const float* bias, float* y, int B, int H, int W,
@@ -600,6 +743,24 @@ TATT_API int tatt_conv3_c64_fwd(const float* x, const float* wpacked, const floa
         const int G = ntiles < 256 ? ntiles : 256;
         hipLaunchKernelGGL(conv3_c64_fwd_v4_kernel, dim3(G), dim3(320), C3_V2_LDS, st, p);
     }
+    return LAUNCH_CHECK();
+}
+
+// x (B,H,W,Cin) NHWC contiguous; wt = filter packed [9][Cout][Cin] (tatt_repack_conv_weight mode 2; mode 3 for the data
+// gradient); y (B,H,W,Cout)
+TATT_API int tatt_conv3_c64_fwd_t(const float* x, const float* wt, const float* bias, float* y, int B, int H, int W, int Cin,
+                                  int Cout, int act, float beta, hipStream_t st) {
+    if (Cin % 64 || Cout % 64 || W % C3_PX) return 1;
+    Conv3P p = {x, wt, bias, y, B, H, W, Cin, Cout, act, beta};
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_fwd_v5_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, C5_LDS);
+        attr_set = true;
+    }
+    const int ntiles = B * H * (W / C3_PX) * (Cout / 64);
+    const int G = ntiles < 256 ? ntiles : 256;
+    hipLaunchKernelGGL(conv3_c64_fwd_v5_kernel, dim3(G), dim3(256), C5_LDS, st, p);
     return LAUNCH_CHECK();
 }
 

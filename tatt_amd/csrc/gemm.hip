@@ -26,8 +26,8 @@ struct GemmP {
     int act;
     int splitk, chunks_per_split;
     float* partial;
-    float* rowsum;       // non-null: B gets a virtual all-ones last column (N = data columns + 1) whose result, the row sums of A,
-                         // goes to rowsum[i] instead of C -- bias gradients ride along with the weight-gradient GEMM
+    float* rowsum;       // non-null: the row sums of A (sum_r A(i,r)) are also produced (from the A tiles already staged in LDS, by
+                         // the tile_n == 0 work-groups) -- bias gradients ride along with the weight-gradient GEMM
     // conv geometry (AMODE 3/4): input addressed as X[n*xsn + h*xsh + w*xsw + c*xsc]
     int H, W, Cin, KH, KW, pad, HW, Wshift, HWshift, Cshift;
     long xsn, xsh, xsw, xsc;
@@ -146,9 +146,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmP p) {
             int j, r;
             if (BK) { r = k0 + (t & (KL - 1)); j = n0 + t / KL + RP * q; }
             else    { j = n0 + (t & 63); r = k0 + (t >> 6) + 4 * q; }
-            float bv = 0.f;
-            if (j < p.N && r < p.K) bv = (p.rowsum && j == p.N - 1) ? 1.f : B[r * p.sbk + j * p.sbn];
-            rb[q] = bv;
+            rb[q] = (j < p.N && r < p.K) ? B[r * p.sbk + j * p.sbn] : 0.f;
         }
     };
     auto store_chunk = [&](int buf) {
@@ -164,6 +162,8 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmP p) {
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const bool do_rs = p.rowsum != nullptr && tile_n == 0;
+    float rs_acc = 0.f;
 
     if (c_begin < c_end) {
         load_chunk(c_begin);
@@ -179,8 +179,22 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmP p) {
                 float b = Bs[buf][kk + kq][bc];
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
             }
+            if (do_rs) {
+#pragma unroll
+                for (int kk = 0; kk < KCT / 4; ++kk) rs_acc += As[buf][(t >> 6) * (KCT / 4) + kk][t & 63];
+            }
             if (c + 1 < c_end) store_chunk(buf ^ 1);
             __syncthreads();
+        }
+    }
+    if (do_rs) {
+        // combine the 4 k-groups through LDS (the chunk buffers are free now), thread t < 64 owns row m0 + t
+        As[0][t >> 6][t & 63] = rs_acc;
+        __syncthreads();
+        if (t < 64 && m0 + t < p.M) {
+            const float v = (As[0][0][t] + As[0][1][t]) + (As[0][2][t] + As[0][3][t]);
+            if (p.splitk > 1) p.partial[(long)p.splitk * p.M * p.N + (long)blockIdx.y * p.M + m0 + t] = v;
+            else p.rowsum[m0 + t] = p.alpha * v;
         }
     }
 
@@ -198,11 +212,9 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmP p) {
     }
     float* C = p.C + (long)z * p.bsC;
     const float bj = p.bias ? p.bias[(long)z * p.bsBias + j] : 0.f;
-    const bool rs_col = p.rowsum && j == p.N - 1;
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
         int i = m0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-        if (i < p.M && rs_col) { p.rowsum[i] = p.alpha * acc[reg]; continue; }
         if (i < p.M) {
             float v = apply_act(p.alpha * (acc[reg] + bj), p.act);
             long off = i * p.scm + j * p.scn;
@@ -223,6 +235,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;       // 64 outputs x 4 slab lanes per block
     const long idx = (long)blockIdx.x * 64 + tx;
     const long total = (long)Z * M * N;
+    const long total64 = ((total + 63) / 64) * 64;
+    if (rowsum && idx >= total64) {
+        // trailing blocks: row sums of A, partial slabs [S][M] stored behind the S (M x N) slabs  (Z == 1)
+        const long i2 = idx - total64;
+        float r = 0.f;
+        if (i2 < M) for (int k = ty; k < S; k += 4) r += partial[(long)S * M * N + (long)k * M + i2];
+        sh[ty][tx] = r;
+        __syncthreads();
+        if (ty == 0 && i2 < M) rowsum[i2] = alpha * ((sh[0][tx] + sh[1][tx]) + (sh[2][tx] + sh[3][tx]));
+        return;
+    }
     const bool ok = idx < total;
     int j = 0, i = 0, z = 0;
     float s = 0.f;
@@ -246,7 +269,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     __syncthreads();
     if (ty != 0 || !ok) return;
     s = (sh[0][tx] + sh[1][tx]) + (sh[2][tx] + sh[3][tx]);
-    if (rowsum && j == N - 1) { rowsum[i] = alpha * s; return; }
     float bj = bias ? bias[(long)z * bsBias + j] : 0.f;
     float v = apply_act(alpha * (s + bj), act);
     long off;
@@ -287,6 +309,7 @@ static int launch_gemm(const GemmP& p, int Z, bool ak, bool bk, hipStream_t st) 
 
 static int finish_splitk(const GemmP& p, int Z, int remap_cin, int remap_taps, hipStream_t st) {
     long total = (long)Z * p.M * p.N;
+    if (p.rowsum) total = cdiv(total, 64) * 64 + p.M;       // extra thread range (64-aligned start) for the row sums of A
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(total, 64)), dim3(256), 0, st, p.partial, p.C, p.bias,
                        p.M, p.N, p.splitk, Z, p.scm, p.scn, p.bsC, p.bsBias, p.alpha, p.beta, p.act,
                        remap_cin, remap_taps, p.rowsum);
@@ -322,7 +345,7 @@ TATT_API int tatt_gemm(const float* A, long sam, long sak, const float* A2, long
     p.sam = sam; p.sak = sak; p.sa2m = sa2m; p.sa2k = sa2k; p.sbk = sbk; p.sbn = sbn; p.scm = scm; p.scn = scn;
     p.bsA = bsA; p.bsA2 = bsA2; p.bsB = bsB; p.bsC = bsC; p.bsBias = bsBias;
     p.alpha = alpha; p.beta = beta; p.act = act;
-    p.rowsum = rowsum;                    // when set, N counts the virtual ones column
+    p.rowsum = rowsum;                    // row sums of A (bias gradient); with split-K, ws needs splitk*M extra floats
     // 64-deep chunks (KCT = 64) measured SLOWER than 16-deep on the token GEMMs (12.3 -> 16.7 us at M=49152, K=N=64:
     // 2 work-groups/CU instead of 8 outweighs the fewer load round trips); kept as a template option, not dispatched.
     const bool big = false;
@@ -383,6 +406,7 @@ TATT_API int tatt_conv2d_wgrad(const float* x, long xsn, long xsh, long xsw, lon
 
 // OIHW filter -> implicit-GEMM operand.  mode 0: [KH][KW][Cin][Cout] (forward);
 // mode 1: [KH][KW][Cout][Cin] spatially flipped (data-gradient: dX = conv(dY, flip(W)^T)).
+// modes 2 / 3: the same two filters with the contraction axis contiguous ([tap][out][in]) for tatt_conv3_c64_fwd_t.
 __global__ void repack_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin,
                                      int KH, int KW, int mode) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -393,8 +417,14 @@ __global__ void repack_weight_kernel(const float* __restrict__ w, float* __restr
     if (mode == 0) {
         int co = idx % Cout; int r = idx / Cout; int ci = r % Cin; int tap = r / Cin;
         out[idx] = w[((long)co * Cin + ci) * T + tap];
-    } else {
+    } else if (mode == 1) {
         int ci = idx % Cin; int r = idx / Cin; int co = r % Cout; int tap = r / Cout;
+        out[idx] = w[((long)co * Cin + ci) * T + (T - 1 - tap)];
+    } else if (mode == 2) {      // [tap][Cout][Cin]: forward filter with the contraction (input-channel) axis contiguous
+        int ci = idx % Cin; int r = idx / Cin; int co = r % Cout; int tap = r / Cout;
+        out[idx] = w[((long)co * Cin + ci) * T + tap];
+    } else {                     // mode 3: [tap][Cin][Cout] flipped: data-gradient filter, contraction (Cout) axis contiguous
+        int co = idx % Cout; int r = idx / Cout; int ci = r % Cin; int tap = r / Cin;
         out[idx] = w[((long)co * Cin + ci) * T + (T - 1 - tap)];
     }
 }

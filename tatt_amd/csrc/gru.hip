@@ -217,17 +217,24 @@ __global__ __launch_bounds__(256) void qgru_fwd_step_kernel(QStepP p) {
         const int kspan = HID / 4;
         const int kbeg = wave * kspan;
         const int arow = min(m0 + i, p.Wb - 1);
-        for (int kb = kbeg; kb < kbeg + kspan; kb += 16) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(hprev + (long)arow * HID + kb + 4 * q);
-            f32x4 b[3];
+        // 4 sub-steps (64 k) per trip: 16 independent 16-byte loads are in flight before the first MFMA needs data -- the
+        // step is latency-bound (one short wave per SIMD), so load-level parallelism is what matters.
+        for (int kb = kbeg; kb < kbeg + kspan; kb += 64) {
+            f32x4 a[4], b[3][4];
 #pragma unroll
-            for (int g = 0; g < 3; ++g)
-                b[g] = *reinterpret_cast<const f32x4*>(whh + ((long)g * HID + j0 + i) * HID + kb + 4 * q);
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int sstep = 0; sstep < 4; ++sstep) {
+                a[sstep] = *reinterpret_cast<const f32x4*>(hprev + (long)arow * HID + kb + 16 * sstep + 4 * q);
 #pragma unroll
                 for (int g = 0; g < 3; ++g)
-                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[g][u], acc[g], 0, 0, 0);
+                    b[g][sstep] = *reinterpret_cast<const f32x4*>(whh + ((long)g * HID + j0 + i) * HID + kb + 16 * sstep + 4 * q);
+            }
+#pragma unroll
+            for (int sstep = 0; sstep < 4; ++sstep)
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int g = 0; g < 3; ++g)
+                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[sstep][u], b[g][sstep][u], acc[g], 0, 0, 0);
         }
     }
     {
@@ -262,7 +269,7 @@ TATT_API int tatt_qgru_fwd_step(const float* gi0, const float* gi1, const float*
                                 const float* bhh0, const float* bhh1, const float* hprev0, const float* hprev1,
                                 float* hnew0, float* hnew1, float* gsave0, float* gsave1, int Wb, int HID,
                                 hipStream_t st) {
-    if (HID % 64) return 1;
+    if (HID % 256) return 1;          // each of the 4 waves reduces HID/4 columns in trips of 64
     QStepP p = {{gi0, gi1}, {whh0, whh1}, {bhh0, bhh1}, {hprev0, hprev1}, {hnew0, hnew1}, {gsave0, gsave1}, Wb, HID};
     hipLaunchKernelGGL(qgru_fwd_step_kernel, dim3(cdiv(Wb, 16), HID / 16, 2), dim3(256), 0, st, p);
     return LAUNCH_CHECK();
@@ -323,11 +330,17 @@ __global__ __launch_bounds__(256) void qgru_bwd_mm_kernel(QBwdMmP p) {
     const int i = lane & 15, q = lane >> 4;
     const int kspan = K / 4, kbeg = wave * kspan;
     const int arow = min(m0 + i, p.Wb - 1);
-    for (int kb = kbeg; kb < kbeg + kspan; kb += 16) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(dgh + (long)arow * K + kb + 4 * q);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(whh + (long)(j0 + i) * K + kb + 4 * q);
+    for (int kb = kbeg; kb < kbeg + kspan; kb += 64) {         // 4 sub-steps per trip: 8 loads in flight (see forward step)
+        f32x4 a[4], b[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc, 0, 0, 0);
+        for (int sstep = 0; sstep < 4; ++sstep) {
+            a[sstep] = *reinterpret_cast<const f32x4*>(dgh + (long)arow * K + kb + 16 * sstep + 4 * q);
+            b[sstep] = *reinterpret_cast<const f32x4*>(whh + (long)(j0 + i) * K + kb + 16 * sstep + 4 * q);
+        }
+#pragma unroll
+        for (int sstep = 0; sstep < 4; ++sstep)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[sstep][u], b[sstep][u], acc, 0, 0, 0);
     }
     {
         const int col = lane & 15, rb = (lane >> 4) * 4;
@@ -342,7 +355,7 @@ __global__ __launch_bounds__(256) void qgru_bwd_mm_kernel(QBwdMmP p) {
 }
 TATT_API int tatt_qgru_bwd_mm(const float* dgh0, const float* dgh1, const float* whhT0, const float* whhT1,
                               float* dhcarry0, float* dhcarry1, int Wb, int HID, hipStream_t st) {
-    if ((3 * HID) % 64) return 1;
+    if (HID % 256) return 1;           // each wave reduces 3*HID/4 rows in trips of 64
     QBwdMmP p = {{dgh0, dgh1}, {whhT0, whhT1}, {dhcarry0, dhcarry1}, Wb, HID};
     hipLaunchKernelGGL(qgru_bwd_mm_kernel, dim3(cdiv(Wb, 16), HID / 16, 2), dim3(256), 0, st, p);
     return LAUNCH_CHECK();

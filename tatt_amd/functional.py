@@ -45,8 +45,7 @@ class Conv2dFn(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, act):
         Cout, Cin, KH, KW = weight.shape
-        wp = ops.repack_weight(weight, 0)
-        y = ops.conv_fwd(x, wp, bias, Cout, KH, KW, act=act)
+        y = ops.conv2d_forward(x, weight, bias, act)
         ctx.save_for_backward(x, weight, y if act != ACT_NONE else None)
         ctx.act = act
         ctx.has_bias = bias is not None
@@ -61,10 +60,7 @@ class Conv2dFn(Function):
             dy = ops.act_bwd(y, dy, ctx.act, True)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            wd = ops.repack_weight(weight, 1)
-            dx = ops.conv_fwd(dy, wd, None, Cin, KH, KW)
-            if not x.is_contiguous():
-                dx = dx  # gradient is returned in contiguous NHWC indexing; autograd only needs matching shape
+            dx = ops.conv2d_dgrad(dy, weight)
         if ctx.needs_input_grad[1]:
             dw = ops.conv_wgrad(x, dy, Cout, KH, KW)
         if ctx.has_bias and ctx.needs_input_grad[2]:

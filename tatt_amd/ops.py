@@ -61,7 +61,7 @@ def gemm(A, sam, sak, B, sbk, sbn, C, scm, scn, M, N, K, *, A2=None, sa2m=0, sa2
         nchunks = cdiv(K, 16)
         splitk = max(1, min(splitk, nchunks))
         if splitk > 1:
-            ws = new(C, Z * splitk * M * N)
+            ws = new(C, Z * splitk * M * N + (splitk * M if rowsum is not None else 0))
     call("tatt_gemm", P(A), sam, sak, P(A2), sa2m, sa2k, K1, P(B), sbk, sbn, P(bias), P(C), scm, scn,
          M, N, K, Z, bsA, bsA2, bsB, bsC, bsBias, alpha, beta, act, splitk, P(ws), P(rowsum), stream())
     return C
@@ -109,9 +109,8 @@ def linear_bwd_weight(dy, x2, *, alpha=1.0, out=None, out_ld=None, beta=0.0, row
     K = x2.shape[1]
     dW = out if out is not None else new(dy, N, K)
     ld = out_ld if out_ld is not None else dW.stride(0)
-    Kv = K + 1 if rowsum is not None else K
-    gemm(dy, dy.stride(1), dy.stride(0), x2, x2.stride(0), x2.stride(1), dW, ld, 1, N, Kv, M, alpha=alpha, beta=beta,
-         splitk=_auto_split(N, Kv, M), rowsum=rowsum)
+    gemm(dy, dy.stride(1), dy.stride(0), x2, x2.stride(0), x2.stride(1), dW, ld, 1, N, K, M, alpha=alpha, beta=beta,
+         splitk=_auto_split(N, K, M), rowsum=rowsum)
     return dW
 
 
@@ -161,6 +160,35 @@ def conv_fwd(x_bhwc, wpacked, bias, Cout, KH, KW, *, act=ACT_NONE, out=None, bet
     call("tatt_conv2d_fwd", P(x_bhwc), sn, sh, sw, sc, P(wpacked), P(bias), P(y), Cout, B, H, W, Cin, Cout, KH, KW,
          act, beta, splitk, P(ws), stream())
     return y
+
+
+def _conv3_fast_ok(x_bhwc, Cin, Cout, KH, KW):
+    return (x_bhwc.is_contiguous() and KH == 3 and KW == 3 and Cin % 64 == 0 and Cout % 64 == 0
+            and x_bhwc.shape[2] % 64 == 0)
+
+
+def conv2d_forward(x_bhwc, weight_oihw, bias, act=ACT_NONE):
+    """y = act(conv(x, W) + b) from the reference-layout (OIHW) filter: picks the kernel and the filter packing it wants."""
+    Cout, Cin, KH, KW = weight_oihw.shape
+    if _conv3_fast_ok(x_bhwc, Cin, Cout, KH, KW):
+        B, H, W, _ = x_bhwc.shape
+        y = new(x_bhwc, B, H, W, Cout)
+        wt = repack_weight(weight_oihw, 2)                       # [9][Cout][Cin]
+        call("tatt_conv3_c64_fwd_t", P(x_bhwc), P(wt), P(bias), P(y), B, H, W, Cin, Cout, act, 0.0, stream())
+        return y
+    return conv_fwd(x_bhwc, repack_weight(weight_oihw, 0), bias, Cout, KH, KW, act=act)
+
+
+def conv2d_dgrad(dy_bhwc, weight_oihw):
+    """dx = conv(dy, flip(W)^T): the data gradient as a forward convolution with Cout input / Cin output channels."""
+    Cout, Cin, KH, KW = weight_oihw.shape
+    if _conv3_fast_ok(dy_bhwc, Cout, Cin, KH, KW):
+        B, H, W, _ = dy_bhwc.shape
+        dx = new(dy_bhwc, B, H, W, Cin)
+        wt = repack_weight(weight_oihw, 3)                       # [9][Cin][Cout], taps flipped
+        call("tatt_conv3_c64_fwd_t", P(dy_bhwc), P(wt), None, P(dx), B, H, W, Cout, Cin, ACT_NONE, 0.0, stream())
+        return dx
+    return conv_fwd(dy_bhwc, repack_weight(weight_oihw, 1), None, Cin, KH, KW)
 
 
 def conv_wgrad(x_bhwc, dy_bhwc, Cout, KH, KW):
