@@ -72,6 +72,8 @@ int tatt_conv3_c64_fwd(const float* x, const float* wpacked, const float* bias, 
  * from LDS with 16-byte loads along the contraction axis -- the production kernel (8x fewer LDS instructions) */
 int tatt_conv3_c64_fwd_t(const float* x, const float* wt, const float* bias, float* y, int B, int H, int W, int Cin,
                          int Cout, int act, float beta, hipStream_t st);
+/* diagnostics: when non-NULL, the following tatt_conv3_c64_fwd_t launches write a per-wave cycle breakdown (256*4*6 int64) */
+int tatt_conv3_set_prof(long long* buf);
 /* weight-gradient partials part[G][9*Cin][Cout] (G persistent work-groups, G <= B*H*W/64); finish with
  * tatt_splitk_reduce(part, dw_oihw, 9*Cin, Cout, G, Cin, 9, beta) */
 int tatt_conv3_c64_wgrad_partial(const float* x, const float* dy, float* part, int B, int H, int W, int Cin,

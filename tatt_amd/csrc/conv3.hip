@@ -21,6 +21,7 @@ struct Conv3P {
     const float* x; const float* w; const float* bias; float* y;
     int B, H, W, Cin, Cout, act;
     float beta;
+    long long* prof;      // diagnostics only (tools/bench_kernels.py --prof): per-work-group cycle breakdown, else nullptr
 };
 
 __global__ __launch_bounds__(256, 2) void conv3_c64_fwd_kernel(Conv3P p) {
@@ -636,6 +637,9 @@ __global__ __launch_bounds__(256) void conv3_c64_fwd_v5_kernel(Conv3P p) {
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    long long pc[6] = {0, 0, 0, 0, 0, 0};       // issue-loads | mfma block | publish (vmcnt wait + LDS writes) | barrier | epilogue | total
+    const bool prof = p.prof != nullptr;
+    const long long tstart = prof ? clock64() : 0;
     while (true) {
         int ntile = tile, nchk = ch + 1;
         if (nchk == nch) { nchk = 0; ntile = tile + G; }
@@ -647,6 +651,7 @@ __global__ __launch_bounds__(256) void conv3_c64_fwd_v5_kernel(Conv3P p) {
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {
             // ---- issue the loads that the MFMAs below will hide: next filter slice + 1/9 of the next halo ----
+            const long long c0 = prof ? clock64() : 0;
             const bool more_w = tap < 8 || has_next;
             if (tap < 8) load_w(tap + 1, ch * 64, co0);
             else if (has_next) load_w(0, nchk * 64, nco0);
@@ -657,6 +662,7 @@ __global__ __launch_bounds__(256) void conv3_c64_fwd_v5_kernel(Conv3P p) {
                 if (t < C3_SLICE - 256) h1 = halo_load(nn, nh + r - 1, nw0, nchk * 64, pxb, 256 + t);
             }
             // ---- 32 MFMAs fed by 8 + 8 sixteen-byte LDS reads, kept two steps ahead ----
+            const long long c1 = prof ? clock64() : 0;
             const int kh = r, kw = tap - 3 * r;
             const float* arow = Xs + (kh * C3_HW + wm * 32 + (lane & 31) + kw) * C5_XP + 4 * (lane >> 5);
             const float* brow = WsB + wbuf * C5_WT + (wn * 32 + (lane & 31)) * C5_XP + 4 * (lane >> 5);
@@ -680,15 +686,19 @@ __global__ __launch_bounds__(256) void conv3_c64_fwd_v5_kernel(Conv3P p) {
             C5_MM(6) C5_MM(7)
             __builtin_amdgcn_sched_barrier(0);
             // ---- publish the prefetched data ----
+            const long long c2 = prof ? clock64() : 0;
             if (more_w) store_w(WsB + (wbuf ^ 1) * C5_WT);
             if (has_next) {
                 *reinterpret_cast<f32x4*>(XsN + (r * C3_HW + pxb + (t >> 4)) * C5_XP + 4 * (t & 15)) = h0;
                 if (t < C3_SLICE - 256)
                     *reinterpret_cast<f32x4*>(XsN + (r * C3_HW + pxb + 16 + (t >> 4)) * C5_XP + 4 * (t & 15)) = h1;
             }
+            const long long c3 = prof ? clock64() : 0;
             __syncthreads();
+            if (prof) { const long long c4 = clock64(); pc[0] += c1 - c0; pc[1] += c2 - c1; pc[2] += c3 - c2; pc[3] += c4 - c3; }
             wbuf ^= 1;
         }
+        const long long e0 = prof ? clock64() : 0;
         if (ch == nch - 1) {
             const int co = co0 + wn * 32 + (lane & 31);
             const float bj = p.bias ? p.bias[co] : 0.f;
@@ -703,9 +713,14 @@ __global__ __launch_bounds__(256) void conv3_c64_fwd_v5_kernel(Conv3P p) {
                 acc[reg] = 0.f;
             }
         }
+        if (prof) pc[4] += clock64() - e0;
         if (!has_next) break;
         tile = ntile; ch = nchk; n = nn; h = nh; w0 = nw0; co0 = nco0;
         xbuf ^= 1;
+    }
+    if (prof && lane == 0) {
+        pc[5] = clock64() - tstart;
+        for (int i = 0; i < 6; ++i) p.prof[((long)blockIdx.x * 4 + wave) * 6 + i] = pc[i];
     }
 }
 
@@ -714,7 +729,7 @@ __global__ __launch_bounds__(256) void conv3_c64_fwd_v5_kernel(Conv3P p) {
 TATT_API int tatt_conv3_c64_fwd(const float* x, const float* wpacked, const float* bias, float* y, int B, int H, int W,
                                 int Cin, int Cout, int act, float beta, hipStream_t st) {
     if (Cin % 64 || Cout % 64 || W % C3_PX) return 1;
-    Conv3P p = {x, wpacked, bias, y, B, H, W, Cin, Cout, act, beta};
+    Conv3P p = {x, wpacked, bias, y, B, H, W, Cin, Cout, act, beta, nullptr};
     static bool attr_set = false;
     static int variant = 4;
     if (!attr_set) {
@@ -748,10 +763,14 @@ TATT_API int tatt_conv3_c64_fwd(const float* x, const float* wpacked, const floa
 
 // x (B,H,W,Cin) NHWC contiguous; wt = filter packed [9][Cout][Cin] (tatt_repack_conv_weight mode 2; mode 3 for the data
 // gradient); y (B,H,W,Cout)
+static long long* g_conv3_prof = nullptr;
+// diagnostics: cycle breakdown buffer (256 work-groups x 4 waves x 6 counters) filled by the next conv3 launches; NULL disables
+TATT_API int tatt_conv3_set_prof(long long* buf) { g_conv3_prof = buf; return 0; }
+
 TATT_API int tatt_conv3_c64_fwd_t(const float* x, const float* wt, const float* bias, float* y, int B, int H, int W, int Cin,
                                   int Cout, int act, float beta, hipStream_t st) {
     if (Cin % 64 || Cout % 64 || W % C3_PX) return 1;
-    Conv3P p = {x, wt, bias, y, B, H, W, Cin, Cout, act, beta};
+    Conv3P p = {x, wt, bias, y, B, H, W, Cin, Cout, act, beta, g_conv3_prof};
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_fwd_v5_kernel),
