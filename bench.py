@@ -7,7 +7,7 @@ dropout ON, STN ON) on synthetic 16x64 -> 32x128 batches, B = 48 per GPU, fp32 (
         bench.py --gpus N --steps K --warmup W
 
 Prints ONE JSON line on rank 0.  `value` is the whole-job aggregate (weak scaling: 48 images per GPU per step).
-Extra objects: `roofline` (the dominant kernel -- the fp32-MFMA implicit-GEMM 3x3 convolution -- timed live with HIP
+Extra objects: `roofline` (the dominant kernel -- the fp32-MFMA 3x3 convolution -- timed live with HIP
 events on the launch stream after the timed region) and `cpu_baseline` (the CPU oracle timed on this host's cores,
 N=1 only, a bounded sample).
 """
@@ -49,22 +49,26 @@ def make_batch(B, rank, dev):
 
 
 def time_dominant_kernel(dev, B):
-    """Average duration of the dominant kernel (implicit-GEMM 3x3 conv, 64->64 channels, B x 16 x 64 pixels) measured with
-    HIP events on the stream it is launched on.  Algorithmic FLOPs per launch = 2 * pixels * (3*3*64) * 64."""
+    """Average duration of the dominant kernel -- conv3_c64_fwd_v5_kernel, the 3x3 convolution 64->64 channels on B x 16 x 64
+    pixels (22 forward/data-gradient launches of this exact shape per training step) -- measured with HIP events on the
+    stream it is launched on.  Algorithmic FLOPs per launch = 2 * pixels * (3*3*64) * 64."""
     from tatt_amd import ops
     x = torch.randn(B, 16, 64, 64, device=dev)
     w = torch.randn(64, 64, 3, 3, device=dev) * 0.05
     b = torch.zeros(64, device=dev)
-    wp = ops.repack_weight(w, 0)
+    wt = ops.repack_weight(w, 2)
     y = torch.empty(B, 16, 64, 64, device=dev)
+
+    def run():
+        ops.call("tatt_conv3_c64_fwd_t", ops.P(x), ops.P(wt), ops.P(b), ops.P(y), B, 16, 64, 64, 64, 0, 0.0, ops.stream())
     for _ in range(5):
-        ops.conv_fwd(x, wp, b, 64, 3, 3, out=y)
+        run()
     n = 50
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
     for _ in range(n):
-        ops.conv_fwd(x, wp, b, 64, 3, 3, out=y)
+        run()
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
@@ -176,7 +180,7 @@ def main():
                        "whole_step_tflops": round(ips * FLOP_PER_IMAGE_FWD_BWD / 1e12, 2)},
             "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-                         "kernel": "gemm_mfma_kernel<3,1,0> (implicit-GEMM conv 3x3, 64->64 ch, %d x16x64 px)" % a.batch,
+                         "kernel": "conv3_c64_fwd_v5_kernel (3x3 conv, 64->64 ch, %d x16x64 px, fp32 MFMA)" % a.batch,
                          "kernel_ms": round(kms, 4), "flops_per_launch": kflops},
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -574,17 +574,32 @@ __global__ __launch_bounds__(320) void conv3_c64_fwd_v4_kernel(Conv3P p) {
 // contiguous (halo [row][px][68], filter slice transposed [co][68]; pitch 68 = conflict-free for ds_read_b128), each lane
 // reads 4 consecutive input channels per 16-byte load and feeds 4 MFMAs with it: lane (i, kq = lane>>5) uses channels
 // 8c + 4kq + u for u = 0..3 on BOTH operands, which is all the contraction needs.  8x fewer LDS instructions.
-#define C5_XP 68
-#define C5_HALO (3 * C3_HW * C5_XP)              // 13464 floats (16-byte aligned)
-#define C5_WT (64 * C5_XP)                       // 4352 floats
-#define C5_LDS ((2 * C5_HALO + 2 * C5_WT) * 4)   // 142,528 B
-__global__ __launch_bounds__(256) void conv3_c64_fwd_v5_kernel(Conv3P p) {
+// Template CK = input channels per work item: 64 (one work-group per CU, 142.5 KB LDS) or 32 (75.5 KB LDS => TWO work-groups per
+// CU: the in-kernel cycle breakdown (tools/conv3_prof.py) shows a wave spends 2.17k cycles per tap in its 32 MFMAs and another
+// ~1.6k in load issue, LDS publishes, barrier and epilogue that a lone wave per SIMD cannot overlap; a second resident
+// work-group fills those gaps).
+template <int CK>
+struct C5 {
+    static constexpr int XP = CK + 4;                     // pitch: 16-byte aligned rows, conflict-free ds_read_b128
+    static constexpr int HALO = 3 * C3_HW * XP;
+    static constexpr int WT = 64 * XP;
+    static constexpr int LDS = (2 * HALO + 2 * WT) * 4;   // CK=64: 142,528 B; CK=32: 75,456 B
+    static constexpr int Q4 = CK / 4;                     // float4 per pixel
+    static constexpr int SLICE = 22 * Q4;                 // float4 of the next halo fetched per tap
+    static constexpr int WF4 = 64 * Q4;                   // float4 of one filter slice
+};
+template <int CK>
+__global__ __launch_bounds__(256, (CK == 32 ? 2 : 1)) void conv3_c64_fwd_v5_kernel(Conv3P p) {
+    constexpr int C5_XP = C5<CK>::XP, C5_HALO = C5<CK>::HALO, C5_WT = C5<CK>::WT, Q4 = C5<CK>::Q4;
+    constexpr int SLICE = C5<CK>::SLICE, WF4 = C5<CK>::WF4, QS = (CK == 64 ? 4 : 5);   // log2(Q4)+... see idx split below
+    constexpr int Q4S = (CK == 64 ? 4 : 3);               // log2(Q4)
+    (void)QS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* XsB = smem;                                   // [2][3][66][68]
     float* WsB = smem + 2 * C5_HALO;                     // [2][64 co][68]   (filter slice, ci contiguous)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave & 1, wn = wave >> 1;
-    const int segs = p.W / C3_PX, cob = p.Cout / 64, nch = p.Cin / 64;
+    const int segs = p.W / C3_PX, cob = p.Cout / 64, nch = p.Cin / CK;
     const int ntiles = p.B * p.H * segs * cob;
     const int G = gridDim.x;
     auto decode = [&](int tile, int& n, int& h, int& w0, int& co0) {
@@ -594,29 +609,33 @@ __global__ __launch_bounds__(256) void conv3_c64_fwd_v5_kernel(Conv3P p) {
         h = bid % p.H; n = bid / p.H;
         w0 = seg * C3_PX; co0 = cb * 64;
     };
-    // float4 #idx (c4 = idx&15, pixel = idx>>4) of halo row r, pixels [pxb, pxb+22)
+    // float4 #idx (c4 = idx % Q4, pixel = idx / Q4) of halo row r, pixels [pxb, pxb+22)
     auto halo_load = [&](int n, int hh, int w0, int ci0, int pxb, int idx) -> f32x4 {
-        const int ww = w0 + pxb + (idx >> 4) - 1;
+        const int ww = w0 + pxb + (idx >> Q4S) - 1;
         f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (hh >= 0 && hh < p.H && ww >= 0 && ww < p.W)
-            v = *reinterpret_cast<const f32x4*>(p.x + (((long)n * p.H + hh) * p.W + ww) * p.Cin + ci0 + 4 * (idx & 15));
+            v = *reinterpret_cast<const f32x4*>(p.x + (((long)n * p.H + hh) * p.W + ww) * p.Cin + ci0 + 4 * (idx & (Q4 - 1)));
         return v;
     };
+    auto halo_store = [&](float* Xs, int r, int pxb, int idx, f32x4 v) {
+        *reinterpret_cast<f32x4*>(Xs + (r * C3_HW + pxb + (idx >> Q4S)) * C5_XP + 4 * (idx & (Q4 - 1))) = v;
+    };
     // packed filter (mode 2/3 of tatt_repack_conv_weight): wt[tap][co][ci], ci contiguous
-    f32x4 wreg[4];
+    constexpr int WQ = WF4 / 256;                        // filter float4 per thread per tap: 4 (CK=64) or 2 (CK=32)
+    f32x4 wreg[WQ];
     auto load_w = [&](int tap, int ci0, int co0) {
         const float* src = p.w + ((long)tap * p.Cout + co0) * p.Cin + ci0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int idx = t + 256 * q;                 // co = idx>>4, ci quad = idx&15
-            wreg[q] = *reinterpret_cast<const f32x4*>(src + (long)(idx >> 4) * p.Cin + 4 * (idx & 15));
+        for (int q = 0; q < WQ; ++q) {
+            const int idx = t + 256 * q;                 // co = idx / Q4, ci quad = idx % Q4
+            wreg[q] = *reinterpret_cast<const f32x4*>(src + (long)(idx >> Q4S) * p.Cin + 4 * (idx & (Q4 - 1)));
         }
     };
     auto store_w = [&](float* Ws) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < WQ; ++q) {
             const int idx = t + 256 * q;
-            *reinterpret_cast<f32x4*>(Ws + (idx >> 4) * C5_XP + 4 * (idx & 15)) = wreg[q];
+            *reinterpret_cast<f32x4*>(Ws + (idx >> Q4S) * C5_XP + 4 * (idx & (Q4 - 1))) = wreg[q];
         }
     };
     int tile = blockIdx.x;
@@ -626,8 +645,7 @@ __global__ __launch_bounds__(256) void conv3_c64_fwd_v5_kernel(Conv3P p) {
     // ---- prologue ----
     for (int s9 = 0; s9 < 9; ++s9) {
         const int r = s9 / 3, pxb = (s9 - 3 * r) * 22;
-        for (int i = t; i < C3_SLICE; i += 256)
-            *reinterpret_cast<f32x4*>(XsB + (r * C3_HW + pxb + (i >> 4)) * C5_XP + 4 * (i & 15)) = halo_load(n, h + r - 1, w0, 0, pxb, i);
+        for (int i = t; i < SLICE; i += 256) halo_store(XsB, r, pxb, i, halo_load(n, h + r - 1, w0, 0, pxb, i));
     }
     load_w(0, 0, co0);
     store_w(WsB);
@@ -653,20 +671,20 @@ __global__ __launch_bounds__(256) void conv3_c64_fwd_v5_kernel(Conv3P p) {
             // ---- issue the loads that the MFMAs below will hide: next filter slice + 1/9 of the next halo ----
             const long long c0 = prof ? clock64() : 0;
             const bool more_w = tap < 8 || has_next;
-            if (tap < 8) load_w(tap + 1, ch * 64, co0);
-            else if (has_next) load_w(0, nchk * 64, nco0);
+            if (tap < 8) load_w(tap + 1, ch * CK, co0);
+            else if (has_next) load_w(0, nchk * CK, nco0);
             const int r = tap / 3, pxb = (tap - 3 * r) * 22;      // this tap's slice of the NEXT halo: row r, 22 pixels
             f32x4 h0 = (f32x4){0.f, 0.f, 0.f, 0.f}, h1 = h0;
             if (has_next) {
-                h0 = halo_load(nn, nh + r - 1, nw0, nchk * 64, pxb, t);
-                if (t < C3_SLICE - 256) h1 = halo_load(nn, nh + r - 1, nw0, nchk * 64, pxb, 256 + t);
+                if (t < SLICE) h0 = halo_load(nn, nh + r - 1, nw0, nchk * CK, pxb, t);
+                if (SLICE > 256 && t < SLICE - 256) h1 = halo_load(nn, nh + r - 1, nw0, nchk * CK, pxb, 256 + t);
             }
             // ---- 32 MFMAs fed by 8 + 8 sixteen-byte LDS reads, kept two steps ahead ----
             const long long c1 = prof ? clock64() : 0;
             const int kh = r, kw = tap - 3 * r;
             const float* arow = Xs + (kh * C3_HW + wm * 32 + (lane & 31) + kw) * C5_XP + 4 * (lane >> 5);
             const float* brow = WsB + wbuf * C5_WT + (wn * 32 + (lane & 31)) * C5_XP + 4 * (lane >> 5);
-            f32x4 va[8], vb[8];
+            f32x4 va[CK / 8], vb[CK / 8];
 #define C5_LD(c) va[c] = *reinterpret_cast<const f32x4*>(arow + 8 * (c)); vb[c] = *reinterpret_cast<const f32x4*>(brow + 8 * (c));
 #define C5_MM(c) _Pragma("unroll") for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(va[c][u], vb[c][u], acc, 0, 0, 0);
             C5_LD(0) C5_LD(1)
@@ -675,23 +693,26 @@ __global__ __launch_bounds__(256) void conv3_c64_fwd_v5_kernel(Conv3P p) {
             __builtin_amdgcn_sched_barrier(0);
             C5_MM(0) C5_MM(1)
             __builtin_amdgcn_sched_barrier(0);
-            C5_LD(4) C5_LD(5)
-            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (CK == 64) {
+                C5_LD(4) C5_LD(5)
+                __builtin_amdgcn_sched_barrier(0);
+            }
             C5_MM(2) C5_MM(3)
             __builtin_amdgcn_sched_barrier(0);
-            C5_LD(6) C5_LD(7)
-            __builtin_amdgcn_sched_barrier(0);
-            C5_MM(4) C5_MM(5)
-            __builtin_amdgcn_sched_barrier(0);
-            C5_MM(6) C5_MM(7)
-            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (CK == 64) {
+                C5_LD(6) C5_LD(7)
+                __builtin_amdgcn_sched_barrier(0);
+                C5_MM(4) C5_MM(5)
+                __builtin_amdgcn_sched_barrier(0);
+                C5_MM(6) C5_MM(7)
+                __builtin_amdgcn_sched_barrier(0);
+            }
             // ---- publish the prefetched data ----
             const long long c2 = prof ? clock64() : 0;
             if (more_w) store_w(WsB + (wbuf ^ 1) * C5_WT);
             if (has_next) {
-                *reinterpret_cast<f32x4*>(XsN + (r * C3_HW + pxb + (t >> 4)) * C5_XP + 4 * (t & 15)) = h0;
-                if (t < C3_SLICE - 256)
-                    *reinterpret_cast<f32x4*>(XsN + (r * C3_HW + pxb + 16 + (t >> 4)) * C5_XP + 4 * (t & 15)) = h1;
+                if (t < SLICE) halo_store(XsN, r, pxb, t, h0);
+                if (SLICE > 256 && t < SLICE - 256) halo_store(XsN, r, pxb, 256 + t, h1);
             }
             const long long c3 = prof ? clock64() : 0;
             __syncthreads();
@@ -772,14 +793,24 @@ TATT_API int tatt_conv3_c64_fwd_t(const float* x, const float* wt, const float* 
     if (Cin % 64 || Cout % 64 || W % C3_PX) return 1;
     Conv3P p = {x, wt, bias, y, B, H, W, Cin, Cout, act, beta, g_conv3_prof};
     static bool attr_set = false;
+    static int ck = 32;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_fwd_v5_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, C5_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_fwd_v5_kernel<64>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, C5<64>::LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_fwd_v5_kernel<32>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, C5<32>::LDS);
+        const char* e = getenv("TATT_CONV3_CK");           // 64: one work-group per CU; 32 (default): two per CU
+        if (e) ck = atoi(e);
         attr_set = true;
     }
     const int ntiles = B * H * (W / C3_PX) * (Cout / 64);
-    const int G = ntiles < 256 ? ntiles : 256;
-    hipLaunchKernelGGL(conv3_c64_fwd_v5_kernel, dim3(G), dim3(256), C5_LDS, st, p);
+    if (ck == 64) {
+        const int G = ntiles < 256 ? ntiles : 256;
+        hipLaunchKernelGGL(conv3_c64_fwd_v5_kernel<64>, dim3(G), dim3(256), C5<64>::LDS, st, p);
+    } else {
+        const int G = ntiles < 512 ? ntiles : 512;          // two resident work-groups per CU
+        hipLaunchKernelGGL(conv3_c64_fwd_v5_kernel<32>, dim3(G), dim3(256), C5<32>::LDS, st, p);
+    }
     return LAUNCH_CHECK();
 }
 
