@@ -180,6 +180,14 @@ int tatt_gru32_bwd(const float* gi, const float* out, const float* dout, const f
                    float* hprev, int nseq, int T, int s_in, long stride_hi, long stride_lo, long stride_t,
                    hipStream_t st);
 
+/* backward step, fused form: dh = dhseq_next + dhcarry + dgh_cur @ whh, then the gate part of the NEXT step on the same tile:
+ * dgi_acc += input-side gate grads, dgh_next = recurrent-side gate grads, dhcarry = dh*z  (whhT = whh transposed) */
+int tatt_qgru_bwd_fused(const float* dgh_cur0, const float* dgh_cur1, const float* whhT0, const float* whhT1,
+                        const float* dhseq_next0, const float* dhseq_next1, const float* gsave_next0,
+                        const float* gsave_next1, const float* hprev_next0, const float* hprev_next1,
+                        float* dhcarry0, float* dhcarry1, float* dgi_acc0, float* dgi_acc1, float* dgh_next0,
+                        float* dgh_next1, int Wb, int HID, hipStream_t st);
+
 /* GruBlock glue: compose the 1x1 conv (Wc (64,K), bc) with the GRU input projections into Wp (192,K) = [wih_f; wih_r] Wc,
  * bp (192) = [wih_f; wih_r] bc + [bih_f; bih_r]  (reference GruBlock.forward, model/tsrn.py:1075-1081) */
 int tatt_gru_compose(const float* wih_f, const float* wih_r, const float* bih_f, const float* bih_r,

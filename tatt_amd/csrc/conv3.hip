@@ -589,10 +589,10 @@ struct C5 {
     static constexpr int WF4 = 64 * Q4;                   // float4 of one filter slice
 };
 template <int CK>
-__global__ __launch_bounds__(256, (CK == 32 ? 2 : 1)) void conv3_c64_fwd_v5_kernel(Conv3P p) {
+__global__ __launch_bounds__(256, (CK == 64 ? 1 : (CK == 32 ? 2 : 3))) void conv3_c64_fwd_v5_kernel(Conv3P p) {
     constexpr int C5_XP = C5<CK>::XP, C5_HALO = C5<CK>::HALO, C5_WT = C5<CK>::WT, Q4 = C5<CK>::Q4;
     constexpr int SLICE = C5<CK>::SLICE, WF4 = C5<CK>::WF4, QS = (CK == 64 ? 4 : 5);   // log2(Q4)+... see idx split below
-    constexpr int Q4S = (CK == 64 ? 4 : 3);               // log2(Q4)
+    constexpr int Q4S = (CK == 64 ? 4 : (CK == 32 ? 3 : 2));   // log2(Q4)
     (void)QS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* XsB = smem;                                   // [2][3][66][68]
@@ -687,25 +687,32 @@ __global__ __launch_bounds__(256, (CK == 32 ? 2 : 1)) void conv3_c64_fwd_v5_kern
             f32x4 va[CK / 8], vb[CK / 8];
 #define C5_LD(c) va[c] = *reinterpret_cast<const f32x4*>(arow + 8 * (c)); vb[c] = *reinterpret_cast<const f32x4*>(brow + 8 * (c));
 #define C5_MM(c) _Pragma("unroll") for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(va[c][u], vb[c][u], acc, 0, 0, 0);
-            C5_LD(0) C5_LD(1)
-            __builtin_amdgcn_sched_barrier(0);
-            C5_LD(2) C5_LD(3)
-            __builtin_amdgcn_sched_barrier(0);
-            C5_MM(0) C5_MM(1)
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (CK == 64) {
-                C5_LD(4) C5_LD(5)
+            if constexpr (CK == 16) {
+                C5_LD(0) C5_LD(1)
                 __builtin_amdgcn_sched_barrier(0);
-            }
-            C5_MM(2) C5_MM(3)
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (CK == 64) {
-                C5_LD(6) C5_LD(7)
+                C5_MM(0) C5_MM(1)
                 __builtin_amdgcn_sched_barrier(0);
-                C5_MM(4) C5_MM(5)
+            } else {
+                C5_LD(0) C5_LD(1)
                 __builtin_amdgcn_sched_barrier(0);
-                C5_MM(6) C5_MM(7)
+                C5_LD(2) C5_LD(3)
                 __builtin_amdgcn_sched_barrier(0);
+                C5_MM(0) C5_MM(1)
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (CK == 64) {
+                    C5_LD(4) C5_LD(5)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                C5_MM(2) C5_MM(3)
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (CK == 64) {
+                    C5_LD(6) C5_LD(7)
+                    __builtin_amdgcn_sched_barrier(0);
+                    C5_MM(4) C5_MM(5)
+                    __builtin_amdgcn_sched_barrier(0);
+                    C5_MM(6) C5_MM(7)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             // ---- publish the prefetched data ----
             const long long c2 = prof ? clock64() : 0;
@@ -740,8 +747,8 @@ __global__ __launch_bounds__(256, (CK == 32 ? 2 : 1)) void conv3_c64_fwd_v5_kern
         xbuf ^= 1;
     }
     if (prof && lane == 0) {
-        pc[5] = clock64() - tstart;
-        for (int i = 0; i < 6; ++i) p.prof[((long)blockIdx.x * 4 + wave) * 6 + i] = pc[i];
+        pc[5] = clock64() - tstart;   // (only the first 256 work-groups report)
+        if (blockIdx.x < 256) for (int i = 0; i < 6; ++i) p.prof[((long)blockIdx.x * 4 + wave) * 6 + i] = pc[i];
     }
 }
 
@@ -799,6 +806,8 @@ TATT_API int tatt_conv3_c64_fwd_t(const float* x, const float* wt, const float* 
                                   hipFuncAttributeMaxDynamicSharedMemorySize, C5<64>::LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_fwd_v5_kernel<32>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, C5<32>::LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_fwd_v5_kernel<16>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, C5<16>::LDS);
         const char* e = getenv("TATT_CONV3_CK");           // 64: one work-group per CU; 32 (default): two per CU
         if (e) ck = atoi(e);
         attr_set = true;
@@ -807,6 +816,9 @@ TATT_API int tatt_conv3_c64_fwd_t(const float* x, const float* wt, const float* 
     if (ck == 64) {
         const int G = ntiles < 256 ? ntiles : 256;
         hipLaunchKernelGGL(conv3_c64_fwd_v5_kernel<64>, dim3(G), dim3(256), C5<64>::LDS, st, p);
+    } else if (ck == 16) {
+        const int G = ntiles < 768 ? ntiles : 768;          // three resident work-groups per CU
+        hipLaunchKernelGGL(conv3_c64_fwd_v5_kernel<16>, dim3(G), dim3(256), C5<16>::LDS, st, p);
     } else {
         const int G = ntiles < 512 ? ntiles : 512;          // two resident work-groups per CU
         hipLaunchKernelGGL(conv3_c64_fwd_v5_kernel<32>, dim3(G), dim3(256), C5<32>::LDS, st, p);

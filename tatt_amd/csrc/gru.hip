@@ -361,6 +361,76 @@ TATT_API int tatt_qgru_bwd_mm(const float* dgh0, const float* dgh1, const float*
     return LAUNCH_CHECK();
 }
 
+// backward step, fused: the matmul part of step s followed, on the same (row, hidden unit) tile, by the gate part of step s+1
+//   dh = dhseq_next + dhcarry + dgh_cur @ whh   ->   dgi_acc += ..., dgh_next = ..., dhcarry = dh * z
+// (dhcarry holds dh_s * z_s from the previous gate evaluation).  Halves the launches of the backward recurrence.
+struct QBwdFusedP {
+    const float* dgh_cur[2]; const float* whhT[2];
+    const float* dhseq_next[2]; const float* gsave_next[2]; const float* hprev_next[2];
+    float* dhcarry[2]; float* dgi_acc[2]; float* dgh_next[2];
+    int Wb, HID;
+};
+__global__ __launch_bounds__(256) void qgru_bwd_fused_kernel(QBwdFusedP p) {
+    __shared__ float red[4][16][17];
+    const int d = blockIdx.z;
+    const int m0 = blockIdx.x * 16, j0 = blockIdx.y * 16;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int HID = p.HID, K = 3 * p.HID;
+    const float* dgh = p.dgh_cur[d];
+    const float* whh = p.whhT[d];
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int i = lane & 15, q = lane >> 4;
+    const int kspan = K / 4, kbeg = wave * kspan;
+    const int arow = min(m0 + i, p.Wb - 1);
+    for (int kb = kbeg; kb < kbeg + kspan; kb += 64) {
+        f32x4 a[4], b[4];
+#pragma unroll
+        for (int sstep = 0; sstep < 4; ++sstep) {
+            a[sstep] = *reinterpret_cast<const f32x4*>(dgh + (long)arow * K + kb + 16 * sstep + 4 * q);
+            b[sstep] = *reinterpret_cast<const f32x4*>(whh + (long)(j0 + i) * K + kb + 16 * sstep + 4 * q);
+        }
+#pragma unroll
+        for (int sstep = 0; sstep < 4; ++sstep)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[sstep][u], b[sstep][u], acc, 0, 0, 0);
+    }
+    {
+        const int col = lane & 15, rb = (lane >> 4) * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][rb + r][col] = acc[r];
+    }
+    __syncthreads();
+    const int m = t >> 4, j = t & 15;
+    if (m0 + m >= p.Wb) return;
+    const long row = m0 + m, e = row * HID + j0 + j;
+    const long n_el = (long)p.Wb * HID;
+    const float dh = p.dhseq_next[d][e] + p.dhcarry[d][e] + ((red[0][m][j] + red[1][m][j]) + (red[2][m][j] + red[3][m][j]));
+    const float* gs = p.gsave_next[d];
+    const float r = gs[e], z = gs[n_el + e], n = gs[2 * n_el + e], hn = gs[3 * n_el + e];
+    const float hp = p.hprev_next[d] ? p.hprev_next[d][e] : 0.f;
+    const float dn = dh * (1.f - z), dz = dh * (hp - n);
+    const float dnp = dn * (1.f - n * n);
+    const float drp = dnp * hn * r * (1.f - r);
+    const float dzp = dz * z * (1.f - z);
+    const long g3 = row * 3 * HID + j0 + j;
+    float* ga = p.dgi_acc[d];
+    ga[g3] += drp; ga[g3 + HID] += dzp; ga[g3 + 2 * HID] += dnp;
+    float* dg = p.dgh_next[d];
+    dg[g3] = drp; dg[g3 + HID] = dzp; dg[g3 + 2 * HID] = dnp * r;
+    p.dhcarry[d][e] = dh * z;
+}
+TATT_API int tatt_qgru_bwd_fused(const float* dgh_cur0, const float* dgh_cur1, const float* whhT0, const float* whhT1,
+                                 const float* dhseq_next0, const float* dhseq_next1, const float* gsave_next0,
+                                 const float* gsave_next1, const float* hprev_next0, const float* hprev_next1,
+                                 float* dhcarry0, float* dhcarry1, float* dgi_acc0, float* dgi_acc1, float* dgh_next0,
+                                 float* dgh_next1, int Wb, int HID, hipStream_t st) {
+    if (HID % 256) return 1;
+    QBwdFusedP p = {{dgh_cur0, dgh_cur1}, {whhT0, whhT1}, {dhseq_next0, dhseq_next1}, {gsave_next0, gsave_next1},
+                    {hprev_next0, hprev_next1}, {dhcarry0, dhcarry1}, {dgi_acc0, dgi_acc1}, {dgh_next0, dgh_next1}, Wb, HID};
+    hipLaunchKernelGGL(qgru_bwd_fused_kernel, dim3(cdiv(Wb, 16), HID / 16, 2), dim3(256), 0, st, p);
+    return LAUNCH_CHECK();
+}
+
 // ------------------------------------------------------------------------------------------------
 // GruBlock glue (reference GruBlock = 1x1 conv + BiGRU, model/tsrn.py:1067-1084): the 1x1 conv W_c (64 x K), b_c and the
 // GRU input projections W_ih (2 x 96 x 64), b_ih are composed into ONE projection  W' = W_ih W_c (192 x K),

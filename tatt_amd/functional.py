@@ -509,16 +509,22 @@ class QueryGruFn(Function):
             tT = ops.new(dev, HID, 3 * HID)
             ops.copy4d(whh, tT, (1, 1, HID, 3 * HID), (0, 0, 1, HID), (0, 0, 3 * HID, 1))
             whhT.append(tT)
-        for s in range(B):
-            t0, t1 = B - 1 - s, s            # reverse of the forward order in each direction
-            hp0 = hseq[0, t0 - 1] if t0 > 0 else None
-            hp1 = hseq[1, t1 + 1] if t1 < B - 1 else None
-            ops.call("tatt_qgru_bwd_gates", ops.P(dhseq[0, t0]), ops.P(dhseq[1, t1]), ops.P(gsave[0, t0]),
-                     ops.P(gsave[1, t1]), ops.P(hp0), ops.P(hp1), ops.P(dhc[0]), ops.P(dhc[1]), ops.P(dgi_acc[0]),
-                     ops.P(dgi_acc[1]), ops.P(dgh[0, t0]), ops.P(dgh[1, t1]), W, HID, int(s == 0), ops.stream())
-            if s < B - 1:
-                ops.call("tatt_qgru_bwd_mm", ops.P(dgh[0, t0]), ops.P(dgh[1, t1]), ops.P(whhT[0]), ops.P(whhT[1]),
-                         ops.P(dhc[0]), ops.P(dhc[1]), W, HID, ops.stream())
+        def prev_h(t0, t1):
+            return (hseq[0, t0 - 1] if t0 > 0 else None), (hseq[1, t1 + 1] if t1 < B - 1 else None)
+
+        # backward sweep: step s visits time B-1-s in the forward direction and time s in the reverse direction
+        hp0, hp1 = prev_h(B - 1, 0)
+        ops.call("tatt_qgru_bwd_gates", ops.P(dhseq[0, B - 1]), ops.P(dhseq[1, 0]), ops.P(gsave[0, B - 1]),
+                 ops.P(gsave[1, 0]), ops.P(hp0), ops.P(hp1), ops.P(dhc[0]), ops.P(dhc[1]), ops.P(dgi_acc[0]),
+                 ops.P(dgi_acc[1]), ops.P(dgh[0, B - 1]), ops.P(dgh[1, 0]), W, HID, 1, ops.stream())
+        for s in range(B - 1):
+            c0, c1 = B - 1 - s, s                # current step's time indices
+            n0, n1 = c0 - 1, c1 + 1              # next step's
+            hp0, hp1 = prev_h(n0, n1)
+            ops.call("tatt_qgru_bwd_fused", ops.P(dgh[0, c0]), ops.P(dgh[1, c1]), ops.P(whhT[0]), ops.P(whhT[1]),
+                     ops.P(dhseq[0, n0]), ops.P(dhseq[1, n1]), ops.P(gsave[0, n0]), ops.P(gsave[1, n1]), ops.P(hp0),
+                     ops.P(hp1), ops.P(dhc[0]), ops.P(dhc[1]), ops.P(dgi_acc[0]), ops.P(dgi_acc[1]),
+                     ops.P(dgh[0, n0]), ops.P(dgh[1, n1]), W, HID, ops.stream())
         grads = []
         dx = ops.new(dev, W, IN)
         for d, (wih, whh) in enumerate(((wih0, whh0), (wih1, whh1))):
