@@ -588,7 +588,7 @@ struct C5 {
     static constexpr int SLICE = 22 * Q4;                 // float4 of the next halo fetched per tap
     static constexpr int WF4 = 64 * Q4;                   // float4 of one filter slice
 };
-template <int CK>
+template <int CK, bool PROF>
 __global__ __launch_bounds__(256, (CK == 64 ? 1 : (CK == 32 ? 2 : 3))) void conv3_c64_fwd_v5_kernel(Conv3P p) {
     constexpr int C5_XP = C5<CK>::XP, C5_HALO = C5<CK>::HALO, C5_WT = C5<CK>::WT, Q4 = C5<CK>::Q4;
     constexpr int SLICE = C5<CK>::SLICE, WF4 = C5<CK>::WF4, QS = (CK == 64 ? 4 : 5);   // log2(Q4)+... see idx split below
@@ -656,7 +656,7 @@ __global__ __launch_bounds__(256, (CK == 64 ? 1 : (CK == 32 ? 2 : 3))) void conv
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     long long pc[6] = {0, 0, 0, 0, 0, 0};       // issue-loads | mfma block | publish (vmcnt wait + LDS writes) | barrier | epilogue | total
-    const bool prof = p.prof != nullptr;
+    constexpr bool prof = PROF;
     const long long tstart = prof ? clock64() : 0;
     while (true) {
         int ntile = tile, nchk = ch + 1;
@@ -802,27 +802,20 @@ TATT_API int tatt_conv3_c64_fwd_t(const float* x, const float* wt, const float* 
     static bool attr_set = false;
     static int ck = 32;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_fwd_v5_kernel<64>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, C5<64>::LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_fwd_v5_kernel<32>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, C5<32>::LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_fwd_v5_kernel<16>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, C5<16>::LDS);
-        const char* e = getenv("TATT_CONV3_CK");           // 64: one work-group per CU; 32 (default): two per CU
+#define C5_ATTR(CKV, PV) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_fwd_v5_kernel<CKV, PV>), \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, C5<CKV>::LDS);
+        C5_ATTR(64, false) C5_ATTR(32, false) C5_ATTR(16, false) C5_ATTR(64, true) C5_ATTR(32, true) C5_ATTR(16, true)
+        const char* e = getenv("TATT_CONV3_CK");   // 64: one work-group per CU; 32 (default): two per CU; 16: three per CU
         if (e) ck = atoi(e);
         attr_set = true;
     }
     const int ntiles = B * H * (W / C3_PX) * (Cout / 64);
-    if (ck == 64) {
-        const int G = ntiles < 256 ? ntiles : 256;
-        hipLaunchKernelGGL(conv3_c64_fwd_v5_kernel<64>, dim3(G), dim3(256), C5<64>::LDS, st, p);
-    } else if (ck == 16) {
-        const int G = ntiles < 768 ? ntiles : 768;          // three resident work-groups per CU
-        hipLaunchKernelGGL(conv3_c64_fwd_v5_kernel<16>, dim3(G), dim3(256), C5<16>::LDS, st, p);
-    } else {
-        const int G = ntiles < 512 ? ntiles : 512;          // two resident work-groups per CU
-        hipLaunchKernelGGL(conv3_c64_fwd_v5_kernel<32>, dim3(G), dim3(256), C5<32>::LDS, st, p);
-    }
+    const int per_cu = ck == 64 ? 1 : (ck == 16 ? 3 : 2);
+    const int G = ntiles < 256 * per_cu ? ntiles : 256 * per_cu;
+#define C5_LAUNCH(CKV)                                                                                              \
+    if (p.prof) hipLaunchKernelGGL((conv3_c64_fwd_v5_kernel<CKV, true>), dim3(G), dim3(256), C5<CKV>::LDS, st, p); \
+    else hipLaunchKernelGGL((conv3_c64_fwd_v5_kernel<CKV, false>), dim3(G), dim3(256), C5<CKV>::LDS, st, p);
+    if (ck == 64) { C5_LAUNCH(64) } else if (ck == 16) { C5_LAUNCH(16) } else { C5_LAUNCH(32) }
     return LAUNCH_CHECK();
 }
 
