@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=48)
-    ap.add_argument("--arch", default="tatt", choices=["tatt", "tsrn"])
+    ap.add_argument("--arch", default="tatt", choices=["tatt", "tsrn", "tbsrn"])
     return ap.parse_args()
 
 
@@ -76,22 +76,30 @@ def time_dominant_kernel(dev, B):
     return ms, flops
 
 
+def make_model(arch):
+    import tatt_amd
+    kw = dict(scale_factor=2, width=128, height=32, STN=True, mask=True, srb_nums=5, hidden_units=32)
+    if arch == "tbsrn":
+        return tatt_amd.TBSRN(input_channel=4, **kw)
+    return (tatt_amd.TSRN_TL_TRANS if arch == "tatt" else tatt_amd.TSRN)(**kw)
+
+
 def cpu_baseline(arch, B):
     """The CPU oracle (validated against the reference, tests/golden/REPORT.txt) timed on this host: ONE full training
     step (fwd + loss + bwd + clip + Adam, dropout on) on the same synthetic workload."""
     from oracle import tatt_oracle as O
     import tatt_amd
     torch.manual_seed(1234)
-    cls = tatt_amd.TSRN_TL_TRANS if arch == "tatt" else tatt_amd.TSRN
-    sd = cls(scale_factor=2, width=128, height=32, STN=True, mask=True, srb_nums=5, hidden_units=32).state_dict()
+    sd = make_model(arch).state_dict()
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(0)
     x, hr = torch.rand(B, 4, 16, 64, generator=g), torch.rand(B, 4, 32, 128, generator=g)
     tp = torch.softmax(torch.randn(B, 37, 1, 26, generator=g), 1) if arch == "tatt" else None
-    O.train_step(sd, x[:2], None if tp is None else tp[:2], hr[:2], tatt=arch == "tatt", stn=True, drop_on=True)   # warm-up
+    kw = dict(tatt=arch == "tatt", stn=True, drop_on=True, tbsrn=arch == "tbsrn")
+    O.train_step(sd, x[:2], None if tp is None else tp[:2], hr[:2], **kw)   # warm-up
     t0 = time.time()
-    O.train_step(sd, x, tp, hr, tatt=arch == "tatt", stn=True, drop_on=True)
+    O.train_step(sd, x, tp, hr, **kw)
     dt = time.time() - t0
     return {"value": round(B / dt, 3), "unit": "LR images/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": "1 full train step (fwd+loss+bwd+clip+Adam, dropout on) of the CPU oracle at B=%d, fp32, "
@@ -120,8 +128,7 @@ def main():
     build()
 
     torch.manual_seed(1234)
-    kw = dict(scale_factor=2, width=128, height=32, STN=True, mask=True, srb_nums=5, hidden_units=32)
-    model = (tatt_amd.TSRN_TL_TRANS if a.arch == "tatt" else tatt_amd.TSRN)(**kw).to(dev).train()
+    model = make_model(a.arch).to(dev).train()
     use_graph = (not a.no_graph) and a.warmup >= 3
     tr = Trainer(model, use_graph=use_graph, warmup_eager=2, process_group=pg)
     x, tp, hr = make_batch(a.batch, rank, dev)
@@ -174,7 +181,7 @@ def main():
             "dtype": "fp32", "data": "synthetic",
             "config": {"workload": "TATT (TSRN_TL_TRANS, STN on, dropout on) train step, batch %d/GPU, 16x64 LR -> 32x128 SR, "
                                    "ImageLoss + clip 0.25 + Adam(1e-3,(0.5,0.999))" % a.batch if a.arch == "tatt" else
-                       "TSRN train step, batch %d/GPU" % a.batch,
+                       "%s train step, batch %d/GPU" % (a.arch.upper(), a.batch),
                        "global_batch": a.batch * world, "parallelism": "dp%d" % world,
                        "launch": "hipGraph replay" if graph_ok else "eager", "final_loss": round(loss_v, 5),
                        "whole_step_tflops": round(ips * FLOP_PER_IMAGE_FWD_BWD / 1e12, 2)},

@@ -54,7 +54,8 @@ int tatt_conv2d_wgrad(const float* x, long xsn, long xsh, long xsw, long xsc, co
 
 /* OIHW nn.Conv2d weight -> GEMM operand; mode 0: [KH][KW][Cin][Cout]; mode 1: [KH][KW][Cout][Cin], taps flipped (data gradient);
  * mode 2: [KH][KW][Cout][Cin]; mode 3: [KH][KW][Cin][Cout], taps flipped -- forward / data-gradient filters with the
- * contraction axis contiguous, for tatt_conv3_c64_fwd_t */
+ * contraction axis contiguous, for tatt_conv3_c64_fwd_t; modes 4 / 5: the same two 3x3 filters (64 contraction channels) in the
+ * per-lane register order of tatt_conv3_c64_fwd_ws */
 int tatt_repack_conv_weight(const float* w_oihw, float* out, int Cout, int Cin, int KH, int KW,
                             int mode, hipStream_t st);
 
@@ -72,6 +73,11 @@ int tatt_conv3_c64_fwd(const float* x, const float* wpacked, const float* bias, 
  * from LDS with 16-byte loads along the contraction axis -- the production kernel (8x fewer LDS instructions) */
 int tatt_conv3_c64_fwd_t(const float* x, const float* wt, const float* bias, float* y, int B, int H, int W, int Cin,
                          int Cout, int act, float beta, hipStream_t st);
+/* weight-stationary 3x3 convolution for 64 input channels (reference nn.Conv2d(64, Cout, 3, padding=1): model/tsrn.py:877,885,
+ * 612,1043 and their data gradients): every wave keeps its 32 output channels' whole filter in registers; wl = filter from
+ * tatt_repack_conv_weight mode 4 (forward) / mode 5 (data gradient of a 64-output-channel convolution) */
+int tatt_conv3_c64_fwd_ws(const float* x, const float* wl, const float* bias, float* y, int B, int H, int W,
+                          int Cout, int act, float beta, hipStream_t st);
 /* diagnostics: when non-NULL, the following tatt_conv3_c64_fwd_t launches write a per-wave cycle breakdown (256*4*6 int64) */
 int tatt_conv3_set_prof(long long* buf);
 /* weight-gradient partials part[G][9*Cin][Cout] (G persistent work-groups, G <= B*H*W/64); finish with
@@ -110,13 +116,15 @@ int tatt_bn_bwd(const float* X, long ldx, const float* dY, long lddy, float* dX,
                 const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
                 int training, float* dgamma, float* dbeta, float* sums, double* ws, hipStream_t st);
 
-/* Y = LayerNorm(A + Bres) * gamma + beta over the last axis (C <= 256), stats[M][2] = (mean, rstd).
+/* Y = LayerNorm(A + Bres) * gamma + beta over the last axis (C <= 256), stats[M][2] = (mean, 1/denominator).
+ * mode 0 = nn.LayerNorm (biased variance, eps inside the sqrt); mode 1 = the TBSRN variant's own LayerNorm
+ * (model/tbsrn.py:23-36: unbiased std, eps added to the std).
  * nn.LayerNorm + the residual add in front of it (model/transformer_v2.py:478-483,826-832,380-387). */
 int tatt_ln_fwd(const float* A, const float* Bres, float* Y, float* stats, int M, int C,
-                const float* gamma, const float* beta, float eps, hipStream_t st);
+                const float* gamma, const float* beta, float eps, int mode, hipStream_t st);
 /* dX = d(A+Bres); part >= ceil(M/64)*2*C floats; ws >= 256*2*C doubles */
 int tatt_ln_bwd(const float* A, const float* Bres, const float* dY, const float* stats, float* dX, int M,
-                int C, const float* gamma, float* dgamma, float* dbeta, float* part, double* ws,
+                int C, const float* gamma, float* dgamma, float* dbeta, float* part, double* ws, float eps, int mode,
                 hipStream_t st);
 
 /* ---- element-wise ------------------------------------------------------------------------------------ */
@@ -225,6 +233,14 @@ int tatt_attn_fwd(const float* Q, const float* K, const float* V, float* ctx, fl
 int tatt_attn_bwd(const float* Q, const float* K, const float* V, const float* dctx, const float* dwavg,
                   float* dQ, float* dK, float* dV, float* part, int B, int Lq, int S, float pdrop,
                   const unsigned long long* seed, unsigned site, hipStream_t st);
+
+/* Row softmax over materialised attention scores (TBSRN FeatureEnhancer self-attention, model/tbsrn.py:130-151):
+ * S (rows x L, L <= 4096) is overwritten by softmax(S); Pd (nullable) receives dropout(softmax(S)) */
+int tatt_softmax_rows_fwd(float* S, float* Pd, long rows, int L, float pdrop, const unsigned long long* seed,
+                          unsigned site, hipStream_t st);
+/* dP (gradient w.r.t. the dropped probabilities) is overwritten by the gradient w.r.t. the scores */
+int tatt_softmax_rows_bwd(const float* P, float* dP, long rows, int L, float pdrop, const unsigned long long* seed,
+                          unsigned site, hipStream_t st);
 
 /* ---- TPS rectification ---------------------------------------------------------------------------------- */
 

@@ -364,6 +364,79 @@ def generator_forward(sd: SD, x: Tensor, text_emb: Optional[Tensor] = None, *, t
 
 
 # ----------------------------------------------------------------------------
+# TBSRN variant (reference model/tbsrn.py) -- SURVEY.md §8a-16
+# ----------------------------------------------------------------------------
+def positionalencoding2d(d_model: int, height: int, width: int) -> Tensor:
+    """model/tbsrn.py:39-61: first half of the channels encode the column, second half the row."""
+    pe = torch.zeros(d_model, height, width)
+    half = d_model // 2
+    div_term = torch.exp(torch.arange(0., half, 2) * -(math.log(10000.0) / half))
+    pos_w = torch.arange(0., width).unsqueeze(1)
+    pos_h = torch.arange(0., height).unsqueeze(1)
+    pe[0:half:2] = torch.sin(pos_w * div_term).t().unsqueeze(1).repeat(1, height, 1)
+    pe[1:half:2] = torch.cos(pos_w * div_term).t().unsqueeze(1).repeat(1, height, 1)
+    pe[half::2] = torch.sin(pos_h * div_term).t().unsqueeze(2).repeat(1, 1, width)
+    pe[half + 1::2] = torch.cos(pos_h * div_term).t().unsqueeze(2).repeat(1, 1, width)
+    return pe
+
+
+def tbsrn_layer_norm(x: Tensor, a: Tensor, b: Tensor, eps: float = 1e-6) -> Tensor:
+    """The variant's own LayerNorm -- model/tbsrn.py:23-36: UNBIASED std, eps added to the std (outside the root)."""
+    mean = x.mean(-1, keepdim=True)
+    std = torch.sqrt(((x - mean) ** 2).sum(-1, keepdim=True) / (x.shape[-1] - 1))
+    return a * (x - mean) / (std + eps) + b
+
+
+def feature_enhancer(feat: Tensor, sd: SD, prefix: str, drop_on: bool = False) -> Tensor:
+    """FeatureEnhancer.forward -- model/tbsrn.py:77-93 (MultiHeadedAttention :96-128, attention :130-151,
+    PositionwiseFeedForward :154-164).  feat (B,64,H,W) -> (B,64,H,W)."""
+    B, C, H, W = feat.shape
+    Pn = H * W
+    # reference: positionalencoding2d(64,16,256) viewed as (1,64,4096) -- only defined for H*W == 4096; other sizes use (H, W)
+    pe = positionalencoding2d(64, 16, 256).reshape(1, 64, 4096) if Pn == 4096 else positionalencoding2d(64, H, W).reshape(1, 64, Pn)
+    x = torch.cat([feat.reshape(B, C, Pn), pe.expand(B, 64, Pn)], 1).permute(0, 2, 1)          # (B,P,128)
+    h, d = 4, 32
+    lin = lambda i, t: t @ sd["%s.multihead.linears.%d.weight" % (prefix, i)].t() + sd["%s.multihead.linears.%d.bias" % (prefix, i)]
+    q, k, v = (lin(i, x).reshape(B, Pn, h, d).transpose(1, 2) for i in range(3))
+    p = torch.softmax(q @ k.transpose(-2, -1) / math.sqrt(d), -1)
+    p = dropout(p, 0.1, drop_on)
+    a = lin(3, (p @ v).transpose(1, 2).reshape(B, Pn, h * d))
+    x = tbsrn_layer_norm(x + a, sd[prefix + ".mul_layernorm1.a_2"], sd[prefix + ".mul_layernorm1.b_2"])
+    f = torch.relu(x @ sd[prefix + ".pff.w_1.weight"].t() + sd[prefix + ".pff.w_1.bias"])
+    f = dropout(f, 0.1, drop_on) @ sd[prefix + ".pff.w_2.weight"].t() + sd[prefix + ".pff.w_2.bias"]
+    x = tbsrn_layer_norm(x + f, sd[prefix + ".mul_layernorm3.a_2"], sd[prefix + ".mul_layernorm3.b_2"])
+    x = x @ sd[prefix + ".linear.weight"].t() + sd[prefix + ".linear.bias"]
+    return x.permute(0, 2, 1).reshape(B, C, H, W)
+
+
+def tbsrn_forward(sd: SD, x: Tensor, *, training: bool = False, stn: bool = True, srb_nums: int = 5,
+                  drop_on: bool = False, new_stats: Optional[dict] = None) -> Dict[str, Tensor]:
+    """TBSRN.forward -- model/tbsrn.py:215-227, with RecurrentResidualBlock.forward :366-377."""
+    out: Dict[str, Tensor] = {}
+    if stn and training:
+        ctrl = stn_head(x, sd, "stn_head", training, new_stats)
+        x, _ = tps_transform(x, ctrl, sd, "tps")
+    b1 = prelu(conv2d(x, sd["block1.0.weight"], sd["block1.0.bias"], 4), sd["block1.1.weight"])
+    h = b1
+    for i in range(srb_nums):
+        pre = "block%d" % (i + 2)
+        r = conv2d(h, sd[pre + ".conv1.weight"], sd[pre + ".conv1.bias"], 1)
+        r = mish(batch_norm(r, sd, pre + ".bn1", training, new_stats=new_stats))
+        r = conv2d(r, sd[pre + ".conv2.weight"], sd[pre + ".conv2.bias"], 1)
+        r = batch_norm(r, sd, pre + ".bn2", training, new_stats=new_stats)
+        h = h + feature_enhancer(r, sd, pre + ".feature_enhancer", drop_on)
+        out[pre] = h
+    k = srb_nums + 2
+    h = conv2d(h, sd["block%d.0.weight" % k], sd["block%d.0.bias" % k], 1)
+    h = batch_norm(h, sd, "block%d.1" % k, training, new_stats=new_stats)
+    u = conv2d(b1 + h, sd["block%d.0.conv.weight" % (k + 1)], sd["block%d.0.conv.bias" % (k + 1)], 1)
+    u = mish(pixel_shuffle2(u))
+    u = conv2d(u, sd["block%d.1.weight" % (k + 1)], sd["block%d.1.bias" % (k + 1)], 4)
+    out["block1"], out["sr"] = b1, torch.tanh(u)
+    return out
+
+
+# ----------------------------------------------------------------------------
 # train-step harness (loss / clip / Adam) -- SURVEY.md §8a-17
 # ----------------------------------------------------------------------------
 def gradient_map(x: Tensor) -> Tensor:
@@ -411,7 +484,7 @@ def is_param(key: str) -> bool:
 
 def train_step(sd: SD, x: Tensor, text_emb: Optional[Tensor], hr: Tensor, *, tatt: bool = True,
                stn: bool = True, drop_on: bool = False, opt_state: Optional[dict] = None,
-               step: int = 1, lr: float = 1e-3):
+               step: int = 1, lr: float = 1e-3, tbsrn: bool = False):
     """One reference training step for fixed inputs: forward (train mode), ImageLoss.mean()*100
     (interfaces/super_resolution.py:889-894), backward, clip 0.25, Adam(1e-3,(0.5,0.999)).
 
@@ -420,8 +493,11 @@ def train_step(sd: SD, x: Tensor, text_emb: Optional[Tensor], hr: Tensor, *, tat
     full = dict(sd)
     full.update(leaves)
     new_stats: dict = {}
-    out = generator_forward(full, x, text_emb, training=True, tatt=tatt, stn=stn, drop_on=drop_on,
-                            new_stats=new_stats)
+    if tbsrn:
+        out = tbsrn_forward(full, x, training=True, stn=stn, drop_on=drop_on, new_stats=new_stats)
+    else:
+        out = generator_forward(full, x, text_emb, training=True, tatt=tatt, stn=stn, drop_on=drop_on,
+                                new_stats=new_stats)
     loss = image_loss(out["sr"], hr).mean() * 100.0
     names = list(leaves)
     gs = torch.autograd.grad(loss, [leaves[k] for k in names], allow_unused=True)

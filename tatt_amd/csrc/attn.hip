@@ -245,3 +245,105 @@ TATT_API int tatt_attn_bwd(const float* Q, const float* K, const float* V, const
                        nblk);
     return LAUNCH_CHECK();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Row softmax (+ dropout) over materialised score matrices -- the self-attention of the TBSRN variant's FeatureEnhancer
+// (reference model/tbsrn.py:130-151: softmax(QK^T/sqrt(d_k)) over ALL H*W positions, dropout(0.1), @V).  With 288 GB of HBM
+// the (B,h,P,P) probability tensor is simply kept for the backward pass; the matrix products around it are batched GEMMs
+// (tatt_gemm).  One work-group per row, row length L <= 4096 held in registers.
+// ------------------------------------------------------------------------------------------------
+#define SM_MAXPER 16
+__global__ __launch_bounds__(256) void softmax_rows_fwd_kernel(float* __restrict__ S, float* __restrict__ Pd, int L,
+                                                               float pdrop, const unsigned long long* __restrict__ seed,
+                                                               unsigned site) {
+    __shared__ float sh[4];
+    const long row = blockIdx.x;
+    float* s = S + row * L;
+    const int t = threadIdx.x;
+    float v[SM_MAXPER];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < SM_MAXPER; ++k) {
+        const int c = t + 256 * k;
+        v[k] = c < L ? s[c] : -INFINITY;
+        mx = fmaxf(mx, v[k]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((t & 63) == 0) sh[t >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+    __syncthreads();
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < SM_MAXPER; ++k) {
+        const int c = t + 256 * k;
+        v[k] = c < L ? __expf(v[k] - mx) : 0.f;
+        sum += v[k];
+    }
+    sum = wave_sum(sum);
+    if ((t & 63) == 0) sh[t >> 6] = sum;
+    __syncthreads();
+    const float inv = 1.f / ((sh[0] + sh[1]) + (sh[2] + sh[3]));
+    const bool drop = Pd != nullptr && pdrop > 0.f;
+    const uint32_t th = dropout_thresh(pdrop);
+    const float sc = 1.f / (1.f - pdrop);
+    const uint64_t sd = drop ? seed[0] : 0ull;
+#pragma unroll
+    for (int k = 0; k < SM_MAXPER; ++k) {
+        const int c = t + 256 * k;
+        if (c < L) {
+            const float p = v[k] * inv;
+            s[c] = p;
+            if (Pd) Pd[row * L + c] = (!drop || dropout_keep(sd, site, (uint64_t)row * L + c, th)) ? (drop ? p * sc : p) : 0.f;
+        }
+    }
+}
+// S (rows x L) is overwritten by P = softmax(S); Pd (nullable) receives dropout(P)
+TATT_API int tatt_softmax_rows_fwd(float* S, float* Pd, long rows, int L, float pdrop, const unsigned long long* seed,
+                                   unsigned site, hipStream_t st) {
+    if (L > 256 * SM_MAXPER) return 1;
+    hipLaunchKernelGGL(softmax_rows_fwd_kernel, dim3((unsigned)rows), dim3(256), 0, st, S, Pd, L, pdrop, seed, site);
+    return LAUNCH_CHECK();
+}
+// dS = P * (dPm - sum_j P_j dPm_j), dPm = dropout'(dPd); written over dPd
+__global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float* __restrict__ P, float* __restrict__ dP, int L,
+                                                               float pdrop, const unsigned long long* __restrict__ seed,
+                                                               unsigned site) {
+    __shared__ float sh[4];
+    const long row = blockIdx.x;
+    const int t = threadIdx.x;
+    const bool drop = pdrop > 0.f;
+    const uint32_t th = dropout_thresh(pdrop);
+    const float sc = drop ? 1.f / (1.f - pdrop) : 1.f;
+    const uint64_t sd = drop ? seed[0] : 0ull;
+    float p[SM_MAXPER], g[SM_MAXPER];
+    float dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < SM_MAXPER; ++k) {
+        const int c = t + 256 * k;
+        p[k] = 0.f; g[k] = 0.f;
+        if (c < L) {
+            p[k] = P[row * L + c];
+            float d = dP[row * L + c];
+            if (drop) d = dropout_keep(sd, site, (uint64_t)row * L + c, th) ? d * sc : 0.f;
+            g[k] = d;
+            dot = fmaf(p[k], d, dot);
+        }
+    }
+    dot = wave_sum(dot);
+    if ((t & 63) == 0) sh[t >> 6] = dot;
+    __syncthreads();
+    dot = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+#pragma unroll
+    for (int k = 0; k < SM_MAXPER; ++k) {
+        const int c = t + 256 * k;
+        if (c < L) dP[row * L + c] = p[k] * (g[k] - dot);
+    }
+}
+TATT_API int tatt_softmax_rows_bwd(const float* P, float* dP, long rows, int L, float pdrop,
+                                   const unsigned long long* seed, unsigned site, hipStream_t st) {
+    if (L > 256 * SM_MAXPER) return 1;
+    hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, st, P, dP, L, pdrop, seed, site);
+    return LAUNCH_CHECK();
+}

@@ -819,6 +819,132 @@ TATT_API int tatt_conv3_c64_fwd_t(const float* x, const float* wt, const float* 
     return LAUNCH_CHECK();
 }
 
+// ---- weight-stationary forward (Cin == 64) ---------------------------------------------------------------------------
+// Each wave keeps the WHOLE filter of its 32 output channels (9 taps x 64 ci = K 576 -> 288 B-operand registers per lane) in
+// the unified VGPR/AGPR file for the lifetime of the (persistent) work-group, so the main loop streams only activations:
+// per 64-pixel row tile a wave issues 72 sixteen-byte LDS reads (A operand) and 288 MFMAs, the next tile's halo is
+// prefetched global -> registers -> LDS underneath them, and there is ONE barrier per tile instead of one per tap.  The
+// filter is read from L2 once per work-group (147 KB) instead of once per tile (113 MB per launch in the v5 kernel).
+// One work-group per CU (1 wave / SIMD, 512 registers each); latency is hidden by software pipelining, not occupancy.
+#define WS_XP 68                              // halo pitch (floats): 64 ci + 4 pad -> conflict-free ds_read_b128
+#define WS_HALO (3 * C3_HW * WS_XP)           // floats per halo buffer (53.9 KB)
+#define WS_LDS (2 * WS_HALO * 4)
+__global__ __launch_bounds__(256, 1) void conv3_c64_ws_kernel(Conv3P p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int segs = p.W / C3_PX, cob = p.Cout / 64;
+    const int npt = p.B * p.H * segs;                     // pixel tiles (one 64-pixel row segment each)
+    const int cb = blockIdx.x % cob, stride = gridDim.x / cob;
+    int pt = blockIdx.x / cob;
+    if (pt >= npt) return;
+    const int co0 = cb * 64;
+    // ---- the filter: 72 float4 per lane, packed by tatt_repack_conv_weight mode 4 / 5 ----
+    f32x4 wq[72];
+    {
+        const f32x4* wsrc = reinterpret_cast<const f32x4*>(p.w) + ((long)(cb * 2 + wn) * 72) * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < 72; ++q) wq[q] = wsrc[q * 64];
+    }
+    auto decode = [&](int tile, int& n, int& h, int& w0) {
+        const int seg = tile % segs; tile /= segs;
+        h = tile % p.H; n = tile / p.H; w0 = seg * C3_PX;
+    };
+    // float4 #idx (c4 = idx & 15, pixel = idx >> 4) of halo row r, pixels [pxb, pxb + 22)
+    auto halo_load = [&](int n, int hh, int w0, int pxb, int idx) -> f32x4 {
+        const int ww = w0 + pxb + (idx >> 4) - 1;
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (hh >= 0 && hh < p.H && ww >= 0 && ww < p.W)
+            v = *reinterpret_cast<const f32x4*>(p.x + (((long)n * p.H + hh) * p.W + ww) * 64 + 4 * (idx & 15));
+        return v;
+    };
+    auto halo_store = [&](float* Xs, int r, int pxb, int idx, f32x4 v) {
+        *reinterpret_cast<f32x4*>(Xs + (r * C3_HW + pxb + (idx >> 4)) * WS_XP + 4 * (idx & 15)) = v;
+    };
+    int n, h, w0;
+    decode(pt, n, h, w0);
+    for (int s9 = 0; s9 < 9; ++s9) {
+        const int r = s9 / 3, pxb = (s9 - 3 * r) * 22;
+        for (int i = t; i < 352; i += 256) halo_store(smem, r, pxb, i, halo_load(n, h + r - 1, w0, pxb, i));
+    }
+    __syncthreads();
+    const int abase = (wm * 32 + (lane & 31)) * WS_XP + 4 * (lane >> 5);
+    const int co = co0 + wn * 32 + (lane & 31);
+    const float bj = p.bias ? p.bias[co] : 0.f;
+    int xbuf = 0;
+    while (true) {
+        const int npt_next = pt + stride;
+        const bool has_next = npt_next < npt;
+        int nn = n, nh = h, nw0 = w0;
+        if (has_next) decode(npt_next, nn, nh, nw0);
+        const float* Xs = smem + xbuf * WS_HALO + abase;
+        float* XsN = smem + (xbuf ^ 1) * WS_HALO;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        f32x4 va[8];
+        f32x4 h0, h1;
+        // group g = tap * 8 + c covers input channels [8c, 8c+8) of tap (kh, kw): one 16-byte A read, four MFMAs
+#define WS_AOFF(g) ((((g) >> 3) / 3 * C3_HW + ((g) >> 3) % 3) * WS_XP + 8 * ((g) & 7))
+#define WS_LD(g) va[(g) & 7] = *reinterpret_cast<const f32x4*>(Xs + WS_AOFF(g));
+        WS_LD(0) WS_LD(1) WS_LD(2) WS_LD(3)
+#pragma unroll
+        for (int g = 0; g < 72; ++g) {
+            const int tap = g >> 3, c = g & 7;
+            const int r = tap / 3, pxb = (tap - 3 * r) * 22;
+            if (c == 0) {                                  // this tap's 1/9 of the NEXT tile's halo: global -> registers
+                h0 = (f32x4){0.f, 0.f, 0.f, 0.f}; h1 = h0;
+                if (has_next) {
+                    h0 = halo_load(nn, nh + r - 1, nw0, pxb, t);
+                    if (t < 96) h1 = halo_load(nn, nh + r - 1, nw0, pxb, 256 + t);
+                }
+            }
+            if (g + 4 < 72) { WS_LD(g + 4) }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(va[g & 7][u], wq[g][u], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c == 7 && has_next) {                      // ... registers -> LDS, 28 MFMAs after the loads were issued
+                halo_store(XsN, r, pxb, t, h0);
+                if (t < 96) halo_store(XsN, r, pxb, 256 + t, h1);
+            }
+        }
+        {
+            const long rowbase = ((long)n * p.H + h) * p.W + w0 + wm * 32;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int px = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                float v = apply_act(acc[reg] + bj, p.act);
+                const long o = (rowbase + px) * p.Cout + co;
+                if (p.beta != 0.f) v += p.beta * p.y[o];
+                p.y[o] = v;
+            }
+        }
+        if (!has_next) break;
+        __syncthreads();
+        pt = npt_next; n = nn; h = nh; w0 = nw0;
+        xbuf ^= 1;
+    }
+}
+
+// x (B,H,W,64) NHWC contiguous; wl = filter in the per-lane register order (tatt_repack_conv_weight mode 4; mode 5 for the
+// data gradient of a 64-output-channel convolution); y (B,H,W,Cout)
+TATT_API int tatt_conv3_c64_fwd_ws(const float* x, const float* wl, const float* bias, float* y, int B, int H, int W,
+                                   int Cout, int act, float beta, hipStream_t st) {
+    if (Cout % 64 || W % C3_PX) return 1;
+    Conv3P p = {x, wl, bias, y, B, H, W, 64, Cout, act, beta, nullptr};
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS);
+        attr_set = true;
+    }
+    const int cob = Cout / 64, npt = B * H * (W / C3_PX);
+    int per = 256 / cob;
+    if (per > npt) per = npt;
+    hipLaunchKernelGGL(conv3_c64_ws_kernel, dim3(per * cob), dim3(256), WS_LDS, st, p);
+    return LAUNCH_CHECK();
+}
+
 // ---- weight gradient -------------------------------------------------------------------------------------------------
 struct Conv3WP {
     const float* x; const float* dy; float* part;

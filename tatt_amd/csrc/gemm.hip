@@ -407,6 +407,7 @@ TATT_API int tatt_conv2d_wgrad(const float* x, long xsn, long xsh, long xsw, lon
 // OIHW filter -> implicit-GEMM operand.  mode 0: [KH][KW][Cin][Cout] (forward);
 // mode 1: [KH][KW][Cout][Cin] spatially flipped (data-gradient: dX = conv(dY, flip(W)^T)).
 // modes 2 / 3: the same two filters with the contraction axis contiguous ([tap][out][in]) for tatt_conv3_c64_fwd_t.
+// modes 4 / 5: the same two filters in the register order of the weight-stationary kernel tatt_conv3_c64_fwd_ws.
 __global__ void repack_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin,
                                      int KH, int KW, int mode) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -423,9 +424,17 @@ __global__ void repack_weight_kernel(const float* __restrict__ w, float* __restr
     } else if (mode == 2) {      // [tap][Cout][Cin]: forward filter with the contraction (input-channel) axis contiguous
         int ci = idx % Cin; int r = idx / Cin; int co = r % Cout; int tap = r / Cout;
         out[idx] = w[((long)co * Cin + ci) * T + tap];
-    } else {                     // mode 3: [tap][Cin][Cout] flipped: data-gradient filter, contraction (Cout) axis contiguous
+    } else if (mode == 3) {      // [tap][Cin][Cout] flipped: data-gradient filter, contraction (Cout) axis contiguous
         int co = idx % Cout; int r = idx / Cout; int ci = r % Cin; int tap = r / Cin;
         out[idx] = w[((long)co * Cin + ci) * T + (T - 1 - tap)];
+    } else {
+        // modes 4 / 5 (3x3, 64 contraction channels): the per-lane MFMA B-operand register order of tatt_conv3_c64_fwd_ws:
+        // out[((ob * 72 + tap * 8 + c) * 64 + lane) * 4 + u] = filter[out ch ob*32 + (lane & 31)][in ch 8c + 4 (lane >> 5) + u][tap]
+        const int u = idx & 3, lane = (idx >> 2) & 63, q = (idx >> 8) % 72, ob = idx / (72 * 256);
+        const int tap = q >> 3, c = q & 7;
+        const int o = ob * 32 + (lane & 31), i = 8 * c + 4 * (lane >> 5) + u;
+        if (mode == 4) out[idx] = w[((long)o * Cin + i) * T + tap];                 // forward: o = co, i = ci (Cin == 64)
+        else out[idx] = w[((long)i * Cin + o) * T + (T - 1 - tap)];                 // data gradient: o = ci, i = co (Cout == 64)
     }
 }
 TATT_API int tatt_repack_conv_weight(const float* w_oihw, float* out, int Cout, int Cin, int KH, int KW,

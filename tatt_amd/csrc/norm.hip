@@ -269,9 +269,11 @@ TATT_API int tatt_bn_bwd(const float* X, long ldx, const float* dY, long lddy, f
 // ---------------------------------------------------------------------------------------------
 #define LN_MAXPER 4   // supports C <= 256
 
+// mode 0: nn.LayerNorm  y = (x-mu)/sqrt(biased var + eps)*g + b;   mode 1: the TBSRN variant's own LayerNorm
+// (reference model/tbsrn.py:23-36)  y = g*(x-mu)/(UNBIASED std + eps) + b.  stats = (mu, 1/denominator) in both modes.
 __global__ void ln_fwd_kernel(const float* __restrict__ A, const float* __restrict__ Bres, float* __restrict__ Y,
                               float* __restrict__ stats, int M, int C, const float* __restrict__ gamma,
-                              const float* __restrict__ beta, float eps) {
+                              const float* __restrict__ beta, float eps, int mode) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -288,7 +290,8 @@ __global__ void ln_fwd_kernel(const float* __restrict__ A, const float* __restri
     float q = 0.f;
 #pragma unroll
     for (int k = 0; k < LN_MAXPER; ++k) { int c = lane + 64 * k; if (c < C) { float d = v[k] - mu; q += d * d; } }
-    float rs = 1.f / sqrtf(wave_sum(q) / C + eps);
+    const float ssq = wave_sum(q);
+    float rs = mode == 0 ? 1.f / sqrtf(ssq / C + eps) : 1.f / (sqrtf(ssq / (C - 1)) + eps);
 #pragma unroll
     for (int k = 0; k < LN_MAXPER; ++k) {
         int c = lane + 64 * k;
@@ -297,9 +300,9 @@ __global__ void ln_fwd_kernel(const float* __restrict__ A, const float* __restri
     if (lane == 0 && stats) { stats[row * 2] = mu; stats[row * 2 + 1] = rs; }
 }
 TATT_API int tatt_ln_fwd(const float* A, const float* Bres, float* Y, float* stats, int M, int C,
-                         const float* gamma, const float* beta, float eps, hipStream_t st) {
+                         const float* gamma, const float* beta, float eps, int mode, hipStream_t st) {
     if (C > 64 * LN_MAXPER) return 1;
-    hipLaunchKernelGGL(ln_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, A, Bres, Y, stats, M, C, gamma, beta, eps);
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, A, Bres, Y, stats, M, C, gamma, beta, eps, mode);
     return LAUNCH_CHECK();
 }
 
@@ -307,7 +310,7 @@ TATT_API int tatt_ln_fwd(const float* A, const float* Bres, float* Y, float* sta
 #define LN_BWD_ROWS 64   // rows per wave-loop block (4 waves x 16 rows)
 __global__ void ln_bwd_kernel(const float* __restrict__ A, const float* __restrict__ Bres,
                               const float* __restrict__ dY, const float* __restrict__ stats, float* __restrict__ dX,
-                              int M, int C, const float* __restrict__ gamma, float* __restrict__ part) {
+                              int M, int C, const float* __restrict__ gamma, float* __restrict__ part, float eps, int mode) {
     __shared__ float sh[4][2][64 * LN_MAXPER];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float dg[LN_MAXPER], db[LN_MAXPER];
@@ -333,11 +336,13 @@ __global__ void ln_bwd_kernel(const float* __restrict__ A, const float* __restri
                 s1 += dxh[k]; s2 += dxh[k] * xh[k];
             }
         }
-        s1 = wave_sum(s1) / C; s2 = wave_sum(s2) / C;
+        s1 = wave_sum(s1) / C; s2 = wave_sum(s2);
+        // mode 0: dx = rs*(g - mean(g) - xh*mean(g*xh));  mode 1: dx = rs*(g - mean(g)) - xh*sum(g*xh)/((C-1)*std), std = 1/rs - eps
+        const float c2 = mode == 0 ? rs * s2 / C : s2 / ((C - 1) * (1.f / rs - eps));
 #pragma unroll
         for (int k = 0; k < LN_MAXPER; ++k) {
             int c = lane + 64 * k;
-            if (c < C) dX[row * C + c] = rs * (dxh[k] - s1 - xh[k] * s2);
+            if (c < C) dX[row * C + c] = rs * (dxh[k] - s1) - xh[k] * c2;
         }
     }
 #pragma unroll
@@ -352,11 +357,11 @@ __global__ void ln_bwd_kernel(const float* __restrict__ A, const float* __restri
 }
 // part: cdiv(M,64)*2*C floats;  ws: doubles for the colsum (cdiv(G,256)*2*C)
 TATT_API int tatt_ln_bwd(const float* A, const float* Bres, const float* dY, const float* stats, float* dX, int M,
-                         int C, const float* gamma, float* dgamma, float* dbeta, float* part, double* ws,
-                         hipStream_t st) {
+                         int C, const float* gamma, float* dgamma, float* dbeta, float* part, double* ws, float eps,
+                         int mode, hipStream_t st) {
     if (C > 64 * LN_MAXPER) return 1;
     int G = cdiv(M, LN_BWD_ROWS);
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(G), dim3(256), 0, st, A, Bres, dY, stats, dX, M, C, gamma, part);
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(G), dim3(256), 0, st, A, Bres, dY, stats, dX, M, C, gamma, part, eps, mode);
     // part viewed as (G, 2C) -> column sums give [dgamma | dbeta]
     int G2 = cs_groups(G);
     int rpb = cdiv(G, G2);

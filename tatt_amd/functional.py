@@ -386,10 +386,11 @@ class LayerNormFn(Function):
     """LayerNorm(a + b) over the last axis (b optional)."""
 
     @staticmethod
-    def forward(ctx, a, b, gamma, beta, eps):
+    def forward(ctx, a, b, gamma, beta, eps, mode):
         C = a.shape[-1]
-        y, stats = ops.ln_fwd(a.reshape(-1, C), None if b is None else b.reshape(-1, C), gamma, beta, eps)
+        y, stats = ops.ln_fwd(a.reshape(-1, C), None if b is None else b.reshape(-1, C), gamma, beta, eps, mode)
         ctx.save_for_backward(a, b, stats, gamma)
+        ctx.eps, ctx.mode = eps, mode
         return y.reshape(a.shape)
 
     @staticmethod
@@ -397,13 +398,13 @@ class LayerNormFn(Function):
         a, b, stats, gamma = ctx.saved_tensors
         C = a.shape[-1]
         dx, dg, db = ops.ln_bwd(a.reshape(-1, C), None if b is None else b.reshape(-1, C), _c(dy).reshape(-1, C), stats,
-                                gamma)
+                                gamma, ctx.eps, ctx.mode)
         dx = dx.reshape(a.shape)
-        return dx, (dx if b is not None else None), dg, db, None
+        return dx, (dx if b is not None else None), dg, db, None, None
 
 
 def layer_norm(a, b, ln):
-    return LayerNormFn.apply(_c(a), None if b is None else _c(b), ln.weight, ln.bias, ln.eps)
+    return LayerNormFn.apply(_c(a), None if b is None else _c(b), ln.weight, ln.bias, ln.eps, 0)
 
 
 class DropoutFn(Function):
@@ -582,3 +583,87 @@ class GridSampleFn(Function):
         if ctx.needs_input_grad[0]:
             raise RuntimeError("tatt_amd: gradient w.r.t. the LR image through the TPS sampler is not on the path")
         return None, ops.grid_sample_bwd(x, src, _c(dout))
+
+
+# --------------------------------------------------------------------------------------------------
+# TBSRN variant (reference model/tbsrn.py): full self-attention over the H*W positions
+# --------------------------------------------------------------------------------------------------
+class SelfAttnCoreFn(Function):
+    """softmax(Q K^T / sqrt(d_k)) -> dropout -> @ V for h heads of d_k = E/h (reference `attention`, model/tbsrn.py:130-151).
+    Q, K, V: (B, P, E) already projected.  The (B, h, P, P) probabilities are materialised (288 GB of HBM: B=48, P=1024 is
+    0.8 GB per block) and every product is a batched fp32-MFMA GEMM (tatt_gemm); the row softmax (+dropout) is tatt_softmax_rows_*."""
+
+    @staticmethod
+    def forward(ctx, Q, K, V, h, pdrop, site):
+        B, Pn, E = Q.shape
+        d = E // h
+        scale = 1.0 / math.sqrt(d)
+        seed = seed_tensor(Q.device)
+        S = ops.new(Q, B, h, Pn, Pn)
+        for hh in range(h):
+            ops.gemm(Q.reshape(-1)[hh * d:], E, 1, K.reshape(-1)[hh * d:], 1, E, S.reshape(-1)[hh * Pn * Pn:], Pn, 1, Pn, Pn, d,
+                     Z=B, bsA=Pn * E, bsB=Pn * E, bsC=h * Pn * Pn, alpha=scale)
+        Pd = ops.new(Q, B, h, Pn, Pn) if pdrop > 0.0 else None
+        ops.call("tatt_softmax_rows_fwd", ops.P(S), ops.P(Pd), B * h * Pn, Pn, pdrop, ops.P(seed), site, ops.stream())
+        Pm = Pd if Pd is not None else S
+        O = torch.empty_like(Q)
+        for hh in range(h):
+            ops.gemm(Pm.reshape(-1)[hh * Pn * Pn:], Pn, 1, V.reshape(-1)[hh * d:], E, 1, O.reshape(-1)[hh * d:], E, 1, Pn, d, Pn,
+                     Z=B, bsA=h * Pn * Pn, bsB=Pn * E, bsC=Pn * E)
+        ctx.save_for_backward(Q, K, V, S)          # S now holds the (un-dropped) probabilities
+        ctx.cfg = (h, pdrop, site, seed, scale)
+        return O
+
+    @staticmethod
+    def backward(ctx, dO):
+        Q, K, V, Pp = ctx.saved_tensors
+        h, pdrop, site, seed, scale = ctx.cfg
+        B, Pn, E = Q.shape
+        d = E // h
+        dO = _c(dO)
+        if pdrop > 0.0:                              # regenerate the dropped probabilities (same counter-based mask)
+            Pd = ops.dropout(Pp, pdrop, seed, site)
+        else:
+            Pd = Pp
+        dQ, dK, dV = torch.empty_like(Q), torch.empty_like(K), torch.empty_like(V)
+        dP = ops.new(Q, B, h, Pn, Pn)
+        for hh in range(h):
+            o, so = hh * d, hh * Pn * Pn
+            # dV_h = Pd^T dO_h
+            ops.gemm(Pd.reshape(-1)[so:], 1, Pn, dO.reshape(-1)[o:], E, 1, dV.reshape(-1)[o:], E, 1, Pn, d, Pn,
+                     Z=B, bsA=h * Pn * Pn, bsB=Pn * E, bsC=Pn * E)
+            # dPd = dO_h V_h^T
+            ops.gemm(dO.reshape(-1)[o:], E, 1, V.reshape(-1)[o:], 1, E, dP.reshape(-1)[so:], Pn, 1, Pn, Pn, d,
+                     Z=B, bsA=Pn * E, bsB=Pn * E, bsC=h * Pn * Pn)
+        ops.call("tatt_softmax_rows_bwd", ops.P(Pp), ops.P(dP), B * h * Pn, Pn, pdrop, ops.P(seed), site, ops.stream())
+        for hh in range(h):
+            o, so = hh * d, hh * Pn * Pn
+            # dQ_h = scale * dS K_h ;  dK_h = scale * dS^T Q_h
+            ops.gemm(dP.reshape(-1)[so:], Pn, 1, K.reshape(-1)[o:], E, 1, dQ.reshape(-1)[o:], E, 1, Pn, d, Pn,
+                     Z=B, bsA=h * Pn * Pn, bsB=Pn * E, bsC=Pn * E, alpha=scale)
+            ops.gemm(dP.reshape(-1)[so:], 1, Pn, Q.reshape(-1)[o:], E, 1, dK.reshape(-1)[o:], E, 1, Pn, d, Pn,
+                     Z=B, bsA=h * Pn * Pn, bsB=Pn * E, bsC=Pn * E, alpha=scale)
+        return dQ, dK, dV, None, None, None
+
+
+class CatPEFn(Function):
+    """tokens (B,P,C) ++ positional table (P,Cp) broadcast over the batch -> (B,P,C+Cp)  (reference model/tbsrn.py:84-87)."""
+
+    @staticmethod
+    def forward(ctx, x, pe):
+        B, Pn, C = x.shape
+        Cp = pe.shape[1]
+        out = ops.new(x, B, Pn, C + Cp)
+        ops.copy4d(x, out, (1, B, Pn, C), (0, Pn * C, C, 1), (0, Pn * (C + Cp), C + Cp, 1))
+        ops.copy4d(pe, out.reshape(-1)[C:], (1, B, Pn, Cp), (0, 0, Cp, 1), (0, Pn * (C + Cp), C + Cp, 1))
+        ctx.C = C
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = _c(dout)
+        B, Pn, Ct = dout.shape
+        C = ctx.C
+        dx = ops.new(dout, B, Pn, C)
+        ops.copy4d(dout, dx, (1, B, Pn, C), (0, Pn * Ct, Ct, 1), (0, Pn * C, C, 1))
+        return dx, None

@@ -9,6 +9,8 @@ from __future__ import annotations
 import ctypes
 from typing import Optional
 
+import os
+
 import torch
 
 from ._lib import LIB
@@ -167,12 +169,19 @@ def _conv3_fast_ok(x_bhwc, Cin, Cout, KH, KW):
             and x_bhwc.shape[2] % 64 == 0)
 
 
+_CONV3_WS = os.environ.get("TATT_CONV3_WS", "1") != "0"        # A/B switch for measurements: 0 -> LDS-staged filter (v5 kernel)
+
+
 def conv2d_forward(x_bhwc, weight_oihw, bias, act=ACT_NONE):
     """y = act(conv(x, W) + b) from the reference-layout (OIHW) filter: picks the kernel and the filter packing it wants."""
     Cout, Cin, KH, KW = weight_oihw.shape
     if _conv3_fast_ok(x_bhwc, Cin, Cout, KH, KW):
         B, H, W, _ = x_bhwc.shape
         y = new(x_bhwc, B, H, W, Cout)
+        if Cin == 64 and _CONV3_WS:                              # weight-stationary kernel: the filter lives in registers
+            wl = repack_weight(weight_oihw, 4)
+            call("tatt_conv3_c64_fwd_ws", P(x_bhwc), P(wl), P(bias), P(y), B, H, W, Cout, act, 0.0, stream())
+            return y
         wt = repack_weight(weight_oihw, 2)                       # [9][Cout][Cin]
         call("tatt_conv3_c64_fwd_t", P(x_bhwc), P(wt), P(bias), P(y), B, H, W, Cin, Cout, act, 0.0, stream())
         return y
@@ -185,6 +194,10 @@ def conv2d_dgrad(dy_bhwc, weight_oihw):
     if _conv3_fast_ok(dy_bhwc, Cout, Cin, KH, KW):
         B, H, W, _ = dy_bhwc.shape
         dx = new(dy_bhwc, B, H, W, Cin)
+        if Cout == 64 and _CONV3_WS:
+            wl = repack_weight(weight_oihw, 5)
+            call("tatt_conv3_c64_fwd_ws", P(dy_bhwc), P(wl), None, P(dx), B, H, W, Cin, ACT_NONE, 0.0, stream())
+            return dx
         wt = repack_weight(weight_oihw, 3)                       # [9][Cin][Cout], taps flipped
         call("tatt_conv3_c64_fwd_t", P(dy_bhwc), P(wt), None, P(dx), B, H, W, Cout, Cin, ACT_NONE, 0.0, stream())
         return dx
@@ -251,21 +264,21 @@ def bn_bwd(x2, dy2, mean, rstd, gamma, beta, act, training):
     return dx, dgamma, dbeta
 
 
-def ln_fwd(a2, b2, gamma, beta, eps=1e-5):
+def ln_fwd(a2, b2, gamma, beta, eps=1e-5, mode=0):
     M, C = a2.shape
     y, stats = new(a2, M, C), new(a2, M, 2)
-    call("tatt_ln_fwd", P(a2), P(b2), P(y), P(stats), M, C, P(gamma), P(beta), eps, stream())
+    call("tatt_ln_fwd", P(a2), P(b2), P(y), P(stats), M, C, P(gamma), P(beta), eps, mode, stream())
     return y, stats
 
 
-def ln_bwd(a2, b2, dy2, stats, gamma):
+def ln_bwd(a2, b2, dy2, stats, gamma, eps=1e-5, mode=0):
     M, C = a2.shape
     dx, dgamma, dbeta = new(a2, M, C), new(a2, C), new(a2, C)
     G = cdiv(M, 64)
     part = new(a2, G * 2 * C)
     ws = new(a2, 256 * 2 * C, dtype=torch.float64)
     call("tatt_ln_bwd", P(a2), P(b2), P(dy2), P(stats), P(dx), M, C, P(gamma), P(dgamma), P(dbeta), P(part), P(ws),
-         stream())
+         eps, mode, stream())
     return dx, dgamma, dbeta
 
 

@@ -150,9 +150,9 @@ def test_layernorm(dev):
     from tatt_amd import functional as Fh
     a, b, g, be = R(3, 100, 64), R(3, 100, 64, seed=1), 1 + 0.1 * R(64, seed=2), 0.1 * R(64, seed=3)
     ln = torch.nn.LayerNorm(64)
-    compare_fn("ln_res", lambda a, b, g, be: Fh.LayerNormFn.apply(a, b, g, be, 1e-5),
+    compare_fn("ln_res", lambda a, b, g, be: Fh.LayerNormFn.apply(a, b, g, be, 1e-5, 0),
                lambda a, b, g, be: O.layer_norm(a + b, g, be), [a, b, g, be], dev)
-    compare_fn("ln", lambda a, g, be: Fh.LayerNormFn.apply(a, None, g, be, 1e-5),
+    compare_fn("ln", lambda a, g, be: Fh.LayerNormFn.apply(a, None, g, be, 1e-5, 0),
                lambda a, g, be: O.layer_norm(a, g, be), [a, g, be], dev)
 
 
@@ -380,3 +380,80 @@ def test_tps_golden_and_grad(dev):
     d = (yh.permute(0, 3, 1, 2).cpu() - ys).abs()
     assert float(d[inner].max()) < 1e-4, float(d[inner].max())
     assert float(d.max()) < 2e-3
+
+
+# ---- TBSRN variant kernels -------------------------------------------------------------------------
+def test_tbsrn_layer_norm_mode1(dev):
+    g = torch.Generator().manual_seed(11)
+    a, b = torch.randn(3, 50, 128, generator=g), torch.randn(3, 50, 128, generator=g)
+    ga, be = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g)
+    compare_fn("tbsrn_ln", lambda a, b, g_, be_: Fh.LayerNormFn.apply(a, b, g_, be_, 1e-6, 1),
+               lambda a, b, g_, be_: O.tbsrn_layer_norm(a + b, g_, be_), [a, b, ga, be], dev)
+
+
+def _ref_self_attn(q, k, v, h):
+    B, Pn, E = q.shape
+    d = E // h
+    sp = lambda t: t.reshape(B, Pn, h, d).transpose(1, 2)
+    p = torch.softmax(sp(q) @ sp(k).transpose(-2, -1) / d ** 0.5, -1)
+    return (p @ sp(v)).transpose(1, 2).reshape(B, Pn, E)
+
+
+@pytest.mark.parametrize("B,Pn", [(2, 256), (1, 1024), (3, 192)])
+def test_self_attention_core(dev, B, Pn):
+    g = torch.Generator().manual_seed(12)
+    q, k, v = (torch.randn(B, Pn, 128, generator=g) for _ in range(3))
+    compare_fn("self_attn", lambda q, k, v: Fh.SelfAttnCoreFn.apply(q, k, v, 4, 0.0, 0),
+               lambda q, k, v: _ref_self_attn(q, k, v, 4), [q, k, v], dev, grtol=1e-3)
+
+
+def test_self_attention_dropout_is_consistent(dev):
+    """Dropout on the probabilities: forward and backward must use the same regenerated mask -- check with the
+    linearity of the op in V: out(V) is linear, so <dV, V> == <w, out>."""
+    g = torch.Generator().manual_seed(13)
+    q, k = (torch.randn(2, 128, 128, generator=g).to(dev) for _ in range(2))
+    v = torch.randn(2, 128, 128, generator=g).to(dev).requires_grad_(True)
+    w = torch.randn(2, 128, 128, generator=g).to(dev)
+    out = Fh.SelfAttnCoreFn.apply(q, k, v, 4, 0.1, 77)
+    (out * w).sum().backward()
+    assert abs(float((v.grad * v).sum()) - float((out * w).sum())) < 1e-3 * float((out * w).abs().sum())
+    out0 = Fh.SelfAttnCoreFn.apply(q, k, v.detach(), 4, 0.0, 77)
+    assert float((out - out0).abs().max()) > 1e-3                  # masks were applied
+
+
+def test_cat_positional_table(dev):
+    g = torch.Generator().manual_seed(14)
+    x, pe = torch.randn(3, 40, 64, generator=g), torch.randn(40, 64, generator=g)
+    compare_fn("cat_pe", lambda x, pe: Fh.CatPEFn.apply(x, pe),
+               lambda x, pe: torch.cat([x, pe.unsqueeze(0).expand(3, 40, 64)], -1), [x, pe], dev, grad_mask=[True, False])
+
+
+@pytest.mark.parametrize("B,H,W,Cout,act,beta", [(2, 16, 64, 64, 0, 0.0), (3, 5, 128, 256, 2, 0.0), (1, 1, 64, 64, 0, 0.5),
+                                                 (48, 16, 64, 64, 0, 0.0), (7, 16, 64, 128, 1, 0.0)])
+def test_conv3_weight_stationary_kernel(dev, B, H, W, Cout, act, beta):
+    """tatt_conv3_c64_fwd_ws (filter in registers) against F.conv2d, forward filter (repack mode 4)."""
+    from tatt_amd import ops
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(B, H, W, 64, generator=g)
+    w = torch.randn(Cout, 64, 3, 3, generator=g) * 0.05
+    b = torch.randn(Cout, generator=g)
+    y0 = torch.randn(B, H, W, Cout, generator=g)
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), padding=1).permute(0, 2, 3, 1)
+    ref = {0: lambda t: t, 1: torch.relu, 2: lambda t: O.mish(t.float()).double()}[act](ref) + beta * y0.double()
+    xd, wd, bd, yd = x.to(dev), w.to(dev), b.to(dev), y0.to(dev).clone()
+    wl = ops.repack_weight(wd, 4)
+    ops.call("tatt_conv3_c64_fwd_ws", ops.P(xd), ops.P(wl), ops.P(bd), ops.P(yd), B, H, W, Cout, act, beta, ops.stream())
+    check_close("conv3_ws", yd, ref.float(), 2e-4, 2e-4)
+
+
+def test_conv3_weight_stationary_dgrad(dev):
+    """repack mode 5: the data gradient of a 64-output-channel 3x3 convolution (Cin = 64 and 256)."""
+    from tatt_amd import ops
+    g = torch.Generator().manual_seed(22)
+    for Cin in (64, 256):
+        x = torch.randn(2, 16, 64, Cin, generator=g).permute(0, 3, 1, 2).requires_grad_(True)
+        w = torch.randn(64, Cin, 3, 3, generator=g) * 0.05
+        dy = torch.randn(2, 16, 64, 64, generator=g)
+        torch.nn.functional.conv2d(x, w, None, padding=1).backward(dy.permute(0, 3, 1, 2))
+        dx = ops.conv2d_dgrad(dy.to(dev), w.to(dev))
+        check_close("conv3_ws_dgrad_%d" % Cin, dx, x.grad.permute(0, 2, 3, 1), 2e-4, 2e-4)

@@ -199,3 +199,66 @@ def test_ptflops_style_probe(dev):
     with torch.no_grad():
         y, w = m(torch.rand(1, 4, 16, 64, device=dev))
     assert tuple(y.shape) == (1, 4, 32, 128) and torch.isfinite(y).all()
+
+
+# ---- TBSRN variant (BASELINE.json configs[4]) -------------------------------------------------------
+TBSRN_KW = dict(scale_factor=2, width=512, height=32, STN=True, mask=True, input_channel=4)
+
+
+def test_tbsrn_golden_eval_and_train(dev):
+    """LR 16x256 (H*W = 4096: the only geometry the unmodified reference executes), B=2: eval SR, train SR, loss and
+    every parameter gradient against the reference-generated vectors and the oracle."""
+    from tatt_amd.train import image_loss
+    z = np.load("tests/golden/tbsrn_b2.npz")
+    m = build("TBSRN", dev, **TBSRN_KW).eval()
+    sd0 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    x, hr = torch.from_numpy(z["x"]), torch.from_numpy(z["hr"])
+    with torch.no_grad():
+        y = m(x.to(dev))
+    e = max_err(y, torch.from_numpy(z["sr_eval"]))
+    assert e < 2e-5, e
+    m.train()
+    m.stn = False                     # see tools/gen_golden.py: the reference cannot train with its STN at this geometry
+    m.dropout_on = False
+    sr = m(x.to(dev))
+    loss = image_loss(sr, hr.to(dev)).mean() * 100
+    loss.backward()
+    assert max_err(sr, torch.from_numpy(z["sr_train"])) < 2e-5
+    assert abs(float(loss) - float(z["loss"])) < 1e-4 * float(z["loss"])
+    _, o_grads, o_sd1, _, o_out, _ = O.train_step(sd0, x, None, hr, stn=False, tbsrn=True)
+    worst = compare_param_grads(m.named_parameters(), o_grads, rtol=5e-3)
+    print("tbsrn worst relative gradient error vs oracle: %s %.3e" % worst)
+    assert len([k for k, p in m.named_parameters() if p.grad is None]) == len(z["none_keys"])
+    params = dict(m.named_parameters())
+    scale = max(float(r[0]) for r in z["grad_summary"])
+    for k, ref in zip(z["grad_keys"].tolist(), z["grad_summary"]):
+        got = summarize(params[k].grad.cpu())
+        assert abs(got[0] - ref[0]) < 1e-2 * ref[0] + 1e-6 * scale * params[k].numel() ** 0.5, (k, got[0], ref[0])
+
+
+def test_tbsrn_train_with_stn_at_16x64(dev):
+    """16x64 LR with the STN on (the throughput geometry; the reference's hard-wired 4096-position table cannot run it, the
+    oracle uses positionalencoding2d(64,16,64) -- the commented-out original at model/tbsrn.py:84)."""
+    from tatt_amd.train import image_loss
+    m = build("TBSRN", dev, scale_factor=2, width=128, height=32, STN=True, mask=True, input_channel=4).train()
+    m.dropout_on = False
+    sd0 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    x, _, hr = make_inputs(3, seed=9)
+    sr = m(x.to(dev))
+    loss = image_loss(sr, hr.to(dev)).mean() * 100
+    loss.backward()
+    o_loss, o_grads, _, _, o_out, _ = O.train_step(sd0, x, None, hr, stn=True, tbsrn=True)
+    assert max_err(sr, o_out["sr"]) < 3e-4
+    assert abs(float(loss) - float(o_loss)) < 1e-4 * abs(float(o_loss))
+    compare_param_grads(m.named_parameters(), o_grads, rtol=1e-2, rtol_stn=3e-2)
+
+
+def test_tbsrn_trainer_step_with_dropout(dev):
+    from tatt_amd.train import Trainer
+    m = build("TBSRN", dev, randomize=False, scale_factor=2, width=128, height=32, STN=True, mask=True, input_channel=4).train()
+    tr = Trainer(m, use_graph=False)
+    x, _, hr = make_inputs(4, seed=3)
+    l0 = float(tr.step(x.to(dev), None, hr.to(dev)))
+    for _ in range(5):
+        l1 = float(tr.step(x.to(dev), None, hr.to(dev)))
+    assert l1 == l1 and l1 < l0

@@ -92,3 +92,35 @@ def test_tps_out_of_range_control_points():
     assert float(src.min()) < 0 and float(src.max()) > 1            # the clamp is exercised
     assert max_err(y, torch.from_numpy(z["y"])) < 1e-5
     assert max_err(src, torch.from_numpy(z["src"])) < 1e-5
+
+
+TBSRN_KW = dict(scale_factor=2, width=512, height=32, STN=True, mask=True, input_channel=4)
+
+
+def test_tbsrn_forward_and_gradients():
+    """TBSRN variant at LR 16x256 -- the only size the unmodified reference executes."""
+    z = np.load("tests/golden/tbsrn_b2.npz")
+    sd = product_sd("TBSRN", **TBSRN_KW)
+    assert list(sd.keys()) == z["sd_keys"].tolist()
+    x, hr = torch.from_numpy(z["x"]), torch.from_numpy(z["hr"])
+    with torch.no_grad():
+        o = O.tbsrn_forward(sd, x, training=False)
+    assert max_err(o["sr"], torch.from_numpy(z["sr_eval"])) < 2e-5
+    loss, grads, _, _, out, _ = O.train_step(sd, x, None, hr, stn=False, tbsrn=True)
+    assert max_err(out["sr"], torch.from_numpy(z["sr_train"])) < 2e-5
+    assert abs(float(loss) - float(z["loss"])) < 1e-4 * float(z["loss"])
+    assert sorted(k for k, g in grads.items() if g is None) == sorted(z["none_keys"].tolist())
+    scale = max(float(r[0]) for r in z["grad_summary"])          # largest gradient l2 norm
+    for k, ref in zip(z["grad_keys"].tolist(), z["grad_summary"]):
+        got = summarize(grads[k])
+        assert abs(got[0] - ref[0]) < 1e-2 * ref[0] + 1e-6 * scale * grads[k].numel() ** 0.5, (k, got[0], ref[0])
+
+
+def test_tbsrn_layer_norm_is_not_nn_layernorm():
+    """model/tbsrn.py:23-36: unbiased std with eps outside the root -- differs from nn.LayerNorm by ~1/(2C)."""
+    x = torch.randn(5, 128)
+    a, b = torch.rand(128) + 0.5, torch.randn(128)
+    mine = O.tbsrn_layer_norm(x, a, b)
+    ref = a * (x - x.mean(-1, keepdim=True)) / (x.std(-1, keepdim=True) + 1e-6) + b
+    assert max_err(mine, ref) < 1e-5
+    assert max_err(mine, O.layer_norm(x, a, b, 1e-6)) > 1e-3

@@ -14,6 +14,7 @@ Cases (SURVEY.md §8c "Fixtures to generate"):
   qgru           query-GRU batch-axis quirk at B=1,2,4
   large_tile     32x128 LR, width=256,height=64, STN=False, eval B=1
   tps            TPS grid + sampler with out-of-range control points
+  tbsrn_b2       TBSRN variant at LR 16x256 (the only size the reference runs): eval forward + train fwd/bwd, B=2
 """
 import os
 import sys
@@ -220,6 +221,62 @@ def case_kat(ref, report):
                         sd_summary=np.stack([summarize(v.float()) for v in sd.values()]))
 
 
+def case_tbsrn(ref, report):
+    """TBSRN at LR 16x256 (H*W = 4096, the only size the unmodified reference runs): eval forward + train fwd/bwd, B=2."""
+    from model import tbsrn as rt
+    kw = dict(scale_factor=2, width=512, height=32, STN=True, mask=True, input_channel=4)
+    torch.manual_seed(1234)
+    m = rt.TBSRN(**kw)
+    m.load_state_dict(randomize_state_dict(m.state_dict()))
+    sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x, _, hr = make_inputs(2, 16, 256, seed=2)
+    m.eval()
+    with torch.no_grad():
+        y = m(x)
+        o = O.tbsrn_forward(sd0, x, training=False)
+    d = maxdiff(y, o["sr"])
+    report.append("tbsrn_eval_b2  oracle-vs-reference max|dsr| = %.3e" % d)
+    assert d < 2e-5, d
+    # train mode: the reference's STN head only accepts 16x64 inputs (stn_fc1 takes 512 features) while its FeatureEnhancer
+    # only accepts H*W == 4096, so the unmodified reference TBSRN can only TRAIN with the STN bypassed.  m.stn = False does
+    # that without changing the parameter set.
+    m.train()
+    m.stn = False
+    set_dropout_eval(m)
+    loss_mod = ref_image_loss()
+    sr = m(x)
+    loss = loss_mod(sr, hr).mean() * 100
+    m.zero_grad()
+    loss.backward()
+    grads = {k: (p.grad.detach().clone() if p.grad is not None else None) for k, p in m.named_parameters()}
+    o_loss, o_grads, _, _, o_out, o_total = O.train_step(sd0, x, None, hr, stn=False, tbsrn=True)
+    dsr = maxdiff(sr, o_out["sr"])
+    worst = 0.0
+    none_keys = []
+    scale = max(float(g.abs().max()) for g in grads.values() if g is not None)
+    for k, g in grads.items():
+        if g is None:
+            assert o_grads[k] is None, k
+            none_keys.append(k)
+            continue
+        # conv biases in front of a BatchNorm: mathematically zero gradient, pure round-off -> floor the denominator
+        rel = float((g - o_grads[k]).norm() / (g.norm() + 1e-6 * scale * g.numel() ** 0.5))
+        worst = max(worst, rel)
+        assert rel < 2e-2, (k, rel)
+    report.append("tbsrn_train_b2 loss ref %.6f oracle %.6f  max|dsr| %.3e  worst rel grad err %.3e ; %d params without grad"
+                  % (float(loss), float(o_loss), dsr, worst, len(none_keys)))
+    assert abs(float(loss) - float(o_loss)) < 1e-4 * float(loss) and dsr < 3e-4
+    keys = [k for k in grads if grads[k] is not None]
+    np.savez_compressed(os.path.join(OUT, "tbsrn_b2.npz"), x=np_(x), hr=np_(hr), sr_eval=np_(y), sr_train=np_(sr),
+                        loss=np.float64(float(loss)), grad_keys=np.array(keys), none_keys=np.array(none_keys),
+                        grad_summary=np.stack([summarize(grads[k]) for k in keys]),
+                        sd_keys=np.array(list(m.state_dict().keys())))
+    torch.manual_seed(1234)
+    fresh = rt.TBSRN(**kw).state_dict()
+    np.savez_compressed(os.path.join(OUT, "kat_tbsrn.npz"), sd_keys=np.array(list(fresh.keys())),
+                        sd_summary=np.stack([summarize(v.float()) for v in fresh.values()]))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = import_reference()
@@ -234,6 +291,7 @@ def main():
     case_train(ref, "tsrn_train_b3", "TSRN", 3, False, report)
     case_qgru(ref, report)
     case_tps(ref, report)
+    case_tbsrn(ref, report)
     with open(os.path.join(OUT, "REPORT.txt"), "w") as f:
         f.write("\n".join(report) + "\n")
     print("\n".join(report))
