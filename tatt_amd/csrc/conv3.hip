@@ -835,8 +835,16 @@ __global__ __launch_bounds__(256, 1) void conv3_c64_ws_kernel(Conv3P p) {
     const int wm = wave & 1, wn = wave >> 1;
     const int segs = p.W / C3_PX, cob = p.Cout / 64;
     const int npt = p.B * p.H * segs;                     // pixel tiles (one 64-pixel row segment each)
-    const int cb = blockIdx.x % cob, stride = gridDim.x / cob;
-    int pt = blockIdx.x / cob;
+    // XCD-aware tile order: work-groups are dealt round-robin to the 8 XCDs (private L2 each), so XCD x = blockIdx % 8 takes
+    // a CONTIGUOUS run of row tiles (the 3-row halos of neighbouring rows then hit the same L2 instead of being fetched
+    // through the fabric once per XCD) and a single cout block (one filter per L2).
+    const int stride = gridDim.x / cob;
+    int cb = blockIdx.x % cob, pt = blockIdx.x / cob;
+    if (gridDim.x % 8 == 0 && 8 % cob == 0 && stride % (8 / cob) == 0) {
+        const int x = blockIdx.x & 7, m = blockIdx.x >> 3, xg = 8 / cob;
+        cb = x % cob;
+        pt = (x / cob) * (stride / xg) + m;
+    }
     if (pt >= npt) return;
     const int co0 = cb * 64;
     // ---- the filter: 72 float4 per lane, packed by tatt_repack_conv_weight mode 4 / 5 ----
@@ -863,9 +871,21 @@ __global__ __launch_bounds__(256, 1) void conv3_c64_ws_kernel(Conv3P p) {
     };
     int n, h, w0;
     decode(pt, n, h, w0);
-    for (int s9 = 0; s9 < 9; ++s9) {
-        const int r = s9 / 3, pxb = (s9 - 3 * r) * 22;
-        for (int i = t; i < 352; i += 256) halo_store(smem, r, pxb, i, halo_load(n, h + r - 1, w0, pxb, i));
+    {   // first halo: all 18 loads in flight together with the 72 filter loads (one memory round trip, not 9)
+        f32x4 hp0[9], hp1[9];
+#pragma unroll
+        for (int s9 = 0; s9 < 9; ++s9) {
+            const int r = s9 / 3, pxb = (s9 - 3 * r) * 22;
+            hp0[s9] = halo_load(n, h + r - 1, w0, pxb, t);
+            hp1[s9] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (t < 96) hp1[s9] = halo_load(n, h + r - 1, w0, pxb, 256 + t);
+        }
+#pragma unroll
+        for (int s9 = 0; s9 < 9; ++s9) {
+            const int r = s9 / 3, pxb = (s9 - 3 * r) * 22;
+            halo_store(smem, r, pxb, t, hp0[s9]);
+            if (t < 96) halo_store(smem, r, pxb, 256 + t, hp1[s9]);
+        }
     }
     __syncthreads();
     const int abase = (wm * 32 + (lane & 31)) * WS_XP + 4 * (lane >> 5);
@@ -879,9 +899,9 @@ __global__ __launch_bounds__(256, 1) void conv3_c64_ws_kernel(Conv3P p) {
         if (has_next) decode(npt_next, nn, nh, nw0);
         const float* Xs = smem + xbuf * WS_HALO + abase;
         float* XsN = smem + (xbuf ^ 1) * WS_HALO;
-        f32x16 acc;
+        f32x16 acc, acc1;            // two independent accumulation chains (even / odd groups): no back-to-back dependent MFMAs
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        for (int i = 0; i < 16; ++i) { acc[i] = 0.f; acc1[i] = 0.f; }
         f32x4 va[8];
         f32x4 h0, h1;
         // group g = tap * 8 + c covers input channels [8c, 8c+8) of tap (kh, kw): one 16-byte A read, four MFMAs
@@ -902,7 +922,10 @@ __global__ __launch_bounds__(256, 1) void conv3_c64_ws_kernel(Conv3P p) {
             if (g + 4 < 72) { WS_LD(g + 4) }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(va[g & 7][u], wq[g][u], acc, 0, 0, 0);
+            for (int u = 0; u < 4; ++u) {
+                if (u & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[g & 7][u], wq[g][u], acc1, 0, 0, 0);
+                else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(va[g & 7][u], wq[g][u], acc, 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
             if (c == 7 && has_next) {                      // ... registers -> LDS, 28 MFMAs after the loads were issued
                 halo_store(XsN, r, pxb, t, h0);
@@ -914,7 +937,7 @@ __global__ __launch_bounds__(256, 1) void conv3_c64_ws_kernel(Conv3P p) {
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int px = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-                float v = apply_act(acc[reg] + bj, p.act);
+                float v = apply_act(acc[reg] + acc1[reg] + bj, p.act);
                 const long o = (rowbase + px) * p.Cout + co;
                 if (p.beta != 0.f) v += p.beta * p.y[o];
                 p.y[o] = v;

@@ -23,6 +23,15 @@ __device__ __forceinline__ long seq_base(const SeqGeom& g, int s) {
 // ------------------------------------------------------------------------------------------------
 // small BiGRU forward.  gi: [tok][192] = [fwd r,z,n | rev r,z,n];  out: [tok][64] = [fwd h | rev h]
 // ------------------------------------------------------------------------------------------------
+// The recurrence is latency-bound: a step is ~0.3 us of arithmetic but its operands come from HBM / Infinity Cache
+// (~1-2 us away), so each group keeps GRU_PF steps of input in flight in a register ring.  A 32-lane group lives inside
+// one wave, so the LDS hand-off of h needs only wave-level ordering -- no work-group barrier couples the 8 groups.
+#define GRU_PF 4
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 __global__ __launch_bounds__(256) void gru32_fwd_kernel(const float* __restrict__ gi,
                                                         const float* __restrict__ whh_f, const float* __restrict__ bhh_f,
                                                         const float* __restrict__ whh_r, const float* __restrict__ bhh_r,
@@ -42,38 +51,45 @@ __global__ __launch_bounds__(256) void gru32_fwd_kernel(const float* __restrict_
     }
     const float br = bhh[j], bz = bhh[32 + j], bn = bhh[64 + j];
     const long base = valid ? seq_base(g, seq) : 0;
+    auto token = [&](int step) { return base + (long)(dir ? g.T - 1 - step : step) * g.stride_t; };
+    float pr[GRU_PF], pz[GRU_PF], pn[GRU_PF];
+    auto fetch = [&](int step, float& a, float& b, float& c) {
+        a = b = c = 0.f;
+        if (!valid || step >= g.T) return;
+        const float* q = gi + token(step) * 192 + dir * 96 + j;
+        a = q[0]; b = q[32]; c = q[64];
+    };
+#pragma unroll
+    for (int d = 0; d < GRU_PF; ++d) fetch(d, pr[d], pz[d], pn[d]);
     float h = 0.f;
-    long tok = base + (long)(dir ? g.T - 1 : 0) * g.stride_t;
-    float gr = 0.f, gz = 0.f, gn = 0.f;
-    if (valid) { gr = gi[tok * 192 + dir * 96 + j]; gz = gi[tok * 192 + dir * 96 + 32 + j]; gn = gi[tok * 192 + dir * 96 + 64 + j]; }
-    for (int step = 0; step < g.T; ++step) {
-        // prefetch next step's input projection
-        float ngr = 0.f, ngz = 0.f, ngn = 0.f;
-        long ntok = tok + (dir ? -g.stride_t : g.stride_t);
-        if (valid && step + 1 < g.T) {
-            ngr = gi[ntok * 192 + dir * 96 + j]; ngz = gi[ntok * 192 + dir * 96 + 32 + j]; ngn = gi[ntok * 192 + dir * 96 + 64 + j];
-        }
-        hs[grp][j] = h;
-        __syncthreads();
-        float ar = br, az = bz, an = bn;
-        const f32x4* hv = reinterpret_cast<const f32x4*>(hs[grp]);
+    for (int s0 = 0; s0 < g.T; s0 += GRU_PF) {
 #pragma unroll
-        for (int k4 = 0; k4 < 8; ++k4) {
-            f32x4 hh = hv[k4];
+        for (int u = 0; u < GRU_PF; ++u) {
+            const int step = s0 + u;
+            if (step >= g.T) break;
+            const float gr = pr[u], gz = pz[u], gn = pn[u];
+            fetch(step + GRU_PF, pr[u], pz[u], pn[u]);
+            hs[grp][j] = h;
+            wave_lds_sync();
+            float ar = br, az = bz, an = bn;
+            const f32x4* hv = reinterpret_cast<const f32x4*>(hs[grp]);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                ar = fmaf(wr[k4 * 4 + u], hh[u], ar);
-                az = fmaf(wz[k4 * 4 + u], hh[u], az);
-                an = fmaf(wn[k4 * 4 + u], hh[u], an);
+            for (int k4 = 0; k4 < 8; ++k4) {
+                f32x4 hh = hv[k4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    ar = fmaf(wr[k4 * 4 + e], hh[e], ar);
+                    az = fmaf(wz[k4 * 4 + e], hh[e], az);
+                    an = fmaf(wn[k4 * 4 + e], hh[e], an);
+                }
             }
+            wave_lds_sync();
+            const float r = sigmoid_fast(gr + ar);
+            const float z = sigmoid_fast(gz + az);
+            const float n = tanh_fast(gn + r * an);
+            h = (1.f - z) * n + z * h;
+            if (valid) out[token(step) * 64 + dir * 32 + j] = h;
         }
-        __syncthreads();
-        float r = sigmoid_fast(gr + ar);
-        float z = sigmoid_fast(gz + az);
-        float n = tanh_fast(gn + r * an);
-        h = (1.f - z) * n + z * h;
-        if (valid) out[tok * 64 + dir * 32 + j] = h;
-        tok = ntok; gr = ngr; gz = ngz; gn = ngn;
     }
 }
 TATT_API int tatt_gru32_fwd(const float* gi, const float* whh_f, const float* bhh_f, const float* whh_r,
@@ -115,7 +131,7 @@ __global__ __launch_bounds__(256) void gru32_bwd_kernel(const float* __restrict_
     const float br = bhh[j], bz = bhh[32 + j], bn = bhh[64 + j];
     const long base = valid ? seq_base(g, seq) : 0;
     float dhc = 0.f;   // gradient carried to h_{t-1}
-    // software prefetch: the loads of step s-1 (h_{t-2}, gi, dout) do not depend on step s's arithmetic
+    // register ring: the operands of steps s-1 .. s-GRU_PF (h_{t-1}, gi, dout) are in flight while step s computes
     auto fetch = [&](int step, float& hp, float& gr, float& gz, float& gn, float& go) {
         hp = gr = gz = gn = go = 0.f;
         if (!valid || step < 0) return;
@@ -126,53 +142,59 @@ __global__ __launch_bounds__(256) void gru32_bwd_kernel(const float* __restrict_
         gr = gi[tok * 192 + dir * 96 + j]; gz = gi[tok * 192 + dir * 96 + 32 + j]; gn = gi[tok * 192 + dir * 96 + 64 + j];
         go = dout[tok * 64 + dir * 32 + j];
     };
-    float n_hp, n_gr, n_gz, n_gn, n_go;
-    fetch(g.T - 1, n_hp, n_gr, n_gz, n_gn, n_go);
-    for (int step = g.T - 1; step >= 0; --step) {
-        const int ti = dir ? g.T - 1 - step : step;
-        const long tok = base + (long)ti * g.stride_t;
-        const float hp = n_hp, gr = n_gr, gz = n_gz, gn = n_gn;
-        const float dh = dhc + n_go;
-        fetch(step - 1, n_hp, n_gr, n_gz, n_gn, n_go);
-        hs[grp][j] = hp;
-        __syncthreads();
-        float ar = br, az = bz, an = bn;
-        const f32x4* hv = reinterpret_cast<const f32x4*>(hs[grp]);
+    float p_hp[GRU_PF], p_gr[GRU_PF], p_gz[GRU_PF], p_gn[GRU_PF], p_go[GRU_PF];
 #pragma unroll
-        for (int k4 = 0; k4 < 8; ++k4) {
-            f32x4 hh = hv[k4];
+    for (int d = 0; d < GRU_PF; ++d) fetch(g.T - 1 - d, p_hp[d], p_gr[d], p_gz[d], p_gn[d], p_go[d]);
+    for (int s0 = g.T - 1; s0 >= 0; s0 -= GRU_PF) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                ar = fmaf(wr[k4 * 4 + u], hh[u], ar);
-                az = fmaf(wz[k4 * 4 + u], hh[u], az);
-                an = fmaf(wn[k4 * 4 + u], hh[u], an);
+        for (int u = 0; u < GRU_PF; ++u) {
+            const int step = s0 - u;
+            if (step < 0) break;
+            const int ti = dir ? g.T - 1 - step : step;
+            const long tok = base + (long)ti * g.stride_t;
+            const float hp = p_hp[u], gr = p_gr[u], gz = p_gz[u], gn = p_gn[u];
+            const float dh = dhc + p_go[u];
+            fetch(step - GRU_PF, p_hp[u], p_gr[u], p_gz[u], p_gn[u], p_go[u]);
+            hs[grp][j] = hp;
+            wave_lds_sync();
+            float ar = br, az = bz, an = bn;
+            const f32x4* hv = reinterpret_cast<const f32x4*>(hs[grp]);
+#pragma unroll
+            for (int k4 = 0; k4 < 8; ++k4) {
+                f32x4 hh = hv[k4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    ar = fmaf(wr[k4 * 4 + e], hh[e], ar);
+                    az = fmaf(wz[k4 * 4 + e], hh[e], az);
+                    an = fmaf(wn[k4 * 4 + e], hh[e], an);
+                }
             }
-        }
-        const float r = sigmoid_fast(gr + ar), z = sigmoid_fast(gz + az), n = tanh_fast(gn + r * an);
-        const float dn = dh * (1.f - z);
-        const float dz = dh * (hp - n);
-        const float dnp = dn * (1.f - n * n);
-        const float drp = dnp * an * r * (1.f - r);
-        const float dzp = dz * z * (1.f - z);
-        const float dghn = dnp * r;
-        if (valid) {
-            dgi[tok * 192 + dir * 96 + j] = drp; dgi[tok * 192 + dir * 96 + 32 + j] = dzp; dgi[tok * 192 + dir * 96 + 64 + j] = dnp;
-            dgh[tok * 192 + dir * 96 + j] = drp; dgh[tok * 192 + dir * 96 + 32 + j] = dzp; dgh[tok * 192 + dir * 96 + 64 + j] = dghn;
-            hprev[tok * 64 + dir * 32 + j] = hp;
-        }
-        ds[grp][j] = drp; ds[grp][32 + j] = dzp; ds[grp][64 + j] = dghn;
-        __syncthreads();
-        // 96-term dot product split over 4 accumulators (a single dependent FMA chain would cost ~96 x 8 cycles per step)
-        float c0 = dh * z, c1 = 0.f, c2 = 0.f, c3 = 0.f;
-        const f32x4* dv = reinterpret_cast<const f32x4*>(ds[grp]);
+            const float r = sigmoid_fast(gr + ar), z = sigmoid_fast(gz + az), n = tanh_fast(gn + r * an);
+            const float dn = dh * (1.f - z);
+            const float dz = dh * (hp - n);
+            const float dnp = dn * (1.f - n * n);
+            const float drp = dnp * an * r * (1.f - r);
+            const float dzp = dz * z * (1.f - z);
+            const float dghn = dnp * r;
+            if (valid) {
+                dgi[tok * 192 + dir * 96 + j] = drp; dgi[tok * 192 + dir * 96 + 32 + j] = dzp; dgi[tok * 192 + dir * 96 + 64 + j] = dnp;
+                dgh[tok * 192 + dir * 96 + j] = drp; dgh[tok * 192 + dir * 96 + 32 + j] = dzp; dgh[tok * 192 + dir * 96 + 64 + j] = dghn;
+                hprev[tok * 64 + dir * 32 + j] = hp;
+            }
+            ds[grp][j] = drp; ds[grp][32 + j] = dzp; ds[grp][64 + j] = dghn;
+            wave_lds_sync();
+            // 96-term dot product split over 4 accumulators (a single dependent FMA chain would cost ~96 x 8 cycles per step)
+            float c0 = dh * z, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+            const f32x4* dv = reinterpret_cast<const f32x4*>(ds[grp]);
 #pragma unroll
-        for (int k4 = 0; k4 < 24; ++k4) {
-            f32x4 dd = dv[k4];
-            c0 = fmaf(wt[k4 * 4 + 0], dd[0], c0); c1 = fmaf(wt[k4 * 4 + 1], dd[1], c1);
-            c2 = fmaf(wt[k4 * 4 + 2], dd[2], c2); c3 = fmaf(wt[k4 * 4 + 3], dd[3], c3);
+            for (int k4 = 0; k4 < 24; ++k4) {
+                f32x4 dd = dv[k4];
+                c0 = fmaf(wt[k4 * 4 + 0], dd[0], c0); c1 = fmaf(wt[k4 * 4 + 1], dd[1], c1);
+                c2 = fmaf(wt[k4 * 4 + 2], dd[2], c2); c3 = fmaf(wt[k4 * 4 + 3], dd[3], c3);
+            }
+            dhc = (c0 + c1) + (c2 + c3);
+            wave_lds_sync();
         }
-        dhc = (c0 + c1) + (c2 + c3);
-        __syncthreads();
     }
 }
 TATT_API int tatt_gru32_bwd(const float* gi, const float* out, const float* dout, const float* whh_f,

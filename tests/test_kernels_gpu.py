@@ -384,6 +384,7 @@ def test_tps_golden_and_grad(dev):
 
 # ---- TBSRN variant kernels -------------------------------------------------------------------------
 def test_tbsrn_layer_norm_mode1(dev):
+    from tatt_amd import functional as Fh
     g = torch.Generator().manual_seed(11)
     a, b = torch.randn(3, 50, 128, generator=g), torch.randn(3, 50, 128, generator=g)
     ga, be = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g)
@@ -401,6 +402,7 @@ def _ref_self_attn(q, k, v, h):
 
 @pytest.mark.parametrize("B,Pn", [(2, 256), (1, 1024), (3, 192)])
 def test_self_attention_core(dev, B, Pn):
+    from tatt_amd import functional as Fh
     g = torch.Generator().manual_seed(12)
     q, k, v = (torch.randn(B, Pn, 128, generator=g) for _ in range(3))
     compare_fn("self_attn", lambda q, k, v: Fh.SelfAttnCoreFn.apply(q, k, v, 4, 0.0, 0),
@@ -410,6 +412,7 @@ def test_self_attention_core(dev, B, Pn):
 def test_self_attention_dropout_is_consistent(dev):
     """Dropout on the probabilities: forward and backward must use the same regenerated mask -- check with the
     linearity of the op in V: out(V) is linear, so <dV, V> == <w, out>."""
+    from tatt_amd import functional as Fh
     g = torch.Generator().manual_seed(13)
     q, k = (torch.randn(2, 128, 128, generator=g).to(dev) for _ in range(2))
     v = torch.randn(2, 128, 128, generator=g).to(dev).requires_grad_(True)
@@ -422,6 +425,7 @@ def test_self_attention_dropout_is_consistent(dev):
 
 
 def test_cat_positional_table(dev):
+    from tatt_amd import functional as Fh
     g = torch.Generator().manual_seed(14)
     x, pe = torch.randn(3, 40, 64, generator=g), torch.randn(40, 64, generator=g)
     compare_fn("cat_pe", lambda x, pe: Fh.CatPEFn.apply(x, pe),

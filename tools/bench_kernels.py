@@ -15,6 +15,7 @@ from tatt_amd.build import build  # noqa: E402
 build(verbose=False)
 ap = argparse.ArgumentParser()
 ap.add_argument("--only", default="")
+ap.add_argument("--match", default="", help="substring filter on the kernel name")
 ap.add_argument("--iters", type=int, default=30)
 ap.add_argument("--batch", type=int, default=48)
 a = ap.parse_args()
@@ -23,7 +24,7 @@ B = a.batch
 
 
 def timeit(name, fn, flops=0.0, bytes_=0.0, iters=None):
-    if a.only and a.only != name:
+    if (a.only and a.only != name) or (a.match and a.match not in name):
         return
     iters = iters or a.iters
     for _ in range(3):
