@@ -64,13 +64,10 @@ int tatt_repack_conv_weight(const float* w_oihw, float* out, int Cout, int Cin, 
 int tatt_splitk_reduce(const float* partial, float* C, int M, int N, int S, int remap_cin, int remap_taps,
                        float beta, hipStream_t st);
 
-/* Specialised 3x3 convolution, Cin/Cout/W multiples of 64, NHWC contiguous, halo tile + filter taps staged in LDS,
- * v_mfma_f32_32x32x2_f32: the SRB / block7 / up-sampler convs (model/tsrn.py:877,885,612,1043), forward and (with the
- * mode-1 packed filter) data gradient.  y = act(conv + bias) + beta*y */
-int tatt_conv3_c64_fwd(const float* x, const float* wpacked, const float* bias, float* y, int B, int H, int W,
-                       int Cin, int Cout, int act, float beta, hipStream_t st);
-/* same convolution, filter packed [9][Cout][Cin] (repack mode 2; mode 3 for the data gradient): both MFMA operands are read
- * from LDS with 16-byte loads along the contraction axis -- the production kernel (8x fewer LDS instructions) */
+/* Specialised 3x3 convolution, Cin/Cout/W multiples of 64, NHWC contiguous: the SRB / block7 / up-sampler convs
+ * (model/tsrn.py:877,885,612,1043), forward and data gradient.  y = act(conv + bias) + beta*y.  Filter packed [9][Cout][Cin]
+ * (repack mode 2; mode 3 for the data gradient); the filter slice of each tap is staged through LDS, both MFMA operands are
+ * read with 16-byte LDS loads along the contraction axis.  Used when Cin != 64. */
 int tatt_conv3_c64_fwd_t(const float* x, const float* wt, const float* bias, float* y, int B, int H, int W, int Cin,
                          int Cout, int act, float beta, hipStream_t st);
 /* weight-stationary 3x3 convolution for 64 input channels (reference nn.Conv2d(64, Cout, 3, padding=1): model/tsrn.py:877,885,
@@ -78,8 +75,6 @@ int tatt_conv3_c64_fwd_t(const float* x, const float* wt, const float* bias, flo
  * tatt_repack_conv_weight mode 4 (forward) / mode 5 (data gradient of a 64-output-channel convolution) */
 int tatt_conv3_c64_fwd_ws(const float* x, const float* wl, const float* bias, float* y, int B, int H, int W,
                           int Cout, int act, float beta, hipStream_t st);
-/* diagnostics: when non-NULL, the following tatt_conv3_c64_fwd_t launches write a per-wave cycle breakdown (256*4*6 int64) */
-int tatt_conv3_set_prof(long long* buf);
 /* weight-gradient partials part[G][9*Cin][Cout] (G persistent work-groups, G <= B*H*W/64); finish with
  * tatt_splitk_reduce(part, dw_oihw, 9*Cin, Cout, G, Cin, 9, beta) */
 int tatt_conv3_c64_wgrad_partial(const float* x, const float* dy, float* part, int B, int H, int W, int Cin,

@@ -82,6 +82,14 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
+// LDS hand-off between lanes of ONE wave (a 32-lane group, a wave-private tile): LDS operations of a wave execute in order, so
+// only compiler/memory-model ordering is needed -- no work-group barrier.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // ---- latency-tolerant strided sums ------------------------------------------------------------------------------
 // The reduction kernels run at low occupancy, so a naive `for (...) s += p[i*stride]` serialises on load latency
 // (~1 us per dependent L2 round trip).  U independent loads are issued per trip instead.

@@ -27,11 +27,6 @@ __device__ __forceinline__ long seq_base(const SeqGeom& g, int s) {
 // (~1-2 us away), so each group keeps GRU_PF steps of input in flight in a register ring.  A 32-lane group lives inside
 // one wave, so the LDS hand-off of h needs only wave-level ordering -- no work-group barrier couples the 8 groups.
 #define GRU_PF 4
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 __global__ __launch_bounds__(256) void gru32_fwd_kernel(const float* __restrict__ gi,
                                                         const float* __restrict__ whh_f, const float* __restrict__ bhh_f,
                                                         const float* __restrict__ whh_r, const float* __restrict__ bhh_r,

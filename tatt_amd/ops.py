@@ -83,6 +83,7 @@ def linear_fwd(x2, W, b=None, *, act=ACT_NONE, alpha=1.0, x2b=None, out=None):
     M, K1 = x2.shape
     N, K = W.shape
     y = out if out is not None else new(x2, M, N)
+    assert K1 + (0 if x2b is None else x2b.shape[1]) == K
     if x2b is None:
         assert K1 == K
         gemm(x2, x2.stride(0), x2.stride(1), W, 1, K, y, y.stride(0), 1, M, N, K, bias=b, alpha=alpha, act=act)
@@ -137,17 +138,13 @@ def repack_weight(w_oihw, mode):
 
 
 def conv_fwd(x_bhwc, wpacked, bias, Cout, KH, KW, *, act=ACT_NONE, out=None, beta=0.0):
-    """Stride-1 'same' convolution; dispatches to the specialised kernels where the shape allows:
-    3x3 with Cin, Cout, W multiples of 64 (LDS-halo MFMA kernel), 9x9 64k->4 (vector-ALU kernel), else the generic
-    implicit-GEMM MFMA kernel."""
+    """Stride-1 'same' convolution from a mode-0/1 packed filter: 9x9 64k->4 goes to the vector-ALU kernel, everything else to
+    the generic implicit-GEMM MFMA kernel (the specialised 3x3 kernels take their own packings: conv2d_forward / conv2d_dgrad)."""
     _check_dev(x_bhwc)
     B, H, W, Cin = x_bhwc.shape
     sn, sh, sw, sc = x_bhwc.stride()
     y = out if out is not None else new(x_bhwc, B, H, W, Cout)
     contig = x_bhwc.is_contiguous()
-    if contig and KH == 3 and KW == 3 and Cin % 64 == 0 and Cout % 64 == 0 and W % 64 == 0:
-        call("tatt_conv3_c64_fwd", P(x_bhwc), P(wpacked), P(bias), P(y), B, H, W, Cin, Cout, act, beta, stream())
-        return y
     if contig and KH == 9 and KW == 9 and Cout == 4 and Cin % 16 == 0 and H % 8 == 0 and W % 32 == 0 \
             and act == ACT_NONE and beta == 0.0:
         call("tatt_conv9_c64_to_c4", P(x_bhwc), P(wpacked), P(bias), P(y), B, H, W, Cin, stream())

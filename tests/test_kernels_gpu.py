@@ -97,9 +97,15 @@ def test_conv3_large_tile_and_accumulate(dev):
     xin = x.permute(0, 2, 3, 1).contiguous().to(dev)
     y0 = R(2, 8, 128, 64, seed=3).to(dev)
     y = y0.clone()
-    ops.conv_fwd(xin, ops.repack_weight(w.to(dev), 0), b.to(dev), 64, 3, 3, out=y, beta=1.0)
     ref = F.conv2d(x, w, b, padding=1).permute(0, 2, 3, 1) + y0.cpu()
-    check_close("conv3_beta", y, ref, rtol=5e-4, atol=5e-5)
+    # LDS-staged-filter kernel (filter packed [9][Cout][Cin])
+    ops.call("tatt_conv3_c64_fwd_t", ops.P(xin), ops.P(ops.repack_weight(w.to(dev), 2)), ops.P(b.to(dev)), ops.P(y), 2, 8, 128, 128, 64,
+             0, 1.0, ops.stream())
+    check_close("conv3_t_beta", y, ref, rtol=5e-4, atol=5e-5)
+    # generic implicit-GEMM kernel (filter packed [9][Cin][Cout])
+    y = y0.clone()
+    ops.conv_fwd(xin, ops.repack_weight(w.to(dev), 0), b.to(dev), 64, 3, 3, out=y, beta=1.0)
+    check_close("conv3_generic_beta", y, ref, rtol=5e-4, atol=5e-5)
 
 
 def test_conv_tanh_epilogue(dev):

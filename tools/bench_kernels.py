@@ -55,7 +55,6 @@ b64 = R(64)
 wp = ops.repack_weight(w33, 0)
 y64 = torch.empty_like(x64)
 f33 = 2.0 * M * 576 * 64
-timeit("conv3_fwd_64_64", lambda: ops.conv_fwd(x64, wp, b64, 64, 3, 3, out=y64), f33)
 wt = ops.repack_weight(w33, 2)
 timeit("conv3_fwd_t_64_64", lambda: ops.call("tatt_conv3_c64_fwd_t", ops.P(x64), ops.P(wt), ops.P(b64), ops.P(y64), B, 16, 64, 64, 64,
                                               0, 0.0, ops.stream()), f33)
@@ -68,7 +67,6 @@ timeit("conv3_generic_64_64", lambda: ops.conv_fwd(xs, wp, b64, 64, 3, 3, out=y6
 w256 = R(256, 64, 3, 3) * 0.05
 wp256 = ops.repack_weight(w256, 0)
 y256 = torch.empty(B, 16, 64, 256, device=dev)
-timeit("conv3_fwd_64_256", lambda: ops.conv_fwd(x64, wp256, None, 256, 3, 3, out=y256), 4 * f33)
 wt256 = ops.repack_weight(w256, 2)
 timeit("conv3_fwd_t_64_256", lambda: ops.call("tatt_conv3_c64_fwd_t", ops.P(x64), ops.P(wt256), None, ops.P(y256), B, 16, 64, 64, 256,
                                                0, 0.0, ops.stream()), 4 * f33)
@@ -78,8 +76,6 @@ timeit("conv3_fwd_ws_64_256", lambda: ops.call("tatt_conv3_c64_fwd_ws", ops.P(x6
 wt256d = ops.repack_weight(w256, 3)
 timeit("conv3_dgrad_t_256_64", lambda: ops.call("tatt_conv3_c64_fwd_t", ops.P(y256), ops.P(wt256d), None, ops.P(y64), B, 16, 64, 256, 64,
                                                  0, 0.0, ops.stream()), 4 * f33)
-wd256 = ops.repack_weight(w256, 1)
-timeit("conv3_dgrad_256_64", lambda: ops.conv_fwd(y256, wd256, None, 64, 3, 3, out=y64), 4 * f33)
 timeit("conv3_wgrad_64_256", lambda: ops.conv_wgrad(x64, y256, 256, 3, 3), 4 * f33)
 xhr = R(B, 32, 128, 64)
 w99 = R(4, 64, 9, 9) * 0.02
