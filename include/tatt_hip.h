@@ -196,9 +196,10 @@ int tatt_qgru_bwd_fused(const float* dgh_cur0, const float* dgh_cur1, const floa
 int tatt_gru_compose(const float* wih_f, const float* wih_r, const float* bih_f, const float* bih_r,
                      const float* Wc, const float* bc, float* Wp, float* bp, int K, hipStream_t st);
 /* ... and map the gradients of the composed projection back: dwih_d (96,64) = dWp_d Wc^T + dbp_d bc^T,
- * dWc (64,K) = sum_d wih_d^T dWp_d, dbc (64) = sum_d wih_d^T dbp_d */
+ * dWc (64,K) = sum_d wih_d^T dWp_d, dbc (64) = sum_d wih_d^T dbp_d; dwhh_d (96,32) = d-th diagonal block of dWhh (192,64) */
 int tatt_gru_tail(const float* dWp, const float* dbp, const float* Wc, const float* bc, const float* wih_f,
-                  const float* wih_r, float* dwih_f, float* dwih_r, float* dWc, float* dbc, int K, hipStream_t st);
+                  const float* wih_r, float* dwih_f, float* dwih_r, float* dWc, float* dbc, int K,
+                  const float* dWhh, float* dwhh_f, float* dwhh_r, hipStream_t st);
 
 /* One time step of the query-embedding GRU (nn.GRU(64*H, 32*H, bidirectional), model/transformer_v2.py:177,218;
  * time axis = sample axis), both directions: gi* (Wb,3*HID) incl. b_ih, whh* (3*HID,HID),
@@ -251,6 +252,19 @@ int tatt_grid_sample_fwd(const float* x, long xsn, long xsc, long xsh, long xsw,
 /* gradient w.r.t. src (through the clamp); the LR image carries no gradient */
 int tatt_grid_sample_bwd(const float* x, long xsn, long xsc, long xsh, long xsw, const float* src,
                          const float* dout, float* dsrc, int B, int C, int H, int W, hipStream_t st);
+
+/* ImageLoss(gradient=True, loss_weight=[w0, w1]).forward (reference loss/image_loss.py:19-34,50-58): per-sample
+ * loss[b] = w0*mean((sr-hr)^2) + w1*mean|gradient_map(sr[:3]) - gradient_map(hr[:3])|; when loss_mean != NULL also
+ * loss_mean[0] = scale * mean_b loss[b] (interfaces/super_resolution.py:889-894 uses scale 100).  sr / hr are (B,C,H,W) images
+ * addressed by element strides (n, c, h, w). */
+int tatt_image_loss_fwd(const float* sr, long s_n, long s_c, long s_h, long s_w, const float* hr, long h_n, long h_c,
+                        long h_h, long h_w, float* loss, float* loss_mean, float scale, int B, int C, int H, int W,
+                        float w0, float w1, hipStream_t st);
+/* its gradient w.r.t. sr (dsr has sr's strides); exactly one of gper (B per-sample upstream gradients) and gscalar (upstream
+ * gradient of the scaled batch mean, 1 element) is non-NULL */
+int tatt_image_loss_bwd(const float* sr, long s_n, long s_c, long s_h, long s_w, const float* hr, long h_n, long h_c,
+                        long h_h, long h_w, const float* gper, const float* gscalar, float scale, float* dsr,
+                        int B, int C, int H, int W, float w0, float w1, hipStream_t st);
 
 #ifdef __cplusplus
 }

@@ -370,83 +370,158 @@ TATT_API int tatt_conv3_c64_fwd_ws(const float* x, const float* wl, const float*
 }
 
 // ---- weight gradient -------------------------------------------------------------------------------------------------
+// dW[tap][ci][co] = sum over pixels x[pixel + tap][ci] * dy[pixel][co]: the pixels are the contraction axis.  Persistent
+// work-groups of 8 waves walk 64-pixel row segments; wave w owns the (ci half, co half) quadrant w & 3 of one 64 ci x 64 co
+// block for the taps of its group (waves 0-3: taps 0-4, waves 4-7: taps 5-8 -- five / four 32x32 accumulators that live for
+// the whole kernel), so two waves share each SIMD and hide each other's LDS latency and prefetch traffic.  The halo of x and
+// the dy tile of the NEXT segment are prefetched global -> registers -> LDS under the MFMAs (double-buffered, one barrier per
+// segment).  Per-work-group partials leave as 16-byte stores (transposed through LDS) and are summed deterministically and
+// scattered to the OIHW parameter layout by the split-K reducer of gemm.hip.
 struct Conv3WP {
     const float* x; const float* dy; float* part;
     int B, H, W, Cin, Cout, nseg;
 };
-__global__ __launch_bounds__(256) void conv3_c64_wgrad_kernel(Conv3WP p) {
+#define WG_HALO (3 * C3_HW * 64)                     // floats: x halo [3][66][64 ci]
+#define WG_BUF (WG_HALO + 64 * 64)                   // + dy tile [64 px][64 co]
+#define C3_WG_LDS (2 * WG_BUF * 4)                   // 133.9 KB
+#define WG_F4 (WG_BUF / 4)                           // float4 per buffer: 3168 + 1024 = 4192
+
+template <int T0, int NT>
+__device__ __forceinline__ void wgrad_segment(f32x16 (&acc)[5], const float* __restrict__ acol, const float* __restrict__ bcol,
+                                              const Conv3WP& p, bool has_next, int nn, int nh, int nw0, int ci0, int co0,
+                                              float* __restrict__ nbuf, int t) {
+    // float4 #idx of the next segment's buffer: [0, 3168) halo (c4 = idx & 15, pixel = idx >> 4), then the dy tile
+    auto fetch = [&](int idx) -> f32x4 {
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (idx < WG_HALO / 4) {
+            const int c4 = idx & 15, pp = idx >> 4;
+            const int r = pp / C3_HW, px = pp - r * C3_HW;
+            const int hh = nh + r - 1, ww = nw0 + px - 1;
+            if (hh >= 0 && hh < p.H && ww >= 0 && ww < p.W)
+                v = *reinterpret_cast<const f32x4*>(p.x + (((long)nn * p.H + hh) * p.W + ww) * p.Cin + ci0 + 4 * c4);
+        } else if (idx < WG_F4) {
+            const int j = idx - WG_HALO / 4, c4 = j & 15, px = j >> 4;
+            v = *reinterpret_cast<const f32x4*>(p.dy + (((long)nn * p.H + nh) * p.W + nw0 + px) * p.Cout + co0 + 4 * c4);
+        }
+        return v;
+    };
+    // 32 k-steps (pixel pairs); operands of step k+1 are read (pinned by sched_barrier) before the NT MFMAs of step k issue.
+    // Every 3rd k-step carries one float4 of the next segment: load at k % 6 == 0, publish at k % 6 == 4 (9 rounds of 512).
+    float wa[2][NT], wb[2];
+    f32x4 pf = (f32x4){0.f, 0.f, 0.f, 0.f};
+#define C3W_LOAD(buf, k)                                                                   \
+    wb[buf] = bcol[(k) * 64];                                                              \
+    _Pragma("unroll") for (int tp = 0; tp < NT; ++tp)                                      \
+        wa[buf][tp] = acol[(((T0 + tp) / 3) * C3_HW + (k) + ((T0 + tp) % 3)) * 64];
+    C3W_LOAD(0, 0)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 64; k += 2) {
+        const int cur = (k >> 1) & 1;
+        if (k + 2 < 64) { C3W_LOAD(cur ^ 1, k + 2) }
+        if (has_next && k % 6 == 0 && k / 6 < 9) pf = fetch(t + 512 * (k / 6));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tp = 0; tp < NT; ++tp)
+            acc[tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[cur][tp], wb[cur], acc[tp], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (has_next && k % 6 == 4 && k / 6 < 9) {
+            const int idx = t + 512 * (k / 6);
+            if (idx < WG_F4) *reinterpret_cast<f32x4*>(nbuf + 4 * idx) = pf;
+        }
+    }
+#undef C3W_LOAD
+}
+
+__global__ __launch_bounds__(512, 1) void conv3_c64_wgrad_kernel(Conv3WP p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float (*Xs)[C3_HW][64] = reinterpret_cast<float (*)[C3_HW][64]>(smem);                  // [3][66][64]
-    float (*Ds)[64] = reinterpret_cast<float (*)[64]>(smem + 3 * C3_HW * 64);               // [64 px][64 co]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int qi = wave & 1, qo = wave >> 1;             // (ci half, co half) quadrant of this wave
+    const int qi = wave & 1, qo = (wave >> 1) & 1, tg = wave >> 2;   // (ci half, co half) quadrant; tap group
     const int cib = blockIdx.y % (p.Cin / 64), cob = blockIdx.y / (p.Cin / 64);
     const int ci0 = cib * 64, co0 = cob * 64;
     const int segs = p.W / C3_PX;
-    f32x16 acc[9];
+    f32x16 acc[5];
 #pragma unroll
-    for (int a = 0; a < 9; ++a)
+    for (int a = 0; a < 5; ++a)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[a][i] = 0.f;
-
-    for (int s = blockIdx.x; s < p.nseg; s += gridDim.x) {
-        int bid = s;
-        const int seg = bid % segs; bid /= segs;
-        const int h = bid % p.H; const int n = bid / p.H;
-        const int w0 = seg * C3_PX;
-        __syncthreads();
-        for (int i = t; i < 3 * C3_HW * 16; i += 256) {
-            const int c4 = i & 15, pp = i >> 4;
-            const int r = pp / C3_HW, px = pp - r * C3_HW;
-            const int hh = h + r - 1, ww = w0 + px - 1;
-            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (hh >= 0 && hh < p.H && ww >= 0 && ww < p.W)
-                v = *reinterpret_cast<const f32x4*>(p.x + (((long)n * p.H + hh) * p.W + ww) * p.Cin + ci0 + 4 * c4);
-            *reinterpret_cast<f32x4*>(&Xs[r][px][4 * c4]) = v;
-        }
-        for (int i = t; i < 64 * 16; i += 256) {
-            const int c4 = i & 15, px = i >> 4;
-            *reinterpret_cast<f32x4*>(&Ds[px][4 * c4]) =
-                *reinterpret_cast<const f32x4*>(p.dy + (((long)n * p.H + h) * p.W + w0 + px) * p.Cout + co0 + 4 * c4);
-        }
-        __syncthreads();
-        // A(i = ci, k = pixel) = Xs[kh][pixel + kw][ci];  B(k = pixel, j = co) = Ds[pixel][co]
-        const int kq = lane >> 5;
-        const float* bcol = &Ds[kq][qo * 32 + (lane & 31)];
-        const float* acol = &Xs[0][kq][qi * 32 + (lane & 31)];
-        // 32 k-steps (pixel pairs) x 9 independent accumulators; operands of step k+1 are read (pinned by sched_barrier)
-        // before the 9 MFMAs of step k issue, so the LDS latency hides under 576 cycles of matrix work.
-        float wa[2][9], wb[2];
-#define C3W_LOAD(buf, k)                                                                   \
-        wb[buf] = bcol[(k) * 64];                                                          \
-        _Pragma("unroll") for (int tap = 0; tap < 9; ++tap)                                 \
-            wa[buf][tap] = acol[((tap / 3) * C3_HW + (k) + (tap - 3 * (tap / 3))) * 64];
-        C3W_LOAD(0, 0)
-        __builtin_amdgcn_sched_barrier(0);
+    auto decode = [&](int s, int& n, int& h, int& w0) {
+        const int seg = s % segs; s /= segs;
+        h = s % p.H; n = s / p.H; w0 = seg * C3_PX;
+    };
+    int s = blockIdx.x;
+    if (s < p.nseg) {
+        int n, h, w0;
+        decode(s, n, h, w0);
+        {   // first segment: all loads in flight at once
+            f32x4 v[9];
+            const Conv3WP& q = p;
 #pragma unroll
-        for (int k = 0; k < 64; k += 2) {
-            const int cur = (k >> 1) & 1;
-            if (k + 2 < 64) { C3W_LOAD(cur ^ 1, k + 2) }
-            __builtin_amdgcn_sched_barrier(0);
+            for (int r = 0; r < 9; ++r) {
+                const int idx = t + 512 * r;
+                f32x4 u = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (idx < WG_HALO / 4) {
+                    const int c4 = idx & 15, pp = idx >> 4;
+                    const int rr = pp / C3_HW, px = pp - rr * C3_HW;
+                    const int hh = h + rr - 1, ww = w0 + px - 1;
+                    if (hh >= 0 && hh < q.H && ww >= 0 && ww < q.W)
+                        u = *reinterpret_cast<const f32x4*>(q.x + (((long)n * q.H + hh) * q.W + ww) * q.Cin + ci0 + 4 * c4);
+                } else if (idx < WG_F4) {
+                    const int j = idx - WG_HALO / 4, c4 = j & 15, px = j >> 4;
+                    u = *reinterpret_cast<const f32x4*>(q.dy + (((long)n * q.H + h) * q.W + w0 + px) * q.Cout + co0 + 4 * c4);
+                }
+                v[r] = u;
+            }
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap)
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[cur][tap], wb[cur], acc[tap], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int r = 0; r < 9; ++r) {
+                const int idx = t + 512 * r;
+                if (idx < WG_F4) *reinterpret_cast<f32x4*>(smem + 4 * idx) = v[r];
+            }
+        }
+        __syncthreads();
+        int buf = 0;
+        while (true) {
+            const int sn = s + gridDim.x;
+            const bool has_next = sn < p.nseg;
+            int nn = 0, nh = 0, nw0 = 0;
+            if (has_next) decode(sn, nn, nh, nw0);
+            const float* cur = smem + buf * WG_BUF;
+            float* nxt = smem + (buf ^ 1) * WG_BUF;
+            // A(i = ci, k = pixel) = Xs[kh][pixel + kw][ci];  B(k = pixel, j = co) = Ds[pixel][co]
+            const int kq = lane >> 5;
+            const float* acol = cur + kq * 64 + qi * 32 + (lane & 31);
+            const float* bcol = cur + WG_HALO + kq * 64 + qo * 32 + (lane & 31);
+            if (tg == 0) wgrad_segment<0, 5>(acc, acol, bcol, p, has_next, nn, nh, nw0, ci0, co0, nxt, t);
+            else wgrad_segment<5, 4>(acc, acol, bcol, p, has_next, nn, nh, nw0, ci0, co0, nxt, t);
+            __syncthreads();                               // next buffer published; everyone is done with the current one
+            if (!has_next) break;
+            s = sn;
+            buf ^= 1;
         }
     }
-    // partial[blockIdx.x][(tap*Cin + ci)][Cout]
+    // ---- partial[blockIdx.x][(tap*Cin + ci)][Cout]: each 32 ci x 32 co accumulator is transposed through a per-wave LDS tile
+    // (the segment buffers are free now) and leaves as 4 sixteen-byte stores per lane ----
     float* P = p.part + (long)blockIdx.x * 9 * p.Cin * p.Cout;
-    const int co = co0 + qo * 32 + (lane & 31);
+    float* T = smem + wave * WS_TT;
+    const int ntap = tg == 0 ? 5 : 4, tap0 = tg == 0 ? 0 : 5;
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
+    for (int tp = 0; tp < 5; ++tp) {
+        if (tp < ntap) {
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int ci = ci0 + qi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-            P[((long)tap * p.Cin + ci) * p.Cout + co] = acc[tap][reg];
+            for (int reg = 0; reg < 16; ++reg)
+                T[((reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) * WS_TP + (lane & 31)] = acc[tp][reg];
+            wave_lds_sync();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = (lane >> 3) + 8 * q, c4 = lane & 7;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(T + r * WS_TP + 4 * c4);
+                *reinterpret_cast<f32x4*>(P + ((long)(tap0 + tp) * p.Cin + ci0 + qi * 32 + r) * p.Cout + co0 + qo * 32 + 4 * c4) = v;
+            }
+            wave_lds_sync();
         }
+    }
 }
-#define C3_WG_LDS ((3 * C3_HW * 64 + 64 * 64) * 4)
-// partials: part[G][9*Cin][Cout] with G = *nblocks_out work-groups along x (<= 256); reduce with the split-K reducer
+// partials: part[G][9*Cin][Cout] with G work-groups along x (<= 256 / blocks); reduce with the split-K reducer
 TATT_API int tatt_conv3_c64_wgrad_partial(const float* x, const float* dy, float* part, int B, int H, int W, int Cin,
                                           int Cout, int G, hipStream_t st) {
     if (Cin % 64 || Cout % 64 || W % C3_PX) return 1;
@@ -454,10 +529,10 @@ TATT_API int tatt_conv3_c64_wgrad_partial(const float* x, const float* dy, float
     Conv3WP p = {x, dy, part, B, H, W, Cin, Cout, nseg};
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            C3_WG_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  C3_WG_LDS);
         attr_set = true;
     }
-    hipLaunchKernelGGL(conv3_c64_wgrad_kernel, dim3(G, (Cin / 64) * (Cout / 64)), dim3(256), C3_WG_LDS, st, p);
+    hipLaunchKernelGGL(conv3_c64_wgrad_kernel, dim3(G, (Cin / 64) * (Cout / 64)), dim3(512), C3_WG_LDS, st, p);
     return LAUNCH_CHECK();
 }

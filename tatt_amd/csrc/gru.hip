@@ -477,12 +477,14 @@ TATT_API int tatt_gru_compose(const float* wih_f, const float* wih_r, const floa
                        bc, Wp, bp, K);
     return LAUNCH_CHECK();
 }
-// dW_ih_d (96x64) = dW'_d W_c^T + db'_d b_c^T ;  dW_c (64xK) = sum_d W_ih_d^T dW'_d ;  db_c (64) = sum_d W_ih_d^T db'_d
+// dW_ih_d (96x64) = dW'_d W_c^T + db'_d b_c^T ;  dW_c (64xK) = sum_d W_ih_d^T dW'_d ;  db_c (64) = sum_d W_ih_d^T db'_d ;
+// dW_hh_d (96x32) = the d-th diagonal block of dWhh (192x64) = dgh^T hprev
 __global__ void gru_tail_kernel(const float* __restrict__ dWp, const float* __restrict__ dbp,
                                 const float* __restrict__ Wc, const float* __restrict__ bc,
                                 const float* __restrict__ wih_f, const float* __restrict__ wih_r,
                                 float* __restrict__ dwih_f, float* __restrict__ dwih_r, float* __restrict__ dWc,
-                                float* __restrict__ dbc, int K) {
+                                float* __restrict__ dbc, int K, const float* __restrict__ dWhh,
+                                float* __restrict__ dwhh_f, float* __restrict__ dwhh_r) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < 2 * 96 * 64) {
         const int d = idx / 6144, r = (idx % 6144) / 64, c = idx & 63;
@@ -512,14 +514,20 @@ __global__ void gru_tail_kernel(const float* __restrict__ dWp, const float* __re
             s1 = fmaf(wih_r[row * 64 + idx], dbp[96 + row], s1);
         }
         dbc[idx] = s0 + s1;
+        return;
+    }
+    idx -= 64;
+    if (idx < 2 * 96 * 32) {
+        const int d = idx / 3072, r = (idx % 3072) / 32, c = idx & 31;
+        (d ? dwhh_r : dwhh_f)[r * 32 + c] = dWhh[(long)(96 * d + r) * 64 + 32 * d + c];
     }
 }
 TATT_API int tatt_gru_tail(const float* dWp, const float* dbp, const float* Wc, const float* bc, const float* wih_f,
                            const float* wih_r, float* dwih_f, float* dwih_r, float* dWc, float* dbc, int K,
-                           hipStream_t st) {
+                           const float* dWhh, float* dwhh_f, float* dwhh_r, hipStream_t st) {
     if (K % 2) return 1;
-    const int total = 2 * 96 * 64 + 64 * K + 64;
+    const int total = 2 * 96 * 64 + 64 * K + 64 + 2 * 96 * 32;
     hipLaunchKernelGGL(gru_tail_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, dWp, dbp, Wc, bc, wih_f, wih_r, dwih_f,
-                       dwih_r, dWc, dbc, K);
+                       dwih_r, dWc, dbc, K, dWhh, dwhh_f, dwhh_r);
     return LAUNCH_CHECK();
 }

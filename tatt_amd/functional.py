@@ -241,12 +241,13 @@ class GruBlockFn(Function):
                 dxb = ops.linear_bwd_input(dgi, Wp, col0=K1, ncols=K - K1).reshape(xb.shape)
         dWhh = ops.linear_bwd_weight(dgh, hprev, rowsum=dbhh)     # (192, 64): diagonal blocks are the two directions
         dwih_f, dwih_r = ops.new(dgi, 96, 64), ops.new(dgi, 96, 64)
+        dwhh_f, dwhh_r = ops.new(dgi, 96, 32), ops.new(dgi, 96, 32)
         dWc, dbc = ops.new(dgi, 64, K), ops.new(dgi, 64)
         ops.call("tatt_gru_tail", ops.P(dWp), ops.P(dbp), ops.P(Wc), ops.P(conv_b), ops.P(wih_f), ops.P(wih_r),
-                 ops.P(dwih_f), ops.P(dwih_r), ops.P(dWc), ops.P(dbc), K, ops.stream())
+                 ops.P(dwih_f), ops.P(dwih_r), ops.P(dWc), ops.P(dbc), K, ops.P(dWhh), ops.P(dwhh_f), ops.P(dwhh_r), ops.stream())
         return (dx, dxb, dWc.reshape(ctx.wshape), dbc,
-                dwih_f, dWhh[:96, :32].contiguous(), dbp[:96], dbhh[:96],
-                dwih_r, dWhh[96:, 32:].contiguous(), dbp[96:], dbhh[96:], None)
+                dwih_f, dwhh_f, dbp[:96], dbhh[:96],
+                dwih_r, dwhh_r, dbp[96:], dbhh[96:], None)
 
 
 def gru_block(x, blk, vertical, xb=None):
@@ -443,15 +444,44 @@ class AttnCoreFn(Function):
         return dQ, dK, dV, None, None
 
 
+class MhaInProjFn(Function):
+    """The packed input projection of nn.MultiheadAttention: Q = (q_in W_q^T + b_q) / sqrt(d), K = k_in W_k^T + b_k,
+    V = v_in W_v^T + b_v with in_proj_weight = [W_q; W_k; W_v] (3E, E).  One operator so that the gradient of the PACKED
+    parameter is written in place by the three weight-gradient GEMMs (slicing the parameter in autograd costs a zero-fill,
+    a block copy and an accumulate per slice and per step)."""
+
+    @staticmethod
+    def forward(ctx, q_in, k_in, v_in, w, b, qscale):
+        E = w.shape[1]
+        xs = (q_in, k_in, v_in)
+        outs = []
+        for i, x in enumerate(xs):
+            y = ops.linear_fwd(x.reshape(-1, E), w[i * E:(i + 1) * E], b[i * E:(i + 1) * E], alpha=qscale if i == 0 else 1.0)
+            outs.append(y.reshape(*x.shape[:-1], E))
+        ctx.save_for_backward(q_in, k_in, v_in, w)
+        ctx.qscale = qscale
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, dQ, dK, dV):
+        q_in, k_in, v_in, w = ctx.saved_tensors
+        E = w.shape[1]
+        dw, db = ops.new(w, 3 * E, E), ops.new(w, 3 * E)
+        dxs = []
+        for i, (dy, x) in enumerate(((dQ, q_in), (dK, k_in), (dV, v_in))):
+            a = ctx.qscale if i == 0 else 1.0
+            dy2 = _c(dy).reshape(-1, E)
+            ops.linear_bwd_weight(dy2, x.reshape(-1, E), alpha=a, out=dw[i * E:(i + 1) * E], out_ld=E, rowsum=db[i * E:(i + 1) * E])
+            dxs.append(ops.linear_bwd_input(dy2, w[i * E:(i + 1) * E], alpha=a).reshape(x.shape) if ctx.needs_input_grad[i] else None)
+        return dxs[0], dxs[1], dxs[2], dw, db, None
+
+
 def multihead_attention(q_in, k_in, v_in, mha, training, site):
     """nn.MultiheadAttention forward (batch-major tensors (B,L,E)); mha = parameter holder.
     Returns (output (B,L,E), head-averaged attention weights (B,L,S))."""
     E = mha.embed_dim
     d = E // mha.num_heads
-    w, b = mha.in_proj_weight, mha.in_proj_bias
-    Q = linear(q_in, w[:E], b[:E], alpha=1.0 / math.sqrt(d))
-    K = linear(k_in, w[E:2 * E], b[E:2 * E])
-    V = linear(v_in, w[2 * E:], b[2 * E:])
+    Q, K, V = MhaInProjFn.apply(_c(q_in), _c(k_in), _c(v_in), mha.in_proj_weight, mha.in_proj_bias, 1.0 / math.sqrt(d))
     pdrop = float(mha.dropout) if training else 0.0
     ctx_, wts = AttnCoreFn.apply(Q, K, V, pdrop, site)
     out = linear(ctx_, mha.out_proj.weight, mha.out_proj.bias)
@@ -667,3 +697,35 @@ class CatPEFn(Function):
         dx = ops.new(dout, B, Pn, C)
         ops.copy4d(dout, dx, (1, B, Pn, C), (0, Pn * Ct, Ct, 1), (0, Pn * C, C, 1))
         return dx, None
+
+
+class ImageLossFn(Function):
+    """reference ImageLoss(gradient=True, loss_weight=[w0, w1]) (loss/image_loss.py:19-34): per-sample loss (B,) when `scale` is
+    None, else the scalar scale * mean_b (the training loop's `.mean() * 100`) -- one forward and one backward kernel."""
+
+    @staticmethod
+    def forward(ctx, sr, hr, w0, w1, scale):
+        ops._check_dev(sr)
+        ops._check_dev(hr)
+        B, C, H, W = sr.shape
+        assert hr.shape == sr.shape
+        per = ops.new(sr, B)
+        mean = ops.new(sr, 1) if scale is not None else None
+        ops.call("tatt_image_loss_fwd", ops.P(sr), *sr.stride(), ops.P(hr), *hr.stride(), ops.P(per), ops.P(mean),
+                 0.0 if scale is None else float(scale), B, C, H, W, w0, w1, ops.stream())
+        ctx.save_for_backward(sr, hr)
+        ctx.cfg = (w0, w1, scale)
+        return per if scale is None else mean.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        sr, hr = ctx.saved_tensors
+        w0, w1, scale = ctx.cfg
+        B, C, H, W = sr.shape
+        dsr = torch.empty_like(sr)                       # keeps sr's (channels-last) strides
+        assert dsr.stride() == sr.stride()
+        g = _c(g)
+        ops.call("tatt_image_loss_bwd", ops.P(sr), *sr.stride(), ops.P(hr), *hr.stride(), ops.P(g) if scale is None else None,
+                 None if scale is None else ops.P(g), 0.0 if scale is None else float(scale), ops.P(dsr), B, C, H, W, w0, w1,
+                 ops.stream())
+        return dsr, None, None, None, None

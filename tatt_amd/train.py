@@ -10,36 +10,28 @@ all-reduce of ONE flat gradient buffer over xGMI (`torch.distributed`, backend "
   nn.Parameters are views into the flat parameter buffer, their `.grad`s views into the flat gradient buffer.
 * Clip + Adam are two HIP kernels (tatt_l2norm, tatt_adam_step) whose step-varying scalars live in device
   memory, so a whole step (forward, loss, backward, optimiser) can be captured once as a hipGraph and replayed.
-* ImageLoss itself (harness, not a kernel target) is a handful of torch element-wise ops on
-  the (B,4,2H,2W) images.
+* ImageLoss (loss/image_loss.py) is one fused forward and one fused backward HIP kernel (tatt_image_loss_*) instead of
+  ~80 element-wise torch kernels on the (B,4,2H,2W) images.
 """
 from __future__ import annotations
 
 from typing import Optional
 
 import torch
-import torch.nn.functional as F
 
 from . import functional as Fh
 from . import ops
 from .dp import FlatParams, broadcast_model, allreduce_grads
 
 
-def gradient_map(x):
-    """GradientPriorLoss.gradient_map (reference loss/image_loss.py:50-58)."""
-    h, w = x.shape[-2:]
-    r = F.pad(x, (0, 1, 0, 0))[:, :, :, 1:]
-    l = F.pad(x, (1, 0, 0, 0))[:, :, :, :w]
-    t = F.pad(x, (0, 0, 1, 0))[:, :, :h, :]
-    b = F.pad(x, (0, 0, 0, 1))[:, :, 1:, :]
-    return torch.sqrt(((r - l) * 0.5) ** 2 + ((t - b) * 0.5) ** 2 + 1e-6)
-
-
 def image_loss(sr, hr, weights=(1.0, 1e-4)):
-    """ImageLoss(gradient=True, loss_weight=[1, 1e-4]).forward (reference loss/image_loss.py:19-34): per-sample."""
-    mse = ((sr - hr) ** 2).mean((1, 2, 3))
-    gp = (gradient_map(sr[:, :3]) - gradient_map(hr[:, :3])).abs().mean((1, 2, 3))
-    return weights[0] * mse + weights[1] * gp
+    """ImageLoss(gradient=True, loss_weight=[1, 1e-4]).forward (reference loss/image_loss.py:19-34): per-sample loss (B,)."""
+    return Fh.ImageLossFn.apply(sr, hr, float(weights[0]), float(weights[1]), None)
+
+
+def image_loss_mean(sr, hr, weights=(1.0, 1e-4), scale=100.0):
+    """`ImageLoss(sr, hr).mean() * scale` of the training loop (interfaces/super_resolution.py:889-894) as one scalar."""
+    return Fh.ImageLossFn.apply(sr, hr, float(weights[0]), float(weights[1]), float(scale))
 
 
 class Trainer:
@@ -79,7 +71,7 @@ class Trainer:
             p.grad = None
         out = self.model(x, tp) if tp is not None else self.model(x)
         sr = out[0] if isinstance(out, tuple) else out
-        loss = image_loss(sr, hr).mean() * 100.0
+        loss = image_loss_mean(sr, hr, scale=100.0)
         loss.backward()
         self.model.block = None                      # do not keep the autograd graph of this step alive
         self.flat_g.zero_()

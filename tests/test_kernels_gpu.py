@@ -467,3 +467,37 @@ def test_conv3_weight_stationary_dgrad(dev):
         torch.nn.functional.conv2d(x, w, None, padding=1).backward(dy.permute(0, 3, 1, 2))
         dx = ops.conv2d_dgrad(dy.to(dev), w.to(dev))
         check_close("conv3_ws_dgrad_%d" % Cin, dx, x.grad.permute(0, 2, 3, 1), 2e-4, 2e-4)
+
+
+@pytest.mark.parametrize("B,C,H,W,nhwc", [(3, 4, 32, 128, True), (2, 3, 8, 16, False), (5, 4, 64, 256, True)])
+def test_image_loss_fused(dev, B, C, H, W, nhwc):
+    """tatt_image_loss_fwd/bwd against the oracle's ImageLoss (reference loss/image_loss.py) and its autograd gradient: per-sample
+    form and the scaled batch mean; SR over NHWC memory (what the generator returns) and plain NCHW."""
+    from tatt_amd.train import image_loss, image_loss_mean
+    g = torch.Generator().manual_seed(41)
+    sr = (torch.rand(B, C, H, W, generator=g) * 2 - 1).requires_grad_(True)
+    hr = torch.rand(B, C, H, W, generator=g)
+    wts = torch.rand(B, generator=g)
+    ref = O.image_loss(sr, hr)
+    (ref * wts).sum().backward()
+    srd = sr.detach().to(dev)
+    if nhwc:
+        srd = srd.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    srd.requires_grad_(True)
+    got = image_loss(srd, hr.to(dev))
+    check_close("image_loss", got, ref, 1e-5, 1e-7)
+    (got * wts.to(dev)).sum().backward()
+    check_close("image_loss_grad", srd.grad, sr.grad, 2e-4, 1e-9)
+    srd.grad = None
+    sr.grad = None
+    (O.image_loss(sr, hr).mean() * 100).backward()
+    m = image_loss_mean(srd, hr.to(dev), scale=100.0)
+    assert abs(float(m) - float(ref.mean() * 100)) < 1e-5 * float(ref.mean() * 100)
+    m.backward()
+    check_close("image_loss_mean_grad", srd.grad, sr.grad, 2e-4, 1e-9)
+
+
+def test_image_loss_requires_gpu():
+    from tatt_amd.train import image_loss
+    with pytest.raises(RuntimeError, match="GPU"):
+        image_loss(torch.rand(1, 4, 8, 8), torch.rand(1, 4, 8, 8))
