@@ -23,6 +23,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+# HBM bytes per launch of the dominant kernel at B = 48 from the PMC passes committed as profiles/r01_step7_pmc_conv3_ws.txt:
+# 2 x FETCH_SIZE (gfx950 correction for 16-byte coalesced reads) + WRITE_SIZE = 2 x 6816 KB + 12288 KB
+CONV3_WS_TRAFFIC_B48 = (2 * 6816 + 12288) * 1024
 FLOP_PER_IMAGE_FWD_BWD = 7.613e9     # SURVEY.md 8d (FlopCounterMode on the reference graph, 16x64, STN on)
 
 
@@ -226,7 +229,9 @@ def main():
                        "launch": "hipGraph replay" if graph_ok else "eager", "final_loss": round(loss_v, 5),
                        "whole_step_tflops": round(ips * FLOP_PER_IMAGE_FWD_BWD / 1e12, 2)},
             "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                         "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+                         "traffic": CONV3_WS_TRAFFIC_B48 if a.batch == 48 else None,
+                         "algorithmic_bytes": 2 * a.batch * 16 * 64 * 64 * 4 + 9 * 64 * 64 * 4,
                          "kernel": "conv3_c64_ws_kernel (3x3 conv, 64->64 ch, %d x16x64 px, fp32 MFMA)" % a.batch,
                          "kernel_ms": round(kms, 4), "flops_per_launch": kflops},
         }
