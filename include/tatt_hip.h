@@ -143,11 +143,12 @@ int tatt_pixel_shuffle_fwd(const float* in, float* out, int B, int H, int W, int
                            hipStream_t st);
 int tatt_pixel_shuffle_bwd(const float* in, const float* dout, float* din, int B, int H, int W, int C,
                            int act, hipStream_t st);
-/* nn.MaxPool2d(kernel = stride = (kh,kw)) on NHWC (model/stn_head.py:36-44) */
-int tatt_maxpool_fwd(const float* in, float* out, int B, int H, int W, int C, int kh, int kw,
-                     hipStream_t st);
+/* nn.MaxPool2d(kernel (kh,kw), stride (sh,sw), padding (ph,pw)) on NHWC maps (model/stn_head.py:36-44; model/crnn/crnn.py:57-69);
+ * out is (B, (H+2ph-kh)/sh+1, (W+2pw-kw)/sw+1, C); the gradient goes to the first maximum of each window */
+int tatt_maxpool_fwd(const float* in, float* out, int B, int H, int W, int C, int kh, int kw, int sh, int sw,
+                     int ph, int pw, hipStream_t st);
 int tatt_maxpool_bwd(const float* in, const float* dout, float* din, int B, int H, int W, int C, int kh,
-                     int kw, hipStream_t st);
+                     int kw, int sh, int sw, int ph, int pw, hipStream_t st);
 /* nn.Dropout(p): y = keep ? x/(1-p) : 0 with a counter-based mask keyed by (*seed, site, index); the same call
  * with dy as x is the backward (model/transformer_v2.py:27,456,461-462,789,795-797) */
 int tatt_dropout(const float* x, float* y, long n, float p, const unsigned long long* seed, unsigned site,
@@ -265,6 +266,21 @@ int tatt_image_loss_fwd(const float* sr, long s_n, long s_c, long s_h, long s_w,
 int tatt_image_loss_bwd(const float* sr, long s_n, long s_c, long s_h, long s_w, const float* hr, long h_n, long h_c,
                         long h_h, long h_w, const float* gper, const float* gscalar, float scale, float* dsr,
                         int B, int C, int H, int W, float w0, float w1, hipStream_t st);
+
+/* CRNN text-prior generator.  Bidirectional nn.LSTM (model/crnn/crnn.py:5-26), one launch per time step for
+ * both directions; time-major (T, Bt, *) row-major tensors; gi (T,Bt,8H) = x W_ih^T + b_ih for [fwd | rev] x gates (i,f,g,o);
+ * out (T,Bt,2H) = [h_fwd | h_rev] doubles as the h_{t-1} operand; cseq (2,T,Bt,H), gsave (2,T,Bt,4,H) are kept for the
+ * backward.  H multiple of 256.  Step s handles time s (fwd) / T-1-s (rev). */
+int tatt_lstm_fwd_step(const float* gi, const float* whh_f, const float* whh_r, const float* bhh_f, const float* bhh_r,
+                       float* out, float* cseq, float* gsave, int T, int Bt, int H, int s, hipStream_t st);
+/* backward step s = T-1..0: dgates (2,T,Bt,4H) receives the pre-activation gate gradients of time(s); whhT_d = W_hh_d^T (H,4H);
+ * dccarry (2,Bt,H) scratch carried between steps */
+int tatt_lstm_bwd_step(const float* dout, const float* whhT_f, const float* whhT_r, const float* cseq, const float* gsave,
+                       float* dgates, float* dccarry, int T, int Bt, int H, int s, hipStream_t st);
+/* out (B,OH,OW) = 0.299 R + 0.587 G + 0.114 B of F.interpolate(img[:, :3], (OH,OW), mode='bicubic') (interfaces/base.py:797-815);
+ * img (B,C>=3,H,W) by element strides */
+int tatt_bicubic_luma(const float* img, long sn, long sc, long sh, long sw, float* out, int B, int H, int W, int OH,
+                      int OW, hipStream_t st);
 
 #ifdef __cplusplus
 }

@@ -133,55 +133,74 @@ TATT_API int tatt_pixel_shuffle_bwd(const float* in, const float* dout, float* d
     return LAUNCH_CHECK();
 }
 
-// ---- MaxPool (kh x kw, stride = kernel) on NHWC (reference nn.MaxPool2d: model/stn_head.py:36-44) -----
-__global__ void maxpool_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W, int C,
-                                   int kh, int kw) {
-    const int Ho = H / kh, Wo = W / kw;
-    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    long total = (long)B * Ho * Wo * C;
-    if (idx >= total) return;
-    int c = idx % C; long r = idx / C;
-    int ow = r % Wo; r /= Wo;
-    int oh = r % Ho; int b = r / Ho;
+// ---- nn.MaxPool2d(kernel (kh,kw), stride (sh,sw), padding (ph,pw)) on NHWC maps (reference model/stn_head.py:36-44: 2x2/2;
+// model/crnn/crnn.py:57-69: 2x2/2 and the (2,2),(2,1),(0,1) pools whose windows overlap along W) -------------------------------
+struct PoolP { int B, H, W, C, kh, kw, sh, sw, ph, pw, Ho, Wo; };
+// first maximum of window (oh, ow) in (i, j) scan order (strict '>' like ATen); padding cells never win
+__device__ __forceinline__ float pool_window(const float* __restrict__ in, const PoolP& p, int b, int oh, int ow, int c, int& ai, int& aj) {
     float m = -INFINITY;
-    for (int i = 0; i < kh; ++i)
-        for (int j = 0; j < kw; ++j) {
-            float v = in[(((long)b * H + oh * kh + i) * W + ow * kw + j) * C + c];
-            if (v > m) m = v;
+    ai = -1; aj = -1;
+    for (int i = 0; i < p.kh; ++i) {
+        const int h = oh * p.sh - p.ph + i;
+        if (h < 0 || h >= p.H) continue;
+        for (int j = 0; j < p.kw; ++j) {
+            const int w = ow * p.sw - p.pw + j;
+            if (w < 0 || w >= p.W) continue;
+            const float v = in[(((long)b * p.H + h) * p.W + w) * p.C + c];
+            if (v > m || ai < 0) { m = v; ai = h; aj = w; }
         }
-    out[idx] = m;
+    }
+    return m;
 }
-TATT_API int tatt_maxpool_fwd(const float* in, float* out, int B, int H, int W, int C, int kh, int kw,
-                              hipStream_t st) {
-    long total = (long)B * (H / kh) * (W / kw) * C;
-    hipLaunchKernelGGL(maxpool_fwd_kernel, EW_GRID(total), 0, st, in, out, B, H, W, C, kh, kw);
+__global__ void maxpool_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, PoolP p) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)p.B * p.Ho * p.Wo * p.C;
+    if (idx >= total) return;
+    int c = idx % p.C; long r = idx / p.C;
+    int ow = r % p.Wo; r /= p.Wo;
+    int oh = r % p.Ho; int b = r / p.Ho;
+    int ai, aj;
+    out[idx] = pool_window(in, p, b, oh, ow, c, ai, aj);
+}
+static PoolP make_poolp(int B, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw) {
+    PoolP p = {B, H, W, C, kh, kw, sh, sw, ph, pw, (H + 2 * ph - kh) / sh + 1, (W + 2 * pw - kw) / sw + 1};
+    return p;
+}
+TATT_API int tatt_maxpool_fwd(const float* in, float* out, int B, int H, int W, int C, int kh, int kw, int sh, int sw,
+                              int ph, int pw, hipStream_t st) {
+    PoolP p = make_poolp(B, H, W, C, kh, kw, sh, sw, ph, pw);
+    long total = (long)B * p.Ho * p.Wo * C;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, EW_GRID(total), 0, st, in, out, p);
     return LAUNCH_CHECK();
 }
-// gradient goes to the FIRST maximum of each window in (i, j) scan order (strict '>' like ATen)
+// one thread per INPUT element: it collects the gradient of every window whose (first) maximum it is -- windows may overlap
 __global__ void maxpool_bwd_kernel(const float* __restrict__ in, const float* __restrict__ dout,
-                                   float* __restrict__ din, int B, int H, int W, int C, int kh, int kw) {
-    const int Ho = H / kh, Wo = W / kw;
+                                   float* __restrict__ din, PoolP p) {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    long total = (long)B * Ho * Wo * C;
+    long total = (long)p.B * p.H * p.W * p.C;
     if (idx >= total) return;
-    int c = idx % C; long r = idx / C;
-    int ow = r % Wo; r /= Wo;
-    int oh = r % Ho; int b = r / Ho;
-    float m = -INFINITY; int bi = 0, bj = 0;
-    for (int i = 0; i < kh; ++i)
-        for (int j = 0; j < kw; ++j) {
-            float v = in[(((long)b * H + oh * kh + i) * W + ow * kw + j) * C + c];
-            if (v > m) { m = v; bi = i; bj = j; }
+    int c = idx % p.C; long r = idx / p.C;
+    int w = r % p.W; r /= p.W;
+    int h = r % p.H; int b = r / p.H;
+    // windows containing (h, w): oh*sh - ph <= h < oh*sh - ph + kh
+    int oh0 = h + p.ph - p.kh + 1; oh0 = oh0 <= 0 ? 0 : (oh0 + p.sh - 1) / p.sh;
+    int ow0 = w + p.pw - p.kw + 1; ow0 = ow0 <= 0 ? 0 : (ow0 + p.sw - 1) / p.sw;
+    int oh1 = (h + p.ph) / p.sh; if (oh1 > p.Ho - 1) oh1 = p.Ho - 1;
+    int ow1 = (w + p.pw) / p.sw; if (ow1 > p.Wo - 1) ow1 = p.Wo - 1;
+    float g = 0.f;
+    for (int oh = oh0; oh <= oh1; ++oh)
+        for (int ow = ow0; ow <= ow1; ++ow) {
+            int ai, aj;
+            pool_window(in, p, b, oh, ow, c, ai, aj);
+            if (ai == h && aj == w) g += dout[(((long)b * p.Ho + oh) * p.Wo + ow) * p.C + c];
         }
-    float g = dout[idx];
-    for (int i = 0; i < kh; ++i)
-        for (int j = 0; j < kw; ++j)
-            din[(((long)b * H + oh * kh + i) * W + ow * kw + j) * C + c] = (i == bi && j == bj) ? g : 0.f;
+    din[idx] = g;
 }
 TATT_API int tatt_maxpool_bwd(const float* in, const float* dout, float* din, int B, int H, int W, int C, int kh,
-                              int kw, hipStream_t st) {
-    long total = (long)B * (H / kh) * (W / kw) * C;
-    hipLaunchKernelGGL(maxpool_bwd_kernel, EW_GRID(total), 0, st, in, dout, din, B, H, W, C, kh, kw);
+                              int kw, int sh, int sw, int ph, int pw, hipStream_t st) {
+    PoolP p = make_poolp(B, H, W, C, kh, kw, sh, sw, ph, pw);
+    long total = (long)B * H * W * C;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, EW_GRID(total), 0, st, in, dout, din, p);
     return LAUNCH_CHECK();
 }
 

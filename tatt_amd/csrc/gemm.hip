@@ -11,6 +11,7 @@
 // MFMA operand read  lane -> (row = lane&31, k = lane>>5)  is bank-conflict free).
 // Split-K (grid.y) writes raw partial tiles that tatt_splitk_reduce sums deterministically.
 #include "common.h"
+#include <stdlib.h>
 
 #define BM 64
 #define BN 64
@@ -49,8 +50,7 @@ __device__ __forceinline__ void decode_kidx(const GemmP& p, int k, int& kh, int&
 
 template <int AMODE, int AK, int BK, int KCT>
 __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmP p) {
-    // KCT = K-chunk: 16 (im2col modes, short K) or 64 (token GEMMs: whole 256-B rows per wave load, 4x fewer exposed
-    // global-load round trips per tile)
+    // KCT = K-chunk (16)
     constexpr int NP = KCT / 4;          // elements per thread per operand per chunk
     constexpr int KL = KCT;              // lanes along k when an operand is k-contiguous
     constexpr int RP = 256 / KCT;        // rows covered per pass in that case
@@ -224,6 +224,188 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmP p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fast path of the strided GEMM for aligned operands (M, N multiples of 64, K of 16, 16-byte aligned rows): the same
+// 64x64 tile / 4 waves / K-chunks of 16 / double-buffered LDS, but the per-element address arithmetic and bounds checks of the
+// general kernel -- measured at ~580 VALU + ~320 SALU instructions per wave around 32 MFMAs on the token GEMMs -- are gone:
+// every thread moves ONE 16-byte vector per operand per chunk through a pointer that advances by a constant.
+//   operand contiguous along K ("KC": activations x[m][k], nn.Linear weights W[n][k]):  tile [64 rows][16 k], pitch 20 floats;
+//       MFMA operands come from 16-byte LDS reads (4 consecutive k per lane, the same k <-> (lane>>5, u) map on both sides);
+//   operand contiguous along its row/column index (dy^T for weight gradients, W for input gradients):  tile [16 k][64], pitch
+//       96 floats (the two lane halves hit different bank halves), 4-byte operand reads.
+// The C tile leaves through a per-wave LDS transpose as 16-byte stores when C is row-major.
+// ------------------------------------------------------------------------------------------------
+template <bool AKC, bool BKC, bool CAT>
+__global__ __launch_bounds__(256) void gemm_fast_kernel(GemmP p, int cvec) {
+    constexpr int TKC = 64 * 20, TMC = 16 * 96;
+    constexpr int TA = AKC ? TKC : TMC, TB = BKC ? TKC : TMC;
+    __shared__ __attribute__((aligned(16))) float smem[2 * TA + 2 * TB];
+    float* AsB = smem;
+    float* BsB = smem + 2 * TA;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int tiles_n = p.N >> 6;
+    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+    const int m0 = tile_m * 64, n0 = tile_n * 64;
+    const int z = blockIdx.z;
+    const int nchunks = p.K >> 4;
+    int c_begin = 0, c_end = nchunks;
+    if (p.splitk > 1) {
+        c_begin = blockIdx.y * p.chunks_per_split;
+        c_end = min(nchunks, c_begin + p.chunks_per_split);
+    }
+    // ---- per-thread source pointers (advance by a constant per chunk) and LDS slots ----
+    const float* ap; const float* ap2 = nullptr; const float* bp;
+    long astep, bstep;
+    int aslot, bslot;
+    if (AKC) {
+        const int row = t >> 2, k4 = (t & 3) * 4;
+        ap = p.A + (long)z * p.bsA + (long)(m0 + row) * p.sam + k4 + 16L * c_begin;
+        if (CAT) ap2 = p.A2 + (long)z * p.bsA2 + (long)(m0 + row) * p.sa2m + k4 + 16L * c_begin - p.K1;
+        astep = 16; aslot = row * 20 + k4;
+    } else {
+        const int k = t >> 4, c4 = (t & 15) * 4;
+        ap = p.A + (long)z * p.bsA + (long)(16 * c_begin + k) * p.sak + m0 + c4;
+        astep = 16 * p.sak; aslot = k * 96 + c4;
+    }
+    if (BKC) {
+        const int row = t >> 2, k4 = (t & 3) * 4;
+        bp = p.B + (long)z * p.bsB + (long)(n0 + row) * p.sbn + k4 + 16L * c_begin;
+        bstep = 16; bslot = row * 20 + k4;
+    } else {
+        const int k = t >> 4, c4 = (t & 15) * 4;
+        bp = p.B + (long)z * p.bsB + (long)(16 * c_begin + k) * p.sbk + n0 + c4;
+        bstep = 16 * p.sbk; bslot = k * 96 + c4;
+    }
+    f32x4 ra, rb;
+    auto load_chunk = [&](int c) {
+        if (CAT && 16 * c >= p.K1) ra = *reinterpret_cast<const f32x4*>(ap2);
+        else ra = *reinterpret_cast<const f32x4*>(ap);
+        rb = *reinterpret_cast<const f32x4*>(bp);
+        ap += astep; bp += bstep;
+        if (CAT) ap2 += 16;
+    };
+    auto store_chunk = [&](int buf) {
+        *reinterpret_cast<f32x4*>(AsB + buf * TA + aslot) = ra;
+        *reinterpret_cast<f32x4*>(BsB + buf * TB + bslot) = rb;
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const bool do_rs = !AKC && p.rowsum != nullptr && tile_n == 0;
+    float rs_acc = 0.f;
+    const int arow = wm * 32 + (lane & 31), bcol = wn * 32 + (lane & 31), kq = lane >> 5;
+    if (c_begin < c_end) {
+        load_chunk(c_begin);
+        store_chunk(0);
+        __syncthreads();
+        for (int c = c_begin; c < c_end; ++c) {
+            const int buf = (c - c_begin) & 1;
+            if (c + 1 < c_end) load_chunk(c + 1);
+            const float* As = AsB + buf * TA;
+            const float* Bs = BsB + buf * TB;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f32x4 va, vb;
+                if (AKC) va = *reinterpret_cast<const f32x4*>(As + arow * 20 + 8 * h + 4 * kq);
+                else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) va[u] = As[(8 * h + 4 * kq + u) * 96 + arow];
+                }
+                if (BKC) vb = *reinterpret_cast<const f32x4*>(Bs + bcol * 20 + 8 * h + 4 * kq);
+                else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) vb[u] = Bs[(8 * h + 4 * kq + u) * 96 + bcol];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(va[u], vb[u], acc, 0, 0, 0);
+            }
+            if (do_rs) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) rs_acc += As[((t >> 6) * 4 + kk) * 96 + (t & 63)];
+            }
+            if (c + 1 < c_end) store_chunk(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    if (do_rs) {
+        smem[(t >> 6) * 64 + (t & 63)] = rs_acc;
+        __syncthreads();
+        if (t < 64) {
+            const float v = (smem[t] + smem[64 + t]) + (smem[128 + t] + smem[192 + t]);
+            if (p.splitk > 1) p.partial[(long)p.splitk * p.M * p.N + (long)blockIdx.y * p.M + m0 + t] = v;
+            else p.rowsum[m0 + t] = p.alpha * v;
+        }
+        __syncthreads();
+    }
+    // ---- epilogue ----
+    const bool part = p.splitk > 1;
+    if (part || cvec) {
+        // transpose the wave's 32x32 block through LDS: lane -> (row = lane >> 3 + 8q, 4 consecutive columns)
+        float* T = smem + wave * (32 * 36);
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+            T[((reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) * 36 + (lane & 31)] = acc[reg];
+        wave_lds_sync();
+        const int c4 = lane & 7;
+        const int j = n0 + wn * 32 + 4 * c4;
+        f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (!part && p.bias) b4 = *reinterpret_cast<const f32x4*>(p.bias + (long)z * p.bsBias + j);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = (lane >> 3) + 8 * q;
+            const long i = m0 + wm * 32 + r;
+            f32x4 v = *reinterpret_cast<const f32x4*>(T + r * 36 + 4 * c4);
+            if (part) {
+                *reinterpret_cast<f32x4*>(p.partial + ((long)(z * p.splitk + blockIdx.y) * p.M + i) * p.N + j) = v;
+            } else {
+                float* dst = p.C + (long)z * p.bsC + i * p.scm + j;
+                f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (p.beta != 0.f) o = *reinterpret_cast<const f32x4*>(dst);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = apply_act(p.alpha * (v[e] + b4[e]), p.act) + p.beta * o[e];
+                *reinterpret_cast<f32x4*>(dst) = v;
+            }
+        }
+        return;
+    }
+    const int j = n0 + wn * 32 + (lane & 31);
+    float* C = p.C + (long)z * p.bsC;
+    const float bj = p.bias ? p.bias[(long)z * p.bsBias + j] : 0.f;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const long i = m0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        float v = apply_act(p.alpha * (acc[reg] + bj), p.act);
+        const long off = i * p.scm + j * p.scn;
+        if (p.beta != 0.f) v += p.beta * C[off];
+        C[off] = v;
+    }
+}
+
+static inline bool al16(const void* q) { return ((uintptr_t)q & 15) == 0; }
+// 0 = launched, -1 = shape/alignment not eligible (caller uses the general kernel)
+static int try_gemm_fast(const GemmP& p, int Z, hipStream_t st) {
+    if ((p.M & 63) || (p.N & 63) || (p.K & 15)) return -1;
+    const bool akc = p.sak == 1, amc = p.sam == 1 && !akc;
+    const bool bkc = p.sbk == 1 && p.sbn != 1, bnc = p.sbn == 1;
+    if (!(akc || amc) || !(bkc || bnc)) return -1;
+    if (!al16(p.A) || !al16(p.B) || (p.bsA & 3) || (p.bsB & 3)) return -1;
+    if (akc ? (p.sam & 3) : (p.sak & 3)) return -1;
+    if (bkc ? (p.sbn & 3) : (p.sbk & 3)) return -1;
+    const bool cat = p.A2 != nullptr;
+    if (cat && (!akc || p.sa2k != 1 || (p.sa2m & 3) || (p.K1 & 15) || !al16(p.A2) || (p.bsA2 & 3))) return -1;
+    if (p.rowsum && akc) return -1;
+    if (p.splitk > 1 && !al16(p.partial)) return -1;
+    const int cvec = (p.scn == 1 && !(p.scm & 3) && al16(p.C) && !(p.bsC & 3) && (!p.bias || (al16(p.bias) && !(p.bsBias & 3)))) ? 1 : 0;
+    dim3 grid((p.M >> 6) * (p.N >> 6), p.splitk, Z), block(256);
+#define GF_LAUNCH(A_, B_, C_) hipLaunchKernelGGL((gemm_fast_kernel<A_, B_, C_>), grid, block, 0, st, p, cvec)
+    if (cat) { if (bkc) GF_LAUNCH(true, true, true); else GF_LAUNCH(true, false, true); }
+    else if (akc) { if (bkc) GF_LAUNCH(true, true, false); else GF_LAUNCH(true, false, false); }
+    else { if (bkc) GF_LAUNCH(false, true, false); else GF_LAUNCH(false, false, false); }
+#undef GF_LAUNCH
+    return LAUNCH_CHECK();
+}
+
 // Deterministic split-K reduction + epilogue.  remap_cin > 0: the (i,j) result of a conv
 // weight-gradient GEMM (i = (tap,ci), j = co) is scattered to the reference's OIHW layout
 // dW[co][ci][tap]  (reference nn.Conv2d weight layout, model/tsrn.py:597).
@@ -334,6 +516,7 @@ static void set_split(GemmP& p, int splitk, float* ws, int kc = KC) {
 // A2/K1: optional second A source for r >= K1 (K-concatenation).  splitk > 1 needs `ws` of
 // Z*splitk*M*N floats.  Replaces nn.Linear / 1x1 nn.Conv2d / nn.GRU input projections
 // (reference model/tsrn.py:170,1071-1072; model/transformer_v2.py:455-457,788-790).
+static const bool g_gemm_fast = [] { const char* e = getenv("TATT_GEMM_FAST"); return !(e && e[0] == '0'); }();   // A/B switch
 TATT_API int tatt_gemm(const float* A, long sam, long sak, const float* A2, long sa2m, long sa2k, int K1,
                        const float* B, long sbk, long sbn, const float* bias, float* C, long scm, long scn,
                        int M, int N, int K, int Z, long bsA, long bsA2, long bsB, long bsC, long bsBias,
@@ -346,14 +529,13 @@ TATT_API int tatt_gemm(const float* A, long sam, long sak, const float* A2, long
     p.bsA = bsA; p.bsA2 = bsA2; p.bsB = bsB; p.bsC = bsC; p.bsBias = bsBias;
     p.alpha = alpha; p.beta = beta; p.act = act;
     p.rowsum = rowsum;                    // row sums of A (bias gradient); with split-K, ws needs splitk*M extra floats
-    // 64-deep chunks (KCT = 64) measured SLOWER than 16-deep on the token GEMMs (12.3 -> 16.7 us at M=49152, K=N=64:
-    // 2 work-groups/CU instead of 8 outweighs the fewer load round trips); kept as a template option, not dispatched.
-    const bool big = false;
-    set_split(p, splitk, ws, big ? 64 : KC);
+    // (64-deep K chunks were measured slower than 16-deep on the token GEMMs: 2 work-groups/CU instead of 8.)
+    set_split(p, splitk, ws, KC);
     bool ak = (sak == 1), bk = (sbk == 1 && sbn != 1);
-    int rc;
-    if (big) rc = A2 ? launch_gemm<2, 64>(p, Z, ak, bk, st) : launch_gemm<0, 64>(p, Z, ak, bk, st);
-    else     rc = A2 ? launch_gemm<2, 16>(p, Z, ak, bk, st) : launch_gemm<0, 16>(p, Z, ak, bk, st);
+    int rc = g_gemm_fast ? try_gemm_fast(p, Z, st) : -1;
+    if (rc == 0) return p.splitk > 1 ? finish_splitk(p, Z, 0, 0, st) : 0;
+    if (rc > 0) return rc;
+    rc = A2 ? launch_gemm<2, 16>(p, Z, ak, bk, st) : launch_gemm<0, 16>(p, Z, ak, bk, st);
     if (rc) return rc;
     if (p.splitk > 1) return finish_splitk(p, Z, 0, 0, st);
     return 0;

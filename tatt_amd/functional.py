@@ -355,16 +355,22 @@ class PixelShuffleActFn(Function):
 
 
 class MaxPoolFn(Function):
+    """nn.MaxPool2d((kh,kw), stride (sh,sw), padding (ph,pw)) on an NHWC map; stride defaults to the kernel."""
+
     @staticmethod
-    def forward(ctx, x, kh, kw):
+    def forward(ctx, x, kh, kw, sh, sw, ph, pw):
         ctx.save_for_backward(x)
-        ctx.k = (kh, kw)
-        return ops.maxpool_fwd(x, kh, kw)
+        ctx.k = (kh, kw, sh, sw, ph, pw)
+        return ops.maxpool_fwd(x, *ctx.k)
 
     @staticmethod
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
-        return ops.maxpool_bwd(x, _c(dy), *ctx.k), None, None
+        return (ops.maxpool_bwd(x, _c(dy), *ctx.k),) + (None,) * 6
+
+
+def max_pool(x, kh, kw, sh=None, sw=None, ph=0, pw=0):
+    return MaxPoolFn.apply(x, kh, kw, sh or kh, sw or kw, ph, pw)
 
 
 class Permute4dFn(Function):
@@ -729,3 +735,131 @@ class ImageLossFn(Function):
                  None if scale is None else ops.P(g), 0.0 if scale is None else float(scale), ops.P(dsr), B, C, H, W, w0, w1,
                  ops.stream())
         return dsr, None, None, None, None
+
+
+# --------------------------------------------------------------------------------------------------
+# CRNN text-prior generator pieces
+# --------------------------------------------------------------------------------------------------
+class Conv2x2ValidFn(Function):
+    """nn.Conv2d(Cin, Cout, 2, stride 1, padding 0) on an NHWC map (reference model/crnn/crnn.py:34-47, conv6): evaluated by the
+    implicit-GEMM kernel on the full input grid (its padding for a 2x2 filter is 0), the last row / column are dropped."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        B, H, W, Cin = x.shape
+        Cout = weight.shape[0]
+        full = ops.conv_fwd(x, ops.repack_weight(weight, 0), bias, Cout, 2, 2)
+        y = ops.new(x, B, H - 1, W - 1, Cout)
+        ops.copy4d(full, y, (B, H - 1, W - 1, Cout), full.stride(), y.stride())
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        B, H, W, Cin = x.shape
+        Cout = weight.shape[0]
+        dy = _c(dy)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            # dx[h,w] = sum_{kh,kw} dy[h-kh, w-kw] W[kh,kw]: a forward pass of the flipped filter over dy shifted by (+1,+1)
+            sh = torch.zeros(B, H, W, Cout, device=x.device)
+            ops.copy4d(dy, sh[:, 1:, 1:], dy.shape, dy.stride(), sh.stride())
+            dx = ops.conv_fwd(sh, ops.repack_weight(weight, 1), None, Cin, 2, 2)
+        if ctx.needs_input_grad[1]:
+            full = torch.zeros(B, H, W, Cout, device=x.device)
+            ops.copy4d(dy, full, dy.shape, dy.stride(), full.stride())
+            dw = ops.conv_wgrad(x, full, Cout, 2, 2)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = ops.colsum(dy.reshape(-1, Cout))
+        return dx, dw, db
+
+
+class BiLSTMFn(Function):
+    """nn.LSTM(I, H, bidirectional=True) on a time-major sequence x (T, Bt, I) -> (T, Bt, 2H), h0 = c0 = 0
+    (reference model/crnn/crnn.py:10,20).  Input projections of all steps and both directions: two GEMMs into one (T*Bt, 8H)
+    buffer; recurrence: one fused launch per time step (tatt_lstm_fwd_step / tatt_lstm_bwd_step); weight gradients: GEMMs over
+    the saved sequences."""
+
+    @staticmethod
+    def forward(ctx, x, wih_f, whh_f, bih_f, bhh_f, wih_r, whh_r, bih_r, bhh_r):
+        T, Bt, I = x.shape
+        H = whh_f.shape[1]
+        x2 = x.reshape(T * Bt, I)
+        gi = ops.new(x, T * Bt, 8 * H)
+        ops.linear_fwd(x2, wih_f, bih_f, out=gi[:, :4 * H])
+        ops.linear_fwd(x2, wih_r, bih_r, out=gi[:, 4 * H:])
+        out = ops.new(x, T, Bt, 2 * H)
+        cseq = ops.new(x, 2, T, Bt, H)
+        gsave = ops.new(x, 2, T, Bt, 4, H)
+        for s in range(T):
+            ops.call("tatt_lstm_fwd_step", ops.P(gi), ops.P(whh_f), ops.P(whh_r), ops.P(bhh_f), ops.P(bhh_r), ops.P(out),
+                     ops.P(cseq), ops.P(gsave), T, Bt, H, s, ops.stream())
+        ctx.save_for_backward(x, wih_f, whh_f, wih_r, whh_r, out, cseq, gsave)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, wih_f, whh_f, wih_r, whh_r, out, cseq, gsave = ctx.saved_tensors
+        T, Bt, I = x.shape
+        H = whh_f.shape[1]
+        dout = _c(dout)
+        whhT = [ops.to_contiguous(w.t().reshape(1, 1, H, 4 * H)).reshape(H, 4 * H) for w in (whh_f, whh_r)]
+        dgates = ops.new(x, 2, T, Bt, 4 * H)
+        dcc = ops.new(x, 2, Bt, H)
+        for s in range(T - 1, -1, -1):
+            ops.call("tatt_lstm_bwd_step", ops.P(dout), ops.P(whhT[0]), ops.P(whhT[1]), ops.P(cseq), ops.P(gsave), ops.P(dgates),
+                     ops.P(dcc), T, Bt, H, s, ops.stream())
+        x2 = x.reshape(T * Bt, I)
+        grads = []
+        dx = None
+        for d, (wih, whh) in enumerate(((wih_f, whh_f), (wih_r, whh_r))):
+            dg = dgates[d].reshape(T * Bt, 4 * H)
+            db = ops.new(x, 4 * H)
+            dwih = ops.linear_bwd_weight(dg, x2, rowsum=db)
+            # h_{t-1} of direction d at time t is out[t-1] (forward) / out[t+1] (reverse): contiguous time slices
+            hp = out[:T - 1, :, :H] if d == 0 else out[1:, :, H:]
+            dgs = dgates[0, 1:] if d == 0 else dgates[1, :T - 1]
+            dwhh = ops.linear_bwd_weight(dgs.reshape(-1, 4 * H), _rows(hp, H))
+            if ctx.needs_input_grad[0]:
+                if dx is None:
+                    dx = ops.linear_bwd_input(dg, wih)
+                else:
+                    ops.linear_bwd_input(dg, wih, out=dx, beta=1.0)
+            grads.append((dwih, dwhh, db))
+        (dwih_f, dwhh_f, db_f), (dwih_r, dwhh_r, db_r) = grads
+        return (None if dx is None else dx.reshape(T, Bt, I), dwih_f, dwhh_f, db_f, db_f, dwih_r, dwhh_r, db_r, db_r)
+
+
+def _rows(hp, H):
+    """(T', Bt, H) slice of the (T, Bt, 2H) output -> 2-D (T'*Bt, H) view with row pitch 2H (no copy)."""
+    Tn, Bt, _ = hp.shape
+    return hp.as_strided((Tn * Bt, H), (hp.stride(1), 1), hp.storage_offset())
+
+
+def bilstm(x, rnn):
+    """rnn: an nn.LSTM(I, H, bidirectional=True) used as parameter holder."""
+    return BiLSTMFn.apply(_c(x), rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.bias_ih_l0, rnn.bias_hh_l0,
+                          rnn.weight_ih_l0_reverse, rnn.weight_hh_l0_reverse, rnn.bias_ih_l0_reverse, rnn.bias_hh_l0_reverse)
+
+
+class SoftmaxRowsFn(Function):
+    """softmax over the last axis of a 2-D tensor (rows x L, L <= 4096): the class softmax that turns recogniser logits into the
+    text prior (reference interfaces/super_resolution.py:796)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        rows, L = x.shape
+        p = x.clone()
+        ops.call("tatt_softmax_rows_fwd", ops.P(p), None, rows, L, 0.0, ops.P(seed_tensor(x.device)), 0, ops.stream())
+        ctx.save_for_backward(p)
+        return p
+
+    @staticmethod
+    def backward(ctx, dp):
+        (p,) = ctx.saved_tensors
+        rows, L = p.shape
+        ds = _c(dp).clone()
+        ops.call("tatt_softmax_rows_bwd", ops.P(p), ops.P(ds), rows, L, 0.0, ops.P(seed_tensor(p.device)), 0, ops.stream())
+        return ds

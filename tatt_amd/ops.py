@@ -337,17 +337,18 @@ def pixel_shuffle_bwd(x, dout, act):
     return dx
 
 
-def maxpool_fwd(x, kh, kw):
+def maxpool_fwd(x, kh, kw, sh=None, sw=None, ph=0, pw=0):
     B, H, W, C = x.shape
-    y = new(x, B, H // kh, W // kw, C)
-    call("tatt_maxpool_fwd", P(x), P(y), B, H, W, C, kh, kw, stream())
+    sh, sw = sh or kh, sw or kw
+    y = new(x, B, (H + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw) // sw + 1, C)
+    call("tatt_maxpool_fwd", P(x), P(y), B, H, W, C, kh, kw, sh, sw, ph, pw, stream())
     return y
 
 
-def maxpool_bwd(x, dout, kh, kw):
+def maxpool_bwd(x, dout, kh, kw, sh=None, sw=None, ph=0, pw=0):
     B, H, W, C = x.shape
     dx = torch.empty_like(x)
-    call("tatt_maxpool_bwd", P(x), P(dout), P(dx), B, H, W, C, kh, kw, stream())
+    call("tatt_maxpool_bwd", P(x), P(dout), P(dx), B, H, W, C, kh, kw, sh or kh, sw or kw, ph, pw, stream())
     return dx
 
 

@@ -252,7 +252,7 @@ def _stn_forward(x_nchw, stn: STNHead):
         h = Fh.conv2d(h, conv.weight, conv.bias)
         h = Fh.batch_norm_act(h, bn, ACT_RELU)
         if i in pools:
-            h = Fh.MaxPoolFn.apply(h, *pools[i])
+            h = Fh.max_pool(h, *pools[i])
     B = h.shape[0]
     # x.view(B, -1) of the NCHW map: feature index = c*(H*W) + h*W + w
     h = Fh.Permute4dFn.apply(h, (0, 3, 1, 2)).reshape(B, -1)
@@ -298,7 +298,8 @@ def _tp_interpreter(feat, tp, ig: TPInterpreter, training):
     feat (B,H,W,C) NHWC block1 output; tp (B,37,1,26).  Returns tp_map (B,H,W,C), pr_weights (B,H*W,26)."""
     B, H, W, C = feat.shape
     L = tp.shape[3]
-    x = ops.to_contiguous(tp.permute(0, 3, 2, 1)).reshape(B, L, tp.shape[1])          # (B,26,37)
+    x = Fh.Permute4dFn.apply(tp, (0, 3, 2, 1)).reshape(B, L, tp.shape[1])               # (B,26,37); differentiable: the prior may
+                                                                                       # come from a trainable recogniser (tatt_amd.crnn)
     x = Fh.prelu(Fh.linear(x, ig.fc_in.weight, ig.fc_in.bias), ig.activation.weight)   # (B,26,64)
     pe = ig.pe.pe[0, :L]                                                               # (26,64)
     tr = ig.transformer

@@ -1,0 +1,153 @@
+"""CRNN text-prior generator: oracle vs the reference-generated vectors (CPU) and the HIP path vs both (GPU)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import crnn_oracle as C
+from oracle.fixtures import randomize_state_dict, summarize
+from tests.util import max_err, rel_err, check_close
+
+STRUCT_ZERO = ("cnn.conv2.bias", "cnn.conv4.bias", "cnn.conv6.bias")       # biases in front of a BatchNorm
+
+
+def _is_deep(k):
+    return k.startswith("rnn.") or k.startswith("cnn.conv6") or k.startswith("cnn.batchnorm6")
+
+
+def _sd(randomize=True):
+    import tatt_amd
+    torch.manual_seed(1234)
+    sd = tatt_amd.CRNN(32, 1, 37, 256).state_dict()
+    return randomize_state_dict(sd) if randomize else sd
+
+
+def test_crnn_state_dict_matches_reference():
+    z = np.load("tests/golden/crnn_b3.npz")
+    sd = _sd(randomize=False)
+    assert list(sd.keys()) == z["sd_keys"].tolist() and len(sd) == 49
+    assert sum(v.numel() for k, v in sd.items() if "running" not in k and "num_batches" not in k) == 8331301
+    for k, ref in zip(sd, z["sd_summary"]):
+        assert np.abs(summarize(sd[k].float()) - ref).max() < 1e-6, k
+
+
+def test_crnn_oracle_against_reference_vectors():
+    z = np.load("tests/golden/crnn_b3.npz")
+    sd = _sd()
+    img = torch.from_numpy(z["img"])
+    x = C.parse_crnn_data(img)
+    assert max_err(x, torch.from_numpy(z["x"])) < 2e-6
+    with torch.no_grad():
+        assert max_err(C.crnn_forward(sd, x), torch.from_numpy(z["logits_eval"])) < 1e-6
+    req = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    stats = {}
+    y = C.crnn_forward(req, x, training=True, new_stats=stats)
+    assert max_err(y, torch.from_numpy(z["logits_train"])) < 1e-5
+    assert max_err(C.text_prior(y), torch.from_numpy(z["prior"])) < 1e-6
+    (torch.softmax(y, -1) * torch.from_numpy(z["wts"])).sum().backward()
+    for k, ref in zip(z["grad_keys"].tolist(), z["grad_summary"]):
+        if k in STRUCT_ZERO:
+            continue
+        got = summarize(req[k].grad)
+        lim = 1e-4 if _is_deep(k) else 5e-2            # conditioning below the train-mode BatchNorms: tests/golden/REPORT.txt
+        assert abs(got[0] - ref[0]) < lim * ref[0], (k, got[0], ref[0])
+    assert max_err(stats["cnn.batchnorm4.running_mean"], torch.from_numpy(z["bn_mean"])) < 1e-6
+    assert max_err(stats["cnn.batchnorm4.running_var"], torch.from_numpy(z["bn_var"])) < 1e-6
+
+
+def test_crnn_has_no_cpu_fallback():
+    import tatt_amd
+    from tatt_amd.crnn import parse_crnn_data
+    with pytest.raises(RuntimeError, match="GPU"):
+        tatt_amd.CRNN(32, 1, 37, 256).eval()(torch.rand(1, 1, 32, 100))
+    with pytest.raises(RuntimeError, match="GPU"):
+        parse_crnn_data(torch.rand(1, 3, 16, 64))
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+def test_crnn_input_and_eval_logits(dev):
+    import tatt_amd
+    from tatt_amd.crnn import parse_crnn_data
+    z = np.load("tests/golden/crnn_b3.npz")
+    m = tatt_amd.CRNN(32, 1, 37, 256)
+    m.load_state_dict(_sd())
+    m = m.to(dev).eval()
+    x = parse_crnn_data(torch.from_numpy(z["img"]).to(dev))
+    assert tuple(x.shape) == (3, 1, 32, 100)
+    assert max_err(x, torch.from_numpy(z["x"])) < 5e-6
+    with torch.no_grad():
+        y = m(x)
+    assert tuple(y.shape) == (26, 3, 37)
+    assert max_err(y, torch.from_numpy(z["logits_eval"])) < 2e-6
+
+
+@pytest.mark.gpu
+def test_crnn_train_forward_backward(dev):
+    import tatt_amd
+    from tatt_amd.crnn import text_prior
+    z = np.load("tests/golden/crnn_b3.npz")
+    m = tatt_amd.CRNN(32, 1, 37, 256)
+    sd0 = _sd()
+    m.load_state_dict(sd0)
+    m = m.to(dev).train()
+    x = torch.from_numpy(z["x"]).to(dev)
+    y = m(x)
+    assert max_err(y, torch.from_numpy(z["logits_train"])) < 1e-5
+    prior = text_prior(y)
+    assert tuple(prior.shape) == (3, 37, 1, 26)
+    assert max_err(prior, torch.from_numpy(z["prior"])) < 1e-6
+    w = torch.from_numpy(z["wts"]).to(dev)
+    (prior * w.permute(1, 2, 0).unsqueeze(2)).sum().backward()
+    params = dict(m.named_parameters())
+    scale = max(float(r[0]) for r in z["grad_summary"])
+    for k, ref in zip(z["grad_keys"].tolist(), z["grad_summary"]):
+        g = params[k].grad
+        assert g is not None, k
+        if k in STRUCT_ZERO:
+            assert float(g.abs().max()) < 1e-4 * scale, k
+            continue
+        got = summarize(g.cpu())
+        lim = 2e-4 if _is_deep(k) else 5e-2
+        assert abs(got[0] - ref[0]) < lim * ref[0], (k, got[0], ref[0])
+    for key in z.files:
+        if key.startswith("g:"):
+            k = key[2:]
+            assert rel_err(params[k].grad.cpu(), torch.from_numpy(z[key])) < (2e-4 if _is_deep(k) else 5e-2), k
+    sd1 = m.state_dict()
+    assert max_err(sd1["cnn.batchnorm4.running_mean"], torch.from_numpy(z["bn_mean"])) < 1e-5
+    assert max_err(sd1["cnn.batchnorm4.running_var"], torch.from_numpy(z["bn_var"])) < 1e-5
+    assert int(sd1["cnn.batchnorm4.num_batches_tracked"]) == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,Bt,I,H", [(5, 3, 64, 256), (26, 48, 512, 256), (7, 17, 256, 256)])
+def test_bilstm_kernels(dev, T, Bt, I, H):
+    from tatt_amd import functional as Fh
+    from tests.util import compare_fn
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(T, Bt, I, generator=g)
+    ws = []
+    for _ in range(2):
+        ws += [torch.randn(4 * H, I, generator=g) / I ** 0.5, torch.randn(4 * H, H, generator=g) / H ** 0.5,
+               torch.randn(4 * H, generator=g) * 0.1, torch.randn(4 * H, generator=g) * 0.1]
+
+    def ref(x, *w):
+        return torch.cat([C.lstm_direction(x, *w[:4], False), C.lstm_direction(x, *w[4:], True)], -1)
+    compare_fn("bilstm", lambda x, *w: Fh.BiLSTMFn.apply(x, *w), ref, [x] + ws, dev, rtol=5e-4, atol=5e-5, grtol=2e-3, gatol=2e-4)
+
+
+@pytest.mark.gpu
+def test_general_maxpool_and_valid_conv(dev):
+    from tatt_amd import functional as Fh
+    from tests.util import compare_fn
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(2, 4, 27, 16, generator=g)
+    for k, s, p in (((2, 2), (2, 1), (0, 1)), ((2, 2), (2, 2), (0, 0)), ((3, 2), (1, 2), (1, 0))):
+        compare_fn("maxpool_general", lambda x: Fh.max_pool(x, k[0], k[1], s[0], s[1], p[0], p[1]),
+                   lambda x: torch.nn.functional.max_pool2d(x.permute(0, 3, 1, 2), k, s, p).permute(0, 2, 3, 1), [x], dev)
+    x = torch.randn(3, 2, 27, 64, generator=g)
+    w = torch.randn(96, 64, 2, 2, generator=g) * 0.1
+    b = torch.randn(96, generator=g)
+    compare_fn("conv2x2_valid", lambda x, w, b: Fh.Conv2x2ValidFn.apply(x, w, b),
+               lambda x, w, b: torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w, b).permute(0, 2, 3, 1), [x, w, b], dev,
+               grtol=1e-3, gatol=1e-4)

@@ -67,6 +67,49 @@ def test_linear_fn_autograd(dev):
                [x, xb, W, b], dev)
 
 
+def test_gemm_aligned_fast_path(dev):
+    """Every operand-orientation combination of the aligned fast path (gemm_fast_kernel) against fp64 torch: linear forward
+    (A k-contiguous, W k-contiguous), K-concatenated input, input gradient (W column-contiguous, accumulate), weight gradient
+    with split-K and the bias-gradient row sums, batched with strides, activation + alpha."""
+    from tatt_amd import ops
+    M, K, N = 1024, 128, 192
+    x, W, b = R(M, K), R(N, K, seed=1, scale=0.1), R(N, seed=2)
+    xd, Wd, bd = x.to(dev), W.to(dev), b.to(dev)
+    ref = 0.7 * (x.double() @ W.double().t() + b.double())
+    check_close("fast_fwd", ops.linear_fwd(xd, Wd, bd, alpha=0.7), ref.float(), 2e-4, 2e-4)
+    check_close("fast_fwd_relu", ops.linear_fwd(xd, Wd, bd, act=1), torch.relu(ref / 0.7).float(), 2e-4, 2e-4)
+    y = ops.linear_fwd(xd[:, :64].contiguous(), Wd, bd, x2b=xd[:, 64:].contiguous())
+    check_close("fast_concat", y, (ref / 0.7).float(), 2e-4, 2e-4)
+    # column-strided views of one buffer (row pitch 128, 64 columns each): still 16-byte aligned rows
+    y = ops.linear_fwd(xd[:, :64], Wd, bd, x2b=xd[:, 64:])
+    check_close("fast_concat_views", y, (ref / 0.7).float(), 2e-4, 2e-4)
+    dy = R(M, N, seed=3)
+    dx0 = R(M, K, seed=4)
+    dx = dx0.to(dev).clone()
+    ops.linear_bwd_input(dy.to(dev), Wd, out=dx, beta=1.0)
+    check_close("fast_bwd_input", dx, (dy.double() @ W.double() + dx0.double()).float(), 2e-4, 2e-4)
+    dxc = ops.linear_bwd_input(dy.to(dev), Wd, col0=64, ncols=64, alpha=0.5)
+    check_close("fast_bwd_input_cols", dxc, (0.5 * dy.double() @ W.double()[:, 64:]).float(), 2e-4, 2e-4)
+    Mb = 49152 // 4
+    xb_, dyb = R(Mb, 128, seed=5), R(Mb, 192, seed=6)
+    db = torch.empty(192, device=dev)
+    dW = ops.linear_bwd_weight(dyb.to(dev), xb_.to(dev), rowsum=db)
+    check_close("fast_bwd_weight", dW, (dyb.double().t() @ xb_.double()).float(), 5e-4, 5e-3)
+    check_close("fast_bias_grad", db, dyb.double().sum(0).float(), 5e-4, 5e-3)
+    Z = 3
+    A, B = R(Z, 128, 64, seed=7), R(Z, 64, 128, seed=8)
+    C = torch.zeros(Z, 128, 128, device=dev)
+    ops.gemm(A.to(dev), 64, 1, B.to(dev), 128, 1, C, 128, 1, 128, 128, 64, Z=Z, bsA=128 * 64, bsB=64 * 128, bsC=128 * 128)
+    check_close("fast_batched", C, (A.double() @ B.double()).float(), 2e-4, 2e-4)
+    At = A.transpose(1, 2).contiguous()                     # (Z, 64, 128): A^T stored, i.e. A is row-index-contiguous
+    C2 = torch.zeros(Z, 128, 128, device=dev)
+    ops.gemm(At.to(dev), 1, 128, B.to(dev), 128, 1, C2, 128, 1, 128, 128, 64, Z=Z, bsA=128 * 64, bsB=64 * 128, bsC=128 * 128)
+    check_close("fast_batched_mc", C2, (A.double() @ B.double()).float(), 2e-4, 2e-4)
+    Ct = torch.zeros(Z, 128, 128, device=dev)               # column-major C: scalar epilogue
+    ops.gemm(A.to(dev), 64, 1, B.to(dev), 128, 1, Ct, 1, 128, 128, 128, 64, Z=Z, bsA=128 * 64, bsB=64 * 128, bsC=128 * 128)
+    check_close("fast_batched_ct", Ct.transpose(1, 2), (A.double() @ B.double()).float(), 2e-4, 2e-4)
+
+
 # ------------------------------------------------------------------------------------------- conv
 @pytest.mark.parametrize("B,H,W,Cin,Cout,k", [(2, 16, 64, 64, 64, 3), (1, 16, 64, 64, 256, 3), (2, 16, 64, 4, 64, 9),
                                              (1, 32, 128, 64, 4, 9), (3, 8, 32, 32, 64, 3), (2, 1, 2, 256, 256, 3),
@@ -172,7 +215,7 @@ def test_prelu_pixelshuffle_maxpool_tanh(dev):
                lambda x: O.mish(O.pixel_shuffle2(x.permute(0, 3, 1, 2))).permute(0, 2, 3, 1), [x], dev)
     x = R(2, 8, 16, 12)
     for kh, kw in ((2, 2), (1, 2)):
-        compare_fn("maxpool", lambda x: Fh.MaxPoolFn.apply(x, kh, kw),
+        compare_fn("maxpool", lambda x: Fh.max_pool(x, kh, kw),
                    lambda x: F.max_pool2d(x.permute(0, 3, 1, 2), (kh, kw)).permute(0, 2, 3, 1), [x], dev)
     compare_fn("tanh", lambda x: Fh.ActFn.apply(x, 3), torch.tanh, [x], dev)
     a, b = R(5, 7, 3, 2), R(5, 7, 3, 2, seed=1)

@@ -14,6 +14,7 @@ Cases (SURVEY.md §8c "Fixtures to generate"):
   qgru           query-GRU batch-axis quirk at B=1,2,4
   large_tile     32x128 LR, width=256,height=64, STN=False, eval B=1
   tps            TPS grid + sampler with out-of-range control points
+  crnn_b3        CRNN text-prior generator (bicubic+luminance input, eval / train logits, parameter gradients), B=3
   tbsrn_b2       TBSRN variant at LR 16x256 (the only size the reference runs): eval forward + train fwd/bwd, B=2
 """
 import os
@@ -277,6 +278,64 @@ def case_tbsrn(ref, report):
                         sd_summary=np.stack([summarize(v.float()) for v in fresh.values()]))
 
 
+def case_crnn(ref, report):
+    """CRNN text-prior generator: parse_crnn_data + CRNN(32,1,37,256) eval / train forward + backward, B = 3."""
+    from model.crnn import crnn as rc
+    from oracle import crnn_oracle as C
+    torch.manual_seed(1234)
+    fresh = rc.CRNN(32, 1, 37, 256).state_dict()
+    torch.manual_seed(1234)
+    m = rc.CRNN(32, 1, 37, 256)
+    m.load_state_dict(randomize_state_dict(m.state_dict()))
+    sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(7)
+    img = torch.rand(3, 4, 16, 64, generator=g)
+    # reference interfaces/base.py:797-815 (parse_crnn_data), restated inline because TextBase needs the whole config stack
+    r = torch.nn.functional.interpolate(img[:, :3], (32, 100), mode="bicubic")
+    x_ref = 0.299 * r[:, 0:1] + 0.587 * r[:, 1:2] + 0.114 * r[:, 2:3]
+    x = C.parse_crnn_data(img)
+    d_in = maxdiff(x, x_ref)
+    m.eval()
+    with torch.no_grad():
+        y_eval = m(x_ref)
+        o_eval = C.crnn_forward(sd0, x)
+    m.train()
+    wts = torch.randn(26, 3, 37, generator=g)
+    y = m(x_ref)
+    prior = torch.softmax(y, -1)
+    (prior * wts).sum().backward()
+    grads = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+    sd_req = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd0.items()}
+    stats = {}
+    o = C.crnn_forward(sd_req, x, training=True, new_stats=stats)
+    (torch.softmax(o, -1) * wts).sum().backward()
+    worst = 0.0
+    scale = max(float(gr.abs().max()) for gr in grads.values())
+    for k, gr in grads.items():
+        rel = float((gr - sd_req[k].grad).norm() / (gr.norm() + 1e-6 * scale * gr.numel() ** 0.5))
+        # conditioning: from conv6 on the two agree to 1e-6; below the train-mode BatchNorm4 (B = 3) the fp32 gradient of the
+        # reference ITSELF is 1.6e-2 from its own fp64 gradient at conv0 (ReLU / max-pool selections flip on round-off).
+        if k in ("cnn.conv2.bias", "cnn.conv4.bias", "cnn.conv6.bias"):      # bias in front of a BatchNorm: structurally zero gradient
+            assert float(gr.abs().max()) < 1e-5 * scale and float(sd_req[k].grad.abs().max()) < 1e-5 * scale, k
+            continue
+        deep = k.startswith("rnn.") or any(k.startswith("cnn.%s" % n) for n in ("conv6", "batchnorm6"))
+        worst = max(worst, rel if deep else 0.0)
+        assert rel < (1e-4 if deep else 5e-2), (k, rel)
+    report.append("crnn_b3        input max|d| %.2e  eval logits max|d| %.2e  train logits max|d| %.2e  worst rel grad err (conv6..rnn) %.2e"
+                  % (d_in, maxdiff(y_eval, o_eval), maxdiff(y, o), worst))
+    assert d_in < 2e-6 and maxdiff(y_eval, o_eval) < 1e-6 and maxdiff(y, o) < 1e-5
+    sd1 = m.state_dict()
+    keys = list(grads.keys())
+    np.savez_compressed(os.path.join(OUT, "crnn_b3.npz"), img=np_(img), x=np_(x_ref), wts=np_(wts), logits_eval=np_(y_eval),
+                        logits_train=np_(y), prior=np_(prior.permute(1, 0, 2).unsqueeze(1).permute(0, 3, 1, 2)),
+                        grad_keys=np.array(keys), grad_summary=np.stack([summarize(grads[k]) for k in keys]),
+                        **{"g:" + k: np_(grads[k]) for k in ("cnn.conv0.weight", "cnn.batchnorm6.weight", "rnn.1.embedding.bias",
+                                                            "rnn.0.rnn.bias_hh_l0_reverse")},
+                        bn_mean=np_(sd1["cnn.batchnorm4.running_mean"]), bn_var=np_(sd1["cnn.batchnorm4.running_var"]),
+                        sd_keys=np.array(list(fresh.keys())),
+                        sd_summary=np.stack([summarize(v.float()) for v in fresh.values()]))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = import_reference()
@@ -292,6 +351,7 @@ def main():
     case_qgru(ref, report)
     case_tps(ref, report)
     case_tbsrn(ref, report)
+    case_crnn(ref, report)
     with open(os.path.join(OUT, "REPORT.txt"), "w") as f:
         f.write("\n".join(report) + "\n")
     print("\n".join(report))
