@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=48)
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) child process of the cpu_baseline leg")
-    ap.add_argument("--arch", default="tatt", choices=["tatt", "tsrn", "tbsrn"])
+    ap.add_argument("--arch", default="tatt", choices=["tatt", "tsrn", "tbsrn", "tatt_tpg"])
     return ap.parse_args()
 
 
@@ -85,6 +85,9 @@ def make_model(arch):
     kw = dict(scale_factor=2, width=128, height=32, STN=True, mask=True, srb_nums=5, hidden_units=32)
     if arch == "tbsrn":
         return tatt_amd.TBSRN(input_channel=4, **kw)
+    if arch == "tatt_tpg":                     # the SR generator trained together with its CRNN student prior generator
+        from tatt_amd.train import TextPriorSR
+        return TextPriorSR(tatt_amd.TSRN_TL_TRANS(**kw), tatt_amd.CRNN(32, 1, 37, 256))
     return (tatt_amd.TSRN_TL_TRANS if arch == "tatt" else tatt_amd.TSRN)(**kw)
 
 
@@ -176,7 +179,7 @@ def main():
     tr = Trainer(model, use_graph=use_graph, warmup_eager=2, process_group=pg)
     x, tp, hr = make_batch(a.batch, rank, dev)
     if a.arch != "tatt":
-        tp = None
+        tp = None                      # tsrn / tbsrn take no prior; tatt_tpg computes it from the LR image with the CRNN student
 
     def barrier():
         if world > 1:
@@ -235,7 +238,7 @@ def main():
                          "kernel": "conv3_c64_ws_kernel (3x3 conv, 64->64 ch, %d x16x64 px, fp32 MFMA)" % a.batch,
                          "kernel_ms": round(kms, 4), "flops_per_launch": kflops},
         }
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and a.arch != "tatt_tpg":
             out["cpu_baseline"] = cpu_baseline(a.arch, a.cpu_batch)
         print(json.dumps(out))
     if world > 1:

@@ -34,6 +34,29 @@ def image_loss_mean(sr, hr, weights=(1.0, 1e-4), scale=100.0):
     return Fh.ImageLossFn.apply(sr, hr, float(weights[0]), float(weights[1]), float(scale))
 
 
+class TextPriorSR(torch.nn.Module):
+    """The generator together with its trainable text-prior generator, as the reference's loop composes them
+    (interfaces/super_resolution.py:786-815): lr image -> parse_crnn_data -> CRNN student -> softmax prior -> SR(x, prior).
+    Gradients of the SR loss reach the recogniser through the prior."""
+
+    def __init__(self, sr, tpg, in_width=100):
+        super().__init__()
+        self.sr, self.tpg, self.in_width = sr, tpg, in_width
+
+    @property
+    def block(self):
+        return self.sr.block
+
+    @block.setter
+    def block(self, v):
+        self.sr.block = v
+
+    def forward(self, x):
+        from .crnn import parse_crnn_data, text_prior
+        prior = text_prior(self.tpg(parse_crnn_data(x[:, :3], self.in_width)))
+        return self.sr(x, prior)
+
+
 class Trainer:
     """One training step per `step()` call; optional whole-step hipGraph; optional data parallelism."""
 
