@@ -235,7 +235,12 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmP p) {
 //       96 floats (the two lane halves hit different bank halves), 4-byte operand reads.
 // The C tile leaves through a per-wave LDS transpose as 16-byte stores when C is row-major.
 // ------------------------------------------------------------------------------------------------
-template <bool AKC, bool BKC, bool CAT>
+// IM2COL (requires AKC, !BKC): A is the virtual im2col matrix of an NHWC map with Cin % 16 == 0 -- a K-chunk of 16 lies inside
+// one filter tap, so it is 16 contiguous channels of ONE (shifted) pixel: the thread's pixel is decoded once, the tap walks
+// with wave-uniform counters, and the row count M may be ragged (rows >= M load zeros and are not stored).
+// IM2COLT (requires !AKC, !BKC): the transposed im2col matrix of the weight gradient, A(i = (tap, ci), r = pixel), Cin % 64 == 0:
+// the 64 rows of a tile are 64 consecutive channels of ONE tap, so a K-chunk is 16 pixels x 64 contiguous channels.
+template <bool AKC, bool BKC, bool CAT, bool IM2COL, bool IM2COLT = false>
 __global__ __launch_bounds__(256) void gemm_fast_kernel(GemmP p, int cvec) {
     constexpr int TKC = 64 * 20, TMC = 16 * 96;
     constexpr int TA = AKC ? TKC : TMC, TB = BKC ? TKC : TMC;
@@ -258,7 +263,28 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(GemmP p, int cvec) {
     const float* ap; const float* ap2 = nullptr; const float* bp;
     long astep, bstep;
     int aslot, bslot;
-    if (AKC) {
+    // im2col state: this thread's pixel (fixed) and the wave-uniform tap walk
+    int ih = 0, iw = 0, tkh = 0, tkw = 0, tcc = 0;
+    bool irow = false;
+    const int cpt = IM2COL ? (p.Cin >> 4) : 1;                  // chunks per tap
+    if (IM2COL) {
+        const int row = t >> 2, k4 = (t & 3) * 4;
+        const int pix = m0 + row;
+        irow = pix < p.M;
+        int n = 0;
+        if (irow) decode_pixel(p, pix, n, ih, iw);
+        const int tap = c_begin / cpt;
+        tcc = c_begin - tap * cpt; tkh = tap / p.KW; tkw = tap - tkh * p.KW;
+        ap = p.A + (long)n * p.xsn + k4;
+        astep = 0; aslot = row * 20 + k4;
+    } else if (IM2COLT) {
+        const int kk = t >> 4, c4 = (t & 15) * 4;
+        const int tap = m0 / p.Cin;
+        tkh = tap / p.KW; tkw = tap - tkh * p.KW;
+        ap = p.A + (m0 - tap * p.Cin) + c4;
+        tcc = 16 * c_begin + kk;                                   // this thread's pixel index, advances by 16 per chunk
+        astep = 0; aslot = kk * 96 + c4;
+    } else if (AKC) {
         const int row = t >> 2, k4 = (t & 3) * 4;
         ap = p.A + (long)z * p.bsA + (long)(m0 + row) * p.sam + k4 + 16L * c_begin;
         if (CAT) ap2 = p.A2 + (long)z * p.bsA2 + (long)(m0 + row) * p.sa2m + k4 + 16L * c_begin - p.K1;
@@ -279,7 +305,21 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(GemmP p, int cvec) {
     }
     f32x4 ra, rb;
     auto load_chunk = [&](int c) {
-        if (CAT && 16 * c >= p.K1) ra = *reinterpret_cast<const f32x4*>(ap2);
+        if (IM2COL) {
+            const int hh = ih + tkh - p.pad, ww = iw + tkw - p.pad;
+            ra = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (irow && hh >= 0 && hh < p.H && ww >= 0 && ww < p.W)
+                ra = *reinterpret_cast<const f32x4*>(ap + (long)hh * p.xsh + (long)ww * p.xsw + 16 * tcc);
+            if (++tcc == cpt) { tcc = 0; if (++tkw == p.KW) { tkw = 0; ++tkh; } }
+        } else if (IM2COLT) {
+            int n, h, w;
+            decode_pixel(p, tcc, n, h, w);
+            const int hh = h + tkh - p.pad, ww = w + tkw - p.pad;
+            ra = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (hh >= 0 && hh < p.H && ww >= 0 && ww < p.W)
+                ra = *reinterpret_cast<const f32x4*>(ap + (long)n * p.xsn + (long)hh * p.xsh + (long)ww * p.xsw);
+            tcc += 16;
+        } else if (CAT && 16 * c >= p.K1) ra = *reinterpret_cast<const f32x4*>(ap2);
         else ra = *reinterpret_cast<const f32x4*>(ap);
         rb = *reinterpret_cast<const f32x4*>(bp);
         ap += astep; bp += bstep;
@@ -355,6 +395,7 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(GemmP p, int cvec) {
         for (int q = 0; q < 4; ++q) {
             const int r = (lane >> 3) + 8 * q;
             const long i = m0 + wm * 32 + r;
+            if (IM2COL && i >= p.M) continue;
             f32x4 v = *reinterpret_cast<const f32x4*>(T + r * 36 + 4 * c4);
             if (part) {
                 *reinterpret_cast<f32x4*>(p.partial + ((long)(z * p.splitk + blockIdx.y) * p.M + i) * p.N + j) = v;
@@ -375,6 +416,7 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(GemmP p, int cvec) {
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
         const long i = m0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        if (IM2COL && i >= p.M) continue;
         float v = apply_act(p.alpha * (acc[reg] + bj), p.act);
         const long off = i * p.scm + j * p.scn;
         if (p.beta != 0.f) v += p.beta * C[off];
@@ -382,6 +424,7 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(GemmP p, int cvec) {
     }
 }
 
+static const bool g_gemm_fast = [] { const char* e = getenv("TATT_GEMM_FAST"); return !(e && e[0] == '0'); }();   // A/B switch
 static inline bool al16(const void* q) { return ((uintptr_t)q & 15) == 0; }
 // 0 = launched, -1 = shape/alignment not eligible (caller uses the general kernel)
 static int try_gemm_fast(const GemmP& p, int Z, hipStream_t st) {
@@ -398,11 +441,29 @@ static int try_gemm_fast(const GemmP& p, int Z, hipStream_t st) {
     if (p.splitk > 1 && !al16(p.partial)) return -1;
     const int cvec = (p.scn == 1 && !(p.scm & 3) && al16(p.C) && !(p.bsC & 3) && (!p.bias || (al16(p.bias) && !(p.bsBias & 3)))) ? 1 : 0;
     dim3 grid((p.M >> 6) * (p.N >> 6), p.splitk, Z), block(256);
-#define GF_LAUNCH(A_, B_, C_) hipLaunchKernelGGL((gemm_fast_kernel<A_, B_, C_>), grid, block, 0, st, p, cvec)
+#define GF_LAUNCH(A_, B_, C_) hipLaunchKernelGGL((gemm_fast_kernel<A_, B_, C_, false>), grid, block, 0, st, p, cvec)
     if (cat) { if (bkc) GF_LAUNCH(true, true, true); else GF_LAUNCH(true, false, true); }
     else if (akc) { if (bkc) GF_LAUNCH(true, true, false); else GF_LAUNCH(true, false, false); }
     else { if (bkc) GF_LAUNCH(false, true, false); else GF_LAUNCH(false, false, false); }
 #undef GF_LAUNCH
+    return LAUNCH_CHECK();
+}
+// transposed-im2col fast path of tatt_conv2d_wgrad: NHWC input, Cin % 64 == 0, Cout % 64 == 0, pixel count % 16 == 0
+static int try_wgrad_fast(const GemmP& p, hipStream_t st) {
+    if ((p.N & 63) || (p.Cin & 63) || (p.K & 15) || p.xsc != 1 || p.sbn != 1 || (p.sbk & 3) || p.splitk < 2) return -1;
+    if (!al16(p.A) || !al16(p.B) || !al16(p.partial) || (p.xsn & 3) || (p.xsh & 3) || (p.xsw & 3)) return -1;
+    dim3 grid((p.M >> 6) * (p.N >> 6), p.splitk, 1), block(256);
+    hipLaunchKernelGGL((gemm_fast_kernel<false, false, false, false, true>), grid, block, 0, st, p, 0);
+    return LAUNCH_CHECK();
+}
+// im2col fast path of tatt_conv2d_fwd: NHWC input with unit channel stride, Cin % 16 == 0, Cout % 64 == 0
+static int try_conv_fast(const GemmP& p, hipStream_t st) {
+    if ((p.N & 63) || (p.Cin & 15) || p.xsc != 1 || p.sbn != 1 || (p.sbk & 3)) return -1;
+    if (!al16(p.A) || !al16(p.B) || (p.xsn & 3) || (p.xsh & 3) || (p.xsw & 3)) return -1;
+    if (p.splitk > 1 && !al16(p.partial)) return -1;
+    const int cvec = (p.scn == 1 && !(p.scm & 3) && al16(p.C) && (!p.bias || al16(p.bias))) ? 1 : 0;
+    dim3 grid(cdiv(p.M, 64) * (p.N >> 6), p.splitk, 1), block(256);
+    hipLaunchKernelGGL((gemm_fast_kernel<true, false, false, true>), grid, block, 0, st, p, cvec);
     return LAUNCH_CHECK();
 }
 
@@ -516,7 +577,6 @@ static void set_split(GemmP& p, int splitk, float* ws, int kc = KC) {
 // A2/K1: optional second A source for r >= K1 (K-concatenation).  splitk > 1 needs `ws` of
 // Z*splitk*M*N floats.  Replaces nn.Linear / 1x1 nn.Conv2d / nn.GRU input projections
 // (reference model/tsrn.py:170,1071-1072; model/transformer_v2.py:455-457,788-790).
-static const bool g_gemm_fast = [] { const char* e = getenv("TATT_GEMM_FAST"); return !(e && e[0] == '0'); }();   // A/B switch
 TATT_API int tatt_gemm(const float* A, long sam, long sak, const float* A2, long sa2m, long sa2k, int K1,
                        const float* B, long sbk, long sbn, const float* bias, float* C, long scm, long scn,
                        int M, int N, int K, int Z, long bsA, long bsA2, long bsB, long bsC, long bsBias,
@@ -561,7 +621,10 @@ TATT_API int tatt_conv2d_fwd(const float* x, long xsn, long xsh, long xsw, long 
     p.alpha = 1.f; p.beta = beta; p.act = act;
     fill_conv(p, H, W, Cin, KH, KW, xsn, xsh, xsw, xsc);
     set_split(p, splitk, ws);        // split-K (ws >= splitk*Bn*H*W*Cout floats) spreads small-M / deep-K convs (STN tail) over the CUs
-    int rc = launch_gemm<3, 16>(p, 1, true, false, st);
+    int rc = g_gemm_fast ? try_conv_fast(p, st) : -1;
+    if (rc == 0) return p.splitk > 1 ? finish_splitk(p, 1, 0, 0, st) : 0;
+    if (rc > 0) return rc;
+    rc = launch_gemm<3, 16>(p, 1, true, false, st);
     if (rc) return rc;
     if (p.splitk > 1) return finish_splitk(p, 1, 0, 0, st);
     return 0;
@@ -581,7 +644,8 @@ TATT_API int tatt_conv2d_wgrad(const float* x, long xsn, long xsh, long xsw, lon
     fill_conv(p, H, W, Cin, KH, KW, xsn, xsh, xsw, xsc);
     set_split(p, splitk < 2 ? 2 : splitk, ws);
     if (p.splitk < 2) { p.splitk = 2; p.chunks_per_split = cdiv(cdiv(p.K, KC), 2); }
-    int rc = launch_gemm<4, 16>(p, 1, false, false, st);
+    int rc = g_gemm_fast ? try_wgrad_fast(p, st) : -1;
+    if (rc < 0) rc = launch_gemm<4, 16>(p, 1, false, false, st);
     if (rc) return rc;
     return finish_splitk(p, 1, Cin, KH * KW, st);
 }

@@ -145,6 +145,14 @@ def test_general_maxpool_and_valid_conv(dev):
     for k, s, p in (((2, 2), (2, 1), (0, 1)), ((2, 2), (2, 2), (0, 0)), ((3, 2), (1, 2), (1, 0))):
         compare_fn("maxpool_general", lambda x: Fh.max_pool(x, k[0], k[1], s[0], s[1], p[0], p[1]),
                    lambda x: torch.nn.functional.max_pool2d(x.permute(0, 3, 1, 2), k, s, p).permute(0, 2, 3, 1), [x], dev)
+    # 3x3 convolution at a CRNN geometry (width not a multiple of 64 -> implicit-GEMM kernel, aligned im2col fast paths
+    # for forward, data gradient and weight gradient; 2*8*25 = 400 pixels: ragged last row tile)
+    x = torch.randn(2, 8, 25, 64, generator=g)
+    w = torch.randn(128, 64, 3, 3, generator=g) * 0.05
+    b = torch.randn(128, generator=g)
+    compare_fn("conv3_crnn_geometry", lambda x, w, b: Fh.conv2d(x, w, b, 1),
+               lambda x, w, b: torch.relu(torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w, b, padding=1)).permute(0, 2, 3, 1),
+               [x, w, b], dev, grtol=1e-3, gatol=1e-4)
     x = torch.randn(3, 2, 27, 64, generator=g)
     w = torch.randn(96, 64, 2, 2, generator=g) * 0.1
     b = torch.randn(96, generator=g)
