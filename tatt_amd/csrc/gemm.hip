@@ -286,8 +286,9 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(GemmP p, int cvec) {
         astep = 0; aslot = kk * 96 + c4;
     } else if (AKC) {
         const int row = t >> 2, k4 = (t & 3) * 4;
-        ap = p.A + (long)z * p.bsA + (long)(m0 + row) * p.sam + k4 + 16L * c_begin;
-        if (CAT) ap2 = p.A2 + (long)z * p.bsA2 + (long)(m0 + row) * p.sa2m + k4 + 16L * c_begin - p.K1;
+        const int rowc = min(m0 + row, p.M - 1);                  // ragged M: rows past the end re-read the last row, never stored
+        ap = p.A + (long)z * p.bsA + (long)rowc * p.sam + k4 + 16L * c_begin;
+        if (CAT) ap2 = p.A2 + (long)z * p.bsA2 + (long)rowc * p.sa2m + k4 + 16L * c_begin - p.K1;
         astep = 16; aslot = row * 20 + k4;
     } else {
         const int k = t >> 4, c4 = (t & 15) * 4;
@@ -395,7 +396,7 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(GemmP p, int cvec) {
         for (int q = 0; q < 4; ++q) {
             const int r = (lane >> 3) + 8 * q;
             const long i = m0 + wm * 32 + r;
-            if (IM2COL && i >= p.M) continue;
+            if (AKC && i >= p.M) continue;
             f32x4 v = *reinterpret_cast<const f32x4*>(T + r * 36 + 4 * c4);
             if (part) {
                 *reinterpret_cast<f32x4*>(p.partial + ((long)(z * p.splitk + blockIdx.y) * p.M + i) * p.N + j) = v;
@@ -416,7 +417,7 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(GemmP p, int cvec) {
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
         const long i = m0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-        if (IM2COL && i >= p.M) continue;
+        if (AKC && i >= p.M) continue;
         float v = apply_act(p.alpha * (acc[reg] + bj), p.act);
         const long off = i * p.scm + j * p.scn;
         if (p.beta != 0.f) v += p.beta * C[off];
@@ -428,8 +429,9 @@ static const bool g_gemm_fast = [] { const char* e = getenv("TATT_GEMM_FAST"); r
 static inline bool al16(const void* q) { return ((uintptr_t)q & 15) == 0; }
 // 0 = launched, -1 = shape/alignment not eligible (caller uses the general kernel)
 static int try_gemm_fast(const GemmP& p, int Z, hipStream_t st) {
-    if ((p.M & 63) || (p.N & 63) || (p.K & 15)) return -1;
+    if ((p.N & 63) || (p.K & 15)) return -1;
     const bool akc = p.sak == 1, amc = p.sam == 1 && !akc;
+    if ((p.M & 63) && !akc) return -1;                 // ragged M only when A is read row by row
     const bool bkc = p.sbk == 1 && p.sbn != 1, bnc = p.sbn == 1;
     if (!(akc || amc) || !(bkc || bnc)) return -1;
     if (!al16(p.A) || !al16(p.B) || (p.bsA & 3) || (p.bsB & 3)) return -1;
@@ -440,7 +442,7 @@ static int try_gemm_fast(const GemmP& p, int Z, hipStream_t st) {
     if (p.rowsum && akc) return -1;
     if (p.splitk > 1 && !al16(p.partial)) return -1;
     const int cvec = (p.scn == 1 && !(p.scm & 3) && al16(p.C) && !(p.bsC & 3) && (!p.bias || (al16(p.bias) && !(p.bsBias & 3)))) ? 1 : 0;
-    dim3 grid((p.M >> 6) * (p.N >> 6), p.splitk, Z), block(256);
+    dim3 grid(cdiv(p.M, 64) * (p.N >> 6), p.splitk, Z), block(256);
 #define GF_LAUNCH(A_, B_, C_) hipLaunchKernelGGL((gemm_fast_kernel<A_, B_, C_, false>), grid, block, 0, st, p, cvec)
     if (cat) { if (bkc) GF_LAUNCH(true, true, true); else GF_LAUNCH(true, false, true); }
     else if (akc) { if (bkc) GF_LAUNCH(true, true, false); else GF_LAUNCH(true, false, false); }

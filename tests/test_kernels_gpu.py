@@ -96,6 +96,14 @@ def test_gemm_aligned_fast_path(dev):
     dW = ops.linear_bwd_weight(dyb.to(dev), xb_.to(dev), rowsum=db)
     check_close("fast_bwd_weight", dW, (dyb.double().t() @ xb_.double()).float(), 5e-4, 5e-3)
     check_close("fast_bias_grad", db, dyb.double().sum(0).float(), 5e-4, 5e-3)
+    # ragged row count (48 x 26 text tokens = 1248 = 19.5 tiles): rows past the end are computed but never stored
+    xr, Wr, br = R(1248, 64, seed=9), R(192, 64, seed=10, scale=0.1), R(192, seed=11)
+    yr = torch.full((1248 + 64, 192), 7.0, device=dev)
+    ops.linear_fwd(xr.to(dev), Wr.to(dev), br.to(dev), act=1, out=yr[:1248])
+    check_close("fast_ragged_fwd", yr[:1248], torch.relu(xr.double() @ Wr.double().t() + br.double()).float(), 2e-4, 2e-4)
+    assert float((yr[1248:] - 7.0).abs().max()) == 0.0
+    dxr = ops.linear_bwd_input(yr[:1248].contiguous(), Wr.to(dev))
+    check_close("fast_ragged_bwd_input", dxr, (yr[:1248].double().cpu() @ Wr.double()).float(), 2e-4, 2e-4)
     Z = 3
     A, B = R(Z, 128, 64, seed=7), R(Z, 64, 128, seed=8)
     C = torch.zeros(Z, 128, 128, device=dev)
