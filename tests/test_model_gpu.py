@@ -264,3 +264,31 @@ def test_tbsrn_trainer_step_with_dropout(dev):
     for _ in range(5):
         l1 = float(tr.step(x.to(dev), None, hr.to(dev)))
     assert l1 == l1 and l1 < l0
+
+
+def test_width_not_a_multiple_of_64(dev):
+    """LR 16x48 (width=96): none of the 64-pixel-segment kernels applies -- the convolutions fall back to the implicit-GEMM kernel,
+    the GRUs scan 48-step rows.  Eval and train forward/backward against the oracle, batch of 1 and of 3."""
+    from tatt_amd.train import image_loss
+    kw = dict(scale_factor=2, width=96, height=32, STN=False, mask=True, srb_nums=5, hidden_units=32)
+    m = build("TSRN_TL_TRANS", dev, **kw)
+    sd0 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    for B in (1, 3):
+        x, tp, hr = make_inputs(B, 16, 48, seed=20 + B)
+        m.eval()
+        with torch.no_grad():
+            y, w = m(x.to(dev), tp.to(dev))
+            o = O.generator_forward(sd0, x, tp, training=False, tatt=True, stn=False)
+        assert tuple(y.shape) == (B, 4, 32, 96)
+        assert max_err(y, o["sr"]) < 2e-5
+        assert max_err(w, o["pr_weights"]) < 1e-5
+    m.train()
+    m.infoGen.dropout_on = False
+    for p in m.parameters():
+        p.grad = None
+    sr, _ = m(x.to(dev), tp.to(dev))
+    (image_loss(sr, hr.to(dev)).mean() * 100).backward()
+    _, o_grads, _, _, o_out, _ = O.train_step(sd0, x, tp, hr, tatt=True, stn=False)
+    assert max_err(sr, o_out["sr"]) < 5e-5
+    worst = compare_param_grads(m.named_parameters(), o_grads, rtol=5e-3)
+    assert worst[1] < 5e-3, worst
