@@ -87,7 +87,7 @@ def make_model(arch):
         return tatt_amd.TBSRN(input_channel=4, **kw)
     if arch == "tatt_tpg":                     # the SR generator trained together with its CRNN student prior generator
         from tatt_amd.train import TextPriorSR
-        return TextPriorSR(tatt_amd.TSRN_TL_TRANS(**kw), tatt_amd.CRNN(32, 1, 37, 256))
+        return TextPriorSR(tatt_amd.TSRN_TL_TRANS(**kw), tatt_amd.CRNN(32, 1, 37, 256), teacher=tatt_amd.CRNN(32, 1, 37, 256).eval())
     return (tatt_amd.TSRN_TL_TRANS if arch == "tatt" else tatt_amd.TSRN)(**kw)
 
 

@@ -282,6 +282,14 @@ int tatt_lstm_bwd_step(const float* dout, const float* whhT_f, const float* whhT
 int tatt_bicubic_luma(const float* img, long sn, long sc, long sh, long sw, float* out, int B, int H, int W, int OH,
                       int OW, hipStream_t st);
 
+/* SemanticLoss(pred, gt) = mean|gt - pred| + mean (gt+1e-20)(log(gt+1e-20) - log(pred+1e-20)) over n elements (reference
+ * loss/semantic_loss.py:21-38: the student / teacher prior distillation loss); out[0] scalar; backward w.r.t. pred */
+int tatt_semantic_loss_fwd(const float* pred, const float* gt, long n, float* out, hipStream_t st);
+int tatt_semantic_loss_bwd(const float* pred, const float* gt, const float* gout, long n, float* dpred, hipStream_t st);
+/* calculate_psnr (reference utils/ssim_psnr.py:9-15) of two (B,C,H,W) images in [0,1] given by element strides, first 3 channels */
+int tatt_psnr(const float* a, long a_n, long a_c, long a_h, long a_w, const float* b, long b_n, long b_c, long b_h, long b_w,
+              float* out, int B, int C, int H, int W, hipStream_t st);
+
 #ifdef __cplusplus
 }
 #endif

@@ -456,6 +456,20 @@ def image_loss(sr: Tensor, hr: Tensor, weights=(1.0, 1e-4)) -> Tensor:
     return weights[0] * mse + weights[1] * gp
 
 
+def semantic_loss(pred: Tensor, gt: Tensor) -> Tensor:
+    """SemanticLoss.forward -- loss/semantic_loss.py:21-38: L1 + nn.KLDivLoss() (reduction 'mean' over every element)."""
+    l1 = (gt - pred).abs().mean()
+    t = gt + 1e-20
+    kl = (t * (torch.log(t) - torch.log(pred + 1e-20))).mean()
+    return l1 + kl
+
+
+def calculate_psnr(img1: Tensor, img2: Tensor) -> Tensor:
+    """utils/ssim_psnr.py:9-15."""
+    mse = ((img1[:, :3] * 255 - img2[:, :3] * 255) ** 2).mean()
+    return 20 * torch.log10(255.0 / torch.sqrt(mse))
+
+
 def clip_grad_norm(grads: Dict[str, Tensor], max_norm: float = 0.25) -> Tuple[Dict[str, Tensor], Tensor]:
     """torch.nn.utils.clip_grad_norm_ (global L2) -- interfaces/super_resolution.py:1083-1084."""
     total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())).float()

@@ -139,3 +139,75 @@ TATT_API int tatt_image_loss_bwd(const float* sr, long s_n, long s_c, long s_h, 
     hipLaunchKernelGGL(image_loss_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, p, gper, gscalar, scale / B, dsr);
     return LAUNCH_CHECK();
 }
+
+// ---- SemanticLoss: the distillation loss between the student's and the teacher's text priors (reference
+// loss/semantic_loss.py:21-38, used at interfaces/super_resolution.py:711):
+//   L = mean |gt - pred|  +  mean (gt + e) (log(gt + e) - log(pred + e)),   e = 1e-20   (nn.KLDivLoss, reduction 'mean')
+// One work-group (the priors are B x 26 x 37 values); backward w.r.t. pred only (the teacher is detached). ----
+__global__ __launch_bounds__(1024) void semantic_loss_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ gt, long n,
+                                                                 float* __restrict__ out) {
+    __shared__ double red[16];
+    double a = 0.0;
+    for (long i = threadIdx.x; i < n; i += 1024) {
+        const float p = pred[i], g = gt[i];
+        const float ge = g + 1e-20f;
+        a += (double)fabsf(g - p) + (double)(ge * (logf(ge) - logf(p + 1e-20f)));
+    }
+    a = wave_sum_d(a);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int k = 0; k < 16; ++k) s += red[k];
+        out[0] = (float)(s / (double)n);
+    }
+}
+__global__ void semantic_loss_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ gt, const float* __restrict__ gout,
+                                         long n, float* __restrict__ dpred) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float p = pred[i], g = gt[i];
+    const float d = g - p;
+    const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+    dpred[i] = gout[0] * (-sg - (g + 1e-20f) / (p + 1e-20f)) / (float)n;
+}
+TATT_API int tatt_semantic_loss_fwd(const float* pred, const float* gt, long n, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(semantic_loss_fwd_kernel, dim3(1), dim3(1024), 0, st, pred, gt, n, out);
+    return LAUNCH_CHECK();
+}
+TATT_API int tatt_semantic_loss_bwd(const float* pred, const float* gt, const float* gout, long n, float* dpred, hipStream_t st) {
+    hipLaunchKernelGGL(semantic_loss_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, pred, gt, gout, n, dpred);
+    return LAUNCH_CHECK();
+}
+
+// ---- calculate_psnr (reference utils/ssim_psnr.py:9-15): 20 log10(255 / sqrt(mean((255 a - 255 b)^2))) over the first 3 channels;
+// +inf when the images are identical.  Strided (B,C,H,W) views like the loss above. ----
+__global__ __launch_bounds__(1024) void psnr_kernel(LossP p, float* __restrict__ out) {
+    __shared__ double red[16];
+    const int gc = p.C < 3 ? p.C : 3;
+    const long hw = (long)p.H * p.W, total = (long)p.B * gc * hw;
+    double a = 0.0;
+    for (long i = threadIdx.x; i < total; i += 1024) {
+        const int w = i % p.W; long r = i / p.W;
+        const int h = r % p.H; r /= p.H;
+        const int c = r % gc; const int n = r / gc;
+        const float d = 255.f * p.sr.p[n * p.sr.sn + c * p.sr.sc + h * p.sr.sh + w * p.sr.sw] -
+                        255.f * p.hr.p[n * p.hr.sn + c * p.hr.sc + h * p.hr.sh + w * p.hr.sw];
+        a += (double)(d * d);
+    }
+    a = wave_sum_d(a);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int k = 0; k < 16; ++k) s += red[k];
+        const double mse = s / (double)total;
+        out[0] = mse == 0.0 ? INFINITY : (float)(20.0 * log10(255.0 / sqrt(mse)));
+    }
+}
+TATT_API int tatt_psnr(const float* a, long a_n, long a_c, long a_h, long a_w, const float* b, long b_n, long b_c, long b_h, long b_w,
+                       float* out, int B, int C, int H, int W, hipStream_t st) {
+    LossP p = make_lossp(a, a_n, a_c, a_h, a_w, b, b_n, b_c, b_h, b_w, B, C, H, W, 0.f, 0.f);
+    hipLaunchKernelGGL(psnr_kernel, dim3(1), dim3(1024), 0, st, p, out);
+    return LAUNCH_CHECK();
+}

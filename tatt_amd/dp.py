@@ -3,7 +3,8 @@ gloo in the CPU tests).
 
 Replaces torch.nn.DataParallel of the reference (interfaces/base.py:386-396): one process per GPU, each with a
 full replica; per-replica BatchNorm statistics and query-GRU (same semantics as DataParallel replicas, SURVEY.md 8e);
-gradients are exchanged with ONE sum all-reduce of a flat fp32 buffer (7,608,334 elements = 30.4 MB for TATT), the
+gradients are exchanged with ONE sum all-reduce of a flat fp32 buffer (7,608,334 parameters + alignment padding = 30.4 MB for
+TATT), the
 1/world factor is folded into the optimiser kernel, THEN the global-norm clip and Adam run identically on every rank.
 Parameters that never receive a gradient (14 tensors of the reference) contribute zeros on all ranks.
 """
@@ -14,13 +15,19 @@ import torch.distributed as dist
 
 
 class FlatParams:
-    """Re-homes a module's parameters into one flat buffer and gives every parameter a `.grad` view into a second one."""
+    """Re-homes a module's parameters into one flat buffer and gives every parameter a `.grad` view into a second one.
+    Every parameter starts on a 64-byte boundary (ALIGN floats): the kernels move weights with 16-byte vector loads, and a
+    weight that follows an odd-sized tensor (a 37-wide bias, a single PReLU slope) would otherwise lose its aligned fast paths.
+    The padding elements are zero in every buffer, so norms, Adam and the all-reduce are unaffected."""
+
+    ALIGN = 16
 
     def __init__(self, model: torch.nn.Module):
         self.params = [p for p in model.parameters()]
         dev = self.params[0].device
-        self.n = sum(p.numel() for p in self.params)
-        self.p = torch.empty(self.n, device=dev, dtype=torch.float32)
+        a = self.ALIGN
+        self.n = sum((p.numel() + a - 1) // a * a for p in self.params)
+        self.p = torch.zeros(self.n, device=dev, dtype=torch.float32)
         self.g = torch.zeros(self.n, device=dev, dtype=torch.float32)
         self.offsets = {}
         off = 0
@@ -31,7 +38,7 @@ class FlatParams:
                 p.data = self.p[off:off + k].view_as(p)
                 p.grad = self.g[off:off + k].view_as(p)
                 self.offsets[id(p)] = (off, k)
-                off += k
+                off += (k + a - 1) // a * a
 
     def zero_grad(self):
         self.g.zero_()

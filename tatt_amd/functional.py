@@ -863,3 +863,26 @@ class SoftmaxRowsFn(Function):
         ds = _c(dp).clone()
         ops.call("tatt_softmax_rows_bwd", ops.P(p), ops.P(ds), rows, L, 0.0, ops.P(seed_tensor(p.device)), 0, ops.stream())
         return ds
+
+
+class SemanticLossFn(Function):
+    """reference SemanticLoss.forward (loss/semantic_loss.py:21-38): L1 + KL between the student prior `pred` and the (detached)
+    teacher prior `gt`; scalar."""
+
+    @staticmethod
+    def forward(ctx, pred, gt):
+        ops._check_dev(pred)
+        ops._check_dev(gt)
+        pred, gt = _c(pred), _c(gt)
+        assert pred.shape == gt.shape
+        out = ops.new(pred, 1)
+        ops.call("tatt_semantic_loss_fwd", ops.P(pred), ops.P(gt), pred.numel(), ops.P(out), ops.stream())
+        ctx.save_for_backward(pred, gt)
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, gt = ctx.saved_tensors
+        d = torch.empty_like(pred)
+        ops.call("tatt_semantic_loss_bwd", ops.P(pred), ops.P(gt), ops.P(_c(g)), pred.numel(), ops.P(d), ops.stream())
+        return d, None

@@ -34,14 +34,39 @@ def image_loss_mean(sr, hr, weights=(1.0, 1e-4), scale=100.0):
     return Fh.ImageLossFn.apply(sr, hr, float(weights[0]), float(weights[1]), float(scale))
 
 
+def semantic_loss(pred, gt):
+    """SemanticLoss()(pred, gt) of the reference (loss/semantic_loss.py:21-38): prior distillation, student vs teacher."""
+    return Fh.SemanticLossFn.apply(pred, gt.detach())
+
+
+def calculate_psnr(img1, img2):
+    """calculate_psnr of the reference (utils/ssim_psnr.py:9-15): device scalar, images in [0, 1], first 3 channels."""
+    ops._check_dev(img1)
+    ops._check_dev(img2)
+    B, C, H, W = img1.shape
+    out = ops.new(img1, 1)
+    ops.call("tatt_psnr", ops.P(img1), *img1.stride(), ops.P(img2), *img2.stride(), ops.P(out), B, C, H, W, ops.stream())
+    return out.reshape(())
+
+
 class TextPriorSR(torch.nn.Module):
     """The generator together with its trainable text-prior generator, as the reference's loop composes them
     (interfaces/super_resolution.py:786-815): lr image -> parse_crnn_data -> CRNN student -> softmax prior -> SR(x, prior).
-    Gradients of the SR loss reach the recogniser through the prior."""
+    Gradients of the SR loss reach the recogniser through the prior.  With a frozen `teacher` recogniser the step also carries
+    the prior-distillation term of the reference, `sem_loss(student prior on LR, teacher prior on HR) * 100`
+    (super_resolution.py:767,879): `Trainer` adds `extra_loss(hr)` to the image loss."""
 
-    def __init__(self, sr, tpg, in_width=100):
+    def __init__(self, sr, tpg, teacher=None, in_width=100):
         super().__init__()
         self.sr, self.tpg, self.in_width = sr, tpg, in_width
+        object.__setattr__(self, "_teacher", teacher)        # frozen: deliberately NOT a registered sub-module / parameter owner
+        self._student_probs = None
+
+    def _apply(self, fn, *args, **kwargs):                 # .to(device) moves the (unregistered) teacher too
+        super()._apply(fn, *args, **kwargs)
+        if self._teacher is not None:
+            self._teacher._apply(fn, *args, **kwargs)
+        return self
 
     @property
     def block(self):
@@ -51,10 +76,27 @@ class TextPriorSR(torch.nn.Module):
     def block(self, v):
         self.sr.block = v
 
+    def _probs(self, net, img):
+        from .crnn import parse_crnn_data
+        logits = net(parse_crnn_data(img[:, :3], self.in_width))                 # (T, B, 37)
+        T, B, C = logits.shape
+        return Fh.SoftmaxRowsFn.apply(logits.reshape(T * B, C)).reshape(T, B, C)
+
     def forward(self, x):
-        from .crnn import parse_crnn_data, text_prior
-        prior = text_prior(self.tpg(parse_crnn_data(x[:, :3], self.in_width)))
+        probs = self._probs(self.tpg, x)
+        self._student_probs = probs
+        prior = probs.permute(1, 0, 2).unsqueeze(1).permute(0, 3, 1, 2)           # (B, 37, 1, T)
         return self.sr(x, prior)
+
+    def extra_loss(self, hr):
+        """Distillation term; None without a teacher.  Call after forward()."""
+        if self._teacher is None:
+            return None
+        with torch.no_grad():
+            gt = self._probs(self._teacher, hr)
+        loss = semantic_loss(self._student_probs, gt) * 100.0
+        self._student_probs = None
+        return loss
 
 
 class Trainer:
@@ -95,6 +137,9 @@ class Trainer:
         out = self.model(x, tp) if tp is not None else self.model(x)
         sr = out[0] if isinstance(out, tuple) else out
         loss = image_loss_mean(sr, hr, scale=100.0)
+        extra = self.model.extra_loss(hr) if hasattr(self.model, "extra_loss") else None
+        if extra is not None:
+            loss = loss + extra
         loss.backward()
         self.model.block = None                      # do not keep the autograd graph of this step alive
         self.flat_g.zero_()

@@ -45,7 +45,16 @@ def _worker(rank, world, port, q):
     grads = {"g": gavg}
     clipped, total = O.clip_grad_norm(grads, 0.25)
     p1, _, _ = O.adam_step(flat.p, clipped["g"], torch.zeros_like(flat.p), torch.zeros_like(flat.p), 1)
-    q.put((rank, p1.clone(), float(total), x, y))
+    # parameters start on 64-byte boundaries inside the flat buffers; the padding stays zero through the update
+    used = torch.zeros(flat.n, dtype=torch.bool)
+    per_param = []
+    for prm in flat.params:
+        off, k = flat.offsets[id(prm)]
+        assert off % FlatParams.ALIGN == 0
+        used[off:off + k] = True
+        per_param.append(p1[off:off + k].clone())
+    assert float(p1[~used].abs().max()) == 0.0 and float(flat.g[~used].abs().max()) == 0.0
+    q.put((rank, torch.cat(per_param), float(total), x, y))
     dist.barrier()
     dist.destroy_process_group()
 

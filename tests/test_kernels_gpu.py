@@ -552,3 +552,19 @@ def test_image_loss_requires_gpu():
     from tatt_amd.train import image_loss
     with pytest.raises(RuntimeError, match="GPU"):
         image_loss(torch.rand(1, 4, 8, 8), torch.rand(1, 4, 8, 8))
+
+
+def test_semantic_loss_and_psnr_kernels(dev):
+    """tatt_semantic_loss_fwd/bwd, tatt_psnr against the reference-generated vectors (tests/golden/losses.npz)."""
+    from tatt_amd.train import semantic_loss, calculate_psnr
+    z = np.load("tests/golden/losses.npz")
+    pred = torch.from_numpy(z["pred"]).to(dev).requires_grad_(True)
+    loss = semantic_loss(pred, torch.from_numpy(z["gt"]).to(dev))
+    assert abs(float(loss.detach()) - float(z["sem"])) < 1e-6
+    (loss * 3.0).backward()
+    check_close("semantic_loss_grad", pred.grad, 3.0 * torch.from_numpy(z["dpred"]), 1e-5, 1e-9)
+    a, b = torch.from_numpy(z["a"]).to(dev), torch.from_numpy(z["b"]).to(dev)
+    assert abs(float(calculate_psnr(a, b)) - float(z["psnr"])) < 1e-4
+    a_nhwc = a.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)                 # the generator's output layout
+    assert abs(float(calculate_psnr(a_nhwc, b)) - float(z["psnr"])) < 1e-4
+    assert float(calculate_psnr(a, a)) == float("inf")

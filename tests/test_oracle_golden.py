@@ -124,3 +124,13 @@ def test_tbsrn_layer_norm_is_not_nn_layernorm():
     ref = a * (x - x.mean(-1, keepdim=True)) / (x.std(-1, keepdim=True) + 1e-6) + b
     assert max_err(mine, ref) < 1e-5
     assert max_err(mine, O.layer_norm(x, a, b, 1e-6)) > 1e-3
+
+
+def test_semantic_loss_and_psnr():
+    z = np.load("tests/golden/losses.npz")
+    pred = torch.from_numpy(z["pred"]).requires_grad_(True)
+    loss = O.semantic_loss(pred, torch.from_numpy(z["gt"]))
+    loss.backward()
+    assert abs(float(loss) - float(z["sem"])) < 1e-6
+    assert max_err(pred.grad, torch.from_numpy(z["dpred"])) < 1e-8
+    assert abs(float(O.calculate_psnr(torch.from_numpy(z["a"]), torch.from_numpy(z["b"]))) - float(z["psnr"])) < 1e-4

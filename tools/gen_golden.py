@@ -14,6 +14,7 @@ Cases (SURVEY.md §8c "Fixtures to generate"):
   qgru           query-GRU batch-axis quirk at B=1,2,4
   large_tile     32x128 LR, width=256,height=64, STN=False, eval B=1
   tps            TPS grid + sampler with out-of-range control points
+  losses         SemanticLoss (value + gradient) and calculate_psnr
   crnn_b3        CRNN text-prior generator (bicubic+luminance input, eval / train logits, parameter gradients), B=3
   tbsrn_b2       TBSRN variant at LR 16x256 (the only size the reference runs): eval forward + train fwd/bwd, B=2
 """
@@ -336,6 +337,29 @@ def case_crnn(ref, report):
                         sd_summary=np.stack([summarize(v.float()) for v in fresh.values()]))
 
 
+def case_losses(ref, report):
+    """SemanticLoss (loss/semantic_loss.py) on random student / teacher priors with its gradient, calculate_psnr (utils/ssim_psnr.py)."""
+    ref_image_loss()                                   # installs the PIL / torchvision stubs the loss modules import
+    from loss.semantic_loss import SemanticLoss
+    g = torch.Generator().manual_seed(13)
+    pred = torch.softmax(torch.randn(4, 26, 37, generator=g), -1).requires_grad_(True)
+    gt = torch.softmax(2 * torch.randn(4, 26, 37, generator=g), -1)
+    loss = SemanticLoss()(pred, gt)
+    loss.backward()
+    o_pred = pred.detach().clone().requires_grad_(True)
+    o = O.semantic_loss(o_pred, gt)
+    o.backward()
+    a, b = torch.rand(3, 4, 32, 128, generator=g), torch.rand(3, 4, 32, 128, generator=g)
+    # reference utils/ssim_psnr.py:9-15, restated inline (the module imports cv2 at load)
+    mse = ((a[:, :3] * 255 - b[:, :3] * 255) ** 2).mean()
+    psnr = 20 * torch.log10(255.0 / torch.sqrt(mse))
+    report.append("losses         semantic loss ref %.7f oracle %.7f  max|dgrad| %.2e ; psnr ref %.5f oracle %.5f"
+                  % (float(loss), float(o), maxdiff(pred.grad, o_pred.grad), float(psnr), float(O.calculate_psnr(a, b))))
+    assert abs(float(loss) - float(o)) < 1e-6 and maxdiff(pred.grad, o_pred.grad) < 1e-8
+    np.savez_compressed(os.path.join(OUT, "losses.npz"), pred=np_(pred), gt=np_(gt), sem=np.float64(float(loss)),
+                        dpred=np_(pred.grad), a=np_(a), b=np_(b), psnr=np.float64(float(psnr)))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = import_reference()
@@ -352,6 +376,7 @@ def main():
     case_tps(ref, report)
     case_tbsrn(ref, report)
     case_crnn(ref, report)
+    case_losses(ref, report)
     with open(os.path.join(OUT, "REPORT.txt"), "w") as f:
         f.write("\n".join(report) + "\n")
     print("\n".join(report))
