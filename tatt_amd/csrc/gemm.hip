@@ -425,13 +425,155 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(GemmP p, int cvec) {
     }
 }
 
+// Narrow-N variant of the aligned fast path: 128 x 32 tile (4 waves stacked along M) for N % 64 == 32 -- the per-head products
+// of TBSRN's self-attention (d_k = 32: P.V, P^T.dO, dS.K, dS^T.Q; reference model/tbsrn.py:130-151).  Same loaders and LDS
+// layouts as gemm_fast_kernel with twice the A rows per chunk; no K-concat / im2col / row sums.
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(256) void gemm_fast32_kernel(GemmP p, int cvec) {
+    constexpr int TA = AKC ? 128 * 20 : 16 * 160;            // [128 rows][20] or [16 k][160]
+    constexpr int TB = BKC ? 32 * 20 : 16 * 96;              // [32 cols][20]  or [16 k][96]
+    __shared__ __attribute__((aligned(16))) float smem[(2 * TA + 2 * TB) > 4 * 32 * 36 ? (2 * TA + 2 * TB) : 4 * 32 * 36];
+    float* AsB = smem;
+    float* BsB = smem + 2 * TA;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int tiles_n = p.N >> 5;
+    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+    const int m0 = tile_m * 128, n0 = tile_n * 32;
+    const int z = blockIdx.z;
+    const int nchunks = p.K >> 4;
+    int c_begin = 0, c_end = nchunks;
+    if (p.splitk > 1) {
+        c_begin = blockIdx.y * p.chunks_per_split;
+        c_end = min(nchunks, c_begin + p.chunks_per_split);
+    }
+    const float* ap[2]; const float* bp;
+    long astep, bstep;
+    int aslot[2], bslot;
+    const bool bload = t < 128;
+    if (AKC) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int row = (t >> 2) + 64 * q, k4 = (t & 3) * 4;
+            ap[q] = p.A + (long)z * p.bsA + (long)min(m0 + row, p.M - 1) * p.sam + k4 + 16L * c_begin;
+            aslot[q] = row * 20 + k4;
+        }
+        astep = 16;
+    } else {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int idx = t + 256 * q, k = idx >> 5, c4 = (idx & 31) * 4;
+            ap[q] = p.A + (long)z * p.bsA + (long)(16 * c_begin + k) * p.sak + m0 + c4;
+            aslot[q] = k * 160 + c4;
+        }
+        astep = 16 * p.sak;
+    }
+    if (BKC) {
+        const int row = (t & 127) >> 2, k4 = (t & 3) * 4;
+        bp = p.B + (long)z * p.bsB + (long)(n0 + row) * p.sbn + k4 + 16L * c_begin;
+        bstep = 16; bslot = row * 20 + k4;
+    } else {
+        const int k = (t & 127) >> 3, c4 = (t & 7) * 4;
+        bp = p.B + (long)z * p.bsB + (long)(16 * c_begin + k) * p.sbk + n0 + c4;
+        bstep = 16 * p.sbk; bslot = k * 96 + c4;
+    }
+    f32x4 ra[2], rb = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto load_chunk = [&]() {
+        ra[0] = *reinterpret_cast<const f32x4*>(ap[0]);
+        ra[1] = *reinterpret_cast<const f32x4*>(ap[1]);
+        if (bload) rb = *reinterpret_cast<const f32x4*>(bp);
+        ap[0] += astep; ap[1] += astep; bp += bstep;
+    };
+    auto store_chunk = [&](int buf) {
+        *reinterpret_cast<f32x4*>(AsB + buf * TA + aslot[0]) = ra[0];
+        *reinterpret_cast<f32x4*>(AsB + buf * TA + aslot[1]) = ra[1];
+        if (bload) *reinterpret_cast<f32x4*>(BsB + buf * TB + bslot) = rb;
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const int arow = wave * 32 + (lane & 31), bcol = lane & 31, kq = lane >> 5;
+    if (c_begin < c_end) {
+        load_chunk();
+        store_chunk(0);
+        __syncthreads();
+        for (int c = c_begin; c < c_end; ++c) {
+            const int buf = (c - c_begin) & 1;
+            if (c + 1 < c_end) load_chunk();
+            const float* As = AsB + buf * TA;
+            const float* Bs = BsB + buf * TB;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f32x4 va, vb;
+                if (AKC) va = *reinterpret_cast<const f32x4*>(As + arow * 20 + 8 * h + 4 * kq);
+                else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) va[u] = As[(8 * h + 4 * kq + u) * 160 + arow];
+                }
+                if (BKC) vb = *reinterpret_cast<const f32x4*>(Bs + bcol * 20 + 8 * h + 4 * kq);
+                else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) vb[u] = Bs[(8 * h + 4 * kq + u) * 96 + bcol];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(va[u], vb[u], acc, 0, 0, 0);
+            }
+            if (c + 1 < c_end) store_chunk(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    const bool part = p.splitk > 1;
+    if (part || cvec) {
+        float* T = smem + wave * (32 * 36);
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+            T[((reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) * 36 + (lane & 31)] = acc[reg];
+        wave_lds_sync();
+        const int c4 = lane & 7;
+        const int j = n0 + 4 * c4;
+        f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (!part && p.bias) b4 = *reinterpret_cast<const f32x4*>(p.bias + (long)z * p.bsBias + j);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = (lane >> 3) + 8 * q;
+            const long i = m0 + wave * 32 + r;
+            if (i >= p.M) continue;
+            f32x4 v = *reinterpret_cast<const f32x4*>(T + r * 36 + 4 * c4);
+            if (part) {
+                *reinterpret_cast<f32x4*>(p.partial + ((long)(z * p.splitk + blockIdx.y) * p.M + i) * p.N + j) = v;
+            } else {
+                float* dst = p.C + (long)z * p.bsC + i * p.scm + j;
+                f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (p.beta != 0.f) o = *reinterpret_cast<const f32x4*>(dst);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = apply_act(p.alpha * (v[e] + b4[e]), p.act) + p.beta * o[e];
+                *reinterpret_cast<f32x4*>(dst) = v;
+            }
+        }
+        return;
+    }
+    const int j = n0 + (lane & 31);
+    float* C = p.C + (long)z * p.bsC;
+    const float bj = p.bias ? p.bias[(long)z * p.bsBias + j] : 0.f;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const long i = m0 + wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        if (i >= p.M) continue;
+        float v = apply_act(p.alpha * (acc[reg] + bj), p.act);
+        const long off = i * p.scm + j * p.scn;
+        if (p.beta != 0.f) v += p.beta * C[off];
+        C[off] = v;
+    }
+}
+
 static const bool g_gemm_fast = [] { const char* e = getenv("TATT_GEMM_FAST"); return !(e && e[0] == '0'); }();   // A/B switch
 static inline bool al16(const void* q) { return ((uintptr_t)q & 15) == 0; }
 // 0 = launched, -1 = shape/alignment not eligible (caller uses the general kernel)
 static int try_gemm_fast(const GemmP& p, int Z, hipStream_t st) {
-    if ((p.N & 63) || (p.K & 15)) return -1;
+    const bool narrow = (p.N & 63) == 32;                     // 128 x 32 tiles
+    if ((!narrow && (p.N & 63)) || (p.K & 15)) return -1;
     const bool akc = p.sak == 1, amc = p.sam == 1 && !akc;
-    if ((p.M & 63) && !akc) return -1;                 // ragged M only when A is read row by row
+    if ((p.M & (narrow ? 127 : 63)) && !akc) return -1;       // ragged M only when A is read row by row
+    if (narrow && (p.A2 || p.rowsum)) return -1;
     const bool bkc = p.sbk == 1 && p.sbn != 1, bnc = p.sbn == 1;
     if (!(akc || amc) || !(bkc || bnc)) return -1;
     if (!al16(p.A) || !al16(p.B) || (p.bsA & 3) || (p.bsB & 3)) return -1;
@@ -442,6 +584,14 @@ static int try_gemm_fast(const GemmP& p, int Z, hipStream_t st) {
     if (p.rowsum && akc) return -1;
     if (p.splitk > 1 && !al16(p.partial)) return -1;
     const int cvec = (p.scn == 1 && !(p.scm & 3) && al16(p.C) && !(p.bsC & 3) && (!p.bias || (al16(p.bias) && !(p.bsBias & 3)))) ? 1 : 0;
+    if (narrow) {
+        dim3 grid32(cdiv(p.M, 128) * (p.N >> 5), p.splitk, Z);
+        if (akc && bkc) hipLaunchKernelGGL((gemm_fast32_kernel<true, true>), grid32, dim3(256), 0, st, p, cvec);
+        else if (akc) hipLaunchKernelGGL((gemm_fast32_kernel<true, false>), grid32, dim3(256), 0, st, p, cvec);
+        else if (bkc) hipLaunchKernelGGL((gemm_fast32_kernel<false, true>), grid32, dim3(256), 0, st, p, cvec);
+        else hipLaunchKernelGGL((gemm_fast32_kernel<false, false>), grid32, dim3(256), 0, st, p, cvec);
+        return LAUNCH_CHECK();
+    }
     dim3 grid(cdiv(p.M, 64) * (p.N >> 6), p.splitk, Z), block(256);
 #define GF_LAUNCH(A_, B_, C_) hipLaunchKernelGGL((gemm_fast_kernel<A_, B_, C_, false>), grid, block, 0, st, p, cvec)
     if (cat) { if (bkc) GF_LAUNCH(true, true, true); else GF_LAUNCH(true, false, true); }

@@ -104,6 +104,23 @@ def test_gemm_aligned_fast_path(dev):
     assert float((yr[1248:] - 7.0).abs().max()) == 0.0
     dxr = ops.linear_bwd_input(yr[:1248].contiguous(), Wr.to(dev))
     check_close("fast_ragged_bwd_input", dxr, (yr[:1248].double().cpu() @ Wr.double()).float(), 2e-4, 2e-4)
+    # narrow outputs (N = 32: the per-head products of TBSRN's attention) take the 128 x 32 tile variant: all four operand
+    # orientations, batched with strides, ragged M for row-major A
+    Z = 2
+    A, B = R(Z, 256, 64, seed=12), R(Z, 64, 32, seed=13)
+    ref = (A.double() @ B.double()).float()
+    for a_t in (False, True):
+        for b_t in (False, True):
+            Ad = (A.transpose(1, 2).contiguous() if a_t else A).to(dev)
+            Bd = (B.transpose(1, 2).contiguous() if b_t else B).to(dev)
+            C = torch.zeros(Z, 256, 32, device=dev)
+            ops.gemm(Ad, *((1, 256) if a_t else (64, 1)), Bd, *((1, 64) if b_t else (32, 1)), C, 32, 1, 256, 32, 64,
+                     Z=Z, bsA=256 * 64, bsB=64 * 32, bsC=256 * 32, alpha=0.5)
+            check_close("fast32_%d%d" % (a_t, b_t), C, 0.5 * ref, 2e-4, 2e-4)
+    C = torch.full((Z, 200 + 8, 32), 3.0, device=dev)
+    ops.gemm(A.to(dev), 64, 1, B.to(dev), 32, 1, C, 32, 1, 200, 32, 64, Z=Z, bsA=256 * 64, bsB=64 * 32, bsC=208 * 32)
+    check_close("fast32_ragged", C[:, :200], ref[:, :200], 2e-4, 2e-4)
+    assert float((C[:, 200:] - 3.0).abs().max()) == 0.0
     Z = 3
     A, B = R(Z, 128, 64, seed=7), R(Z, 64, 128, seed=8)
     C = torch.zeros(Z, 128, 128, device=dev)
