@@ -416,7 +416,7 @@ def test_attn_dropout_fwd_bwd_consistent(dev):
     check_close("attn_dropout", got, w[0].sum(0), rtol=1e-4, atol=1e-4)
     zeros = float((w == 0).float().mean())
     assert zeros < 0.01          # head-averaged weights are rarely exactly zero; but mask must have hit some heads
-    assert abs(float(w.sum()) / Lq - 1.0) < 0.1
+    assert abs(float(w.detach().sum()) / Lq - 1.0) < 0.1
 
 
 # ------------------------------------------------------------------------------------------- TPS

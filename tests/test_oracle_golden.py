@@ -131,6 +131,6 @@ def test_semantic_loss_and_psnr():
     pred = torch.from_numpy(z["pred"]).requires_grad_(True)
     loss = O.semantic_loss(pred, torch.from_numpy(z["gt"]))
     loss.backward()
-    assert abs(float(loss) - float(z["sem"])) < 1e-6
+    assert abs(float(loss.detach()) - float(z["sem"])) < 1e-6
     assert max_err(pred.grad, torch.from_numpy(z["dpred"])) < 1e-8
     assert abs(float(O.calculate_psnr(torch.from_numpy(z["a"]), torch.from_numpy(z["b"]))) - float(z["psnr"])) < 1e-4
