@@ -98,3 +98,16 @@ def test_c_abi_exports_every_declared_symbol():
         if f.endswith(".hip"):
             defined |= set(re.findall(r"TATT_API\s+int\s+(\w+)", open(os.path.join(ROOT, "tatt_amd", "csrc", f)).read()))
     assert defined == set(protos), defined ^ set(protos)
+
+
+def test_bench_cpu_baseline_leg_runs_without_a_gpu():
+    """`bench.py --cpu-baseline-only` (the child process of the cpu_baseline leg): bounded thread count, JSON contract."""
+    import json
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-baseline-only", "--arch", "tsrn", "--cpu-batch", "2"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert set(d) == {"value", "unit", "cores", "kind", "sample"}
+    assert d["kind"] == "port" and d["unit"] == "LR images/s" and d["value"] > 0 and 1 <= d["cores"] <= 32
