@@ -470,6 +470,66 @@ def calculate_psnr(img1: Tensor, img2: Tensor) -> Tensor:
     return 20 * torch.log10(255.0 / torch.sqrt(mse))
 
 
+# ----------------------------------------------------------------------------
+# SURVEY.md 8f-2 (next row, oracle side only so far): SSIM / TRI_SSIM losses and the rotation augmentation of the shipped recipe
+# ----------------------------------------------------------------------------
+def gaussian_window(size: int = 11, sigma: float = 1.5) -> Tensor:
+    """create_window -- utils/ssim_psnr.py:28-37: normalised 1-D Gaussian, outer product -> (size, size)."""
+    g = torch.tensor([math.exp(-(x - size // 2) ** 2 / float(2 * sigma ** 2)) for x in range(size)])
+    g = g / g.sum()
+    return torch.outer(g, g).float()
+
+
+def _local_mean(x: Tensor, win: Tensor) -> Tensor:
+    """Depthwise 'same' correlation with zero padding: F.conv2d(x, window, padding=ws//2, groups=C) (utils/ssim_psnr.py:77)."""
+    C = x.shape[1]
+    return F.conv2d(x, win.expand(C, 1, *win.shape).contiguous(), padding=win.shape[0] // 2, groups=C)
+
+
+def ssim(img1: Tensor, img2: Tensor, size_average: bool = True) -> Tensor:
+    """SSIM.forward + _ssim -- utils/ssim_psnr.py:212-228,76-97: on the first 3 channels only (the mask channel is dropped)."""
+    img1, img2 = img1[:, :3], img2[:, :3]
+    win = gaussian_window()
+    mu1, mu2 = _local_mean(img1, win), _local_mean(img2, win)
+    s1 = _local_mean(img1 * img1, win) - mu1 * mu1
+    s2 = _local_mean(img2 * img2, win) - mu2 * mu2
+    s12 = _local_mean(img1 * img2, win) - mu1 * mu2
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    m = ((2 * mu1 * mu2 + C1) * (2 * s12 + C2)) / ((mu1 * mu1 + mu2 * mu2 + C1) * (s1 + s2 + C2))
+    return m.mean() if size_average else m.mean((1, 2, 3))
+
+
+def tri_ssim(img1: Tensor, img2: Tensor, img3: Tensor, size_average: bool = True) -> Tensor:
+    """_tri_ssim -- utils/ssim_psnr.py:99-129 (used as (1 - tri_ssim(sr_rot, sr, hr).mean()) * 10, super_resolution.py:910-914)."""
+    win = gaussian_window()
+    mu = [_local_mean(i, win) for i in (img1, img2, img3)]
+    sq = [_local_mean(i * i, win) - m * m for i, m in zip((img1, img2, img3), mu)]
+    cross = lambda a, b, ma, mb: _local_mean(a * b, win) - ma * mb               # noqa: E731
+    s12, s23, s31 = cross(img1, img2, mu[0], mu[1]), cross(img2, img3, mu[1], mu[2]), cross(img3, img1, mu[2], mu[0])
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    m = ((mu[0] * mu[1] + mu[1] * mu[2] + mu[2] * mu[0] + C1) * (s12 + s23 + s31 + C2)) / \
+        ((mu[0] ** 2 + mu[1] ** 2 + mu[2] ** 2 + C1) * (sq[0] + sq[1] + sq[2] + C2))
+    return m.mean() if size_average else m.mean((1, 2, 3))
+
+
+def affine_grid(theta: Tensor, H: int, W: int) -> Tensor:
+    """F.affine_grid(theta (N,2,3), (N,C,H,W)), align_corners=False: base coordinates (2i+1)/size - 1."""
+    xs = (2 * torch.arange(W, dtype=torch.float32) + 1) / W - 1
+    ys = (2 * torch.arange(H, dtype=torch.float32) + 1) / H - 1
+    base = torch.stack([xs.expand(H, W), ys.unsqueeze(1).expand(H, W), torch.ones(H, W)], -1)      # (H,W,3)
+    return torch.einsum("hwk,njk->nhwj", base, theta)
+
+
+def torch_distortion(img: Tensor, arcs: Tensor, rand_offs: Tensor, off_range: float = 0.2) -> Tensor:
+    """torch_distortion / TextSR.torch_rotate_img -- model/__init__.py:4-29, interfaces/super_resolution.py:126-157: rotation by
+    `arcs` with the aspect ratio jittered by `rand_offs`, bilinear resampling with zero padding."""
+    N, C, H, W = img.shape
+    rm = H / float(W) + rand_offs * off_range * 2 - off_range
+    cos, sin, zero = torch.cos(arcs), torch.sin(arcs), torch.zeros_like(arcs)
+    theta = torch.stack([cos, sin * rm, zero, -sin / rm, cos, zero], 1).reshape(N, 2, 3)
+    return grid_sample_bilinear(img, affine_grid(theta, H, W))
+
+
 def clip_grad_norm(grads: Dict[str, Tensor], max_norm: float = 0.25) -> Tuple[Dict[str, Tensor], Tensor]:
     """torch.nn.utils.clip_grad_norm_ (global L2) -- interfaces/super_resolution.py:1083-1084."""
     total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())).float()

@@ -134,3 +134,14 @@ def test_semantic_loss_and_psnr():
     assert abs(float(loss.detach()) - float(z["sem"])) < 1e-6
     assert max_err(pred.grad, torch.from_numpy(z["dpred"])) < 1e-8
     assert abs(float(O.calculate_psnr(torch.from_numpy(z["a"]), torch.from_numpy(z["b"]))) - float(z["psnr"])) < 1e-4
+
+
+def test_ssim_tri_ssim_and_rotation():
+    """SURVEY.md 8f-2 (oracle side; kernels are next round): SSIM / TRI_SSIM and torch_distortion against reference vectors."""
+    z = np.load("tests/golden/losses.npz")
+    a, b, c = (torch.from_numpy(z[k]) for k in ("a", "b", "c"))
+    assert abs(float(O.ssim(a, b)) - float(z["ssim"])) < 1e-6
+    assert max_err(O.ssim(a, b, size_average=False), torch.from_numpy(z["ssim_per_sample"])) < 1e-6
+    assert abs(float(O.tri_ssim(a, b, c)) - float(z["tri_ssim"])) < 1e-6
+    d = O.torch_distortion(a, torch.from_numpy(z["arcs"]), torch.from_numpy(z["offs"]))
+    assert max_err(d[:, :, ::4, ::4], torch.from_numpy(z["distorted"])) < 1e-5

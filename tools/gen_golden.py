@@ -353,11 +353,27 @@ def case_losses(ref, report):
     # reference utils/ssim_psnr.py:9-15, restated inline (the module imports cv2 at load)
     mse = ((a[:, :3] * 255 - b[:, :3] * 255) ** 2).mean()
     psnr = 20 * torch.log10(255.0 / torch.sqrt(mse))
+    # 8f-2 (oracle side): SSIM / TRI_SSIM (utils/ssim_psnr.py needs only IPython, already stubbed) and torch_distortion
+    from utils import ssim_psnr as sp
+    from model import torch_distortion as ref_distort
+    c = torch.rand(3, 4, 32, 128, generator=g)
+    arcs = (torch.rand(3, generator=g) - 0.5) * 0.2
+    offs = torch.rand(3, generator=g)
+    s_ref, t_ref = sp.SSIM()(a, b), sp.TRI_SSIM()(a, b, c)
+    s_ref_b = sp.SSIM(size_average=False)(a, b)
+    d_ref = ref_distort(a, arcs, offs)
+    ds = max(abs(float(s_ref) - float(O.ssim(a, b))), abs(float(t_ref) - float(O.tri_ssim(a, b, c))),
+             maxdiff(s_ref_b, O.ssim(a, b, size_average=False)))
+    dd = maxdiff(d_ref, O.torch_distortion(a, arcs, offs))
+    report.append("ssim/rotate    |ssim, tri_ssim diff| %.2e ; torch_distortion max|d| %.2e" % (ds, dd))
+    assert ds < 1e-6 and dd < 1e-5
+    extra = dict(c=np_(c), arcs=np_(arcs), offs=np_(offs), ssim=np.float64(float(s_ref)), tri_ssim=np.float64(float(t_ref)),
+                 ssim_per_sample=np_(s_ref_b), distorted=np_(d_ref[:, :, ::4, ::4]))
     report.append("losses         semantic loss ref %.7f oracle %.7f  max|dgrad| %.2e ; psnr ref %.5f oracle %.5f"
                   % (float(loss), float(o), maxdiff(pred.grad, o_pred.grad), float(psnr), float(O.calculate_psnr(a, b))))
     assert abs(float(loss) - float(o)) < 1e-6 and maxdiff(pred.grad, o_pred.grad) < 1e-8
     np.savez_compressed(os.path.join(OUT, "losses.npz"), pred=np_(pred), gt=np_(gt), sem=np.float64(float(loss)),
-                        dpred=np_(pred.grad), a=np_(a), b=np_(b), psnr=np.float64(float(psnr)))
+                        dpred=np_(pred.grad), a=np_(a), b=np_(b), psnr=np.float64(float(psnr)), **extra)
 
 
 def main():
