@@ -1,6 +1,7 @@
 /*
  * tatt_hip.h -- C ABI of libtatt_hip.so, the MI355X (gfx950) kernels of the TATT super-resolution
- * hot path (TSRN backbone + TP interpreter + STN/TPS sampler, forward and backward).
+ * hot path (TSRN backbone + TP interpreter + STN/TPS sampler, the TBSRN variant, the training-step losses / optimiser and the
+ * CRNN text-prior generator in front of the path; forward and backward).
  *
  * Every entry point takes plain DEVICE pointers, sizes/strides and a hipStream_t; none allocates,
  * synchronises or touches host memory, so a call sequence can be captured in a hipGraph.  Return
@@ -10,7 +11,7 @@
  *
  * The reference (mjq11302010044/TATT) is pure PyTorch, so there is no FFI upstream; each function
  * names the torch.nn call site it replaces (file:line in the reference).  The host-side mirror of the
- * reference's nn.Module surface (tatt_amd/tsrn.py) is the only caller.
+ * reference's nn.Module surface (tatt_amd/tsrn.py, tbsrn.py, crnn.py, train.py) is the only caller.
  *
  * Activation codes: 0 none, 1 relu, 2 mish (x*tanh(softplus(x)), model/tsrn.py:1056-1064), 3 tanh.
  */
