@@ -154,8 +154,9 @@ int tatt_maxpool_bwd(const float* in, const float* dout, float* din, int B, int 
  * with dy as x is the backward (model/transformer_v2.py:27,456,461-462,789,795-797) */
 int tatt_dropout(const float* x, float* y, long n, float p, const unsigned long long* seed, unsigned site,
                  hipStream_t st);
-/* advance the device-resident seed word (one call per training step; graph-replay safe) */
-int tatt_bump_seed(unsigned long long* seed, hipStream_t st);
+/* advance the device-resident seed word and (snap != NULL) copy the new value to `snap`: one call per TRAINING FORWARD; every
+   dropout site of that forward and of its backward reads the snapshot (graph-replay safe; several forwards may be in flight) */
+int tatt_bump_seed(unsigned long long* seed, unsigned long long* snap, hipStream_t st);
 /* dst[i0*d0+i1*d1+i2*d2+i3*d3] = src[i0*s0+...] + beta*dst  (layout changes, parameter gathers) */
 int tatt_copy4d(const float* src, float* dst, int n0, int n1, int n2, int n3, long s0, long s1, long s2,
                 long s3, long d0, long d1, long d2, long d3, float beta, hipStream_t st);

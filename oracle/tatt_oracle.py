@@ -587,3 +587,10 @@ def train_step(sd: SD, x: Tensor, text_emb: Optional[Tensor], hr: Tensor, *, tat
         new_sd[k] = p
         opt_state[k] = (m, v)
     return loss.detach(), grads, new_sd, opt_state, {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()}, total
+
+
+def train_step_fp64(sd: SD, x: Tensor, text_emb: Optional[Tensor], hr: Tensor, **kw):
+    """`train_step` evaluated in float64 (same graph, same weights and inputs widened exactly): the yardstick that separates
+    implementation error from the conditioning of the fp32 computation itself (tests: ||g_hip - g_64|| vs ||g_ref32 - g_64||)."""
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    return train_step(sd64, x.double(), None if text_emb is None else text_emb.double(), hr.double(), **kw)

@@ -219,9 +219,15 @@ TATT_API int tatt_dropout(const float* x, float* y, long n, float p, const unsig
     hipLaunchKernelGGL(dropout_kernel, EW_GRID(n), 0, st, x, y, n, p, seed, site);
     return LAUNCH_CHECK();
 }
-__global__ void bump_seed_kernel(unsigned long long* seed) { seed[0] += 0x632BE59BD9B4E019ull; }
-TATT_API int tatt_bump_seed(unsigned long long* seed, hipStream_t st) {
-    hipLaunchKernelGGL(bump_seed_kernel, dim3(1), dim3(1), 0, st, seed);
+// seed word += odd constant; `snap` (optional) receives the new value: a training forward bumps the device-resident word once and
+// hands every dropout site of THAT forward (and of its backward, whenever it runs) the private snapshot.
+__global__ void bump_seed_kernel(unsigned long long* seed, unsigned long long* snap) {
+    const unsigned long long v = seed[0] + 0x632BE59BD9B4E019ull;
+    seed[0] = v;
+    if (snap) snap[0] = v;
+}
+TATT_API int tatt_bump_seed(unsigned long long* seed, unsigned long long* snap, hipStream_t st) {
+    hipLaunchKernelGGL(bump_seed_kernel, dim3(1), dim3(1), 0, st, seed, snap);
     return LAUNCH_CHECK();
 }
 
@@ -281,27 +287,46 @@ TATT_API int tatt_l2norm(const float* g, long n, float* out, double* ws, hipStre
     hipLaunchKernelGGL(sumsq_stage2, dim3(1), dim3(256), 0, st, ws, G, out);
     return LAUNCH_CHECK();
 }
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float coef, float b1, float b2, float a1, float rs2,
+                                         float eps) {
+    const float gi = g * coef;
+    const float mi = b1 * m + (1.f - b1) * gi;
+    const float vi = b2 * v + (1.f - b2) * gi * gi;
+    m = mi; v = vi;
+    p -= a1 * mi / (sqrtf(vi) * rs2 + eps);
+}
+// 16 bytes per lane and array: the four flat buffers start 256-byte aligned and every segment handed in starts on a 64-byte
+// boundary (FlatParams.ALIGN); a ragged tail (n % 4) is finished element-wise by the last thread.
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
                             const float* __restrict__ gnorm, float max_norm, float gscale,
                             const long long* __restrict__ step) {
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long n4 = n >> 2;
+    if (i > n4) return;
     const double t = (double)step[0];
     const float bc1 = (float)(1.0 - pow((double)b1, t)), bc2 = (float)(1.0 - pow((double)b2, t));
     float coef = gscale;
     if (max_norm > 0.f) { float c = max_norm / (gnorm[0] * gscale + 1e-6f); coef *= c < 1.f ? c : 1.f; }
-    const float gi = g[i] * coef;
-    const float mi = b1 * m[i] + (1.f - b1) * gi;
-    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-    m[i] = mi; v[i] = vi;
-    p[i] -= (lr / bc1) * mi / (sqrtf(vi) / sqrtf(bc2) + eps);
+    const float a1 = lr / bc1, rs2 = 1.f / sqrtf(bc2);
+    if (i < n4) {
+        float4 pp = ((float4*)p)[i], mm = ((float4*)m)[i], vv = ((float4*)v)[i];
+        const float4 gg = ((const float4*)g)[i];
+        adam_one(pp.x, gg.x, mm.x, vv.x, coef, b1, b2, a1, rs2, eps);
+        adam_one(pp.y, gg.y, mm.y, vv.y, coef, b1, b2, a1, rs2, eps);
+        adam_one(pp.z, gg.z, mm.z, vv.z, coef, b1, b2, a1, rs2, eps);
+        adam_one(pp.w, gg.w, mm.w, vv.w, coef, b1, b2, a1, rs2, eps);
+        ((float4*)p)[i] = pp; ((float4*)m)[i] = mm; ((float4*)v)[i] = vv;
+    } else {
+        for (long k = n4 << 2; k < n; ++k) adam_one(p[k], g[k], m[k], v[k], coef, b1, b2, a1, rs2, eps);
+    }
 }
-// gnorm: device float = ||g||_2 of the UNSCALED buffer; gscale: constant pre-scale (1/world_size after a sum
-// all-reduce); step: device int64 holding the 1-based step count.
+// gnorm: device float = ||g||_2 of the UNSCALED buffer the clip refers to (a parameter group of its own may pass max_norm = 0:
+// no clipping); gscale: constant pre-scale (1/world_size after a sum all-reduce); step: device int64 holding the 1-based step count.
 TATT_API int tatt_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
                             float eps, const float* gnorm, float max_norm, float gscale, const long long* step,
                             hipStream_t st) {
-    hipLaunchKernelGGL(adam_kernel, EW_GRID(n), 0, st, p, g, m, v, n, lr, b1, b2, eps, gnorm, max_norm, gscale, step);
+    if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return 1001;      // segments must be 16-byte aligned
+    hipLaunchKernelGGL(adam_kernel, EW_GRID((n >> 2) + 1), 0, st, p, g, m, v, n, lr, b1, b2, eps, gnorm, max_norm, gscale, step);
     return LAUNCH_CHECK();
 }

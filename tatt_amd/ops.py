@@ -358,8 +358,8 @@ def dropout(x, p, seed, site):
     return y
 
 
-def bump_seed(seed):
-    call("tatt_bump_seed", P(seed), stream())
+def bump_seed(seed, snap=None):
+    call("tatt_bump_seed", P(seed), P(snap), stream())
 
 
 def copy4d(src, dst, sizes, sstr, dstr, beta=0.0):

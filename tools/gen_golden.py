@@ -17,6 +17,9 @@ Cases (SURVEY.md §8c "Fixtures to generate"):
   losses         SemanticLoss (value + gradient) and calculate_psnr
   crnn_b3        CRNN text-prior generator (bicubic+luminance input, eval / train logits, parameter gradients), B=3
   tbsrn_b2       TBSRN variant at LR 16x256 (the only size the reference runs): eval forward + train fwd/bwd, B=2
+  large_train_b2 32x128 LR (BASELINE configs[4] geometry), STN=False, train fwd/bwd, B=2
+  fp64_error_bars  per-tensor distance of the reference's fp32 gradients from the fp64 gradients (tatt_train_b4 case)
+  bench_losses   first-step losses of bench.py's own model/batch (dropout off), by the reference
 """
 import os
 import sys
@@ -31,6 +34,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 from _ref_import import import_reference  # noqa: E402
 from oracle import tatt_oracle as O  # noqa: E402
 from oracle.fixtures import randomize_state_dict, summarize, make_inputs  # noqa: E402
+from tests.util import STRUCTURAL_ZERO_GRAD  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
 torch.set_num_threads(8)
@@ -376,6 +380,110 @@ def case_losses(ref, report):
                         dpred=np_(pred.grad), a=np_(a), b=np_(b), psnr=np.float64(float(psnr)), **extra)
 
 
+def case_train_large(ref, report):
+    """BASELINE.json configs[4] geometry: TSRN_TL_TRANS(2, 256, 64, STN=False) on LR 32x128, train-mode BN, every nn.Dropout in eval
+    mode, B = 2: SR, loss, gradient fingerprints (+ a few complete small gradients), BatchNorm running statistics."""
+    kw = dict(scale_factor=2, width=256, height=64, STN=False, mask=True, srb_nums=5, hidden_units=32)
+    m = build_ref(ref, "TSRN_TL_TRANS", **kw)
+    m.train()
+    set_dropout_eval(m)
+    sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x, tp, hr = make_inputs(2, 32, 128, seed=11)
+    loss_mod = ref_image_loss()
+    sr, mid = m(x, tp)
+    loss = loss_mod(sr, hr).mean() * 100
+    m.zero_grad()
+    loss.backward()
+    grads = {k: (p.grad.detach().clone() if p.grad is not None else None) for k, p in m.named_parameters()}
+    o_loss, o_grads, o_sd1, _, o_out, o_total = O.train_step(sd0, x, tp, hr, tatt=True, stn=False)
+    dsr = maxdiff(sr, o_out["sr"])
+    worst, none_keys = 0.0, []
+    scale = max(float(g.abs().max()) for g in grads.values() if g is not None)
+    for k, g in grads.items():
+        if g is None:
+            assert o_grads[k] is None, k
+            none_keys.append(k)
+            continue
+        if STRUCTURAL_ZERO_GRAD.match(k):          # conv bias in front of a BatchNorm: mathematically zero gradient, pure round-off
+            assert float(g.abs().max()) < 1e-4 * scale and float(o_grads[k].abs().max()) < 1e-4 * scale, k
+            continue
+        rel = float((g - o_grads[k]).norm() / (g.norm() + 1e-6 * scale * g.numel() ** 0.5))
+        worst = max(worst, rel)
+        assert rel < 5e-3, (k, rel)
+    report.append("large_train_b2 loss ref %.6f oracle %.6f  max|dsr| %.3e  worst rel grad err %.3e ; %d params without grad"
+                  % (float(loss), float(o_loss), dsr, worst, len(none_keys)))
+    assert abs(float(loss) - float(o_loss)) < 1e-5 * float(loss) and dsr < 2e-5
+    keys = [k for k in grads if grads[k] is not None]
+    sd1 = m.state_dict()
+    save = dict(x=np_(x), tp=np_(tp), hr=np_(hr), sr=np_(sr), loss=np.float64(float(loss)),
+                pr_weights=np_(mid["pr_weights"][:, ::16]), tp_map=np_(mid["trans_feat"][:, :4]),
+                grad_keys=np.array(keys), none_keys=np.array(none_keys),
+                grad_summary=np.stack([summarize(grads[k]) for k in keys]),
+                bn_mean=np_(sd1["block4.bn1.running_mean"]), bn_var=np_(sd1["block4.bn1.running_var"]))
+    for k in ("block1.1.weight", "infoGen.fc_in.weight", "block4.gru1.gru.weight_hh_l0", "block4.gru2.gru.weight_ih_l0_reverse",
+              "block8.1.bias", "block2.bn1.weight", "infoGen.transformer.decoder.layers.1.norm3.weight",
+              "infoGen.transformer.gru_encoding.bias_hh_l0", "infoGen.transformer.decoder.layers.0.multihead_attn.in_proj_bias"):
+        save["g:" + k] = np_(grads[k])
+    np.savez_compressed(os.path.join(OUT, "large_train_b2.npz"), **save)
+
+
+def case_fp64_error_bars(ref, report):
+    """How far is the REFERENCE's own fp32 gradient from the fp64 gradient of the same graph?  The tatt_train_b4 case again (same seed,
+    weights and inputs): reference fp32 backward vs the oracle evaluated in fp64.  Stores, per parameter tensor,
+    ||g_ref32 - g_64|| / ||g_64|| -- the yardstick tests/test_model_gpu.py::test_gradients_vs_fp64 holds the HIP gradients to
+    (the fp64 gradients themselves are recomputed by the oracle on the test host: 60 MB would be too much to commit)."""
+    m = build_ref(ref, "TSRN_TL_TRANS", scale_factor=2, width=128, height=32, STN=True, mask=True, srb_nums=5, hidden_units=32)
+    m.train()
+    set_dropout_eval(m)
+    sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x, tp, hr = make_inputs(4)
+    loss = ref_image_loss()(m(x, tp)[0], hr).mean() * 100
+    m.zero_grad()
+    loss.backward()
+    g32 = {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+    l64, g64, _, _, o64, _ = O.train_step_fp64(sd0, x, tp, hr, tatt=True, stn=True)
+    _, o32, _, _, _, _ = O.train_step(sd0, x, tp, hr, tatt=True, stn=True)
+    scale = max(float(g.abs().max()) for g in g64.values() if g is not None)
+    keys, ref_err, ora_err = [], [], []
+    for k, g in g32.items():
+        d = g64[k]
+        den = float(d.norm()) + 1e-7 * scale * d.numel() ** 0.5
+        keys.append(k)
+        ref_err.append(float((g.double() - d).norm()) / den)
+        ora_err.append(float((o32[k].double() - d).norm()) / den)
+    i = int(np.argmax(ref_err))
+    report.append("fp64 yardstick loss fp64 %.7f (ref fp32 %.6f); worst ||g_ref32 - g_64||/||g_64|| = %.3e (%s); oracle fp32: %.3e"
+                  % (float(l64), float(loss), ref_err[i], keys[i], max(ora_err)))
+    np.savez_compressed(os.path.join(OUT, "fp64_error_bars.npz"), keys=np.array(keys), ref32_err=np.array(ref_err),
+                        oracle32_err=np.array(ora_err), loss64=np.float64(float(l64)), scale=np.float64(scale))
+
+
+def case_bench_losses(ref, report):
+    """Known-answer losses for bench.py: the benchmark's own model (seed-1234 default init) and batch (data seed 0), FIRST training-step
+    loss with every nn.Dropout in eval mode, computed by the reference itself.  bench.py replays this forward on the GPU before its
+    timed region and refuses to print a number if the loss is off."""
+    import json
+    out = {}
+    loss_mod = ref_image_loss()
+    for name, kw, B, H, W in (("tatt_b48_16x64", dict(scale_factor=2, width=128, height=32, STN=True, mask=True, srb_nums=5, hidden_units=32), 48, 16, 64),
+                              ("tatt_b16_32x128", dict(scale_factor=2, width=256, height=64, STN=False, mask=True, srb_nums=5, hidden_units=32), 16, 32, 128)):
+        torch.manual_seed(1234)
+        m = ref.TSRN_TL_TRANS(**kw).train()
+        set_dropout_eval(m)
+        g = torch.Generator().manual_seed(0)                      # bench.py make_batch(rank 0)
+        x = torch.rand(B, 4, H, W, generator=g)
+        x[:, 3] = (x[:, 3] > 0.5).float()
+        hr = torch.rand(B, 4, 2 * H, 2 * W, generator=g)
+        tp = torch.softmax(torch.randn(B, 37, 1, 26, generator=g), 1)
+        with torch.no_grad():
+            sr, _ = m(x, tp)
+            loss = float(loss_mod(sr, hr).mean() * 100)
+        out[name] = loss
+        report.append("bench loss     %-16s first-step loss (dropout off) = %.6f" % (name, loss))
+    with open(os.path.join(OUT, "bench_losses.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = import_reference()
@@ -393,6 +501,9 @@ def main():
     case_tbsrn(ref, report)
     case_crnn(ref, report)
     case_losses(ref, report)
+    case_train_large(ref, report)
+    case_fp64_error_bars(ref, report)
+    case_bench_losses(ref, report)
     with open(os.path.join(OUT, "REPORT.txt"), "w") as f:
         f.write("\n".join(report) + "\n")
     print("\n".join(report))
