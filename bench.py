@@ -23,10 +23,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-# HBM bytes per launch of the dominant kernel at B = 48 from the PMC passes committed as profiles/r01_step7_pmc_conv3_ws.txt:
-# 2 x FETCH_SIZE (gfx950 correction for 16-byte coalesced reads) + WRITE_SIZE = 2 x 6816 KB + 12288 KB
-CONV3_WS_TRAFFIC_B48 = (2 * 6816 + 12288) * 1024
-FLOP_PER_IMAGE_FWD_BWD = 7.613e9     # SURVEY.md 8d (FlopCounterMode on the reference graph, 16x64, STN on)
+# SURVEY.md 8d (FlopCounterMode on the reference graph): forward + backward FLOPs per LR image
+TILES = {"std": dict(H=16, W=64, batch=48, flop_per_image=7.613e9, stn=True, loss_key="tatt_b48_16x64"),           # configs[1]/[2]
+         "large": dict(H=32, W=128, batch=16, flop_per_image=36.66e9, stn=False, loss_key="tatt_b16_32x128")}     # configs[4]
+PMC_FILE = os.path.join(ROOT, "profiles", "conv3_ws_pmc.json")      # HBM traffic of the dominant kernel (rocprofv3 --pmc passes)
+LOSS_FILE = os.path.join(ROOT, "tests", "golden", "bench_losses.json")
 
 
 def parse():
@@ -34,8 +35,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=48, help="LR images per GPU per step")
+    ap.add_argument("--tile", default="std", choices=sorted(TILES), help="std: 16x64 LR (headline); large: 32x128 LR, B=16, STN off")
+    ap.add_argument("--batch", type=int, default=None, help="LR images per GPU per step (default: 48 std / 16 large)")
+    ap.add_argument("--dp-selftest", action="store_true",
+                    help="N=1 only: run the data-parallel step (RCCL process group of one rank, staged backward, bucketed all-reduce)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-side-stream", action="store_true", help="A/B: weight-gradient kernels and query GRU on the main stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=48)
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) child process of the cpu_baseline leg")
@@ -43,28 +48,54 @@ def parse():
     return ap.parse_args()
 
 
-def make_batch(B, rank, dev):
+def make_batch(B, rank, dev, H=16, W=64):
     g = torch.Generator().manual_seed(rank)                         # rank r draws data seed r
-    x = torch.rand(B, 4, 16, 64, generator=g)
+    x = torch.rand(B, 4, H, W, generator=g)
     x[:, 3] = (x[:, 3] > 0.5).float()                               # binarised mask channel (dataset/dataset.py:1312-1317)
-    hr = torch.rand(B, 4, 32, 128, generator=g)
+    hr = torch.rand(B, 4, 2 * H, 2 * W, generator=g)
     tp = torch.softmax(torch.randn(B, 37, 1, 26, generator=g), 1)
     return x.to(dev), tp.to(dev), hr.to(dev)
 
 
-def time_dominant_kernel(dev, B):
-    """Average duration of the dominant kernel -- conv3_c64_ws_kernel, the 3x3 convolution 64->64 channels on B x 16 x 64
+def first_step_loss(model, x, tp, hr):
+    """`ImageLoss(sr, hr).mean() * 100` of the first training step with every nn.Dropout in eval mode, on a COPY of the model (the
+    timed model's BatchNorm statistics and seed word stay untouched).  The reference's value for bench.py's own model and rank-0
+    batch is stored in tests/golden/bench_losses.json (tools/gen_golden.py, case_bench_losses)."""
+    import copy
+    from tatt_amd.train import image_loss_mean
+    from tatt_amd import functional as Fh
+    m = copy.deepcopy(model).train()
+    m.infoGen.dropout_on = False
+    seed = Fh.seed_tensor(x.device).clone()
+    with torch.no_grad():
+        sr, _ = m(x, tp)
+        loss = float(image_loss_mean(sr, hr, scale=100.0))
+    Fh.seed_tensor(x.device).copy_(seed)
+    return loss
+
+
+def dominant_kernel_traffic(key):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/conv3_ws_pmc.json: 2 x FETCH_SIZE -- the
+    gfx950 correction for 16-byte coalesced reads, MI355X_MICROARCH.md -- + WRITE_SIZE), or None if that shape was not profiled."""
+    try:
+        return json.load(open(PMC_FILE))["shapes"][key]["traffic_bytes"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def time_dominant_kernel(dev, B, H=16, W=64):
+    """Average duration of the dominant kernel -- conv3_c64_ws_kernel, the 3x3 convolution 64->64 channels on B x H x W
     pixels (22 forward/data-gradient launches of this exact shape per training step) -- measured with HIP events on the
     stream it is launched on.  Algorithmic FLOPs per launch = 2 * pixels * (3*3*64) * 64."""
     from tatt_amd import ops
-    x = torch.randn(B, 16, 64, 64, device=dev)
+    x = torch.randn(B, H, W, 64, device=dev)
     w = torch.randn(64, 64, 3, 3, device=dev) * 0.05
     b = torch.zeros(64, device=dev)
     wl = ops.repack_weight(w, 4)
-    y = torch.empty(B, 16, 64, 64, device=dev)
+    y = torch.empty(B, H, W, 64, device=dev)
 
     def run():
-        ops.call("tatt_conv3_c64_fwd_ws", ops.P(x), ops.P(wl), ops.P(b), ops.P(y), B, 16, 64, 64, 0, 0.0, ops.stream())
+        ops.call("tatt_conv3_c64_fwd_ws", ops.P(x), ops.P(wl), ops.P(b), ops.P(y), B, H, W, 64, 0, 0.0, ops.stream())
     for _ in range(5):
         run()
     n = 50
@@ -76,13 +107,14 @@ def time_dominant_kernel(dev, B):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
-    flops = 2.0 * B * 16 * 64 * 576 * 64
+    flops = 2.0 * B * H * W * 576 * 64
     return ms, flops
 
 
-def make_model(arch):
+def make_model(arch, tile="std"):
     import tatt_amd
-    kw = dict(scale_factor=2, width=128, height=32, STN=True, mask=True, srb_nums=5, hidden_units=32)
+    t = TILES[tile]
+    kw = dict(scale_factor=2, width=2 * t["W"], height=2 * t["H"], STN=t["stn"], mask=True, srb_nums=5, hidden_units=32)
     if arch == "tbsrn":
         return tatt_amd.TBSRN(input_channel=4, **kw)
     if arch == "tatt_tpg":                     # the SR generator trained together with its CRNN student prior generator
@@ -104,7 +136,7 @@ def usable_cores():
     return max(1, min(n, 32))
 
 
-def cpu_baseline_worker(arch, B):
+def cpu_baseline_worker(arch, B, tile="std"):
     """Runs in a CHILD process (no HIP context, bounded by the parent's timeout): the CPU oracle (validated against the
     reference, tests/golden/REPORT.txt) timed on this host -- full training steps (fwd + loss + bwd + clip + Adam, dropout
     on) on the same synthetic workload.  A B=8 step is timed first; the B=`--cpu-batch` step only runs if it is predicted
@@ -113,11 +145,12 @@ def cpu_baseline_worker(arch, B):
     cores = usable_cores()
     torch.set_num_threads(cores)
     torch.manual_seed(1234)
-    sd = make_model(arch).state_dict()
+    sd = make_model(arch, tile).state_dict()
+    t = TILES[tile]
     g = torch.Generator().manual_seed(0)
-    x, hr = torch.rand(B, 4, 16, 64, generator=g), torch.rand(B, 4, 32, 128, generator=g)
+    x, hr = torch.rand(B, 4, t["H"], t["W"], generator=g), torch.rand(B, 4, 2 * t["H"], 2 * t["W"], generator=g)
     tp = torch.softmax(torch.randn(B, 37, 1, 26, generator=g), 1) if arch == "tatt" else None
-    kw = dict(tatt=arch == "tatt", stn=True, drop_on=True, tbsrn=arch == "tbsrn")
+    kw = dict(tatt=arch == "tatt", stn=t["stn"], drop_on=True, tbsrn=arch == "tbsrn")
 
     def run(b):
         t0 = time.time()
@@ -137,9 +170,9 @@ def cpu_baseline_worker(arch, B):
                       "%.1f s in total; the reference itself measured 3.6 img/s on 8 vCPU (BASELINE.md)" % (nrep, b, cores, tot)}
 
 
-def cpu_baseline(arch, B, timeout=240):
+def cpu_baseline(arch, B, tile="std", timeout=240):
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--arch", arch, "--cpu-batch", str(B)]
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--arch", arch, "--cpu-batch", str(B), "--tile", tile]
     env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
@@ -152,7 +185,7 @@ def cpu_baseline(arch, B, timeout=240):
 def main():
     a = parse()
     if a.cpu_baseline_only:
-        print(json.dumps(cpu_baseline_worker(a.arch, a.cpu_batch)))
+        print(json.dumps(cpu_baseline_worker(a.arch, a.cpu_batch, a.tile)))
         return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -160,11 +193,17 @@ def main():
     if a.gpus != world:
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus))
+    tile = TILES[a.tile]
+    if a.batch is None:
+        a.batch = tile["batch"]
+    if a.tile != "std" and a.arch != "tatt":
+        raise SystemExit("--tile large is the TATT configuration (BASELINE.json configs[4])")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     pg = None
-    if world > 1:
+    if world > 1 or a.dp_selftest:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
         pg = torch.distributed.group.WORLD
 
@@ -174,34 +213,28 @@ def main():
     build()
 
     torch.manual_seed(1234)
-    model = make_model(a.arch).to(dev).train()
+    model = make_model(a.arch, a.tile).to(dev).train()
     use_graph = (not a.no_graph) and a.warmup >= 3
-    tr = Trainer(model, use_graph=use_graph, warmup_eager=2, process_group=pg)
-    x, tp, hr = make_batch(a.batch, rank, dev)
+    x, tp, hr = make_batch(a.batch, rank, dev, tile["H"], tile["W"])
+    # known-answer check of the workload before anything is timed: this model, this batch, dropout off -> the reference's loss
+    kat = None
+    if a.arch == "tatt" and rank == 0 and a.batch == tile["batch"]:
+        want = json.load(open(LOSS_FILE))[tile["loss_key"]]
+        got = first_step_loss(model, x, tp, hr)
+        assert abs(got - want) < 2e-4 * want, "first-step loss %.6f differs from the reference's %.6f" % (got, want)
+        kat = {"first_step_loss_dropout_off": round(got, 6), "reference": round(want, 6)}
+    tr = Trainer(model, use_graph=use_graph, warmup_eager=2, process_group=pg, side_stream=not a.no_side_stream)
     if a.arch != "tatt":
         tp = None                      # tsrn / tbsrn take no prior; tatt_tpg computes it from the LR image with the CRNN student
 
     def barrier():
-        if world > 1:
+        if pg is not None:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    graph_ok = use_graph
-    try:
-        for _ in range(a.warmup):
-            tr.step(x, tp, hr)
-        barrier()
-    except Exception as e:                      # graph capture unsupported -> eager
-        if not use_graph:
-            raise
-        print("[bench] hipGraph capture failed (%s); falling back to eager launches" % e, file=sys.stderr)
-        graph_ok = False
-        torch.cuda.synchronize()
-        tr = Trainer(model, use_graph=False, process_group=pg, broadcast_init=False)
-        for _ in range(a.warmup):
-            tr.step(x, tp, hr)
-        barrier()
-
+    graph_ok = use_graph                        # a failed hipGraph capture raises: the line below never reports eager as graph
+    for _ in range(a.warmup):
+        tr.step(x, tp, hr)
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -218,30 +251,32 @@ def main():
     if rank == 0:
         ms = dt / a.steps * 1e3
         ips = a.batch * world * a.steps / dt
-        kms, kflops = time_dominant_kernel(dev, a.batch)
+        kms, kflops = time_dominant_kernel(dev, a.batch, tile["H"], tile["W"])
         ach = kflops / (kms * 1e-3) / 1e12
         out = {
-            "metric": "LR images/s (train fwd+bwd+clip+Adam) at 16x64->32x128",
+            "metric": "LR images/s (train fwd+bwd+clip+Adam) at %dx%d->%dx%d" % (tile["H"], tile["W"], 2 * tile["H"], 2 * tile["W"]),
             "value": round(ips, 2), "unit": "LR images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "fp32", "data": "synthetic",
-            "config": {"workload": "TATT (TSRN_TL_TRANS, STN on, dropout on) train step, batch %d/GPU, 16x64 LR -> 32x128 SR, "
-                                   "ImageLoss + clip 0.25 + Adam(1e-3,(0.5,0.999))" % a.batch if a.arch == "tatt" else
-                       "%s train step, batch %d/GPU" % (a.arch.upper(), a.batch),
-                       "global_batch": a.batch * world, "parallelism": "dp%d" % world,
-                       "launch": "hipGraph replay" if graph_ok else "eager", "final_loss": round(loss_v, 5),
-                       "whole_step_tflops": round(ips * FLOP_PER_IMAGE_FWD_BWD / 1e12, 2)},
+            "config": {"workload": "TATT (TSRN_TL_TRANS, STN %s, dropout on) train step, batch %d/GPU, %dx%d LR -> %dx%d SR, "
+                                   "ImageLoss + clip 0.25 + Adam(1e-3,(0.5,0.999))" % (
+                                       "on" if tile["stn"] else "off", a.batch, tile["H"], tile["W"], 2 * tile["H"], 2 * tile["W"])
+                       if a.arch == "tatt" else "%s train step, batch %d/GPU" % (a.arch.upper(), a.batch),
+                       "global_batch": a.batch * world, "parallelism": "dp%d" % world + (" (self-test: RCCL group of one rank)" if a.dp_selftest else ""),
+                       "launch": ("hipGraph replay" if graph_ok else "eager") + ("" if a.no_side_stream else ", 2 streams"), "final_loss": round(loss_v, 5),
+                       "known_answer": kat,
+                       "whole_step_tflops": round(ips * tile["flop_per_image"] / 1e12, 2) if a.arch == "tatt" else None},
             "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
-                         "traffic": CONV3_WS_TRAFFIC_B48 if a.batch == 48 else None,
-                         "algorithmic_bytes": 2 * a.batch * 16 * 64 * 64 * 4 + 9 * 64 * 64 * 4,
-                         "kernel": "conv3_c64_ws_kernel (3x3 conv, 64->64 ch, %d x16x64 px, fp32 MFMA)" % a.batch,
+                         "traffic": dominant_kernel_traffic("B%d_%dx%d" % (a.batch, tile["H"], tile["W"])),
+                         "algorithmic_bytes": 2 * a.batch * tile["H"] * tile["W"] * 64 * 4 + 9 * 64 * 64 * 4,
+                         "kernel": "conv3_c64_ws_kernel (3x3 conv, 64->64 ch, %d x%dx%d px, fp32 MFMA)" % (a.batch, tile["H"], tile["W"]),
                          "kernel_ms": round(kms, 4), "flops_per_launch": kflops},
         }
         if world == 1 and not a.no_cpu_baseline and a.arch != "tatt_tpg":
-            out["cpu_baseline"] = cpu_baseline(a.arch, a.cpu_batch)
+            out["cpu_baseline"] = cpu_baseline(a.arch, a.cpu_batch if a.tile == "std" else min(a.cpu_batch, a.batch), a.tile)
         print(json.dumps(out))
-    if world > 1:
+    if pg is not None:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

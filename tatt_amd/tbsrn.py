@@ -23,7 +23,7 @@ from . import functional as Fh
 from . import ops
 from .ops import ACT_NONE, ACT_RELU, ACT_MISH, ACT_TANH
 from .tsrn import (_Holder, GruBlock, UpsampleBLock, STNHead, TPSSpatialTransformer, _stn_forward, _tps_forward,
-                   _require_gpu, _nchw)
+                   _require_gpu, _nchw, _TrainPathMixin)
 
 
 def positionalencoding2d(d_model, height, width):
@@ -135,7 +135,7 @@ def _srb(x, blk: RecurrentResidualBlock, training, dropout_on, site0):
     return Fh.add(x, r)
 
 
-class TBSRN(nn.Module):
+class TBSRN(_TrainPathMixin, nn.Module):
     """Drop-in for reference ``TBSRN`` (model/tbsrn.py:167-227)."""
 
     def __init__(self, scale_factor=2, width=128, height=32, STN=True, srb_nums=5, mask=False, hidden_units=32,
@@ -167,6 +167,9 @@ class TBSRN(nn.Module):
         _require_gpu(x)
         training = self.training
         k = self.srb_nums
+        cuts = self._grad_cuts if training else None
+        if training:
+            Fh.begin_training_forward(x.device)                  # fresh dropout masks for this call (and its backward)
         if self.stn and training:
             ctrl = _stn_forward(x, self.stn_head)
             xin, _ = _tps_forward(x, ctrl, self.tps)
@@ -174,6 +177,8 @@ class TBSRN(nn.Module):
             xin = x.permute(0, 2, 3, 1)
         c1 = self.block1[0]
         b1 = Fh.prelu(Fh.conv2d(xin, c1.weight, c1.bias), self.block1[1].weight)
+        if cuts:                                                  # backward stages: trunk (from the loss), then "first" (block1 + STN)
+            b1 = cuts.cut("first", b1)
         h = b1
         for i in range(k):
             h = _srb(h, getattr(self, "block%d" % (i + 2)), training, self.dropout_on, 100 + 10 * i)

@@ -7,7 +7,8 @@ and replaces torch.nn.DataParallel (interfaces/base.py:386-396) by one process p
 all-reduce of ONE flat gradient buffer over xGMI (`torch.distributed`, backend "nccl" = RCCL on ROCm).
 
 * Parameters, gradients and Adam moments live in flat fp32 buffers (7.6 M elements = 30.4 MB each); the module's
-  nn.Parameters are views into the flat parameter buffer, their `.grad`s views into the flat gradient buffer.
+  nn.Parameters are views into the flat parameter buffer; the HIP backward kernels produce fresh gradient tensors which one
+  multi-tensor copy per bucket gathers into the flat gradient buffer (`.grad` is NOT a view of it).
 * Clip + Adam are two HIP kernels (tatt_l2norm, tatt_adam_step) whose step-varying scalars live in device
   memory, so a whole step (forward, loss, backward, optimiser) can be captured once as a hipGraph and replayed.
 * ImageLoss (loss/image_loss.py) is one fused forward and one fused backward HIP kernel (tatt_image_loss_*) instead of
@@ -21,7 +22,7 @@ import torch
 
 from . import functional as Fh
 from . import ops
-from .dp import FlatParams, broadcast_model, allreduce_grads
+from .dp import FlatParams, GradCuts, broadcast_model, allreduce_bucket, rank_dropout_seed
 
 
 def image_loss(sr, hr, weights=(1.0, 1e-4)):
@@ -59,6 +60,9 @@ class TextPriorSR(torch.nn.Module):
     def __init__(self, sr, tpg, teacher=None, in_width=100):
         super().__init__()
         self.sr, self.tpg, self.in_width = sr, tpg, in_width
+        if teacher is not None:                              # the reference calls aster.eval() and never optimises it
+            teacher.eval()
+            teacher.requires_grad_(False)
         object.__setattr__(self, "_teacher", teacher)        # frozen: deliberately NOT a registered sub-module / parameter owner
         self._student_probs = None
 
@@ -76,6 +80,25 @@ class TextPriorSR(torch.nn.Module):
     def block(self, v):
         self.sr.block = v
 
+    # -- Trainer protocol: buckets follow the SR generator's, the recogniser's parameters close the last one -------------
+    def grad_buckets(self):
+        b = [(n, list(ps)) for n, ps in self.sr.grad_buckets()]
+        b[-1][1].extend(self.tpg.parameters())
+        return b
+
+    def set_grad_cuts(self, cuts):
+        self.sr.set_grad_cuts(cuts)
+
+    def clip_groups(self, clip):
+        """The reference clips each model of `model_list` by its own norm (`for model in model_list: clip_grad_norm_(...)`,
+        interfaces/super_resolution.py:1082-1083) and leaves the recogniser's gradients unclipped."""
+        return [(list(self.sr.parameters()), clip), (list(self.tpg.parameters()), 0.0)]
+
+    def frozen_tensors(self):
+        if self._teacher is None:
+            return []
+        return list(self._teacher.parameters()) + list(self._teacher.buffers())
+
     def _probs(self, net, img):
         from .crnn import parse_crnn_data
         logits = net(parse_crnn_data(img[:, :3], self.in_width))                 # (T, B, 37)
@@ -92,6 +115,7 @@ class TextPriorSR(torch.nn.Module):
         """Distillation term; None without a teacher.  Call after forward()."""
         if self._teacher is None:
             return None
+        assert not self._teacher.training, "the teacher recogniser must stay in eval mode (reference: aster.eval())"
         with torch.no_grad():
             gt = self._probs(self._teacher, hr)
         loss = semantic_loss(self._student_probs, gt) * 100.0
@@ -99,82 +123,152 @@ class TextPriorSR(torch.nn.Module):
         return loss
 
 
+class HipStepKernels:
+    """The optimiser side of a step on the GPU: global-norm clip + Adam on flat buffers (tatt_l2norm, tatt_adam_step)."""
+
+    def l2norm(self, g, out, ws):
+        ops.call("tatt_l2norm", ops.P(g), g.numel(), ops.P(out), ops.P(ws), ops.stream())
+
+    def adam(self, p, g, m, v, lr, b1, b2, eps, gnorm, max_norm, gscale, step):
+        ops.call("tatt_adam_step", ops.P(p), ops.P(g), ops.P(m), ops.P(v), p.numel(), lr, b1, b2, eps, ops.P(gnorm), max_norm,
+                 gscale, ops.P(step), ops.stream())
+
+
+def _default_loss(sr, hr):
+    return image_loss_mean(sr, hr, scale=100.0)
+
+
 class Trainer:
-    """One training step per `step()` call; optional whole-step hipGraph; optional data parallelism."""
+    """One training step per `step()` call: forward, ImageLoss.mean()*100, backward, [all-reduce], clip, Adam.
+
+    * `use_graph`: after `warmup_eager` eager steps the step is captured once as hipGraph(s) and replayed.
+    * Weight/bias-gradient kernels and the query GRU run on a second HIP stream (`side_stream`), off the critical path of the
+      activation-gradient chain; inside a captured graph they are parallel branches.
+    * `process_group` (world > 1): the backward runs in the stages the model announces (`grad_buckets` / `set_grad_cuts`); after
+      stage k the bucket's gradients are gathered into the flat buffer and its sum all-reduce is issued asynchronously, so it
+      overlaps stage k+1 (graphs: one per stage, the collectives are launched between the replays); 1/world is folded into
+      the Adam kernel; every rank then clips and updates identically.  Rank 0's weights/buffers are broadcast at start and each
+      rank seeds its dropout stream differently (DataParallel replicas draw independent masks).
+    * `kernels` / `loss_fn`: the device kernels behind the optimiser and the loss (default: the HIP ones; the gloo CPU test of
+      this orchestration injects torch stand-ins -- there is no CPU path in the product)."""
 
     def __init__(self, model, lr=1e-3, betas=(0.5, 0.999), eps=1e-8, clip=0.25, use_graph=False, warmup_eager=2,
-                 process_group=None, broadcast_init=True):
+                 process_group=None, broadcast_init=True, side_stream=True, kernels=None, loss_fn=None, dropout_seed=None):
         self.model = model
         self.lr, self.betas, self.eps, self.clip = lr, betas, eps, clip
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
-        self.flat = FlatParams(model)
+        self.rank = torch.distributed.get_rank(process_group) if process_group is not None else 0
+        self.kernels = kernels if kernels is not None else HipStepKernels()
+        self.loss_fn = loss_fn if loss_fn is not None else _default_loss
+        # a process group switches the data-parallel path on -- also with a single rank (self-test of the staged step on one GPU)
+        self.dp = process_group is not None
+        staged = self.dp and hasattr(model, "grad_buckets") and hasattr(model, "set_grad_cuts")
+        buckets = model.grad_buckets() if hasattr(model, "grad_buckets") else None
+        if buckets is not None and not staged:           # single process: one bucket, same parameter ORDER as the staged layout
+            buckets = [("all", [p for _, ps in buckets for p in ps])]
+        self.flat = FlatParams(model, buckets)
+        self.stages = self.flat.bucket_names             # stage k fills bucket k; stage 0 is the backward from the loss
+        self.cuts = GradCuts() if staged and len(self.stages) > 1 else None
+        if hasattr(model, "set_grad_cuts"):
+            model.set_grad_cuts(self.cuts)
         self.params = self.flat.params
         self.n = self.flat.n
         dev = self.flat.p.device
         self.dev = dev
+        self.cuda = dev.type == "cuda"
         self.flat_p, self.flat_g = self.flat.p, self.flat.g
         self.flat_m = torch.zeros(self.n, device=dev)
         self.flat_v = torch.zeros(self.n, device=dev)
-        if self.world > 1 and broadcast_init:
-            broadcast_model(self.flat, model, process_group)
-        self.gnorm = torch.zeros(1, device=dev)
+        groups = model.clip_groups(clip) if hasattr(model, "clip_groups") else [(self.params, clip)]
+        self.groups = [self.flat.span(ps) + (float(c),) for ps, c in groups]          # (start, end, max_norm)
+        assert sorted(self.groups)[0][0] == 0 and sum(e - s for s, e, _ in self.groups) == self.n
+        if self.dp and broadcast_init:
+            extra = model.frozen_tensors() if hasattr(model, "frozen_tensors") else ()
+            broadcast_model(self.flat, model, process_group, extra=extra)
+        if self.cuda:
+            base = 0x1234ABCD5678EF01 if dropout_seed is None else int(dropout_seed)
+            if self.dp or dropout_seed is not None:
+                Fh.set_seed(dev, rank_dropout_seed(base, self.rank) if self.dp else base)
+        self.gnorms = [torch.zeros(1, device=dev) for _ in self.groups]
+        self.gnorm = self.gnorms[0]
         self.step_count = torch.zeros(1, dtype=torch.int64, device=dev)
         self.norm_ws = torch.empty(1024, dtype=torch.float64, device=dev)
-        self.use_graph = use_graph
+        self.use_graph = use_graph and self.cuda
+        self.side_stream = side_stream and self.cuda
         self.warmup_eager = warmup_eager
         self._graphs = None
         self._static = None
         self._nsteps = 0
+        self._works = []
         self.last_loss = None
 
     # -- pieces ----------------------------------------------------------------------------------
-    def _fwd_bwd(self, x, tp, hr):
-        # gradients are produced as fresh tensors by the HIP backward kernels and gathered into the flat buffer with one
-        # multi-tensor copy (instead of ~290 per-parameter `grad += new` kernels through pre-assigned .grad views)
-        for p in self.params:
-            p.grad = None
-        out = self.model(x, tp) if tp is not None else self.model(x)
-        sr = out[0] if isinstance(out, tuple) else out
-        loss = image_loss_mean(sr, hr, scale=100.0)
-        extra = self.model.extra_loss(hr) if hasattr(self.model, "extra_loss") else None
-        if extra is not None:
-            loss = loss + extra
-        loss.backward()
-        self.model.block = None                      # do not keep the autograd graph of this step alive
-        self.flat_g.zero_()
-        have = [p for p in self.params if p.grad is not None]
-        torch._foreach_copy_([self.flat.grad_view(p) for p in have], [p.grad for p in have])
-        return loss.detach()
+    def _stage(self, k, x=None, tp=None, hr=None):
+        """Stage 0: forward + loss + backward from the loss; stage k > 0: the part of the backward `stages[k]` names.  Ends with
+        bucket k's gradients gathered into the flat buffer."""
+        Fh.SIDE.enabled = self.side_stream
+        try:
+            if k == 0:
+                for p in self.params:
+                    p.grad = None
+                if self.cuts is not None:
+                    self.cuts.reset()
+                out = self.model(x, tp) if tp is not None else self.model(x)
+                sr = out[0] if isinstance(out, tuple) else out
+                loss = self.loss_fn(sr, hr)
+                extra = self.model.extra_loss(hr) if hasattr(self.model, "extra_loss") else None
+                if extra is not None:
+                    loss = loss + extra
+                loss.backward()
+                self.last_loss = loss.detach()
+            else:
+                self.cuts.run(self.stages[k])
+            if self.side_stream:
+                Fh.SIDE.join(self.dev)               # weight-gradient kernels of this stage have landed
+        finally:
+            Fh.SIDE.enabled = False
+        if k == len(self.stages) - 1 and hasattr(self.model, "block"):
+            self.model.block = None                  # do not keep the autograd graph of this step alive
+        self.flat.gather_grads(k)
 
     def _optim(self):
         self.step_count += 1
-        ops.call("tatt_l2norm", ops.P(self.flat_g), self.n, ops.P(self.gnorm), ops.P(self.norm_ws), ops.stream())
-        ops.call("tatt_adam_step", ops.P(self.flat_p), ops.P(self.flat_g), ops.P(self.flat_m), ops.P(self.flat_v),
-                 self.n, self.lr, self.betas[0], self.betas[1], self.eps, ops.P(self.gnorm), self.clip,
-                 1.0 / self.world, ops.P(self.step_count), ops.stream())
-        Fh.next_dropout_step(self.dev)
+        b1, b2 = self.betas
+        for (s, e, max_norm), gn in zip(self.groups, self.gnorms):
+            if max_norm > 0.0:
+                self.kernels.l2norm(self.flat_g[s:e], gn, self.norm_ws)
+            self.kernels.adam(self.flat_p[s:e], self.flat_g[s:e], self.flat_m[s:e], self.flat_v[s:e], self.lr, b1, b2, self.eps,
+                              gn, max_norm, 1.0 / self.world, self.step_count)
 
-    def _allreduce(self):
-        if self.world > 1:
-            allreduce_grads(self.flat, self.pg)       # sum; the 1/world factor is folded into tatt_adam_step
+    def _reduce(self, k):
+        if self.dp:
+            w = allreduce_bucket(self.flat, k, self.pg, async_op=True)
+            self._works.append(w)
+
+    def _wait_reduces(self):
+        for w in self._works:
+            w.wait()                                 # GPU: the current stream waits for the collective; host does not block
+        self._works = []
 
     @property
     def last_grad_norm(self):
-        """||g||_2 of the (rank-averaged) gradient before clipping."""
+        """||g||_2 of the (rank-averaged) gradient of the first clip group (the SR generator) before clipping."""
         return self.gnorm / self.world
 
     # -- public ----------------------------------------------------------------------------------
     def step(self, x, tp, hr):
-        """x (B,4,H,W), tp (B,37,1,26) or None (TSRN), hr (B,4,2H,2W), all on this rank's GPU.  Returns the loss
-        tensor (device scalar, no host sync)."""
+        """x (B,4,H,W), tp (B,37,1,26) or None (TSRN), hr (B,4,2H,2W), all on this rank's GPU.  Returns the loss of this step
+        (a fresh device scalar, no host sync)."""
         self._nsteps += 1
+        nst = len(self.stages)
         if not self.use_graph or self._nsteps <= self.warmup_eager:
-            loss = self._fwd_bwd(x, tp, hr)
-            self._allreduce()
+            for k in range(nst):
+                self._stage(k, x, tp, hr)
+                self._reduce(k)
+            self._wait_reduces()
             self._optim()
-            self.last_loss = loss
-            return loss
+            return self.last_loss
         if self._graphs is None:
             self._capture(x, tp, hr)
         sx, stp, shr = self._static
@@ -182,25 +276,39 @@ class Trainer:
         shr.copy_(hr)
         if stp is not None:
             stp.copy_(tp)
-        g1, g2 = self._graphs
-        g1.replay()
-        if g2 is not None:
-            self._allreduce()
-            g2.replay()
-        return self.last_loss
+        if not self.dp:
+            self._graphs[0].replay()
+        else:
+            for k in range(nst):
+                self._graphs[k].replay()
+                self._reduce(k)
+            self._wait_reduces()
+            self._graphs[nst].replay()
+        return self.last_loss.clone()                # the captured tensor is overwritten by the next replay
 
     def _capture(self, x, tp, hr):
         self._static = (x.clone(), None if tp is None else tp.clone(), hr.clone())
         sx, stp, shr = self._static
         torch.cuda.synchronize()
-        g1 = torch.cuda.CUDAGraph()
-        g2 = None
-        with torch.cuda.graph(g1):
-            self.last_loss = self._fwd_bwd(sx, stp, shr)
-            if self.world == 1:
+        nst = len(self.stages)
+        graphs = []
+        if not self.dp:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for k in range(nst):
+                    self._stage(k, sx, stp, shr)
                 self._optim()
-        if self.world > 1:
-            g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2):
-                self._optim()
-        self._graphs = (g1, g2)
+            graphs.append(g)
+        else:
+            # one graph per backward stage + one for the optimiser, all in one memory pool (activations saved by stage 0 are read by
+            # the later stages); the collectives are issued between the replays, outside the graphs
+            pool = torch.cuda.graph_pool_handle()
+            for k in range(nst + 1):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool):
+                    if k < nst:
+                        self._stage(k, sx, stp, shr)
+                    else:
+                        self._optim()
+                graphs.append(g)
+        self._graphs = graphs                        # nothing has executed yet: step() replays them for the step that captured

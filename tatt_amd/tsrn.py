@@ -243,14 +243,14 @@ def _require_gpu(x):
                            "fallback (the CPU restatement lives in oracle/ and is test infrastructure)." % x.device)
 
 
-def _stn_forward(x_nchw, stn: STNHead):
+def _stn_forward(x_nchw, stn: STNHead, count=True):
     """STNHead.forward (model/stn_head.py:92-106): control points (B, N, 2)."""
     h = x_nchw.permute(0, 2, 3, 1)                    # NHWC-indexed view of the NCHW image
     pools = {0: (2, 2), 2: (2, 2), 4: (2, 2), 6: (2, 2), 8: (1, 2)}
     for i in (0, 2, 4, 6, 8, 10):
         conv, bn = stn.stn_convnet[i][0], stn.stn_convnet[i][1]
         h = Fh.conv2d(h, conv.weight, conv.bias)
-        h = Fh.batch_norm_act(h, bn, ACT_RELU)
+        h = Fh.batch_norm_act(h, bn, ACT_RELU, count)
         if i in pools:
             h = Fh.max_pool(h, *pools[i])
     B = h.shape[0]
@@ -258,7 +258,7 @@ def _stn_forward(x_nchw, stn: STNHead):
     h = Fh.Permute4dFn.apply(h, (0, 3, 1, 2)).reshape(B, -1)
     fc1, bn1 = stn.stn_fc1[0], stn.stn_fc1[1]
     h = Fh.linear(h, fc1.weight, fc1.bias)
-    h = Fh.batch_norm_act(h, bn1, ACT_RELU)
+    h = Fh.batch_norm_act(h, bn1, ACT_RELU, count)
     h = Fh.ScaleFn.apply(h, 0.1)
     h = Fh.linear(h, stn.stn_fc2.weight, stn.stn_fc2.bias)
     return h.reshape(B, stn.num_ctrlpoints, 2)
@@ -278,11 +278,11 @@ def _gru_block(x, blk: GruBlock, vertical, x_cat=None):
 
 
 def _srb(x, tp_map, blk: RecurrentResidualBlock):
-    """RecurrentResidualBlock[TL].forward (model/tsrn.py:862-871, 892-910)."""
+    """RecurrentResidualBlock[TL].forward (model/tsrn.py:862-871, 892-910).  (num_batches_tracked: bumped by the generator.)"""
     r = Fh.conv2d(x, blk.conv1.weight, blk.conv1.bias)
-    r = Fh.batch_norm_act(r, blk.bn1, ACT_MISH)
+    r = Fh.batch_norm_act(r, blk.bn1, ACT_MISH, False)
     r = Fh.conv2d(r, blk.conv2.weight, blk.conv2.bias)
-    r = Fh.batch_norm_act(r, blk.bn2, ACT_NONE)
+    r = Fh.batch_norm_act(r, blk.bn2, ACT_NONE, False)
     r = _gru_block(r, blk.gru1, True, x_cat=tp_map)
     return _gru_block(Fh.add(x, r), blk.gru2, False)
 
@@ -293,7 +293,14 @@ def _ffn(x, layer, training, site):
     return Fh.linear(h, layer.linear2.weight, layer.linear2.bias)
 
 
-def _tp_interpreter(feat, tp, ig: TPInterpreter, training):
+def _query_pos(ig: TPInterpreter, B, H, W):
+    """Query positional embedding (model/transformer_v2.py:201-221) -> (B, H*W, C).  Depends on parameters only; issued on the
+    side stream when that is on -- `_tp_interpreter` joins before its first use."""
+    C = ig.init_factor.weight.shape[1]
+    return Fh.query_embedding(ig.init_factor.weight, ig.transformer.gru_encoding, B, H, W).reshape(B, H * W, C)
+
+
+def _tp_interpreter(feat, tp, ig: TPInterpreter, training, qpos=None):
     """TPInterpreter.forward (model/tsrn.py:194-224) + InfoTransformer.forward (model/transformer_v2.py:198-244).
     feat (B,H,W,C) NHWC block1 output; tp (B,37,1,26).  Returns tp_map (B,H,W,C), pr_weights (B,H*W,26)."""
     B, H, W, C = feat.shape
@@ -311,7 +318,8 @@ def _tp_interpreter(feat, tp, ig: TPInterpreter, training):
     else:
         pos = pe
         add_pos = Fh.AddRowBcastFn.apply
-    qpos = Fh.query_embedding(ig.init_factor.weight, tr.gru_encoding, B, H, W).reshape(B, H * W, C)
+    if qpos is None:
+        qpos = _query_pos(ig, B, H, W)
     tgt = feat.reshape(B, H * W, C)
     # encoder: one layer fed with output + src = 2*src (transformer_v2.py:274)
     enc = tr.encoder.layers[0]
@@ -323,6 +331,7 @@ def _tp_interpreter(feat, tp, ig: TPInterpreter, training):
     memory = Fh.layer_norm(src, Fh.dropout(f, enc.p, drop, 5), enc.norm2)
     # decoder: cross-attention only (self-attention commented out upstream, :817-819)
     kmem = add_pos(memory, pos)
+    Fh.SIDE.join(feat.device)                  # qpos may still be in flight on the side stream
     outs, wts = [], None
     for li, dec in enumerate(tr.decoder.layers):
         s0 = 10 + 10 * li
@@ -338,7 +347,63 @@ def _tp_interpreter(feat, tp, ig: TPInterpreter, training):
 # ---------------------------------------------------------------------------------------------------
 # the two generators
 # ---------------------------------------------------------------------------------------------------
-class _GeneratorBase(nn.Module):
+class _TrainPathMixin:
+    """Training-loop plumbing shared by the generators (tatt_amd.train.Trainer drives it; a plain `loss.backward()` loop never
+    needs it):
+
+    * `grad_buckets()`: the parameters in the order their gradients complete during the backward pass -- trunk + up-sampler
+      (block2..), then the TP interpreter, then block1 + STN head -- one list per bucket of the data-parallel all-reduce;
+    * `set_grad_cuts(cuts)`: with a `tatt_amd.dp.GradCuts` installed the forward detaches the tensors that connect those three
+      parts, so that the backward can be run stage by stage and bucket k's all-reduce overlaps stage k+1;
+    * `_bump_bn_counters()`: ONE launch advances `num_batches_tracked` of every BatchNorm on the path (their buffers are
+      re-homed as views of one int64 vector; `state_dict` keys and values are unchanged)."""
+
+    _grad_cuts = None
+
+    def set_grad_cuts(self, cuts):
+        object.__setattr__(self, "_grad_cuts", cuts)
+
+    def grad_buckets(self):
+        """[(stage name, [parameters])] in backward-completion order; stage names match the `cuts.cut(name, ...)` calls of the
+        forward ("trunk" is the part the loss back-propagates into directly)."""
+        first, tp, trunk = [], [], []
+        for name, p in self.named_parameters():
+            top = name.split(".", 1)[0]
+            (tp if top == "infoGen" else first if top in ("block1", "stn_head", "tps", "conv", "bn") else trunk).append(p)
+        return [(n, b) for n, b in (("trunk", trunk), ("tp", tp), ("first", first)) if b]
+
+    def _bn_on_path(self):
+        skip = () if getattr(self, "stn", False) else ("stn_head",)
+        return [m for n, m in self.named_modules()
+                if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d)) and m.track_running_stats and n.split(".", 1)[0] not in skip
+                and n != "bn"]                        # TBSRN's unused top-level `bn` never runs
+
+    def _bump_bn_counters(self):
+        bns = self.__dict__.get("_bn_list")
+        if bns is None:
+            bns = self._bn_on_path()
+            object.__setattr__(self, "_bn_list", bns)
+        if not bns:
+            return
+        grp = self.__dict__.get("_nbt_group")
+        ok = grp is not None and grp.device == bns[0].num_batches_tracked.device and all(
+            bn.num_batches_tracked.data_ptr() == grp.data_ptr() + 8 * i for i, bn in enumerate(bns))
+        if not ok:
+            # (re-)group: happens on the first training forward and after .to(device); never inside a captured step, the Trainer
+            # runs eager steps first
+            grp = torch.stack([bn.num_batches_tracked.reshape(()) for bn in bns])
+            for i, bn in enumerate(bns):
+                bn._buffers["num_batches_tracked"] = grp[i]
+            object.__setattr__(self, "_nbt_group", grp)
+        if all(bn.training for bn in bns):
+            grp += 1
+        else:                                    # some BatchNorms frozen by the caller: only the live ones count
+            for bn in bns:
+                if bn.training:
+                    bn.num_batches_tracked += 1
+
+
+class _GeneratorBase(_TrainPathMixin, nn.Module):
     def _build_trunk(self, scale_factor, width, height, STN, srb_nums, mask, hidden_units, text_channels):
         in_planes = 4 if mask else 3
         assert math.log(scale_factor, 2) % 1 == 0
@@ -372,8 +437,17 @@ class _GeneratorBase(nn.Module):
             raise RuntimeError("tatt_amd computes in fp32; got %s" % x.dtype)
         training = self.training
         k = self.srb_nums
+        cuts = self._grad_cuts if training else None
+        qpos = None
+        if training:
+            Fh.begin_training_forward(x.device)                  # fresh dropout masks for this call (and its backward)
+            self._bump_bn_counters()
+        if use_tp:
+            if text_emb is None:
+                text_emb = torch.zeros(1, 37, 1, 26, device=x.device)     # reference :653-654
+            qpos = _query_pos(self.infoGen, x.shape[0], x.shape[2], x.shape[3])   # parameters only: runs beside the STN head / block1 / text encoder
         if self.stn and training:
-            ctrl = _stn_forward(x, self.stn_head)
+            ctrl = _stn_forward(x, self.stn_head, False)
             xin, _ = _tps_forward(x, ctrl, self.tps)             # NHWC
         else:
             xin = x.permute(0, 2, 3, 1)                          # NHWC-indexed view, read through strides
@@ -381,20 +455,25 @@ class _GeneratorBase(nn.Module):
         b1 = Fh.prelu(Fh.conv2d(xin, c1.weight, c1.bias), self.block1[1].weight)
         feats = {"1": b1}
         tp_map = pr_weights = None
+        b1_trunk = b1
         if use_tp:
-            if text_emb is None:
-                text_emb = torch.zeros(1, 37, 1, 26, device=x.device)     # reference :653-654
-            tp_map, pr_weights = _tp_interpreter(b1, text_emb.float(), self.infoGen, training)
-        h = b1
+            tp_map, pr_weights = _tp_interpreter(cuts.cut("first", b1) if cuts else b1, text_emb.float(), self.infoGen, training,
+                                                 qpos)
+        tp_ret = tp_map
+        if cuts:                                 # backward stages: trunk (implicit, from the loss), then "tp", then "first"
+            b1_trunk = cuts.cut("first", b1)
+            if tp_map is not None:
+                tp_map = cuts.cut("tp", tp_map)
+        h = b1_trunk
         for i in range(k):
             h = _srb(h, tp_map, getattr(self, "block%d" % (i + 2)))
             feats[str(i + 2)] = h
         b7 = getattr(self, "block%d" % (k + 2))
         h = Fh.conv2d(h, b7[0].weight, b7[0].bias)
-        h = Fh.batch_norm_act(h, b7[1], ACT_NONE)
+        h = Fh.batch_norm_act(h, b7[1], ACT_NONE, False)
         feats[str(k + 2)] = h
         b8 = getattr(self, "block%d" % (k + 3))
-        u = Fh.add(b1, h)
+        u = Fh.add(b1_trunk, h)
         for m in list(b8)[:-1]:
             u = Fh.conv2d(u, m.conv.weight, m.conv.bias)
             u = Fh.PixelShuffleActFn.apply(u, ACT_MISH)
@@ -403,7 +482,7 @@ class _GeneratorBase(nn.Module):
         feats[str(k + 3)] = u
         sr = Fh.ActFn.apply(u, ACT_TANH)                         # reference :675
         self.block = {kk: _nchw(v) for kk, v in feats.items()}
-        return _nchw(sr), tp_map, pr_weights, b1
+        return _nchw(sr), tp_ret, pr_weights, b1
 
 
 class TSRN(_GeneratorBase):

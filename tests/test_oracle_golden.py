@@ -145,3 +145,55 @@ def test_ssim_tri_ssim_and_rotation():
     assert abs(float(O.tri_ssim(a, b, c)) - float(z["tri_ssim"])) < 1e-6
     d = O.torch_distortion(a, torch.from_numpy(z["arcs"]), torch.from_numpy(z["offs"]))
     assert max_err(d[:, :, ::4, ::4], torch.from_numpy(z["distorted"])) < 1e-5
+
+
+LARGE = dict(scale_factor=2, width=256, height=64, STN=False, mask=True, srb_nums=5, hidden_units=32)
+
+
+def test_large_tile_train_step():
+    """BASELINE.json configs[4] geometry (LR 32x128), train-mode forward + backward, B=2: oracle vs the reference's vectors."""
+    z = np.load("tests/golden/large_train_b2.npz")
+    sd = product_sd("TSRN_TL_TRANS", **LARGE)
+    x, tp, hr = (torch.from_numpy(z[k]) for k in ("x", "tp", "hr"))
+    loss, grads, sd1, _, out, _ = O.train_step(sd, x, tp, hr, tatt=True, stn=False)
+    assert abs(float(loss) - float(z["loss"])) < 1e-5 * float(z["loss"])
+    assert max_err(out["sr"], torch.from_numpy(z["sr"])) < 2e-5
+    assert sorted(k for k, g in grads.items() if g is None) == sorted(z["none_keys"].tolist())
+    for key in z.files:
+        if key.startswith("g:"):
+            assert rel_err(grads[key[2:]], torch.from_numpy(z[key])) < 1e-3, key
+    assert max_err(sd1["block4.bn1.running_var"], torch.from_numpy(z["bn_var"])) < 1e-6
+
+
+def test_bench_first_step_losses():
+    """bench.py's known-answer check: the oracle reproduces the reference's first-step loss on bench.py's own model and batch."""
+    import json
+    from bench import TILES
+    want = json.load(open("tests/golden/bench_losses.json"))
+    for tile in ("std", "large"):
+        t = TILES[tile]
+        sd = product_sd("TSRN_TL_TRANS", randomize=False, scale_factor=2, width=2 * t["W"], height=2 * t["H"], STN=t["stn"], mask=True,
+                        srb_nums=5, hidden_units=32)
+        g = torch.Generator().manual_seed(0)
+        B = t["batch"]
+        x = torch.rand(B, 4, t["H"], t["W"], generator=g)
+        x[:, 3] = (x[:, 3] > 0.5).float()
+        hr = torch.rand(B, 4, 2 * t["H"], 2 * t["W"], generator=g)
+        tp = torch.softmax(torch.randn(B, 37, 1, 26, generator=g), 1)
+        with torch.no_grad():
+            o = O.generator_forward(sd, x, tp, training=True, tatt=True, stn=t["stn"])
+            loss = float(O.image_loss(o["sr"], hr).mean() * 100)
+        assert abs(loss - want[t["loss_key"]]) < 1e-4 * loss, (tile, loss, want[t["loss_key"]])
+
+
+def test_fp64_error_bars_reproduce():
+    """The fp64 yardstick: the oracle in float64 reproduces the stored fp64 loss, and its own fp32 errors match the stored ones."""
+    z = np.load("tests/golden/tatt_train_b4.npz")
+    bars = np.load("tests/golden/fp64_error_bars.npz")
+    sd = product_sd("TSRN_TL_TRANS")
+    x, hr, tp = (torch.from_numpy(z[k]) for k in ("x", "hr", "tp"))
+    l64, g64, _, _, _, _ = O.train_step_fp64(sd, x, tp, hr, tatt=True, stn=True)
+    assert abs(float(l64) - float(bars["loss64"])) < 1e-10 * float(l64)
+    assert g64["block2.conv1.weight"].dtype == torch.float64
+    med = float(np.median(bars["ref32_err"]))
+    assert 1e-6 < med < 1e-3                       # the reference's own fp32 gradients: ~2e-5 from fp64 in the median, 7e-3 in the STN head

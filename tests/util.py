@@ -87,3 +87,20 @@ def compare_param_grads(named_params, oracle_grads, rtol, rtol_stn=None):
         if r > worst[1]:
             worst = (k, r)
     return worst
+
+
+class TorchStepKernels:
+    """TEST INFRASTRUCTURE: torch stand-ins for tatt_l2norm / tatt_adam_step (same argument meaning), injected into
+    tatt_amd.train.Trainer by the CPU (gloo) tests of its data-parallel orchestration.  Formulas = oracle.clip_grad_norm /
+    oracle.adam_step; the product's own default (HipStepKernels) has no CPU path."""
+
+    def l2norm(self, g, out, ws):
+        out.copy_(torch.sqrt((g.double() ** 2).sum()).float().reshape(1))
+
+    def adam(self, p, g, m, v, lr, b1, b2, eps, gnorm, max_norm, gscale, step):
+        from oracle import tatt_oracle as O
+        coef = gscale
+        if max_norm > 0.0:
+            coef = coef * min(1.0, max_norm / (float(gnorm) * gscale + 1e-6))
+        p1, m1, v1 = O.adam_step(p, g * coef, m, v, int(step), lr, (b1, b2), eps)
+        p.copy_(p1), m.copy_(m1), v.copy_(v1)
