@@ -18,18 +18,18 @@ TATT_API int tatt_prelu_fwd(const float* x, float* y, const float* alpha, long n
 // dx = dy * (x>=0 ? 1 : a);  dalpha partial[block] = sum dy*x*[x<0]
 __global__ void prelu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
                                  const float* __restrict__ a, long n, float* __restrict__ part) {
-    __shared__ float sh[4];
+    __shared__ double sh[4];
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    float s = 0.f;
+    double s = 0.0;                                   // the slope gradient is one cancelling sum over every element: fp64 partials
     if (i < n) {
         float v = x[i], g = dy[i];
         dx[i] = v >= 0.f ? g : a[0] * g;
-        if (v < 0.f) s = g * v;
+        if (v < 0.f) s = (double)g * (double)v;
     }
-    s = wave_sum(s);
+    s = wave_sum_d(s);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) part[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+    if (threadIdx.x == 0) part[blockIdx.x] = (float)((sh[0] + sh[1]) + (sh[2] + sh[3]));
 }
 // part: cdiv(n,256) floats (reduce with tatt_colsum(part, 1, G, 1, dalpha, ...))
 TATT_API int tatt_prelu_bwd(const float* x, const float* dy, float* dx, const float* alpha, long n, float* part,

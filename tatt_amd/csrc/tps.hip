@@ -47,8 +47,8 @@ TATT_API int tatt_tps_grid_fwd(const float* ctrl, const float* inv, const float*
 __global__ __launch_bounds__(256) void tps_grid_bwd_kernel(const float* __restrict__ dsrc, const float* __restrict__ inv,
                                                            const float* __restrict__ repr, float* __restrict__ dctrl,
                                                            int N, int P) {
-    __shared__ float red[4][TPS_MAXNP * 2];
-    __shared__ float dM[TPS_MAXNP][2];
+    __shared__ double red[4][TPS_MAXNP * 2];
+    __shared__ double dM[TPS_MAXNP][2];       // the kernel inverse has large cancelling entries: reduce and contract in fp64
     const int NP = N + 3, b = blockIdx.x, t = threadIdx.x;
     float acc[TPS_MAXNP * 2];
 #pragma unroll
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void tps_grid_bwd_kernel(const float* __restri
     }
 #pragma unroll
     for (int k = 0; k < TPS_MAXNP * 2; ++k) {
-        float v = wave_sum(acc[k]);
+        double v = wave_sum_d((double)acc[k]);   // per-thread sums hold P/256 = 4 terms
         if ((t & 63) == 0) red[t >> 6][k] = v;
     }
     __syncthreads();
@@ -72,9 +72,9 @@ __global__ __launch_bounds__(256) void tps_grid_bwd_kernel(const float* __restri
     __syncthreads();
     if (t < N * 2) {
         int i = t >> 1, d = t & 1;
-        float s = 0.f;
-        for (int j = 0; j < NP; ++j) s = fmaf(inv[j * NP + i], dM[j][d], s);
-        dctrl[((long)b * N + i) * 2 + d] = s;
+        double s = 0.0;
+        for (int j = 0; j < NP; ++j) s += (double)inv[j * NP + i] * dM[j][d];
+        dctrl[((long)b * N + i) * 2 + d] = (float)s;
     }
 }
 TATT_API int tatt_tps_grid_bwd(const float* dsrc, const float* inv, const float* repr, float* dctrl, int B, int N,

@@ -121,7 +121,12 @@ def broadcast_model(flat: FlatParams, model: torch.nn.Module, group=None, src: i
     outside `model.parameters()/buffers()` that must agree as well (a frozen teacher's weights)."""
     dist.broadcast(flat.p, src, group=group)
     for b in list(model.buffers()) + list(extra):
-        dist.broadcast(b, src, group=group)
+        if b.is_contiguous():
+            dist.broadcast(b, src, group=group)
+        else:                                        # e.g. tps.inverse_kernel: torch.inverse hands back column-major strides
+            t = b.contiguous()
+            dist.broadcast(t, src, group=group)
+            b.copy_(t)
 
 
 def allreduce_bucket(flat: FlatParams, k: int, group=None, async_op: bool = False):

@@ -57,62 +57,45 @@ def current_seed(device) -> torch.Tensor:
 
 
 # --------------------------------------------------------------------------------------------------
-# second HIP stream for work that is off the critical path
+# parameter gradients off the critical path
 # --------------------------------------------------------------------------------------------------
-class _SideStream:
-    """Weight / bias gradients (and their split-K reductions), the query-GRU (which depends on parameters only): many small
-    launches that nothing on the activation-gradient chain waits for.  With `enabled` (the Trainer switches it on around a
-    step) they are issued on a second HIP stream: fork = the side stream waits for an event recorded on the current stream,
-    join = the current stream waits for the side stream.  Inside a hipGraph capture these become parallel branches of the graph.
+class _DeferredParamGrads:
+    """Weight / bias gradients (and their split-K reductions) and the whole backward of the query GRU feed nothing but the
+    optimiser: a third of a training step's kernel time that the activation-gradient chain never waits for.  With `enabled`
+    (the Trainer switches it on around a backward stage) an operator's backward does NOT compute them: it hands a closure to
+    `submit`, returns None to autograd for those inputs, and the Trainer `flush`es the closures at the end of the stage, which
+    assigns the results to `param.grad` directly.  The activation-gradient chain then runs without the small reduction kernels
+    between its links (4 % of the step), and a data-parallel bucket is complete -- and on the wire -- one stage earlier.
 
-    Memory safety with torch's stream-ordered caching allocator: a tensor allocated on the main stream must not be freed (and
-    re-used by a later main-stream allocation) while a side-stream kernel still reads it -- `run` keeps its operands alive
-    until the next `join`; tensors allocated inside `run` belong to the side stream's pool and are only read on the main
-    stream after a join, and every later side-stream use starts with a fresh fork."""
+    Operands are kept referenced until `release()`."""
 
     def __init__(self):
         self.enabled = False
-        self._streams = {}
+        self._pending = []
         self._keep = []
-        self._dirty = {}
 
-    def stream(self, device):
-        k = str(device)
-        if k not in self._streams:
-            self._streams[k] = torch.cuda.Stream(device=device)
-        return self._streams[k]
-
-    def active(self, t: torch.Tensor) -> bool:
-        return self.enabled and t.is_cuda
-
-    def run(self, ref: torch.Tensor, fn, *keep):
-        """fn() on the side stream of ref's device (directly when disabled)."""
-        if not self.active(ref):
+    def submit(self, params, fn, *keep):
+        """params: tuple of leaf tensors (or None); fn() -> tuple of their gradients (or None), same order."""
+        if not self.enabled or any(p is not None and not p.is_leaf for p in params):
             return fn()
-        main = torch.cuda.current_stream(ref.device)
-        side = self.stream(ref.device)
-        if side == main:                           # already inside a side-stream region (autograd replays forward streams)
-            return fn()
-        ev = torch.cuda.Event()
-        ev.record(main)
-        side.wait_event(ev)
-        with torch.cuda.stream(side):
-            out = fn()
-        self._keep.append((keep, out))
-        self._dirty[str(ref.device)] = True
-        return out
+        self._pending.append((params, fn))
+        self._keep.append(keep)
+        return (None,) * len(params)
 
-    def join(self, device=None):
-        """Current stream waits for everything issued through `run` so far."""
-        for k, dirty in list(self._dirty.items()):
-            if dirty and (device is None or str(device) == k):
-                dev = torch.device(k)
-                torch.cuda.current_stream(dev).wait_stream(self.stream(dev))
-                self._dirty[k] = False
+    def flush(self):
+        """Run the pending closures in submission order on the CURRENT stream; results become / are added to `.grad`."""
+        pending, self._pending = self._pending, []
+        for params, fn in pending:
+            for p, g in zip(params, fn()):
+                if p is not None and g is not None:
+                    p.grad = g if p.grad is None else p.grad + g
+
+    def release(self):
+        assert not self._pending, "deferred parameter gradients were never flushed"
         self._keep.clear()
 
 
-SIDE = _SideStream()
+SIDE = _DeferredParamGrads()
 
 
 def _c(t):
@@ -131,6 +114,7 @@ class Conv2dFn(Function):
         ctx.save_for_backward(x, weight, y if act != ACT_NONE else None)
         ctx.act = act
         ctx.has_bias = bias is not None
+        ctx.leaves = (weight, bias)
         return y
 
     @staticmethod
@@ -149,7 +133,7 @@ class Conv2dFn(Function):
             dw = ops.conv_wgrad(x, dy, Cout, KH, KW) if want_dw else None
             db = ops.colsum(dy.reshape(-1, Cout)) if want_db else None
             return dw, db
-        dw, db = SIDE.run(dy, param_grads, x, dy)
+        dw, db = SIDE.submit(ctx.leaves, param_grads, x, dy)
         return dx, dw, db, None
 
 
@@ -204,6 +188,7 @@ class LinearFn(Function):
         y = ops.linear_fwd(x2, weight, bias, act=act, alpha=alpha, x2b=xb2)
         ctx.save_for_backward(x, xb, weight, y if act != ACT_NONE else None)
         ctx.act, ctx.alpha, ctx.has_bias = act, alpha, bias is not None
+        ctx.leaves = (weight, bias)
         return y.reshape(*x.shape[:-1], weight.shape[0])
 
     @staticmethod
@@ -234,7 +219,7 @@ class LinearFn(Function):
             elif want_db:
                 db = ops.colsum(dy2, scale=ctx.alpha)
             return dw, db
-        dw, db = SIDE.run(dy2, param_grads, dy2, x, xb)
+        dw, db = SIDE.submit(ctx.leaves, param_grads, dy2, x, xb)
         return dx, dxb, dw, db, None, None
 
 
@@ -312,6 +297,7 @@ class GruBlockFn(Function):
         ctx.save_for_backward(x, xb, Wc, Wp, gi, out, wih_f, whh_f, bhh_f, wih_r, whh_r, bhh_r, conv_b)
         ctx.geom = geom
         ctx.wshape = conv_w.shape
+        ctx.leaves = (conv_w, conv_b, wih_f, whh_f, bih_f, bhh_f, wih_r, whh_r, bih_r, bhh_r)
         return out.reshape(B, H, W, 64)
 
     @staticmethod
@@ -339,11 +325,8 @@ class GruBlockFn(Function):
             dWc, dbc = ops.new(dgi, 64, K), ops.new(dgi, 64)
             ops.call("tatt_gru_tail", ops.P(dWp), ops.P(dbp), ops.P(Wc), ops.P(conv_b), ops.P(wih_f), ops.P(wih_r),
                      ops.P(dwih_f), ops.P(dwih_r), ops.P(dWc), ops.P(dbc), K, ops.P(dWhh), ops.P(dwhh_f), ops.P(dwhh_r), ops.stream())
-            return dbp, dbhh, dwih_f, dwih_r, dwhh_f, dwhh_r, dWc, dbc
-        dbp, dbhh, dwih_f, dwih_r, dwhh_f, dwhh_r, dWc, dbc = SIDE.run(dgi, param_grads, dgi, dgh, hprev, x, xb, Wp, Wc)
-        return (dx, dxb, dWc.reshape(ctx.wshape), dbc,
-                dwih_f, dwhh_f, dbp[:96], dbhh[:96],
-                dwih_r, dwhh_r, dbp[96:], dbhh[96:], None)
+            return (dWc.reshape(ctx.wshape), dbc, dwih_f, dwhh_f, dbp[:96], dbhh[:96], dwih_r, dwhh_r, dbp[96:], dbhh[96:])
+        return (dx, dxb) + tuple(SIDE.submit(ctx.leaves, param_grads, dgi, dgh, hprev, x, xb, Wp, Wc)) + (None,)
 
 
 def gru_block(x, blk, vertical, xb=None):
@@ -562,6 +545,7 @@ class MhaInProjFn(Function):
             outs.append(y.reshape(*x.shape[:-1], E))
         ctx.save_for_backward(q_in, k_in, v_in, w)
         ctx.qscale = qscale
+        ctx.leaves = (w, b)
         return tuple(outs)
 
     @staticmethod
@@ -581,7 +565,7 @@ class MhaInProjFn(Function):
                 a = ctx.qscale if i == 0 else 1.0
                 ops.linear_bwd_weight(dy2, x.reshape(-1, E), alpha=a, out=dw[i * E:(i + 1) * E], out_ld=E, rowsum=db[i * E:(i + 1) * E])
             return dw, db
-        dw, db = SIDE.run(dys[0], param_grads, dys, q_in, k_in, v_in)
+        dw, db = SIDE.submit(ctx.leaves, param_grads, dys, q_in, k_in, v_in)
         return dxs[0], dxs[1], dxs[2], dw, db, None
 
 
@@ -604,12 +588,7 @@ class QueryGruFn(Function):
 
     @staticmethod
     def forward(ctx, emb, wih0, whh0, bih0, bhh0, wih1, whh1, bih1, bhh1, B, H, W):
-        # the embedding depends on parameters only: with the side stream on it runs next to the STN head / first convolution /
-        # text encoder, and its backward next to theirs -- the CALLER joins (SIDE.join) before the first use of the result
-        return SIDE.run(emb, lambda: QueryGruFn._forward(ctx, emb, wih0, whh0, bih0, bhh0, wih1, whh1, bih1, bhh1, B, H, W))
-
-    @staticmethod
-    def _forward(ctx, emb, wih0, whh0, bih0, bhh0, wih1, whh1, bih1, bhh1, B, H, W):
+        ctx.leaves = (emb, wih0, whh0, bih0, bhh0, wih1, whh1, bih1, bhh1)
         C = emb.shape[1]
         HID = whh0.shape[1]
         IN = wih0.shape[1]
@@ -639,12 +618,14 @@ class QueryGruFn(Function):
 
     @staticmethod
     def backward(ctx, dq):
+        # every output of this backward is a parameter gradient (the embedding depends on parameters only): all of it is deferrable
         dq = _c(dq)
-        return SIDE.run(dq, lambda: QueryGruFn._backward(ctx, dq), dq)
+        saved = ctx.saved_tensors
+        return tuple(SIDE.submit(ctx.leaves, lambda: QueryGruFn._backward(ctx, saved, dq), dq, saved)) + (None, None, None)
 
     @staticmethod
-    def _backward(ctx, dq):
-        emb, x, wih0, whh0, wih1, whh1, hseq, gsave = ctx.saved_tensors
+    def _backward(ctx, saved, dq):
+        emb, x, wih0, whh0, wih1, whh1, hseq, gsave = saved
         B, H, W, C, HID, IN = ctx.dims
         dq = _c(dq)
         dev = emb
@@ -696,7 +677,7 @@ class QueryGruFn(Function):
         demb = torch.empty_like(emb)
         ops.copy4d(dx, demb, (1, W, H, C), (0, IN, C, 1), (0, C, W * C, 1))
         (a0, b0, c0, d0), (a1, b1, c1, d1) = grads
-        return demb, a0, b0, c0, d0, a1, b1, c1, d1, None, None, None
+        return demb, a0, b0, c0, d0, a1, b1, c1, d1
 
 
 def query_embedding(emb, gru, B, H, W):
@@ -709,6 +690,9 @@ def query_embedding(emb, gru, B, H, W):
 class TpsGridFn(Function):
     @staticmethod
     def forward(ctx, ctrl, inv, pad, repr_):
+        # torch.inverse hands the kernel inverse back with column-major strides; the kernels index it row-major.  (The matrix is
+        # symmetric up to round-off, so reading it transposed "works" -- with 7e-6 of error in the sampling grid.)
+        inv, pad, repr_ = _c(inv), _c(pad), _c(repr_)
         ctx.save_for_backward(inv, repr_)
         ctx.N = ctrl.shape[1]
         return ops.tps_grid_fwd(ctrl, inv, pad, repr_)
@@ -724,6 +708,9 @@ class GridSampleFn(Function):
 
     @staticmethod
     def forward(ctx, x, src):
+        # the kernels take the OUTPUT size from the input image (the reference's TPS output size equals its input size)
+        assert src.dim() == 3 and src.shape[0] == x.shape[0] and src.shape[1] == x.shape[2] * x.shape[3] and src.shape[2] == 2, \
+            "sampling grid (B, H*W, 2) does not match the image (B, C, H, W): %s vs %s" % (tuple(src.shape), tuple(x.shape))
         ctx.save_for_backward(x, src)
         return ops.grid_sample_fwd(x, src)
 

@@ -141,31 +141,42 @@ def _default_loss(sr, hr):
 class Trainer:
     """One training step per `step()` call: forward, ImageLoss.mean()*100, backward, [all-reduce], clip, Adam.
 
-    * `use_graph`: after `warmup_eager` eager steps the step is captured once as hipGraph(s) and replayed.
-    * Weight/bias-gradient kernels and the query GRU run on a second HIP stream (`side_stream`), off the critical path of the
-      activation-gradient chain; inside a captured graph they are parallel branches.
-    * `process_group` (world > 1): the backward runs in the stages the model announces (`grad_buckets` / `set_grad_cuts`); after
-      stage k the bucket's gradients are gathered into the flat buffer and its sum all-reduce is issued asynchronously, so it
-      overlaps stage k+1 (graphs: one per stage, the collectives are launched between the replays); 1/world is folded into
-      the Adam kernel; every rank then clips and updates identically.  Rank 0's weights/buffers are broadcast at start and each
-      rank seeds its dropout stream differently (DataParallel replicas draw independent masks).
-    * `kernels` / `loss_fn`: the device kernels behind the optimiser and the loss (default: the HIP ones; the gloo CPU test of
-      this orchestration injects torch stand-ins -- there is no CPU path in the product)."""
+    The backward runs in the stages the model announces (`grad_buckets` / `set_grad_cuts`: trunk + up-sampler, TP interpreter,
+    block1 + STN head).  Inside a stage the activation-gradient chain runs first; weight / bias gradients and the query GRU's
+    backward -- a third of the step's kernel time that nothing on that chain waits for -- are only REGISTERED while it runs
+    (`defer_param_grads`, tatt_amd.functional.SIDE) and are issued back to back at the end of the stage, followed by the gather
+    of the stage's gradients into its bucket of the flat buffer and (data parallel) the bucket's asynchronous sum all-reduce over
+    RCCL, which then travels while the next stage computes.
+    `use_graph`: after `warmup_eager` eager steps the step is captured as hipGraph(s) and replayed: one graph for the whole step
+    on a single GPU, one per stage + one for the optimiser under data parallelism (the collectives are launched between them).
+    `process_group`: data parallelism, one process per GPU: rank 0's weights/buffers are broadcast at start, every rank seeds its
+    dropout stream differently (DataParallel replicas draw independent masks), 1/world is folded into the Adam kernel, every rank
+    then clips and updates identically.
+    `kernels` / `loss_fn`: the device kernels behind the optimiser and the loss (default: the HIP ones; the gloo CPU test of
+    this orchestration injects torch stand-ins -- there is no CPU path in the product).
+
+    (Measured and dropped, profiles/README.md round 2: running the deferred kernels on a second HIP stream.  Within one hipGraph
+    the ROCm 7 executor overlaps short parallel branches but serialises long ones; separate graphs, or eager launches, on a second
+    stream do not run beside a graph in flight at all.  Deferring alone is worth 4 % of the step.)"""
 
     def __init__(self, model, lr=1e-3, betas=(0.5, 0.999), eps=1e-8, clip=0.25, use_graph=False, warmup_eager=2,
-                 process_group=None, broadcast_init=True, side_stream=True, kernels=None, loss_fn=None, dropout_seed=None):
+                 process_group=None, broadcast_init=True, defer_param_grads=True, kernels=None, loss_fn=None, dropout_seed=None):
         self.model = model
         self.lr, self.betas, self.eps, self.clip = lr, betas, eps, clip
         self.pg = process_group
-        self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
-        self.rank = torch.distributed.get_rank(process_group) if process_group is not None else 0
+        # a process group switches the data-parallel path on -- also with a single rank (self-test of the path on one GPU)
+        self.dp = process_group is not None
+        self.world = torch.distributed.get_world_size(process_group) if self.dp else 1
+        self.rank = torch.distributed.get_rank(process_group) if self.dp else 0
         self.kernels = kernels if kernels is not None else HipStepKernels()
         self.loss_fn = loss_fn if loss_fn is not None else _default_loss
-        # a process group switches the data-parallel path on -- also with a single rank (self-test of the staged step on one GPU)
-        self.dp = process_group is not None
-        staged = self.dp and hasattr(model, "grad_buckets") and hasattr(model, "set_grad_cuts")
+        dev = next(model.parameters()).device
+        self.dev = dev
+        self.cuda = dev.type == "cuda"
+        self.defer = bool(defer_param_grads)
+        staged = (self.dp or self.defer) and hasattr(model, "grad_buckets") and hasattr(model, "set_grad_cuts")
         buckets = model.grad_buckets() if hasattr(model, "grad_buckets") else None
-        if buckets is not None and not staged:           # single process: one bucket, same parameter ORDER as the staged layout
+        if buckets is not None and not staged:           # one stage: one bucket, same parameter ORDER as the staged layout
             buckets = [("all", [p for _, ps in buckets for p in ps])]
         self.flat = FlatParams(model, buckets)
         self.stages = self.flat.bucket_names             # stage k fills bucket k; stage 0 is the backward from the loss
@@ -174,9 +185,6 @@ class Trainer:
             model.set_grad_cuts(self.cuts)
         self.params = self.flat.params
         self.n = self.flat.n
-        dev = self.flat.p.device
-        self.dev = dev
-        self.cuda = dev.type == "cuda"
         self.flat_p, self.flat_g = self.flat.p, self.flat.g
         self.flat_m = torch.zeros(self.n, device=dev)
         self.flat_v = torch.zeros(self.n, device=dev)
@@ -195,7 +203,6 @@ class Trainer:
         self.step_count = torch.zeros(1, dtype=torch.int64, device=dev)
         self.norm_ws = torch.empty(1024, dtype=torch.float64, device=dev)
         self.use_graph = use_graph and self.cuda
-        self.side_stream = side_stream and self.cuda
         self.warmup_eager = warmup_eager
         self._graphs = None
         self._static = None
@@ -205,9 +212,9 @@ class Trainer:
 
     # -- pieces ----------------------------------------------------------------------------------
     def _stage(self, k, x=None, tp=None, hr=None):
-        """Stage 0: forward + loss + backward from the loss; stage k > 0: the part of the backward `stages[k]` names.  Ends with
-        bucket k's gradients gathered into the flat buffer."""
-        Fh.SIDE.enabled = self.side_stream
+        """Stage 0: forward + loss + backward from the loss; stage k > 0: the part of the backward `stages[k]` names; then the
+        deferred parameter-gradient kernels of the stage; then bucket k of the flat gradient buffer."""
+        Fh.SIDE.enabled = self.defer
         try:
             if k == 0:
                 for p in self.params:
@@ -224,10 +231,10 @@ class Trainer:
                 self.last_loss = loss.detach()
             else:
                 self.cuts.run(self.stages[k])
-            if self.side_stream:
-                Fh.SIDE.join(self.dev)               # weight-gradient kernels of this stage have landed
         finally:
             Fh.SIDE.enabled = False
+        Fh.SIDE.flush()
+        Fh.SIDE.release()
         if k == len(self.stages) - 1 and hasattr(self.model, "block"):
             self.model.block = None                  # do not keep the autograd graph of this step alive
         self.flat.gather_grads(k)
@@ -242,13 +249,14 @@ class Trainer:
                               gn, max_norm, 1.0 / self.world, self.step_count)
 
     def _reduce(self, k):
+        """Data parallel: asynchronous sum all-reduce of bucket k, ordered behind the work already issued on the current stream
+        (RCCL runs it on its own stream: it overlaps the stages launched next)."""
         if self.dp:
-            w = allreduce_bucket(self.flat, k, self.pg, async_op=True)
-            self._works.append(w)
+            self._works.append(allreduce_bucket(self.flat, k, self.pg, async_op=True))
 
     def _wait_reduces(self):
         for w in self._works:
-            w.wait()                                 # GPU: the current stream waits for the collective; host does not block
+            w.wait()                                 # GPU: the current stream waits for the collective; the host does not block
         self._works = []
 
     @property
@@ -287,6 +295,7 @@ class Trainer:
         return self.last_loss.clone()                # the captured tensor is overwritten by the next replay
 
     def _capture(self, x, tp, hr):
+        """Capturing executes nothing: step() replays right away, so the step that captured is a real step."""
         self._static = (x.clone(), None if tp is None else tp.clone(), hr.clone())
         sx, stp, shr = self._static
         torch.cuda.synchronize()
@@ -301,14 +310,15 @@ class Trainer:
             graphs.append(g)
         else:
             # one graph per backward stage + one for the optimiser, all in one memory pool (activations saved by stage 0 are read by
-            # the later stages); the collectives are issued between the replays, outside the graphs
+            # the later stages); the collectives are issued between the replays.  The RCCL watchdog thread polls events while we
+            # capture: only THIS thread's calls are policed (thread_local).
             pool = torch.cuda.graph_pool_handle()
             for k in range(nst + 1):
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=pool):
+                with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
                     if k < nst:
                         self._stage(k, sx, stp, shr)
                     else:
                         self._optim()
                 graphs.append(g)
-        self._graphs = graphs                        # nothing has executed yet: step() replays them for the step that captured
+        self._graphs = graphs

@@ -221,7 +221,7 @@ class TPSSpatialTransformer(_Holder):
         fk[-3, :N].fill_(1)
         fk[:N, -2:].copy_(tcp)
         fk[-2:, :N].copy_(tcp.transpose(0, 1))
-        inverse_kernel = torch.inverse(fk)
+        inverse_kernel = torch.inverse(fk).contiguous()       # (torch.inverse returns column-major strides)
         ys, xs_ = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
         coord = torch.stack([xs_.reshape(-1).float(), ys.reshape(-1).float()], 1)
         Y = coord[:, 1:2] / (H - 1)
@@ -294,8 +294,7 @@ def _ffn(x, layer, training, site):
 
 
 def _query_pos(ig: TPInterpreter, B, H, W):
-    """Query positional embedding (model/transformer_v2.py:201-221) -> (B, H*W, C).  Depends on parameters only; issued on the
-    side stream when that is on -- `_tp_interpreter` joins before its first use."""
+    """Query positional embedding (model/transformer_v2.py:201-221) -> (B, H*W, C).  Depends on parameters only."""
     C = ig.init_factor.weight.shape[1]
     return Fh.query_embedding(ig.init_factor.weight, ig.transformer.gru_encoding, B, H, W).reshape(B, H * W, C)
 
@@ -331,7 +330,6 @@ def _tp_interpreter(feat, tp, ig: TPInterpreter, training, qpos=None):
     memory = Fh.layer_norm(src, Fh.dropout(f, enc.p, drop, 5), enc.norm2)
     # decoder: cross-attention only (self-attention commented out upstream, :817-819)
     kmem = add_pos(memory, pos)
-    Fh.SIDE.join(feat.device)                  # qpos may still be in flight on the side stream
     outs, wts = [], None
     for li, dec in enumerate(tr.decoder.layers):
         s0 = 10 + 10 * li
@@ -445,7 +443,7 @@ class _GeneratorBase(_TrainPathMixin, nn.Module):
         if use_tp:
             if text_emb is None:
                 text_emb = torch.zeros(1, 37, 1, 26, device=x.device)     # reference :653-654
-            qpos = _query_pos(self.infoGen, x.shape[0], x.shape[2], x.shape[3])   # parameters only: runs beside the STN head / block1 / text encoder
+            qpos = _query_pos(self.infoGen, x.shape[0], x.shape[2], x.shape[3])
         if self.stn and training:
             ctrl = _stn_forward(x, self.stn_head, False)
             xin, _ = _tps_forward(x, ctrl, self.tps)             # NHWC
