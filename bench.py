@@ -40,7 +40,10 @@ def parse():
     ap.add_argument("--dp-selftest", action="store_true",
                     help="N=1 only: run the data-parallel step (RCCL process group of one rank, staged backward, bucketed all-reduce)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--tssim", action="store_true",
+                    help="the shipped recipe (train_TATT.sh --tssim_loss --rotate_train=5): rotation + second forward + TRI_SSIM")
     ap.add_argument("--no-defer", action="store_true", help="A/B: weight-gradient kernels inline in the backward (no staging)")
+    ap.add_argument("--no-side-stream", action="store_true", help="A/B: deferred weight-gradient kernels on the main stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=48)
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) child process of the cpu_baseline leg")
@@ -223,7 +226,11 @@ def main():
         got = first_step_loss(model, x, tp, hr)
         assert abs(got - want) < 2e-4 * want, "first-step loss %.6f differs from the reference's %.6f" % (got, want)
         kat = {"first_step_loss_dropout_off": round(got, 6), "reference": round(want, 6)}
-    tr = Trainer(model, use_graph=use_graph, warmup_eager=2, process_group=pg, defer_param_grads=not a.no_defer)
+    recipe = None
+    if a.tssim:
+        from tatt_amd.train import TssimRecipe
+        recipe = TssimRecipe(5.0, seed=rank)
+    tr = Trainer(model, use_graph=use_graph, warmup_eager=2, process_group=pg, recipe=recipe, defer_param_grads=not a.no_defer, side_stream=not a.no_side_stream)
     if a.arch != "tatt":
         tp = None                      # tsrn / tbsrn take no prior; tatt_tpg computes it from the LR image with the CRNN student
 
@@ -261,9 +268,10 @@ def main():
             "config": {"workload": "TATT (TSRN_TL_TRANS, STN %s, dropout on) train step, batch %d/GPU, %dx%d LR -> %dx%d SR, "
                                    "ImageLoss + clip 0.25 + Adam(1e-3,(0.5,0.999))" % (
                                        "on" if tile["stn"] else "off", a.batch, tile["H"], tile["W"], 2 * tile["H"], 2 * tile["W"])
+                       + (" + rotate_train 5 deg + second forward + TRI_SSIM (train_TATT.sh recipe)" if a.tssim else "")
                        if a.arch == "tatt" else "%s train step, batch %d/GPU" % (a.arch.upper(), a.batch),
                        "global_batch": a.batch * world, "parallelism": "dp%d" % world + (" (self-test: RCCL group of one rank)" if a.dp_selftest else ""),
-                       "launch": ("hipGraph replay" if graph_ok else "eager") + ("" if a.no_defer else ", staged backward"), "final_loss": round(loss_v, 5),
+                       "launch": ("hipGraph replay" if graph_ok else "eager") + ("" if a.no_defer else ", staged backward" + ("" if a.no_side_stream else " on 2 streams")), "final_loss": round(loss_v, 5),
                        "known_answer": kat,
                        "whole_step_tflops": round(ips * tile["flop_per_image"] / 1e12, 2) if a.arch == "tatt" else None},
             "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",

@@ -292,6 +292,28 @@ int tatt_semantic_loss_bwd(const float* pred, const float* gt, const float* gout
 int tatt_psnr(const float* a, long a_n, long a_c, long a_h, long a_w, const float* b, long b_n, long b_c, long b_h, long b_w,
               float* out, int B, int C, int H, int W, hipStream_t st);
 
+/* ---- SSIM / TRI_SSIM losses and the rotation augmentation of the shipped recipe (train_TATT.sh: --tssim_loss
+ * --rotate_train=5) -------------------------------------------------------------------------------------------------------- */
+/* out[n] = mean over (C,H,W) of the SSIM map of sample n -- reference utils/ssim_psnr.py:76-97 (_ssim, x3 == NULL) or :99-129
+ * (_tri_ssim); 11x11 Gaussian window (sigma 1.5, :28-37), zero padding, one depth-wise filter per channel.  Images (B,C,H,W) are
+ * given by element strides.  ws: B*C*ceil(H/16)*ceil(W/64) doubles. */
+int tatt_ssim_fwd(const float* x1, long a_n, long a_c, long a_h, long a_w, const float* x2, long b_n, long b_c, long b_h,
+                  long b_w, const float* x3, long c_n, long c_c, long c_h, long c_w, int B, int C, int H, int W,
+                  float* out, double* ws, hipStream_t st);
+/* gradients of sum_n gs[n] * out[n] w.r.t. the images (contiguous (B,C,H,W) outputs; any of dx1/dx2/dx3 may be NULL).
+ * maps: workspace of B*C*5*H*W floats. */
+int tatt_ssim_bwd(const float* x1, long a_n, long a_c, long a_h, long a_w, const float* x2, long b_n, long b_c, long b_h,
+                  long b_w, const float* x3, long c_n, long c_c, long c_h, long c_w, int B, int C, int H, int W,
+                  const float* gs, float* maps, float* dx1, float* dx2, float* dx3, hipStream_t st);
+/* out (B,C,H,W contiguous) = F.grid_sample(x, F.affine_grid(theta (B,2,3), x.shape)) -- bilinear, zeros padding,
+ * align_corners=False: the resampling of torch_distortion / TextSR.torch_rotate_img (reference model/__init__.py:4-29,
+ * interfaces/super_resolution.py:126-157).  x by element strides. */
+int tatt_affine_sample_fwd(const float* x, long xsn, long xsc, long xsh, long xsw, const float* theta, float* out, int B,
+                           int C, int H, int W, hipStream_t st);
+/* gradient w.r.t. the image (deterministic gather; dout, dimg contiguous (B,C,H,W), C <= 4) */
+int tatt_affine_sample_bwd(const float* theta, const float* dout, float* dimg, int B, int C, int H, int W,
+                           hipStream_t st);
+
 #ifdef __cplusplus
 }
 #endif

@@ -987,3 +987,63 @@ class SemanticLossFn(Function):
         d = torch.empty_like(pred)
         ops.call("tatt_semantic_loss_bwd", ops.P(pred), ops.P(gt), ops.P(_c(g)), pred.numel(), ops.P(d), ops.stream())
         return d, None
+
+
+# --------------------------------------------------------------------------------------------------
+# SSIM / TRI_SSIM and the rotation augmentation of the shipped recipe
+# --------------------------------------------------------------------------------------------------
+class SsimFn(Function):
+    """Per-sample mean of the SSIM map over (C,H,W): reference _ssim (utils/ssim_psnr.py:76-97) for two images, _tri_ssim
+    (:99-129) for three; 11x11 Gaussian window, zero padding.  One forward kernel; backward = coefficient maps + one filter pass."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, x3):
+        ops._check_dev(x1)
+        ops._check_dev(x2)
+        B, C, H, W = x1.shape
+        assert x2.shape == x1.shape and (x3 is None or x3.shape == x1.shape)
+        out = ops.new(x1, B)
+        tiles = ops.cdiv(H, 16) * ops.cdiv(W, 64)
+        ws = ops.new(x1, B * C * tiles, dtype=torch.float64)
+        s3 = x3.stride() if x3 is not None else (0, 0, 0, 0)
+        ops.call("tatt_ssim_fwd", ops.P(x1), *x1.stride(), ops.P(x2), *x2.stride(), ops.P(x3), *s3, B, C, H, W, ops.P(out), ops.P(ws),
+                 ops.stream())
+        ctx.save_for_backward(x1, x2, x3)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x1, x2, x3 = ctx.saved_tensors
+        B, C, H, W = x1.shape
+        need = ctx.needs_input_grad
+        maps = ops.new(x1, B * C * 5 * H * W)
+        dx = [ops.new(x1, B, C, H, W) if (need[i] and (i < 2 or x3 is not None)) else None for i in range(3)]
+        s3 = x3.stride() if x3 is not None else (0, 0, 0, 0)
+        ops.call("tatt_ssim_bwd", ops.P(x1), *x1.stride(), ops.P(x2), *x2.stride(), ops.P(x3), *s3, B, C, H, W, ops.P(_c(g)), ops.P(maps),
+                 ops.P(dx[0]), ops.P(dx[1]), ops.P(dx[2]), ops.stream())
+        return dx[0], dx[1], dx[2]
+
+
+class AffineSampleFn(Function):
+    """F.grid_sample(x, F.affine_grid(theta, x.shape)) -- bilinear, zeros padding, align_corners=False -- with the gradient
+    w.r.t. the IMAGE (theta carries none): the rotation of the training recipe is applied to a network output
+    (interfaces/super_resolution.py:910-914)."""
+
+    @staticmethod
+    def forward(ctx, x, theta):
+        ops._check_dev(x)
+        B, C, H, W = x.shape
+        theta = _c(theta.reshape(B, 6).to(x.device, torch.float32))
+        out = ops.new(x, B, C, H, W)
+        ops.call("tatt_affine_sample_fwd", ops.P(x), *x.stride(), ops.P(theta), ops.P(out), B, C, H, W, ops.stream())
+        ctx.save_for_backward(theta)
+        ctx.shape = (B, C, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (theta,) = ctx.saved_tensors
+        B, C, H, W = ctx.shape
+        dimg = ops.new(dout, B, C, H, W)
+        ops.call("tatt_affine_sample_bwd", ops.P(theta), ops.P(_c(dout)), ops.P(dimg), B, C, H, W, ops.stream())
+        return dimg, None

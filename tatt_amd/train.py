@@ -123,6 +123,57 @@ class TextPriorSR(torch.nn.Module):
         return loss
 
 
+class TssimRecipe:
+    """The shipped training recipe (train_TATT.sh: --tssim_loss --rotate_train=5), reference interfaces/super_resolution.py:637-654
+    and :873-914: every step draws a rotation angle in [-rotate_train, rotate_train] degrees and an aspect jitter per sample;
+
+        x_rot, hr_rot = rotate(x), rotate(hr);   x_ret = rotate(x_rot, -angle)
+        sr = G(x_rot, prior);                    sr_ret = G(x_ret, prior)
+        loss = ImageLoss(sr, hr_rot).mean() * 100 + (1 - TRI_SSIM(rotate(sr_ret), sr, hr_rot).mean()) * 10
+
+    Two generator forwards per step (their parameter gradients add up), four image resamplings, one TRI_SSIM.  The angles live in
+    device tensors that `new_step` refreshes from the host RNG, so the step stays replayable as a hipGraph."""
+
+    def __init__(self, rotate_train=5.0, seed=0, off_range=0.2):
+        import numpy as np
+        self.rotate_train, self.off_range = float(rotate_train), off_range
+        self.rng = np.random.RandomState(seed)
+        self.theta_pos = self.theta_neg = None
+        self.last = None
+
+    def draw(self, B):
+        """(arcs, rand_offs) as the reference draws them (np.random.rand(B) * 2r - r degrees; np.random.rand(B))."""
+        import math
+        arcs = torch.tensor((self.rng.rand(B) * self.rotate_train * 2 - self.rotate_train) / 180.0 * math.pi).float()
+        offs = torch.tensor(self.rng.rand(B)).float()
+        return arcs, offs
+
+    def new_step(self, x, arcs=None, offs=None):
+        from .losses import rotation_theta
+        B, _, H, W = x.shape
+        if arcs is None:
+            arcs, offs = self.draw(B)
+        self.last = (arcs, offs)
+        pos, neg = rotation_theta(arcs, offs, H, W, self.off_range), rotation_theta(-arcs, offs, H, W, self.off_range)
+        if self.theta_pos is None:
+            self.theta_pos, self.theta_neg = pos.to(x.device), neg.to(x.device)
+        else:
+            self.theta_pos.copy_(pos)
+            self.theta_neg.copy_(neg)
+
+    def loss(self, model, x, tp, hr):
+        from .losses import TRI_SSIM
+        rot = Fh.AffineSampleFn.apply
+        with torch.no_grad():
+            x_rot, hr_rot = rot(x, self.theta_pos), rot(hr, self.theta_pos)
+            x_ret = rot(x_rot, self.theta_neg)
+        sr = model(x_rot, tp)[0]
+        sr_ret = model(x_ret, tp)[0]
+        l_img = image_loss_mean(sr, hr_rot, scale=100.0)
+        l_tssim = (1.0 - TRI_SSIM()(rot(sr_ret, self.theta_pos), sr, hr_rot)) * 10.0
+        return l_img + l_tssim
+
+
 class HipStepKernels:
     """The optimiser side of a step on the GPU: global-norm clip + Adam on flat buffers (tatt_l2norm, tatt_adam_step)."""
 
@@ -155,12 +206,16 @@ class Trainer:
     `kernels` / `loss_fn`: the device kernels behind the optimiser and the loss (default: the HIP ones; the gloo CPU test of
     this orchestration injects torch stand-ins -- there is no CPU path in the product).
 
-    (Measured and dropped, profiles/README.md round 2: running the deferred kernels on a second HIP stream.  Within one hipGraph
-    the ROCm 7 executor overlaps short parallel branches but serialises long ones; separate graphs, or eager launches, on a second
-    stream do not run beside a graph in flight at all.  Deferring alone is worth 4 % of the step.)"""
+    `side_stream` (needs `defer_param_grads`): the deferred kernels, the gather and the collective of stage k are issued on a second
+    HIP stream behind an event, so that they may run beside the activation-gradient chain of stage k+1; with `use_graph` every
+    lane of every stage is its own single-stream hipGraph (one memory pool, one capture stream per lane).  What this buys on
+    ROCm 7 is modest (profiles/README.md, round 2): hipGraph launches on different streams mostly execute one after the other
+    and only overlap around their boundaries -- 0.4-0.5 ms of a 10 ms step; within ONE graph the executor overlaps short parallel
+    branches but serialises long ones (tools/graph_sched_probe.py)."""
 
     def __init__(self, model, lr=1e-3, betas=(0.5, 0.999), eps=1e-8, clip=0.25, use_graph=False, warmup_eager=2,
-                 process_group=None, broadcast_init=True, defer_param_grads=True, kernels=None, loss_fn=None, dropout_seed=None):
+                 process_group=None, broadcast_init=True, defer_param_grads=True, side_stream=True, kernels=None, loss_fn=None,
+                 dropout_seed=None, recipe=None):
         self.model = model
         self.lr, self.betas, self.eps, self.clip = lr, betas, eps, clip
         self.pg = process_group
@@ -170,10 +225,12 @@ class Trainer:
         self.rank = torch.distributed.get_rank(process_group) if self.dp else 0
         self.kernels = kernels if kernels is not None else HipStepKernels()
         self.loss_fn = loss_fn if loss_fn is not None else _default_loss
+        self.recipe = recipe                             # e.g. TssimRecipe: computes the step's loss itself (several forwards)
         dev = next(model.parameters()).device
         self.dev = dev
         self.cuda = dev.type == "cuda"
         self.defer = bool(defer_param_grads)
+        self.two_lanes = self.defer and bool(side_stream) and self.cuda
         staged = (self.dp or self.defer) and hasattr(model, "grad_buckets") and hasattr(model, "set_grad_cuts")
         buckets = model.grad_buckets() if hasattr(model, "grad_buckets") else None
         if buckets is not None and not staged:           # one stage: one bucket, same parameter ORDER as the staged layout
@@ -198,6 +255,7 @@ class Trainer:
             base = 0x1234ABCD5678EF01 if dropout_seed is None else int(dropout_seed)
             if self.dp or dropout_seed is not None:
                 Fh.set_seed(dev, rank_dropout_seed(base, self.rank) if self.dp else base)
+        self.side = torch.cuda.Stream(device=dev) if self.two_lanes else None
         self.gnorms = [torch.zeros(1, device=dev) for _ in self.groups]
         self.gnorm = self.gnorms[0]
         self.step_count = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -211,9 +269,8 @@ class Trainer:
         self.last_loss = None
 
     # -- pieces ----------------------------------------------------------------------------------
-    def _stage(self, k, x=None, tp=None, hr=None):
-        """Stage 0: forward + loss + backward from the loss; stage k > 0: the part of the backward `stages[k]` names; then the
-        deferred parameter-gradient kernels of the stage; then bucket k of the flat gradient buffer."""
+    def _main_lane(self, k, x=None, tp=None, hr=None):
+        """Stage 0: forward + loss + backward from the loss; stage k > 0: the part of the backward `stages[k]` names."""
         Fh.SIDE.enabled = self.defer
         try:
             if k == 0:
@@ -221,23 +278,37 @@ class Trainer:
                     p.grad = None
                 if self.cuts is not None:
                     self.cuts.reset()
-                out = self.model(x, tp) if tp is not None else self.model(x)
-                sr = out[0] if isinstance(out, tuple) else out
-                loss = self.loss_fn(sr, hr)
-                extra = self.model.extra_loss(hr) if hasattr(self.model, "extra_loss") else None
-                if extra is not None:
-                    loss = loss + extra
+                if self.recipe is not None:
+                    loss = self.recipe.loss(self.model, x, tp, hr)
+                else:
+                    out = self.model(x, tp) if tp is not None else self.model(x)
+                    sr = out[0] if isinstance(out, tuple) else out
+                    loss = self.loss_fn(sr, hr)
+                    extra = self.model.extra_loss(hr) if hasattr(self.model, "extra_loss") else None
+                    if extra is not None:
+                        loss = loss + extra
                 loss.backward()
                 self.last_loss = loss.detach()
             else:
                 self.cuts.run(self.stages[k])
         finally:
             Fh.SIDE.enabled = False
-        Fh.SIDE.flush()
-        Fh.SIDE.release()
         if k == len(self.stages) - 1 and hasattr(self.model, "block"):
             self.model.block = None                  # do not keep the autograd graph of this step alive
+
+    def _side_lane(self, k):
+        """The deferred parameter-gradient kernels of stage k, then bucket k of the flat gradient buffer."""
+        Fh.SIDE.flush()
         self.flat.gather_grads(k)
+
+    def _stage(self, k, x=None, tp=None, hr=None):
+        self._main_lane(k, x, tp, hr)
+        self._side_lane(k)
+
+    def _on_side(self):
+        """Context: the side stream, ordered behind everything issued on the current stream so far."""
+        self.side.wait_stream(torch.cuda.current_stream(self.dev))
+        return torch.cuda.stream(self.side)
 
     def _optim(self):
         self.step_count += 1
@@ -254,10 +325,15 @@ class Trainer:
         if self.dp:
             self._works.append(allreduce_bucket(self.flat, k, self.pg, async_op=True))
 
-    def _wait_reduces(self):
+    def _join(self):
+        """The current stream waits for the side lane and for the collectives (device-side waits; the host does not block on a
+        GPU); operands kept alive for deferred kernels may go."""
+        if self.two_lanes:
+            torch.cuda.current_stream(self.dev).wait_stream(self.side)
         for w in self._works:
-            w.wait()                                 # GPU: the current stream waits for the collective; the host does not block
+            w.wait()
         self._works = []
+        Fh.SIDE.release()
 
     @property
     def last_grad_norm(self):
@@ -270,28 +346,44 @@ class Trainer:
         (a fresh device scalar, no host sync)."""
         self._nsteps += 1
         nst = len(self.stages)
-        if not self.use_graph or self._nsteps <= self.warmup_eager:
-            for k in range(nst):
-                self._stage(k, x, tp, hr)
+        if self.recipe is not None:
+            self.recipe.new_step(x)
+        graphs = None
+        if self.use_graph and self._nsteps > self.warmup_eager:
+            if self._graphs is None:
+                self._capture(x, tp, hr)
+            graphs = self._graphs
+            sx, stp, shr = self._static
+            sx.copy_(x)
+            shr.copy_(hr)
+            if stp is not None:
+                stp.copy_(tp)
+        if graphs is not None and "step" in graphs:
+            graphs["step"].replay()                  # single GPU, single stream: the whole step is one graph
+            return self.last_loss.clone()
+        for k in range(nst):
+            if graphs is None:
+                self._main_lane(k, x, tp, hr)
+            else:
+                graphs["main"][k].replay()
+            if self.two_lanes:
+                with self._on_side():
+                    if graphs is None:
+                        self._side_lane(k)
+                    else:
+                        graphs["side"][k].replay()
+                    self._reduce(k)
+            else:
+                if graphs is None:
+                    self._side_lane(k)
+                else:
+                    graphs["side"][k].replay()
                 self._reduce(k)
-            self._wait_reduces()
+        self._join()
+        if graphs is None:
             self._optim()
             return self.last_loss
-        if self._graphs is None:
-            self._capture(x, tp, hr)
-        sx, stp, shr = self._static
-        sx.copy_(x)
-        shr.copy_(hr)
-        if stp is not None:
-            stp.copy_(tp)
-        if not self.dp:
-            self._graphs[0].replay()
-        else:
-            for k in range(nst):
-                self._graphs[k].replay()
-                self._reduce(k)
-            self._wait_reduces()
-            self._graphs[nst].replay()
+        graphs["optim"].replay()
         return self.last_loss.clone()                # the captured tensor is overwritten by the next replay
 
     def _capture(self, x, tp, hr):
@@ -300,25 +392,37 @@ class Trainer:
         sx, stp, shr = self._static
         torch.cuda.synchronize()
         nst = len(self.stages)
-        graphs = []
-        if not self.dp:
+        if not self.dp and not self.two_lanes:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 for k in range(nst):
                     self._stage(k, sx, stp, shr)
+                Fh.SIDE.release()
                 self._optim()
-            graphs.append(g)
-        else:
-            # one graph per backward stage + one for the optimiser, all in one memory pool (activations saved by stage 0 are read by
-            # the later stages); the collectives are issued between the replays.  The RCCL watchdog thread polls events while we
-            # capture: only THIS thread's calls are policed (thread_local).
-            pool = torch.cuda.graph_pool_handle()
-            for k in range(nst + 1):
+            self._graphs = {"step": g}
+            return
+        # One single-stream graph per lane and stage + one for the optimiser, all in one memory pool (activations saved by stage 0
+        # are read by the later stages and by the side lanes); the collectives are launched between the replays.
+        # One capture stream per lane: the caching allocator hands a block freed during capture only to later allocations on the
+        # SAME stream, so a temporary of side lane k can never be recycled by main lane k+1, which may run beside it at replay.
+        pool = torch.cuda.graph_pool_handle()
+        cap_main = torch.cuda.Stream(device=self.dev)
+        cap_side = self.side if self.two_lanes else cap_main
+        # data parallel: the RCCL watchdog thread polls events while we capture -- only THIS thread's calls are policed
+        kw = dict(pool=pool, capture_error_mode="thread_local" if self.dp else "global")
+        graphs = {"main": [], "side": []}
+        for k in range(nst):
+            for lane, cap in (("main", cap_main), ("side", cap_side)):
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
-                    if k < nst:
-                        self._stage(k, sx, stp, shr)
+                with torch.cuda.graph(g, stream=cap, **kw):
+                    if lane == "main":
+                        self._main_lane(k, sx, stp, shr)
                     else:
-                        self._optim()
-                graphs.append(g)
+                        self._side_lane(k)
+                graphs[lane].append(g)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=cap_main, **kw):
+            self._optim()
+        graphs["optim"] = g
+        Fh.SIDE.release()
         self._graphs = graphs

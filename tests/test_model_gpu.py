@@ -361,12 +361,15 @@ def test_staged_deferred_backward_equals_single_pass(dev):
     against the single-pass backward: identical kernels on identical inputs, only their order and the points where the autograd
     engine is re-entered differ -> identical results."""
     l1, s1, _, g1 = _run_steps(dev, 3, 6, True, use_graph=False, defer_param_grads=False)
-    l2, s2, _, g2 = _run_steps(dev, 3, 6, True, use_graph=False, defer_param_grads=True)
-    l3, s3, _, g3 = _run_steps(dev, 5, 6, True, use_graph=True, defer_param_grads=True)
+    l2, s2, _, g2 = _run_steps(dev, 3, 6, True, use_graph=False, defer_param_grads=True, side_stream=True)
+    l3, s3, _, g3 = _run_steps(dev, 5, 6, True, use_graph=True, defer_param_grads=True, side_stream=True)
+    l4, s4, _, g4 = _run_steps(dev, 5, 6, True, use_graph=True, defer_param_grads=True, side_stream=False)
     assert l1 == l2 and g1 == g2
     for k in s1:
         assert torch.equal(s1[k], s2[k]), k
-    assert l3[:3] == l1
+    assert l3[:3] == l1 and l4 == l3
+    for k in s3:
+        assert torch.equal(s3[k], s4[k]), k
 
 
 def test_single_rank_process_group_runs_the_staged_step(dev):
