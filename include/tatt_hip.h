@@ -59,6 +59,9 @@ int tatt_conv2d_wgrad(const float* x, long xsn, long xsh, long xsw, long xsc, co
  * per-lane register order of tatt_conv3_c64_fwd_ws */
 int tatt_repack_conv_weight(const float* w_oihw, float* out, int Cout, int Cin, int KH, int KW,
                             int mode, hipStream_t st);
+/* the same for n filters in one launch (all packed layouts of a model, refreshed once per optimiser step): ws / outs are HOST arrays
+ * of n device pointers, dims a host array of n x 5 ints (Cout, Cin, KH, KW, mode) */
+int tatt_repack_conv_weight_batch(const float* const* ws, float* const* outs, const int* dims, int n, hipStream_t st);
 
 /* C = sum over S partial (M x N) slabs (+ beta*C); remap_cin > 0: row i = tap*remap_cin + ci, col j = co is scattered to
  * the OIHW filter layout dW[co][ci][tap] */

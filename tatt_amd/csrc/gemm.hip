@@ -843,6 +843,50 @@ TATT_API int tatt_repack_conv_weight(const float* w_oihw, float* out, int Cout, 
     return LAUNCH_CHECK();
 }
 
+// All packed filter layouts of a model in ONE launch (after the optimiser has moved the weights): up to REPACK_MAX entries, the
+// descriptor table travels in the kernel arguments (fixed at hipGraph capture: the buffers are persistent).
+#define REPACK_MAX 96
+struct RepackEntry { const float* w; float* out; int Cout, Cin, KH, KW, mode, block0; };
+struct RepackTable { RepackEntry e[REPACK_MAX]; int n; };
+__global__ void repack_batch_kernel(RepackTable t) {
+    int k = 0;
+    while (k + 1 < t.n && (int)blockIdx.x >= t.e[k + 1].block0) ++k;          // wave-uniform walk over <= 96 entries
+    const RepackEntry& e = t.e[k];
+    const int idx = ((int)blockIdx.x - e.block0) * blockDim.x + threadIdx.x;
+    const int total = e.Cout * e.Cin * e.KH * e.KW;
+    if (idx >= total) return;
+    const int T = e.KH * e.KW, Cout = e.Cout, Cin = e.Cin;
+    const float* w = e.w;
+    float v;
+    if (e.mode == 0) { int co = idx % Cout; int r = idx / Cout; int ci = r % Cin; int tap = r / Cin; v = w[((long)co * Cin + ci) * T + tap]; }
+    else if (e.mode == 1) { int ci = idx % Cin; int r = idx / Cin; int co = r % Cout; int tap = r / Cout; v = w[((long)co * Cin + ci) * T + (T - 1 - tap)]; }
+    else if (e.mode == 2) { int ci = idx % Cin; int r = idx / Cin; int co = r % Cout; int tap = r / Cout; v = w[((long)co * Cin + ci) * T + tap]; }
+    else if (e.mode == 3) { int co = idx % Cout; int r = idx / Cout; int ci = r % Cin; int tap = r / Cin; v = w[((long)co * Cin + ci) * T + (T - 1 - tap)]; }
+    else {
+        const int u = idx & 3, lane = (idx >> 2) & 63, q = (idx >> 8) % 72, ob = idx / (72 * 256);
+        const int tap = q >> 3, c = q & 7;
+        const int o = ob * 32 + (lane & 31), i = 8 * c + 4 * (lane >> 5) + u;
+        v = e.mode == 4 ? w[((long)o * Cin + i) * T + tap] : w[((long)i * Cin + o) * T + (T - 1 - tap)];
+    }
+    e.out[idx] = v;
+}
+// ws/outs: n source / destination pointers; dims: n x 5 ints (Cout, Cin, KH, KW, mode).  Host arrays, read during the call.
+TATT_API int tatt_repack_conv_weight_batch(const float* const* ws, float* const* outs, const int* dims, int n, hipStream_t st) {
+    if (n <= 0) return 0;
+    for (int base = 0; base < n; base += REPACK_MAX) {
+        RepackTable t;
+        t.n = n - base < REPACK_MAX ? n - base : REPACK_MAX;
+        int blocks = 0;
+        for (int k = 0; k < t.n; ++k) {
+            const int* d = dims + (long)(base + k) * 5;
+            t.e[k] = {ws[base + k], outs[base + k], d[0], d[1], d[2], d[3], d[4], blocks};
+            blocks += cdiv((long)d[0] * d[1] * d[2] * d[3], 256);
+        }
+        hipLaunchKernelGGL(repack_batch_kernel, dim3(blocks), dim3(256), 0, st, t);
+    }
+    return LAUNCH_CHECK();
+}
+
 // Deterministic reduction of S partial (M x N) slabs: C = sum_s partial[s] (+ beta*C).  remap_cin > 0 scatters row
 // i = tap*remap_cin + ci, column j = co to the OIHW filter layout dW[co][ci][tap] (used by the specialised conv
 // weight-gradient kernels of conv3.hip).

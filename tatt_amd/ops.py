@@ -130,7 +130,52 @@ def colsum(x2, *, out=None, scale=1.0, beta=0.0):
 # --------------------------------------------------------------------------------------------------
 # convolution (x given as a (B,H,W,C)-indexed tensor with arbitrary strides)
 # --------------------------------------------------------------------------------------------------
-def repack_weight(w_oihw, mode):
+class _PackedFilters:
+    """Packed copies of convolution filters (the layouts the conv kernels want, see tatt_repack_conv_weight), kept per
+    (parameter storage, layout) instead of being rebuilt at every use -- 39 launches of a training step.
+
+    An entry is valid while the parameter's torch version counter is unchanged; in-place updates torch does not see (the
+    Trainer's Adam kernel writes through raw pointers) are followed by `refresh()`: ONE launch that rebuilds every entry
+    (captured into the optimiser's hipGraph; the buffers are persistent, so the captured pointers stay valid)."""
+
+    def __init__(self):
+        self.entries = {}
+
+    def get(self, w, mode):
+        key = (w.data_ptr(), tuple(w.shape), mode, str(w.device))
+        e = self.entries.get(key)
+        if e is not None and e[1] == w._version and e[2].data_ptr() == w.data_ptr():
+            return e[0]
+        Cout, Cin, KH, KW = w.shape
+        if e is None and len(self.entries) >= 1024:          # entries pin their parameter's storage: bound what a long-lived
+            self.entries.clear()                             # process that keeps building models can accumulate
+        out = e[0] if e is not None else torch.empty(KH * KW * Cin * Cout, device=w.device, dtype=torch.float32)
+        call("tatt_repack_conv_weight", P(w), P(out), Cout, Cin, KH, KW, mode, stream())
+        self.entries[key] = (out, w._version, w.detach())
+        return out
+
+    def refresh(self, device=None):
+        """Rebuild every cached layout from the current weights (one launch per 96 entries)."""
+        ent = [(k, e) for k, e in self.entries.items() if device is None or k[3] == str(device)]
+        if not ent:
+            return
+        n = len(ent)
+        ws = (ctypes.c_void_p * n)(*[e[2].data_ptr() for _, e in ent])
+        outs = (ctypes.c_void_p * n)(*[e[0].data_ptr() for _, e in ent])
+        dims = (ctypes.c_int * (5 * n))(*[v for k, _ in ent for v in (k[1][0], k[1][1], k[1][2], k[1][3], k[2])])
+        call("tatt_repack_conv_weight_batch", ws, outs, dims, n, stream())
+
+    def clear(self):
+        self.entries.clear()
+
+
+PACKED = _PackedFilters()
+
+
+def repack_weight(w_oihw, mode, cache=True):
+    """Packed layout `mode` of an OIHW filter.  Parameters (leaf tensors) go through the cache; anything else is packed on the spot."""
+    if cache and w_oihw.is_leaf and w_oihw.is_contiguous():
+        return PACKED.get(w_oihw, mode)
     Cout, Cin, KH, KW = w_oihw.shape
     out = new(w_oihw, KH * KW * Cin * Cout)
     call("tatt_repack_conv_weight", P(w_oihw), P(out), Cout, Cin, KH, KW, mode, stream())

@@ -184,6 +184,10 @@ class HipStepKernels:
         ops.call("tatt_adam_step", ops.P(p), ops.P(g), ops.P(m), ops.P(v), p.numel(), lr, b1, b2, eps, ops.P(gnorm), max_norm,
                  gscale, ops.P(step), ops.stream())
 
+    def after_update(self, device):
+        """The weights moved behind torch's back (raw-pointer kernel): rebuild the cached packed filter layouts, one launch."""
+        ops.PACKED.refresh(device)
+
 
 def _default_loss(sr, hr):
     return image_loss_mean(sr, hr, scale=100.0)
@@ -318,6 +322,8 @@ class Trainer:
                 self.kernels.l2norm(self.flat_g[s:e], gn, self.norm_ws)
             self.kernels.adam(self.flat_p[s:e], self.flat_g[s:e], self.flat_m[s:e], self.flat_v[s:e], self.lr, b1, b2, self.eps,
                               gn, max_norm, 1.0 / self.world, self.step_count)
+        if hasattr(self.kernels, "after_update"):
+            self.kernels.after_update(self.dev)
 
     def _reduce(self, k):
         """Data parallel: asynchronous sum all-reduce of bucket k, ordered behind the work already issued on the current stream
