@@ -94,11 +94,11 @@ def time_dominant_kernel(dev, B, H=16, W=64):
     x = torch.randn(B, H, W, 64, device=dev)
     w = torch.randn(64, 64, 3, 3, device=dev) * 0.05
     b = torch.zeros(64, device=dev)
-    wl = ops.repack_weight(w, 4)
+    wl = ops.repack_weight(w, ops._WS_FWD_MODE)
     y = torch.empty(B, H, W, 64, device=dev)
 
     def run():
-        ops.call("tatt_conv3_c64_fwd_ws", ops.P(x), ops.P(wl), ops.P(b), ops.P(y), B, H, W, 64, 0, 0.0, ops.stream())
+        ops.call(ops._WS_ENTRY, ops.P(x), ops.P(wl), ops.P(b), ops.P(y), B, H, W, 64, 0, 0.0, ops.stream())
     for _ in range(5):
         run()
     n = 50
@@ -259,6 +259,7 @@ def main():
         ms = dt / a.steps * 1e3
         ips = a.batch * world * a.steps / dt
         kms, kflops = time_dominant_kernel(dev, a.batch, tile["H"], tile["W"])
+        from tatt_amd.ops import CONV3_WS as ops_variant
         ach = kflops / (kms * 1e-3) / 1e12
         out = {
             "metric": "LR images/s (train fwd+bwd+clip+Adam) at %dx%d->%dx%d" % (tile["H"], tile["W"], 2 * tile["H"], 2 * tile["W"]),
@@ -278,7 +279,8 @@ def main():
                          "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
                          "traffic": dominant_kernel_traffic("B%d_%dx%d" % (a.batch, tile["H"], tile["W"])),
                          "algorithmic_bytes": 2 * a.batch * tile["H"] * tile["W"] * 64 * 4 + 9 * 64 * 64 * 4,
-                         "kernel": "conv3_c64_ws_kernel (3x3 conv, 64->64 ch, %d x%dx%d px, fp32 MFMA)" % (a.batch, tile["H"], tile["W"]),
+                         "kernel": "%s (3x3 conv, 64->64 ch, %d x%dx%d px, fp32 MFMA)" % (
+                             "conv3_c64_ws16_kernel" if ops_variant == "16" else "conv3_c64_ws_kernel", a.batch, tile["H"], tile["W"]),
                          "kernel_ms": round(kms, 4), "flops_per_launch": kflops},
         }
         if world == 1 and not a.no_cpu_baseline and a.arch != "tatt_tpg":

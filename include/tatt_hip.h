@@ -56,7 +56,7 @@ int tatt_conv2d_wgrad(const float* x, long xsn, long xsh, long xsw, long xsc, co
 /* OIHW nn.Conv2d weight -> GEMM operand; mode 0: [KH][KW][Cin][Cout]; mode 1: [KH][KW][Cout][Cin], taps flipped (data gradient);
  * mode 2: [KH][KW][Cout][Cin]; mode 3: [KH][KW][Cin][Cout], taps flipped -- forward / data-gradient filters with the
  * contraction axis contiguous, for tatt_conv3_c64_fwd_t; modes 4 / 5: the same two 3x3 filters (64 contraction channels) in the
- * per-lane register order of tatt_conv3_c64_fwd_ws */
+ * per-lane register order of tatt_conv3_c64_fwd_ws; modes 6 / 7: in the register order of tatt_conv3_c64_fwd_ws16 */
 int tatt_repack_conv_weight(const float* w_oihw, float* out, int Cout, int Cin, int KH, int KW,
                             int mode, hipStream_t st);
 /* the same for n filters in one launch (all packed layouts of a model, refreshed once per optimiser step): ws / outs are HOST arrays
@@ -79,6 +79,10 @@ int tatt_conv3_c64_fwd_t(const float* x, const float* wt, const float* bias, flo
  * tatt_repack_conv_weight mode 4 (forward) / mode 5 (data gradient of a 64-output-channel convolution) */
 int tatt_conv3_c64_fwd_ws(const float* x, const float* wl, const float* bias, float* y, int B, int H, int W,
                           int Cout, int act, float beta, hipStream_t st);
+/* the same convolution with the 64 px x 64 co tile cut along the output channels: every wave owns 32 pixels x 16 channels and the
+ * whole 9 x 64 contraction (v_mfma_f32_16x16x4_f32), no partial sums to exchange; wl = tatt_repack_conv_weight mode 6 / mode 7 */
+int tatt_conv3_c64_fwd_ws16(const float* x, const float* wl, const float* bias, float* y, int B, int H, int W,
+                            int Cout, int act, float beta, hipStream_t st);
 /* weight-gradient partials part[G][9*Cin][Cout] (G persistent work-groups, G <= B*H*W/64); finish with
  * tatt_splitk_reduce(part, dw_oihw, 9*Cin, Cout, G, Cin, 9, beta) */
 int tatt_conv3_c64_wgrad_partial(const float* x, const float* dy, float* part, int B, int H, int W, int Cin,

@@ -369,6 +369,140 @@ TATT_API int tatt_conv3_c64_fwd_ws(const float* x, const float* wl, const float*
     return LAUNCH_CHECK();
 }
 
+// ---- weight-stationary forward, 16 output channels per wave (Cin == 64) ----------------------------------------------------------
+// Same idea as conv3_c64_ws_kernel -- the filter lives in registers, the loop streams activations through a double-buffered LDS
+// halo -- but the 64 px x 64 co tile is cut along the OUTPUT CHANNELS: wave (pxh, cq) owns 32 pixels x 16 channels and contracts
+// all 9 x 64 input channels itself on v_mfma_f32_16x16x4_f32 (144 filter registers per lane again, two waves per SIMD).  There is
+// no partial sum to exchange, so the epilogue is nothing but stores (they retire under the next tile's MFMAs) and ONE barrier
+// per tile is left (the halo hand-off).  In the kernel above the two barriers + LDS exchange of the epilogue stall all eight waves
+// at once: 24 k of a launch's 79 k resident cycles (profiles/r01_step10_pmc_sq_counters.txt).
+//   A operand (activations): lane (i = lane & 15, kq = lane >> 4) reads 4 consecutive input channels 16 g + 4 kq + u of pixel i
+//     with one ds_read_b128 and feeds MFMA u of group (tap, g) with element u -- the k-slot kq of that MFMA then stands for input
+//     channel 16 g + 4 kq + u on BOTH operands (any bijection slot -> channel is a valid contraction order).
+//   halo pitch 72 floats: pixel i -> 16-byte slot 2 i (mod 16), k-slot kq -> +kq: the lane groups ds_read_b128 is served in
+//     ({0-3,12-15,20-27}, ...) touch 16 distinct slots -- conflict-free (pitch 68 of the kernel above is 2-way on two of four groups).
+#define W16_XP 72
+#define W16_HALO (3 * C3_HW * W16_XP)                        // floats per halo buffer (57.0 KB)
+#define W16_LDS (2 * W16_HALO * 4)
+__global__ __launch_bounds__(512, 1) void conv3_c64_ws16_kernel(Conv3P p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int cq = wave & 3, pxh = wave >> 2;
+    const int segs = p.W / C3_PX, cob = p.Cout / 64;
+    const int npt = p.B * p.H * segs;
+    // XCD-aware tile order (see conv3_c64_ws_kernel)
+    const int stride = gridDim.x / cob;
+    int cb = blockIdx.x % cob, pt = blockIdx.x / cob;
+    if (gridDim.x % 8 == 0 && 8 % cob == 0 && stride % (8 / cob) == 0) {
+        const int x = blockIdx.x & 7, m = blockIdx.x >> 3, xg = 8 / cob;
+        cb = x % cob;
+        pt = (x / cob) * (stride / xg) + m;
+    }
+    if (pt >= npt) return;
+    const int co0 = cb * 64 + cq * 16;
+    f32x4 wq[36];                                             // [tap * 4 + g][u]: input channel 16 g + 4 (lane >> 4) + u, output channel co0 + (lane & 15)
+    {
+        const f32x4* wsrc = reinterpret_cast<const f32x4*>(p.w) + (long)(cb * 4 + cq) * 36 * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < 36; ++q) wq[q] = wsrc[q * 64];
+    }
+    auto decode = [&](int tile, int& n, int& h, int& w0) {
+        const int seg = tile % segs; tile /= segs;
+        h = tile % p.H; n = tile / p.H; w0 = seg * C3_PX;
+    };
+    // halo float4 #idx of 3168: c4 = idx & 15, pixel = (idx >> 4) % 66, row = (idx >> 4) / 66
+    auto halo_load = [&](int n, int h, int w0, int idx) -> f32x4 {
+        const int pix = idx >> 4, r = pix / C3_HW, px = pix - r * C3_HW;
+        const int hh = h + r - 1, ww = w0 + px - 1;
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (idx < 3 * C3_HW * 16 && hh >= 0 && hh < p.H && ww >= 0 && ww < p.W)
+            v = *reinterpret_cast<const f32x4*>(p.x + (((long)n * p.H + hh) * p.W + ww) * 64 + 4 * (idx & 15));
+        return v;
+    };
+    auto halo_store = [&](float* Xs, int idx, f32x4 v) {
+        if (idx < 3 * C3_HW * 16) *reinterpret_cast<f32x4*>(Xs + (idx >> 4) * W16_XP + 4 * (idx & 15)) = v;
+    };
+    int n, h, w0;
+    decode(pt, n, h, w0);
+    {
+        f32x4 hp[7];
+#pragma unroll
+        for (int q = 0; q < 7; ++q) hp[q] = halo_load(n, h, w0, t + 512 * q);
+#pragma unroll
+        for (int q = 0; q < 7; ++q) halo_store(smem, t + 512 * q, hp[q]);
+    }
+    __syncthreads();
+    const int abase = (pxh * 32 + (lane & 15)) * W16_XP + 4 * (lane >> 4);
+    const float bj = p.bias ? p.bias[co0 + (lane & 15)] : 0.f;
+    int xbuf = 0;
+    while (true) {
+        const int npt_next = pt + stride;
+        const bool has_next = npt_next < npt;
+        int nn = n, nh = h, nw0 = w0;
+        if (has_next) decode(npt_next, nn, nh, nw0);
+        const float* Xs = smem + xbuf * W16_HALO + abase;
+        float* XsN = smem + (xbuf ^ 1) * W16_HALO;
+        f32x4 acc[2];
+        acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 va[3][2];                                      // ring: the reads of group l + 2 are issued before the MFMAs of group l
+        f32x4 hq = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // group l = tap * 4 + g; M-tile m: pixels pxh * 32 + 16 m + i
+#define W16_AOFF(l, m) ((((l) >> 2) / 3 * C3_HW + ((l) >> 2) % 3 + 16 * (m)) * W16_XP + 16 * ((l) & 3))
+#define W16_LD(l) va[(l) % 3][0] = *reinterpret_cast<const f32x4*>(Xs + W16_AOFF(l, 0)); \
+                  va[(l) % 3][1] = *reinterpret_cast<const f32x4*>(Xs + W16_AOFF(l, 1));
+        W16_LD(0) W16_LD(1)
+#pragma unroll
+        for (int l = 0; l < 36; ++l) {
+            if (l % 5 == 0 && has_next) hq = halo_load(nn, nh, nw0, t + 512 * (l / 5));       // 7 rounds: l = 0,5,...,30
+            if (l + 2 < 36) { W16_LD(l + 2) }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[l % 3][0][u], wq[l][u], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[l % 3][1][u], wq[l][u], acc[1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (l % 5 == 4 && has_next) halo_store(XsN, t + 512 * (l / 5), hq);
+        }
+        // ---- epilogue: C layout of the 16x16 tile: row (pixel) = 4 (lane >> 4) + reg, column (channel) = lane & 15.  Each
+        // 16-lane group stores 64 contiguous bytes of one pixel; the four waves of a pixel half complete its 256-byte row. ----
+        {
+            const long rowbase = ((long)n * p.H + h) * p.W + w0 + pxh * 32 + 4 * (lane >> 4);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float* dst = p.y + (rowbase + 16 * m + r) * p.Cout + co0 + (lane & 15);
+                    float v = apply_act(acc[m][r] + bj, p.act);
+                    if (p.beta != 0.f) v += p.beta * *dst;
+                    *dst = v;
+                }
+        }
+        if (!has_next) break;
+        __syncthreads();                                     // the next halo is complete; every wave has left the current one
+        pt = npt_next; n = nn; h = nh; w0 = nw0;
+        xbuf ^= 1;
+    }
+}
+
+// wl = filter from tatt_repack_conv_weight mode 6 (forward) / mode 7 (data gradient of a 64-output-channel convolution)
+TATT_API int tatt_conv3_c64_fwd_ws16(const float* x, const float* wl, const float* bias, float* y, int B, int H, int W,
+                                     int Cout, int act, float beta, hipStream_t st) {
+    if (Cout % 64 || W % C3_PX) return 1;
+    Conv3P p = {x, wl, bias, y, B, H, W, 64, Cout, act, beta};
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_ws16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W16_LDS);
+        attr_set = true;
+    }
+    const int cob = Cout / 64, npt = B * H * (W / C3_PX);
+    int per = 256 / cob;
+    if (per > npt) per = npt;
+    hipLaunchKernelGGL(conv3_c64_ws16_kernel, dim3(per * cob), dim3(512), W16_LDS, st, p);
+    return LAUNCH_CHECK();
+}
+
 // ---- weight gradient -------------------------------------------------------------------------------------------------
 // dW[tap][ci][co] = sum over pixels x[pixel + tap][ci] * dy[pixel][co]: the pixels are the contraction axis.  Persistent
 // work-groups of 8 waves walk 64-pixel row segments; wave w owns the (ci half, co half) quadrant w & 3 of one 64 ci x 64 co

@@ -805,7 +805,8 @@ TATT_API int tatt_conv2d_wgrad(const float* x, long xsn, long xsh, long xsw, lon
 // OIHW filter -> implicit-GEMM operand.  mode 0: [KH][KW][Cin][Cout] (forward);
 // mode 1: [KH][KW][Cout][Cin] spatially flipped (data-gradient: dX = conv(dY, flip(W)^T)).
 // modes 2 / 3: the same two filters with the contraction axis contiguous ([tap][out][in]) for tatt_conv3_c64_fwd_t.
-// modes 4 / 5: the same two filters in the register order of the weight-stationary kernel tatt_conv3_c64_fwd_ws.
+// modes 4 / 5: the same two filters in the register order of the weight-stationary kernel tatt_conv3_c64_fwd_ws;
+// modes 6 / 7: in the register order of tatt_conv3_c64_fwd_ws16.
 __global__ void repack_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin,
                                      int KH, int KW, int mode) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -832,7 +833,16 @@ __global__ void repack_weight_kernel(const float* __restrict__ w, float* __restr
         const int tap = q >> 3, c = q & 7;
         const int o = ob * 32 + (lane & 31), i = 8 * c + 4 * (lane >> 5) + u;
         if (mode == 4) out[idx] = w[((long)o * Cin + i) * T + tap];                 // forward: o = co, i = ci (Cin == 64)
-        else out[idx] = w[((long)i * Cin + o) * T + (T - 1 - tap)];                 // data gradient: o = ci, i = co (Cout == 64)
+        else if (mode == 5) out[idx] = w[((long)i * Cin + o) * T + (T - 1 - tap)];  // data gradient: o = ci, i = co (Cout == 64)
+        else {
+            // modes 6 / 7: register order of tatt_conv3_c64_fwd_ws16 (16 output channels per wave, v_mfma_f32_16x16x4_f32):
+            // out[((blk * 36 + tap * 4 + g) * 64 + lane) * 4 + u] = filter[out ch 16 blk + (lane & 15)][in ch 16 g + 4 (lane >> 4) + u][tap]
+            const int q6 = (idx >> 8) % 36, blk = idx / (36 * 256);
+            const int tap6 = q6 >> 2, g6 = q6 & 3;
+            const int o6 = blk * 16 + (lane & 15), i6 = 16 * g6 + 4 * (lane >> 4) + u;
+            if (mode == 6) out[idx] = w[((long)o6 * Cin + i6) * T + tap6];
+            else out[idx] = w[((long)i6 * Cin + o6) * T + (T - 1 - tap6)];
+        }
     }
 }
 TATT_API int tatt_repack_conv_weight(const float* w_oihw, float* out, int Cout, int Cin, int KH, int KW,
@@ -866,7 +876,14 @@ __global__ void repack_batch_kernel(RepackTable t) {
         const int u = idx & 3, lane = (idx >> 2) & 63, q = (idx >> 8) % 72, ob = idx / (72 * 256);
         const int tap = q >> 3, c = q & 7;
         const int o = ob * 32 + (lane & 31), i = 8 * c + 4 * (lane >> 5) + u;
-        v = e.mode == 4 ? w[((long)o * Cin + i) * T + tap] : w[((long)i * Cin + o) * T + (T - 1 - tap)];
+        if (e.mode == 4) v = w[((long)o * Cin + i) * T + tap];
+        else if (e.mode == 5) v = w[((long)i * Cin + o) * T + (T - 1 - tap)];
+        else {
+            const int q6 = (idx >> 8) % 36, blk = idx / (36 * 256);
+            const int tap6 = q6 >> 2, g6 = q6 & 3;
+            const int o6 = blk * 16 + (lane & 15), i6 = 16 * g6 + 4 * (lane >> 4) + u;
+            v = e.mode == 6 ? w[((long)o6 * Cin + i6) * T + tap6] : w[((long)i6 * Cin + o6) * T + (T - 1 - tap6)];
+        }
     }
     e.out[idx] = v;
 }

@@ -211,7 +211,11 @@ def _conv3_fast_ok(x_bhwc, Cin, Cout, KH, KW):
             and x_bhwc.shape[2] % 64 == 0)
 
 
-_CONV3_WS = os.environ.get("TATT_CONV3_WS", "1") != "0"        # A/B switch for measurements: 0 -> LDS-staged filter (v5 kernel)
+# A/B switch for measurements: "16" (default): weight-stationary kernel, 16 output channels per wave (no partial-sum exchange);
+# "1": weight-stationary, 32 x 32 blocks with the contraction split over a wave pair; "0": LDS-staged filter (v5 kernel)
+CONV3_WS = os.environ.get("TATT_CONV3_WS", "16")
+_CONV3_WS = CONV3_WS != "0"
+_WS_ENTRY, _WS_FWD_MODE, _WS_DGRAD_MODE = (("tatt_conv3_c64_fwd_ws16", 6, 7) if CONV3_WS == "16" else ("tatt_conv3_c64_fwd_ws", 4, 5))
 
 
 def conv2d_forward(x_bhwc, weight_oihw, bias, act=ACT_NONE):
@@ -221,8 +225,8 @@ def conv2d_forward(x_bhwc, weight_oihw, bias, act=ACT_NONE):
         B, H, W, _ = x_bhwc.shape
         y = new(x_bhwc, B, H, W, Cout)
         if Cin == 64 and _CONV3_WS:                              # weight-stationary kernel: the filter lives in registers
-            wl = repack_weight(weight_oihw, 4)
-            call("tatt_conv3_c64_fwd_ws", P(x_bhwc), P(wl), P(bias), P(y), B, H, W, Cout, act, 0.0, stream())
+            wl = repack_weight(weight_oihw, _WS_FWD_MODE)
+            call(_WS_ENTRY, P(x_bhwc), P(wl), P(bias), P(y), B, H, W, Cout, act, 0.0, stream())
             return y
         wt = repack_weight(weight_oihw, 2)                       # [9][Cout][Cin]
         call("tatt_conv3_c64_fwd_t", P(x_bhwc), P(wt), P(bias), P(y), B, H, W, Cin, Cout, act, 0.0, stream())
@@ -237,8 +241,8 @@ def conv2d_dgrad(dy_bhwc, weight_oihw):
         B, H, W, _ = dy_bhwc.shape
         dx = new(dy_bhwc, B, H, W, Cin)
         if Cout == 64 and _CONV3_WS:
-            wl = repack_weight(weight_oihw, 5)
-            call("tatt_conv3_c64_fwd_ws", P(dy_bhwc), P(wl), None, P(dx), B, H, W, Cin, ACT_NONE, 0.0, stream())
+            wl = repack_weight(weight_oihw, _WS_DGRAD_MODE)
+            call(_WS_ENTRY, P(dy_bhwc), P(wl), None, P(dx), B, H, W, Cin, ACT_NONE, 0.0, stream())
             return dx
         wt = repack_weight(weight_oihw, 3)                       # [9][Cin][Cout], taps flipped
         call("tatt_conv3_c64_fwd_t", P(dy_bhwc), P(wt), None, P(dx), B, H, W, Cout, Cin, ACT_NONE, 0.0, stream())

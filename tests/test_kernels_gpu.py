@@ -509,7 +509,7 @@ def test_cat_positional_table(dev):
 @pytest.mark.parametrize("B,H,W,Cout,act,beta", [(2, 16, 64, 64, 0, 0.0), (3, 5, 128, 256, 2, 0.0), (1, 1, 64, 64, 0, 0.5),
                                                  (48, 16, 64, 64, 0, 0.0), (7, 16, 64, 128, 1, 0.0)])
 def test_conv3_weight_stationary_kernel(dev, B, H, W, Cout, act, beta):
-    """tatt_conv3_c64_fwd_ws (filter in registers) against F.conv2d, forward filter (repack mode 4)."""
+    """tatt_conv3_c64_fwd_ws / _ws16 (filter in registers) against F.conv2d, forward filters (repack modes 4 / 6)."""
     from tatt_amd import ops
     g = torch.Generator().manual_seed(21)
     x = torch.randn(B, H, W, 64, generator=g)
@@ -519,9 +519,11 @@ def test_conv3_weight_stationary_kernel(dev, B, H, W, Cout, act, beta):
     ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), padding=1).permute(0, 2, 3, 1)
     ref = {0: lambda t: t, 1: torch.relu, 2: lambda t: O.mish(t.float()).double()}[act](ref) + beta * y0.double()
     xd, wd, bd, yd = x.to(dev), w.to(dev), b.to(dev), y0.to(dev).clone()
-    wl = ops.repack_weight(wd, 4)
-    ops.call("tatt_conv3_c64_fwd_ws", ops.P(xd), ops.P(wl), ops.P(bd), ops.P(yd), B, H, W, Cout, act, beta, ops.stream())
-    check_close("conv3_ws", yd, ref.float(), 2e-4, 2e-4)
+    for entry, mode in (("tatt_conv3_c64_fwd_ws", 4), ("tatt_conv3_c64_fwd_ws16", 6)):
+        yd = y0.to(dev).clone()
+        wl = ops.repack_weight(wd, mode)
+        ops.call(entry, ops.P(xd), ops.P(wl), ops.P(bd), ops.P(yd), B, H, W, Cout, act, beta, ops.stream())
+        check_close(entry, yd, ref.float(), 2e-4, 2e-4)
 
 
 def test_conv3_weight_stationary_dgrad(dev):
@@ -535,6 +537,10 @@ def test_conv3_weight_stationary_dgrad(dev):
         torch.nn.functional.conv2d(x, w, None, padding=1).backward(dy.permute(0, 3, 1, 2))
         dx = ops.conv2d_dgrad(dy.to(dev), w.to(dev))
         check_close("conv3_ws_dgrad_%d" % Cin, dx, x.grad.permute(0, 2, 3, 1), 2e-4, 2e-4)
+        for entry, mode in (("tatt_conv3_c64_fwd_ws", 5), ("tatt_conv3_c64_fwd_ws16", 7)):
+            dxe = torch.empty(2, 16, 64, Cin, device=dev)
+            ops.call(entry, ops.P(dy.to(dev)), ops.P(ops.repack_weight(w.to(dev), mode)), None, ops.P(dxe), 2, 16, 64, Cin, 0, 0.0, ops.stream())
+            check_close("%s_dgrad_%d" % (entry, Cin), dxe, x.grad.permute(0, 2, 3, 1), 2e-4, 2e-4)
 
 
 @pytest.mark.parametrize("B,C,H,W,nhwc", [(3, 4, 32, 128, True), (2, 3, 8, 16, False), (5, 4, 64, 256, True)])

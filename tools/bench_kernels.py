@@ -61,6 +61,9 @@ timeit("conv3_fwd_t_64_64", lambda: ops.call("tatt_conv3_c64_fwd_t", ops.P(x64),
 wl = ops.repack_weight(w33, 4)
 timeit("conv3_fwd_ws_64_64", lambda: ops.call("tatt_conv3_c64_fwd_ws", ops.P(x64), ops.P(wl), ops.P(b64), ops.P(y64), B, 16, 64, 64,
                                                0, 0.0, ops.stream()), f33)
+wl16 = ops.repack_weight(w33, 6)
+timeit("conv3_fwd_ws16_64_64", lambda: ops.call("tatt_conv3_c64_fwd_ws16", ops.P(x64), ops.P(wl16), ops.P(b64), ops.P(y64), B, 16, 64, 64,
+                                                 0, 0.0, ops.stream()), f33)
 timeit("conv3_wgrad_64_64", lambda: ops.conv_wgrad(x64, y64, 64, 3, 3), f33)
 xs = x64.permute(0, 3, 1, 2).contiguous().permute(0, 2, 3, 1)       # strided view -> generic implicit-GEMM kernel
 timeit("conv3_generic_64_64", lambda: ops.conv_fwd(xs, wp, b64, 64, 3, 3, out=y64), f33)
@@ -73,6 +76,9 @@ timeit("conv3_fwd_t_64_256", lambda: ops.call("tatt_conv3_c64_fwd_t", ops.P(x64)
 wl256 = ops.repack_weight(w256, 4)
 timeit("conv3_fwd_ws_64_256", lambda: ops.call("tatt_conv3_c64_fwd_ws", ops.P(x64), ops.P(wl256), None, ops.P(y256), B, 16, 64, 256,
                                                 0, 0.0, ops.stream()), 4 * f33)
+wl16_256 = ops.repack_weight(w256, 6)
+timeit("conv3_fwd_ws16_64_256", lambda: ops.call("tatt_conv3_c64_fwd_ws16", ops.P(x64), ops.P(wl16_256), None, ops.P(y256), B, 16, 64, 256,
+                                                  0, 0.0, ops.stream()), 4 * f33)
 wt256d = ops.repack_weight(w256, 3)
 timeit("conv3_dgrad_t_256_64", lambda: ops.call("tatt_conv3_c64_fwd_t", ops.P(y256), ops.P(wt256d), None, ops.P(y64), B, 16, 64, 256, 64,
                                                  0, 0.0, ops.stream()), 4 * f33)
