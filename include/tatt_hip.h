@@ -67,6 +67,12 @@ int tatt_repack_conv_weight_batch(const float* const* ws, float* const* outs, co
  * the OIHW filter layout dW[co][ci][tap] */
 int tatt_splitk_reduce(const float* partial, float* C, int M, int N, int S, int remap_cin, int remap_taps,
                        float beta, hipStream_t st);
+/* on != 0: split-K reductions issued from now on (tatt_gemm / tatt_conv2d_wgrad with splitk > 1, tatt_splitk_reduce) are only
+ * REGISTERED -- their partial slabs must stay allocated -- and are summed by one launch per 36 entries at tatt_reduce_flush or
+ * tatt_reduce_defer(0): the 70 small reduction launches behind the weight-gradient GEMMs of a training step become 6.  Results
+ * are undefined until the flush.  Accumulating reductions (beta != 0) flush and run immediately.  Host-side state: one thread. */
+int tatt_reduce_defer(int on, hipStream_t st);
+int tatt_reduce_flush(hipStream_t st);
 
 /* Specialised 3x3 convolution, Cin/Cout/W multiples of 64, NHWC contiguous: the SRB / block7 / up-sampler convs
  * (model/tsrn.py:877,885,612,1043), forward and data gradient.  y = act(conv + bias) + beta*y.  Filter packed [9][Cout][Cin]

@@ -622,23 +622,30 @@ static int try_conv_fast(const GemmP& p, hipStream_t st) {
 // Deterministic split-K reduction + epilogue.  remap_cin > 0: the (i,j) result of a conv
 // weight-gradient GEMM (i = (tap,ci), j = co) is scattered to the reference's OIHW layout
 // dW[co][ci][tap]  (reference nn.Conv2d weight layout, model/tsrn.py:597).
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ C,
-                                     const float* __restrict__ bias, int M, int N, int S, int Z,
-                                     long scm, long scn, long bsC, long bsBias, float alpha, float beta,
-                                     int act, int remap_cin, int remap_taps, float* __restrict__ rowsum) {
+struct ReduceArgs {
+    const float* partial; float* C; const float* bias; float* rowsum;
+    long scm, scn, bsC, bsBias;
+    int M, N, S, Z;
+    float alpha, beta;
+    int act, remap_cin, remap_taps, block0;
+};
+__device__ __forceinline__ void splitk_reduce_body(const ReduceArgs& a, long block) {
     __shared__ float sh[4][64];
+    const float* __restrict__ partial = a.partial;
+    float* __restrict__ C = a.C;
+    const int M = a.M, N = a.N, S = a.S, Z = a.Z;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;       // 64 outputs x 4 slab lanes per block
-    const long idx = (long)blockIdx.x * 64 + tx;
+    const long idx = block * 64 + tx;
     const long total = (long)Z * M * N;
     const long total64 = ((total + 63) / 64) * 64;
-    if (rowsum && idx >= total64) {
+    if (a.rowsum && idx >= total64) {
         // trailing blocks: row sums of A, partial slabs [S][M] stored behind the S (M x N) slabs  (Z == 1)
         const long i2 = idx - total64;
         float r = 0.f;
         if (i2 < M) for (int k = ty; k < S; k += 4) r += partial[(long)S * M * N + (long)k * M + i2];
         sh[ty][tx] = r;
         __syncthreads();
-        if (ty == 0 && i2 < M) rowsum[i2] = alpha * ((sh[0][tx] + sh[1][tx]) + (sh[2][tx] + sh[3][tx]));
+        if (ty == 0 && i2 < M) a.rowsum[i2] = a.alpha * ((sh[0][tx] + sh[1][tx]) + (sh[2][tx] + sh[3][tx]));
         return;
     }
     const bool ok = idx < total;
@@ -664,18 +671,69 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     __syncthreads();
     if (ty != 0 || !ok) return;
     s = (sh[0][tx] + sh[1][tx]) + (sh[2][tx] + sh[3][tx]);
-    float bj = bias ? bias[(long)z * bsBias + j] : 0.f;
-    float v = apply_act(alpha * (s + bj), act);
+    float bj = a.bias ? a.bias[(long)z * a.bsBias + j] : 0.f;
+    float v = apply_act(a.alpha * (s + bj), a.act);
     long off;
-    if (remap_cin > 0) {
-        int tap = i / remap_cin, ci = i - tap * remap_cin;
-        off = ((long)j * remap_cin + ci) * remap_taps + tap;
+    if (a.remap_cin > 0) {
+        int tap = i / a.remap_cin, ci = i - tap * a.remap_cin;
+        off = ((long)j * a.remap_cin + ci) * a.remap_taps + tap;
     } else {
-        off = (long)z * bsC + i * scm + j * scn;
+        off = (long)z * a.bsC + i * a.scm + j * a.scn;
     }
-    if (beta != 0.f) v += beta * C[off];
+    if (a.beta != 0.f) v += a.beta * C[off];
     C[off] = v;
 }
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(ReduceArgs a) { splitk_reduce_body(a, blockIdx.x); }
+
+// Many reductions in ONE launch: weight-gradient GEMMs of a whole backward stage leave their partial slabs behind and register
+// here (tatt_reduce_defer); tatt_reduce_flush sums them all.  The table travels in the kernel arguments (pointers fixed at
+// hipGraph capture; the slabs stay allocated until the flush).
+#define REDUCE_MAX 36
+struct ReduceTable { ReduceArgs e[REDUCE_MAX]; int n; };
+__global__ __launch_bounds__(256) void splitk_reduce_batch_kernel(ReduceTable t) {
+    int k = 0;
+    while (k + 1 < t.n && (int)blockIdx.x >= t.e[k + 1].block0) ++k;
+    splitk_reduce_body(t.e[k], (long)blockIdx.x - t.e[k].block0);
+}
+static bool g_reduce_defer = false;
+static ReduceArgs g_reduce_pending[REDUCE_MAX];
+static int g_reduce_n = 0;
+static long reduce_blocks(const ReduceArgs& a) {
+    long total = (long)a.Z * a.M * a.N;
+    if (a.rowsum) total = (long)cdiv(total, 64) * 64 + a.M;       // extra thread range (64-aligned start) for the row sums of A
+    return cdiv(total, 64);
+}
+static int reduce_flush(hipStream_t st) {
+    if (g_reduce_n == 0) return 0;
+    ReduceTable t;
+    t.n = g_reduce_n;
+    int blocks = 0;
+    for (int k = 0; k < t.n; ++k) {
+        t.e[k] = g_reduce_pending[k];
+        t.e[k].block0 = blocks;
+        blocks += (int)reduce_blocks(t.e[k]);
+    }
+    g_reduce_n = 0;
+    hipLaunchKernelGGL(splitk_reduce_batch_kernel, dim3(blocks), dim3(256), 0, st, t);
+    return LAUNCH_CHECK();
+}
+static int reduce_submit(const ReduceArgs& a, hipStream_t st) {
+    if (!g_reduce_defer || a.beta != 0.f) {                       // an accumulating reduce must see earlier ones: flush, then run it
+        int rc = reduce_flush(st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)reduce_blocks(a)), dim3(256), 0, st, a);
+        return LAUNCH_CHECK();
+    }
+    g_reduce_pending[g_reduce_n++] = a;
+    return g_reduce_n == REDUCE_MAX ? reduce_flush(st) : 0;
+}
+// on != 0: split-K reductions issued from now on are only registered (their workspaces must stay allocated);
+// on == 0 (or tatt_reduce_flush): everything registered is reduced by one launch per 36 entries.  Host-side state, one thread.
+TATT_API int tatt_reduce_defer(int on, hipStream_t st) {
+    g_reduce_defer = on != 0;
+    return on ? 0 : reduce_flush(st);
+}
+TATT_API int tatt_reduce_flush(hipStream_t st) { return reduce_flush(st); }
 
 static int ilog2_or_neg(int v) {
     if (v <= 0 || (v & (v - 1))) return -1;
@@ -703,12 +761,9 @@ static int launch_gemm(const GemmP& p, int Z, bool ak, bool bk, hipStream_t st) 
 }
 
 static int finish_splitk(const GemmP& p, int Z, int remap_cin, int remap_taps, hipStream_t st) {
-    long total = (long)Z * p.M * p.N;
-    if (p.rowsum) total = cdiv(total, 64) * 64 + p.M;       // extra thread range (64-aligned start) for the row sums of A
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(total, 64)), dim3(256), 0, st, p.partial, p.C, p.bias,
-                       p.M, p.N, p.splitk, Z, p.scm, p.scn, p.bsC, p.bsBias, p.alpha, p.beta, p.act,
-                       remap_cin, remap_taps, p.rowsum);
-    return LAUNCH_CHECK();
+    ReduceArgs a = {p.partial, p.C, p.bias, p.rowsum, p.scm, p.scn, p.bsC, p.bsBias, p.M, p.N, p.splitk, Z, p.alpha, p.beta,
+                    p.act, remap_cin, remap_taps, 0};
+    return reduce_submit(a, st);
 }
 
 static void set_split(GemmP& p, int splitk, float* ws, int kc = KC) {
@@ -909,8 +964,6 @@ TATT_API int tatt_repack_conv_weight_batch(const float* const* ws, float* const*
 // weight-gradient kernels of conv3.hip).
 TATT_API int tatt_splitk_reduce(const float* partial, float* C, int M, int N, int S, int remap_cin, int remap_taps,
                                 float beta, hipStream_t st) {
-    long total = (long)M * N;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(total, 64)), dim3(256), 0, st, partial, C, (const float*)nullptr,
-                       M, N, S, 1, (long)N, 1L, 0L, 0L, 1.f, beta, (int)ACT_NONE, remap_cin, remap_taps, (float*)nullptr);
-    return LAUNCH_CHECK();
+    ReduceArgs a = {partial, C, nullptr, nullptr, (long)N, 1L, 0L, 0L, M, N, S, 1, 1.f, beta, (int)ACT_NONE, remap_cin, remap_taps, 0};
+    return reduce_submit(a, st);
 }

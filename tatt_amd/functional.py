@@ -75,18 +75,47 @@ class _DeferredParamGrads:
         self._keep = []
 
     def submit(self, params, fn, *keep):
-        """params: tuple of leaf tensors (or None); fn() -> tuple of their gradients (or None), same order."""
+        """params: tuple of leaf tensors (or None); fn() -> tuple of their gradients (or None), same order (or a generator that
+        yields once between its split-K GEMMs and their consumer and returns the tuple)."""
         if not self.enabled or any(p is not None and not p.is_leaf for p in params):
-            return fn()
+            r = fn()
+            if hasattr(r, "send"):
+                try:
+                    while True:
+                        next(r)
+                except StopIteration as stop:
+                    r = stop.value
+            return r
         self._pending.append((params, fn))
         self._keep.append(keep)
         return (None,) * len(params)
 
     def flush(self):
-        """Run the pending closures in submission order on the CURRENT stream; results become / are added to `.grad`."""
+        """Run the pending closures in submission order on the CURRENT stream; results become / are added to `.grad`.
+        While they run, the split-K reductions behind their weight-gradient GEMMs are only registered and then summed by one
+        launch per 36 (ops.reduce_defer); a closure that consumes such a result itself is a GENERATOR: it yields once after
+        issuing its GEMMs and is resumed after the batched reduction."""
         pending, self._pending = self._pending, []
-        for params, fn in pending:
-            for p, g in zip(params, fn()):
+        if not pending:
+            return
+        results = []
+        ops.reduce_defer(True)
+        try:
+            for params, fn in pending:
+                r = fn()
+                if hasattr(r, "send"):                # generator: run up to its yield
+                    next(r)
+                results.append((params, r))
+        finally:
+            ops.reduce_defer(False)                   # one launch per 36 registered reductions
+        for params, r in results:
+            if hasattr(r, "send"):
+                try:
+                    next(r)
+                    raise RuntimeError("a deferred gradient closure may yield only once")
+                except StopIteration as stop:
+                    r = stop.value
+            for p, g in zip(params, r):
                 if p is not None and g is not None:
                     p.grad = g if p.grad is None else p.grad + g
 
@@ -320,6 +349,7 @@ class GruBlockFn(Function):
             if xb is not None:
                 ops.linear_bwd_weight(dgi, xb.reshape(-1, K - K1), out=dWp.reshape(-1)[K1:], out_ld=K)
             dWhh = ops.linear_bwd_weight(dgh, hprev, rowsum=dbhh)     # (192, 64): diagonal blocks are the two directions
+            yield                                                     # (batched split-K reduction of the three GEMMs above)
             dwih_f, dwih_r = ops.new(dgi, 96, 64), ops.new(dgi, 96, 64)
             dwhh_f, dwhh_r = ops.new(dgi, 96, 32), ops.new(dgi, 96, 32)
             dWc, dbc = ops.new(dgi, 64, K), ops.new(dgi, 64)

@@ -54,6 +54,32 @@ def new(ref: torch.Tensor, *shape, dtype=torch.float32):
 # --------------------------------------------------------------------------------------------------
 # GEMM family
 # --------------------------------------------------------------------------------------------------
+_REDUCE_DEFER = False
+_REDUCE_KEEP = []
+
+
+def reduce_defer(on: bool):
+    """Split-K reductions behind the GEMMs / convolution weight gradients issued from now on are batched into one launch per 36
+    (tatt_reduce_defer); `reduce_defer(False)` (or `reduce_flush`) runs them.  Until then their outputs are undefined."""
+    global _REDUCE_DEFER
+    _REDUCE_DEFER = bool(on)
+    call("tatt_reduce_defer", int(bool(on)), stream())
+    if not on:
+        _REDUCE_KEEP.clear()
+
+
+def reduce_flush():
+    call("tatt_reduce_flush", stream())
+    _REDUCE_KEEP.clear()
+
+
+def _split_ws(t):
+    """A split-K workspace: must outlive a deferred reduction."""
+    if _REDUCE_DEFER and t is not None:
+        _REDUCE_KEEP.append(t)
+    return t
+
+
 def gemm(A, sam, sak, B, sbk, sbn, C, scm, scn, M, N, K, *, A2=None, sa2m=0, sa2k=0, K1=0, bias=None,
          Z=1, bsA=0, bsA2=0, bsB=0, bsC=0, bsBias=0, alpha=1.0, beta=0.0, act=ACT_NONE, splitk=1, rowsum=None):
     """C = act(alpha*(A@B + bias)) + beta*C with explicit element strides (see tatt_gemm)."""
@@ -63,7 +89,7 @@ def gemm(A, sam, sak, B, sbk, sbn, C, scm, scn, M, N, K, *, A2=None, sa2m=0, sa2
         nchunks = cdiv(K, 16)
         splitk = max(1, min(splitk, nchunks))
         if splitk > 1:
-            ws = new(C, Z * splitk * M * N + (splitk * M if rowsum is not None else 0))
+            ws = _split_ws(new(C, Z * splitk * M * N + (splitk * M if rowsum is not None else 0)))
     call("tatt_gemm", P(A), sam, sak, P(A2), sa2m, sa2k, K1, P(B), sbk, sbn, P(bias), P(C), scm, scn,
          M, N, K, Z, bsA, bsA2, bsB, bsC, bsBias, alpha, beta, act, splitk, P(ws), P(rowsum), stream())
     return C
@@ -258,7 +284,7 @@ def conv_wgrad(x_bhwc, dy_bhwc, Cout, KH, KW):
     if contig and KH == 3 and KW == 3 and Cin % 64 == 0 and Cout % 64 == 0 and W % 64 == 0:
         nseg = B * H * (W // 64)
         G = min(nseg, max(1, 256 // ((Cin // 64) * (Cout // 64))))
-        part = new(x_bhwc, G * 9 * Cin * Cout)
+        part = _split_ws(new(x_bhwc, G * 9 * Cin * Cout))
         call("tatt_conv3_c64_wgrad_partial", P(x_bhwc), P(dy_bhwc), P(part), B, H, W, Cin, Cout, G, stream())
         call("tatt_splitk_reduce", P(part), P(dw), 9 * Cin, Cout, G, Cin, 9, 0.0, stream())
         return dw
@@ -269,7 +295,7 @@ def conv_wgrad(x_bhwc, dy_bhwc, Cout, KH, KW):
         return dw
     Mo, Kred = KH * KW * Cin, B * H * W
     splitk = max(2, _auto_split(Mo, Cout, Kred))
-    ws = new(x_bhwc, (splitk + 1) * Mo * Cout)
+    ws = _split_ws(new(x_bhwc, (splitk + 1) * Mo * Cout))
     call("tatt_conv2d_wgrad", P(x_bhwc), sn, sh, sw, sc, P(dy_bhwc), Cout, P(dw), B, H, W, Cin, Cout, KH, KW, 0.0,
          splitk, P(ws), stream())
     return dw
