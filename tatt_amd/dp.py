@@ -106,7 +106,7 @@ class GradCuts:
         outs, grads = [], []
         for orig, copies in self._stages.pop(stage, {}).values():
             g = None
-            for d in copies:
+            for d in reversed(copies):               # later consumers deliver their gradient first, like the single-pass engine
                 if d.grad is not None:
                     g = d.grad if g is None else g + d.grad
             if g is not None and orig.requires_grad:

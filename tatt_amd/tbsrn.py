@@ -177,11 +177,16 @@ class TBSRN(_TrainPathMixin, nn.Module):
             xin = x.permute(0, 2, 3, 1)
         c1 = self.block1[0]
         b1 = Fh.prelu(Fh.conv2d(xin, c1.weight, c1.bias), self.block1[1].weight)
-        if cuts:                                                  # backward stages: trunk (from the loss), then "first" (block1 + STN)
-            b1 = cuts.cut("first", b1)
-        h = b1
+        b1_in = b1
+        if cuts:                                                  # backward stages: "trunk" (from the loss), "srb4" ... "srb0", "first"
+            b1 = cuts.cut("first", b1_in)
+        h = b1_in
         for i in range(k):
+            if cuts:
+                h = cuts.cut("first", b1_in) if i == 0 else cuts.cut("srb%d" % (i - 1), h)
             h = _srb(h, getattr(self, "block%d" % (i + 2)), training, self.dropout_on, 100 + 10 * i)
+        if cuts and k > 0:
+            h = cuts.cut("srb%d" % (k - 1), h)
         b7 = getattr(self, "block%d" % (k + 2))
         h = Fh.conv2d(h, b7[0].weight, b7[0].bias)
         h = Fh.batch_norm_act(h, b7[1], ACT_NONE)

@@ -196,26 +196,28 @@ def _default_loss(sr, hr):
 class Trainer:
     """One training step per `step()` call: forward, ImageLoss.mean()*100, backward, [all-reduce], clip, Adam.
 
-    The backward runs in the stages the model announces (`grad_buckets` / `set_grad_cuts`: trunk + up-sampler, TP interpreter,
-    block1 + STN head).  Inside a stage the activation-gradient chain runs first; weight / bias gradients and the query GRU's
-    backward -- a third of the step's kernel time that nothing on that chain waits for -- are only REGISTERED while it runs
-    (`defer_param_grads`, tatt_amd.functional.SIDE) and are issued back to back at the end of the stage, followed by the gather
-    of the stage's gradients into its bucket of the flat buffer and (data parallel) the bucket's asynchronous sum all-reduce over
-    RCCL, which then travels while the next stage computes.
-    `use_graph`: after `warmup_eager` eager steps the step is captured as hipGraph(s) and replayed: one graph for the whole step
-    on a single GPU, one per stage + one for the optimiser under data parallelism (the collectives are launched between them).
+    The backward runs in the stages the model announces (`grad_buckets` / `set_grad_cuts`: up-sampler + block7, the five SRBs one
+    by one, the TP interpreter, block1 + STN head).  Each stage has two lanes:
+      * main lane: the activation-gradient chain of the stage; weight / bias gradients and the query GRU's backward -- a third of
+        the step's kernel time that nothing on that chain waits for -- are only REGISTERED while it runs (`defer_param_grads`,
+        tatt_amd.functional.SIDE);
+      * side lane: those registered kernels (their split-K reductions batched into one launch), then the gather of the stage's
+        gradients into its bucket of the flat buffer.
+    Pass k of a step runs main lane k beside side lane k-1: with `side_stream` the side lane is a short branch forked onto a
+    second HIP stream and joined at the end of the pass.  (Data parallel) bucket k-1 is complete after pass k and its asynchronous
+    sum all-reduce over RCCL travels while pass k+1 computes.
+    `use_graph`: after `warmup_eager` eager steps the step is captured and replayed: ONE hipGraph for the whole step on a single
+    GPU (the forks and joins become parallel branches), one per pass + one for the optimiser under data parallelism (the
+    collectives are launched between them).
     `process_group`: data parallelism, one process per GPU: rank 0's weights/buffers are broadcast at start, every rank seeds its
     dropout stream differently (DataParallel replicas draw independent masks), 1/world is folded into the Adam kernel, every rank
     then clips and updates identically.
     `kernels` / `loss_fn`: the device kernels behind the optimiser and the loss (default: the HIP ones; the gloo CPU test of
     this orchestration injects torch stand-ins -- there is no CPU path in the product).
 
-    `side_stream` (needs `defer_param_grads`): the deferred kernels, the gather and the collective of stage k are issued on a second
-    HIP stream behind an event, so that they may run beside the activation-gradient chain of stage k+1; with `use_graph` every
-    lane of every stage is its own single-stream hipGraph (one memory pool, one capture stream per lane).  What this buys on
-    ROCm 7 is modest (profiles/README.md, round 2): hipGraph launches on different streams mostly execute one after the other
-    and only overlap around their boundaries -- 0.4-0.5 ms of a 10 ms step; within ONE graph the executor overlaps short parallel
-    branches but serialises long ones (tools/graph_sched_probe.py)."""
+    What the second stream buys on ROCm 7 was measured (profiles/README.md round 2, tools/graph_sched_probe.py): parallel branches
+    INSIDE one hipGraph overlap well when they are short or their kernels long; separate graph launches (or eager launches) on
+    two streams execute one after the other.  Hence short per-stage branches inside the step's graph."""
 
     def __init__(self, model, lr=1e-3, betas=(0.5, 0.999), eps=1e-8, clip=0.25, use_graph=False, warmup_eager=2,
                  process_group=None, broadcast_init=True, defer_param_grads=True, side_stream=True, kernels=None, loss_fn=None,
@@ -305,14 +307,23 @@ class Trainer:
         Fh.SIDE.flush()
         self.flat.gather_grads(k)
 
-    def _stage(self, k, x=None, tp=None, hr=None):
-        self._main_lane(k, x, tp, hr)
-        self._side_lane(k)
-
-    def _on_side(self):
-        """Context: the side stream, ordered behind everything issued on the current stream so far."""
-        self.side.wait_stream(torch.cuda.current_stream(self.dev))
-        return torch.cuda.stream(self.side)
+    def _pass(self, k, x=None, tp=None, hr=None):
+        """Pass k of a step = the main lane of stage k (k < stages) beside the side lane of stage k - 1 (k >= 1): with
+        `two_lanes` the side lane is forked onto the second stream at the start of the pass and joined at its end -- a short
+        parallel branch, which the hipGraph executor does overlap (tools/graph_sched_probe.py); otherwise it simply runs first."""
+        nst = len(self.stages)
+        main = torch.cuda.current_stream(self.dev) if self.cuda else None
+        if k >= 1:
+            if self.two_lanes:
+                self.side.wait_stream(main)
+                with torch.cuda.stream(self.side):
+                    self._side_lane(k - 1)
+            else:
+                self._side_lane(k - 1)
+        if k < nst:
+            self._main_lane(k, x, tp, hr)
+        if k >= 1 and self.two_lanes:
+            main.wait_stream(self.side)
 
     def _optim(self):
         self.step_count += 1
@@ -331,15 +342,11 @@ class Trainer:
         if self.dp:
             self._works.append(allreduce_bucket(self.flat, k, self.pg, async_op=True))
 
-    def _join(self):
-        """The current stream waits for the side lane and for the collectives (device-side waits; the host does not block on a
-        GPU); operands kept alive for deferred kernels may go."""
-        if self.two_lanes:
-            torch.cuda.current_stream(self.dev).wait_stream(self.side)
+    def _wait_reduces(self):
+        """The current stream waits for the collectives (device-side waits; the host does not block on a GPU)."""
         for w in self._works:
             w.wait()
         self._works = []
-        Fh.SIDE.release()
 
     @property
     def last_grad_norm(self):
@@ -365,32 +372,22 @@ class Trainer:
             if stp is not None:
                 stp.copy_(tp)
         if graphs is not None and "step" in graphs:
-            graphs["step"].replay()                  # single GPU, single stream: the whole step is one graph
-            return self.last_loss.clone()
-        for k in range(nst):
+            graphs["step"].replay()                  # single GPU: the whole step is one graph
+            return self.last_loss.clone()            # (the captured tensor is overwritten by the next replay)
+        for k in range(nst + 1):
             if graphs is None:
-                self._main_lane(k, x, tp, hr)
+                self._pass(k, x, tp, hr)
             else:
-                graphs["main"][k].replay()
-            if self.two_lanes:
-                with self._on_side():
-                    if graphs is None:
-                        self._side_lane(k)
-                    else:
-                        graphs["side"][k].replay()
-                    self._reduce(k)
-            else:
-                if graphs is None:
-                    self._side_lane(k)
-                else:
-                    graphs["side"][k].replay()
-                self._reduce(k)
-        self._join()
+                graphs["pass"][k].replay()
+            if k >= 1:
+                self._reduce(k - 1)                  # bucket k-1 is complete: on the wire while pass k+1 computes
+        self._wait_reduces()
         if graphs is None:
+            Fh.SIDE.release()
             self._optim()
             return self.last_loss
         graphs["optim"].replay()
-        return self.last_loss.clone()                # the captured tensor is overwritten by the next replay
+        return self.last_loss.clone()
 
     def _capture(self, x, tp, hr):
         """Capturing executes nothing: step() replays right away, so the step that captured is a real step."""
@@ -398,36 +395,28 @@ class Trainer:
         sx, stp, shr = self._static
         torch.cuda.synchronize()
         nst = len(self.stages)
-        if not self.dp and not self.two_lanes:
+        if not self.dp:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                for k in range(nst):
-                    self._stage(k, sx, stp, shr)
+                for k in range(nst + 1):
+                    self._pass(k, sx, stp, shr)
                 Fh.SIDE.release()
                 self._optim()
             self._graphs = {"step": g}
             return
-        # One single-stream graph per lane and stage + one for the optimiser, all in one memory pool (activations saved by stage 0
-        # are read by the later stages and by the side lanes); the collectives are launched between the replays.
-        # One capture stream per lane: the caching allocator hands a block freed during capture only to later allocations on the
-        # SAME stream, so a temporary of side lane k can never be recycled by main lane k+1, which may run beside it at replay.
+        # Data parallel: one graph per pass + one for the optimiser, all in one memory pool (activations saved by stage 0 are read
+        # by the later stages); the collectives are launched between the replays.  The RCCL watchdog thread polls events while we
+        # capture: only THIS thread's calls are policed (thread_local).
         pool = torch.cuda.graph_pool_handle()
-        cap_main = torch.cuda.Stream(device=self.dev)
-        cap_side = self.side if self.two_lanes else cap_main
-        # data parallel: the RCCL watchdog thread polls events while we capture -- only THIS thread's calls are policed
-        kw = dict(pool=pool, capture_error_mode="thread_local" if self.dp else "global")
-        graphs = {"main": [], "side": []}
-        for k in range(nst):
-            for lane, cap in (("main", cap_main), ("side", cap_side)):
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=cap, **kw):
-                    if lane == "main":
-                        self._main_lane(k, sx, stp, shr)
-                    else:
-                        self._side_lane(k)
-                graphs[lane].append(g)
+        kw = dict(pool=pool, capture_error_mode="thread_local")
+        graphs = {"pass": []}
+        for k in range(nst + 1):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, **kw):
+                self._pass(k, sx, stp, shr)
+            graphs["pass"].append(g)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=cap_main, **kw):
+        with torch.cuda.graph(g, **kw):
             self._optim()
         graphs["optim"] = g
         Fh.SIDE.release()

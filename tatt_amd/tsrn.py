@@ -363,12 +363,23 @@ class _TrainPathMixin:
 
     def grad_buckets(self):
         """[(stage name, [parameters])] in backward-completion order; stage names match the `cuts.cut(name, ...)` calls of the
-        forward ("trunk" is the part the loss back-propagates into directly)."""
-        first, tp, trunk = [], [], []
+        forward: "trunk" (block7 + up-sampler: what the loss back-propagates into directly), "srb4" ... "srb0" (the residual
+        blocks, last to first), "tp" (TP interpreter), "first" (block1 + STN head)."""
+        k = self.srb_nums
+        groups = {"trunk": [], "tp": [], "first": []}
+        groups.update({"srb%d" % i: [] for i in range(k)})
         for name, p in self.named_parameters():
             top = name.split(".", 1)[0]
-            (tp if top == "infoGen" else first if top in ("block1", "stn_head", "tps", "conv", "bn") else trunk).append(p)
-        return [(n, b) for n, b in (("trunk", trunk), ("tp", tp), ("first", first)) if b]
+            if top == "infoGen":
+                groups["tp"].append(p)
+            elif top.startswith("block") and 2 <= int(top[5:]) <= k + 1:
+                groups["srb%d" % (int(top[5:]) - 2)].append(p)
+            elif top.startswith("block") and int(top[5:]) > k + 1:
+                groups["trunk"].append(p)
+            else:                                  # block1, stn_head, (TBSRN's unused conv / bn)
+                groups["first"].append(p)
+        order = ["trunk"] + ["srb%d" % i for i in range(k - 1, -1, -1)] + ["tp", "first"]
+        return [(n, groups[n]) for n in order if groups[n]]
 
     def _bn_on_path(self):
         skip = () if getattr(self, "stn", False) else ("stn_head",)
@@ -458,14 +469,19 @@ class _GeneratorBase(_TrainPathMixin, nn.Module):
             tp_map, pr_weights = _tp_interpreter(cuts.cut("first", b1) if cuts else b1, text_emb.float(), self.infoGen, training,
                                                  qpos)
         tp_ret = tp_map
-        if cuts:                                 # backward stages: trunk (implicit, from the loss), then "tp", then "first"
+        if cuts:                                 # backward stages: "trunk" (from the loss), "srb4" ... "srb0", "tp", "first"
             b1_trunk = cuts.cut("first", b1)
-            if tp_map is not None:
-                tp_map = cuts.cut("tp", tp_map)
-        h = b1_trunk
+        h = b1
         for i in range(k):
-            h = _srb(h, tp_map, getattr(self, "block%d" % (i + 2)))
+            if cuts:                             # the block's inputs: the stream from the block below, its own copy of the prior map
+                h_in = cuts.cut("first", b1) if i == 0 else cuts.cut("srb%d" % (i - 1), h)
+                tp_in = cuts.cut("tp", tp_map) if tp_map is not None else None
+            else:
+                h_in, tp_in = h, tp_map
+            h = _srb(h_in, tp_in, getattr(self, "block%d" % (i + 2)))
             feats[str(i + 2)] = h
+        if cuts and k > 0:
+            h = cuts.cut("srb%d" % (k - 1), h)
         b7 = getattr(self, "block%d" % (k + 2))
         h = Fh.conv2d(h, b7[0].weight, b7[0].bias)
         h = Fh.batch_norm_act(h, b7[1], ACT_NONE, False)

@@ -537,9 +537,11 @@ def test_conv3_weight_stationary_dgrad(dev):
         torch.nn.functional.conv2d(x, w, None, padding=1).backward(dy.permute(0, 3, 1, 2))
         dx = ops.conv2d_dgrad(dy.to(dev), w.to(dev))
         check_close("conv3_ws_dgrad_%d" % Cin, dx, x.grad.permute(0, 2, 3, 1), 2e-4, 2e-4)
+        dyd, wd = dy.to(dev), w.to(dev)                # keep the operands alive while the kernels run
         for entry, mode in (("tatt_conv3_c64_fwd_ws", 5), ("tatt_conv3_c64_fwd_ws16", 7)):
             dxe = torch.empty(2, 16, 64, Cin, device=dev)
-            ops.call(entry, ops.P(dy.to(dev)), ops.P(ops.repack_weight(w.to(dev), mode)), None, ops.P(dxe), 2, 16, 64, Cin, 0, 0.0, ops.stream())
+            wl = ops.repack_weight(wd, mode)
+            ops.call(entry, ops.P(dyd), ops.P(wl), None, ops.P(dxe), 2, 16, 64, Cin, 0, 0.0, ops.stream())
             check_close("%s_dgrad_%d" % (entry, Cin), dxe, x.grad.permute(0, 2, 3, 1), 2e-4, 2e-4)
 
 

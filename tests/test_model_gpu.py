@@ -357,19 +357,22 @@ def test_graph_replay_equals_eager(dev, dropout):
 
 
 def test_staged_deferred_backward_equals_single_pass(dev):
-    """Backward in three stages with the weight-gradient kernels and the query GRU's backward deferred to the end of each stage
-    against the single-pass backward: identical kernels on identical inputs, only their order and the points where the autograd
-    engine is re-entered differ -> identical results."""
-    l1, s1, _, g1 = _run_steps(dev, 3, 6, True, use_graph=False, defer_param_grads=False)
-    l2, s2, _, g2 = _run_steps(dev, 3, 6, True, use_graph=False, defer_param_grads=True, side_stream=True)
+    """Backward in eight stages (up-sampler, five SRBs, TP interpreter, block1 + STN) with the weight-gradient kernels and the
+    query GRU's backward deferred to the side lane of each stage, against the plain single-pass backward.  Identical kernels on
+    identical inputs; only the order in which fan-in gradients are added differs (fp32 round-off), so losses agree to 1e-5 over
+    five steps -- a race between the lanes, a stale packed filter or a lost gradient would not.  The lane layouts themselves
+    (one stream / two streams, eager / hipGraph) run the same kernels in the same order: bit-identical."""
+    l1, s1, _, g1 = _run_steps(dev, 5, 6, True, use_graph=False, defer_param_grads=False)
+    l2, s2, _, g2 = _run_steps(dev, 5, 6, True, use_graph=False, defer_param_grads=True, side_stream=True)
     l3, s3, _, g3 = _run_steps(dev, 5, 6, True, use_graph=True, defer_param_grads=True, side_stream=True)
     l4, s4, _, g4 = _run_steps(dev, 5, 6, True, use_graph=True, defer_param_grads=True, side_stream=False)
-    assert l1 == l2 and g1 == g2
-    for k in s1:
-        assert torch.equal(s1[k], s2[k]), k
-    assert l3[:3] == l1 and l4 == l3
-    for k in s3:
-        assert torch.equal(s3[k], s4[k]), k
+    for a, b in zip(l1, l2):
+        assert abs(a - b) <= 2e-5 * abs(a), (l1, l2)
+    assert abs(g1 - g2) <= 1e-4 * g1
+    assert float((s1["bn"] - s2["bn"]).abs().max()) < 1e-4 and torch.equal(s1["nbt"], s2["nbt"])
+    assert l3 == l2 and l4 == l2
+    for k in s2:
+        assert torch.equal(s2[k], s3[k]) and torch.equal(s2[k], s4[k]), k
 
 
 def test_single_rank_process_group_runs_the_staged_step(dev):

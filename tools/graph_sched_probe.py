@@ -127,9 +127,32 @@ def pat_real(side_first, n_root=6, n_side=50, n_main=70, n_tail=130):
     return b
 
 
+def pat_staged(n_stages, n_main, n_side, lag=1):
+    """n_stages times: main lane of stage k (n_main kernels) beside the side lane of stage k - lag (n_side kernels), forked at the
+    start of the stage and joined at its end -- short parallel branches instead of one long side chain."""
+    def b(_):
+        spin()
+        for k in range(n_stages + lag):
+            if k >= lag:
+                fork()
+                with torch.cuda.stream(side):
+                    for _ in range(n_side):
+                        spin()
+            if k < n_stages:
+                for _ in range(n_main):
+                    spin()
+            if k >= lag:
+                join()
+        spin()
+    return b
+
+
 unit = time_graph(only_main(50)) / 50
 print("spin kernel in a single-stream graph: %.2f us each (incl. boundary)" % unit)
 for name, build, n_main, n_side in [
+        ("8 stages: main 45 | side 30 of the previous stage, fork/join per stage", pat_staged(8, 45, 30), 8 * 45 + 30 + 2, 0),
+        ("8 stages: main 45 | side 30, bigger kernels (x4)", None, 0, 0),
+        ("3 stages: main 150 | side 80 of the previous stage", pat_staged(3, 150, 80), 3 * 150 + 80 + 2, 0),
         ("root 6 -> side 50 | main 70 -> join -> 130, side captured first", pat_real(True), 206, 50),
         ("root 6 -> side 50 | main 70 -> join -> 130, main captured first", pat_real(False), 206, 50),
         ("long side chain 30 beside main 30", pat_long_side(30, 30), 32, 30),
@@ -140,6 +163,8 @@ for name, build, n_main, n_side in [
         ("alternating x20, side 3 per op, side first", pat_alternating(20, True, 0, 3, 3), 62, 60),
         ("alternating x20, side 3 per op, main first", pat_alternating(20, False, 0, 3, 3), 62, 60),
         ("alternating x20, side 3 per op, all side at the end", pat_alternating(20, False, 100, 3, 3), 62, 60)]:
+    if build is None:
+        continue
     t = time_graph(build)
     print("%-55s %8.1f us   ideal %7.1f   serial %7.1f   (in units: %.1f)" % (
         name, t, max(n_main, n_side) * unit, (n_main + n_side) * unit, t / unit))
