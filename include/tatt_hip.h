@@ -56,7 +56,8 @@ int tatt_conv2d_wgrad(const float* x, long xsn, long xsh, long xsw, long xsc, co
 /* OIHW nn.Conv2d weight -> GEMM operand; mode 0: [KH][KW][Cin][Cout]; mode 1: [KH][KW][Cout][Cin], taps flipped (data gradient);
  * mode 2: [KH][KW][Cout][Cin]; mode 3: [KH][KW][Cin][Cout], taps flipped -- forward / data-gradient filters with the
  * contraction axis contiguous, for tatt_conv3_c64_fwd_t; modes 4 / 5: the same two 3x3 filters (64 contraction channels) in the
- * per-lane register order of tatt_conv3_c64_fwd_ws; modes 6 / 7: in the register order of tatt_conv3_c64_fwd_ws16 */
+ * per-lane register order of tatt_conv3_c64_fwd_ws; modes 6 / 7: in the register order of tatt_conv3_c64_fwd_ws16;
+ * modes 8 / 9: the Toeplitz-expanded 9x9 filter [9][64][16][20] of tatt_conv9_c64_to_c4_mfma (out needs 184,320 floats) */
 int tatt_repack_conv_weight(const float* w_oihw, float* out, int Cout, int Cin, int KH, int KW,
                             int mode, hipStream_t st);
 /* the same for n filters in one launch (all packed layouts of a model, refreshed once per optimiser step): ws / outs are HOST arrays
@@ -99,6 +100,11 @@ int tatt_conv3_c64_wgrad_partial(const float* x, const float* dy, float* part, i
  * x (B,H,W,C) NHWC, C % 16 == 0, H % 8 == 0, W % 32 == 0; wpacked [81][C][4]; y (B,H,W,4) */
 int tatt_conv9_c64_to_c4(const float* x, const float* wpacked, const float* bias, float* y, int B, int H, int W,
                          int C, hipStream_t st);
+/* the same convolution on v_mfma_f32_16x16x4_f32: tile columns = (4 neighbouring pixels x 4 output channels), Toeplitz-expanded
+ * filter wt [9][64][16][20] from tatt_repack_conv_weight mode 8 (forward, reference model/tsrn.py:623) / mode 9 (data gradient of
+ * block1's 4->64 convolution, :597); x (B,H,W,64) NHWC contiguous, H % 8 == 0, W % 64 == 0; y (B,H,W,4) */
+int tatt_conv9_c64_to_c4_mfma(const float* x, const float* wt, const float* bias, float* y, int B, int H, int W,
+                              hipStream_t st);
 /* dw (4,64,9,9) = sum_px x[px+tap][ci] * dy[px][co]; part >= min(B*H*W/256, 256)*81*64*4 floats */
 int tatt_conv9_c64_c4_wgrad(const float* x, const float* dy, float* dw, float* part, int B, int H, int W,
                             hipStream_t st);

@@ -76,6 +76,108 @@ TATT_API int tatt_conv9_c64_to_c4(const float* x, const float* wpacked, const fl
     return LAUNCH_CHECK();
 }
 
+// ---- the same convolution on the matrix cores ---------------------------------------------------------------------------------
+// Four output channels do not fill an MFMA tile -- four output channels of FOUR NEIGHBOURING PIXELS do: the 16 columns of a
+// v_mfma_f32_16x16x4_f32 tile are n = (j, o) = (pixel offset 0..3, output channel 0..3), its 16 rows are 16 groups of 4 pixels
+// (64 pixels of one image row), and the contraction runs over (ky, dx, ci) with dx = kx + j in [0, 12): the filter becomes a
+// Toeplitz-expanded matrix Wt[ky][ci][n][dx] = w[o][ci][ky][dx - j] (zero outside the 9 taps) -- 12/9 of the useful FLOPs instead
+// of 4x, i.e. 75 % of the fp32 matrix peak is the ceiling (the vector-ALU kernel above reaches 24 %).
+//   work-group = 8 rows x 64 pixels, 4 waves x 2 rows; input channels in chunks of 16:
+//   Xs[16 halo rows][16 ci][96]  (pixel-contiguous): lane (i, kq) reads pixels 4 g(i) + 4 d .. + 3 of channel 4 cq + kq with one
+//       ds_read_b128 and feeds MFMA u (dx = 4 d + u) with element u.  Channel rows are 96 floats = 24 slots of 16 bytes apart
+//       (= 8 mod 16) and matrix row i stands for pixel group g(i) = i ^ 4 for i < 8, i otherwise: with that the four lane groups a
+//       ds_read_b128 is served in hit 16 distinct slots each.
+//   Ws[16 ci][16 n][20]  (dx-contiguous, one (ky, chunk) slab of the expanded filter, 20 KB, re-staged per ky): pitch 20 floats =
+//       5 slots per n, channel rows 80 slots (= 0 mod 16) apart -- conflict-free as well.
+#define M9_TH 8
+#define M9_TW 64
+#define M9_PW 96
+#define M9_ROWS (M9_TH + 8)
+#define M9_XS (M9_ROWS * 16 * M9_PW)          // floats: 24,576
+#define M9_WS (16 * 16 * 20)                  // floats: 5,120
+#define M9_LDS ((M9_XS + M9_WS) * 4)          // 118,784 B
+__global__ __launch_bounds__(256) void conv9_c64_to_c4_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wt,
+                                                                   const float* __restrict__ bias, float* __restrict__ y,
+                                                                   int B, int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) float smem9[];
+    float* Xs = smem9;
+    float* Ws = smem9 + M9_XS;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int tiles_w = W / M9_TW, tiles_h = H / M9_TH;
+    int bid = blockIdx.x;
+    const int tw = bid % tiles_w; bid /= tiles_w;
+    const int th = bid % tiles_h; const int n = bid / tiles_h;
+    const int h0 = th * M9_TH, w0 = tw * M9_TW;
+    const int i = lane & 15, kq = lane >> 4;
+    const int g = (i & 8) ? i : (i ^ 4);                      // pixel group of matrix row i
+    f32x4 acc[2];
+    acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* xa = Xs + (2 * wave * 16 + kq) * M9_PW + 4 * g;      // + ((ky + r2) * 16 + 4 cq) * PW + 4 d
+    const float* wb = Ws + (kq * 16 + i) * 20;                         // + (4 cq * 16) * 20 + 4 d
+    for (int c0 = 0; c0 < 64; c0 += 16) {
+        __syncthreads();                                      // every wave has left the previous chunk's halo
+        // halo rows h0-4 .. h0+11, pixels w0-4 .. w0+67, channels c0 .. c0+15 (quads of lanes read 64 contiguous bytes)
+        for (int idx = t; idx < M9_ROWS * 72 * 4; idx += 256) {
+            const int c4 = idx & 3, pp = idx >> 2;
+            const int r = pp / 72, px = pp - r * 72;
+            const int hh = h0 + r - 4, ww = w0 + px - 4;
+            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (hh >= 0 && hh < H && ww >= 0 && ww < W)
+                v = *reinterpret_cast<const f32x4*>(x + (((long)n * H + hh) * W + ww) * 64 + c0 + 4 * c4);
+            float* d = Xs + (r * 16 + 4 * c4) * M9_PW + px;
+            d[0] = v[0]; d[M9_PW] = v[1]; d[2 * M9_PW] = v[2]; d[3 * M9_PW] = v[3];
+        }
+        for (int ky = 0; ky < 9; ++ky) {
+            __syncthreads();                                  // halo complete / previous filter slab consumed
+            {
+                const f32x4* src = reinterpret_cast<const f32x4*>(wt + ((long)ky * 64 + c0) * 320);
+                f32x4* dst = reinterpret_cast<f32x4*>(Ws);
+#pragma unroll
+                for (int q = 0; q < 5; ++q) dst[t + 256 * q] = src[t + 256 * q];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+#pragma unroll
+                for (int cq = 0; cq < 4; ++cq) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(wb + cq * 4 * 320 + 4 * d);
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(xa + ((ky + 0) * 16 + 4 * cq) * M9_PW + 4 * d);
+                    const f32x4 a1 = *reinterpret_cast<const f32x4*>(xa + ((ky + 1) * 16 + 4 * cq) * M9_PW + 4 * d);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u], bv[u], acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u], bv[u], acc[1], 0, 0, 0);
+                    }
+                }
+        }
+    }
+    // C layout: column n = lane & 15 = (j, o); row 4 (lane >> 4) + reg -> pixel group g(row).  The 16 columns of a row are 16
+    // consecutive floats of y: pixel 4 g + j, channel o.
+    const float bo = bias ? bias[i & 3] : 0.f;
+#pragma unroll
+    for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int row = 4 * kq + reg;
+            const int gg = (row & 8) ? row : (row ^ 4);
+            y[(((long)n * H + h0 + 2 * wave + r2) * W + w0 + 4 * gg) * 4 + i] = acc[r2][reg] + bo;
+        }
+}
+// x (B,H,W,64) NHWC contiguous, H % 8 == 0, W % 64 == 0; wt = Toeplitz-expanded filter [9][64][16][20] from
+// tatt_repack_conv_weight mode 8 (forward filter of a 64->4 convolution) / mode 9 (data gradient of a 4->64 one); y (B,H,W,4)
+TATT_API int tatt_conv9_c64_to_c4_mfma(const float* x, const float* wt, const float* bias, float* y, int B, int H, int W,
+                                       hipStream_t st) {
+    if (H % M9_TH || W % M9_TW) return 1;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv9_c64_to_c4_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, M9_LDS);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv9_c64_to_c4_mfma_kernel, dim3(B * (H / M9_TH) * (W / M9_TW)), dim3(256), M9_LDS, st, x, wt, bias, y, B, H, W);
+    return LAUNCH_CHECK();
+}
+
 // ---- weight gradient ---------------------------------------------------------------------------------------------
 // thread (ci = t & 15, tap lane tl = t >> 4): taps tl, tl+16, ..., 4 output channels each -> 6 x 4 accumulators per 16-channel
 // chunk, kept in registers over all the tiles a (persistent) block walks.  Halo tile channel-contiguous: Xc[row][col][16].

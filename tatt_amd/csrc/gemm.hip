@@ -862,9 +862,25 @@ TATT_API int tatt_conv2d_wgrad(const float* x, long xsn, long xsh, long xsw, lon
 // modes 2 / 3: the same two filters with the contraction axis contiguous ([tap][out][in]) for tatt_conv3_c64_fwd_t.
 // modes 4 / 5: the same two filters in the register order of the weight-stationary kernel tatt_conv3_c64_fwd_ws;
 // modes 6 / 7: in the register order of tatt_conv3_c64_fwd_ws16.
+// modes 8 / 9: Toeplitz-expanded 9x9 filter of tatt_conv9_c64_to_c4_mfma, out[ky][ci 64][n = 4 j + o][20]:
+//   value(dx < 12) = f[o][ci][ky][dx - j] if 0 <= dx - j < 9 else 0, 0 for dx >= 12;  mode 8: f = w (OIHW, Cout = 4, Cin = 64);
+//   mode 9 (data gradient of a 4 -> 64 convolution, w OIHW with Cout = 64, Cin = 4): f[o][ci][ky][kx] = w[ci][o][8 - ky][8 - kx].
+__device__ __forceinline__ float toeplitz9(const float* __restrict__ w, int idx, int mode) {
+    const int dx = idx % 20, nn = (idx / 20) & 15, ci = (idx / 320) & 63, ky = idx / (320 * 64);
+    const int j = nn >> 2, o = nn & 3, kx = dx - j;
+    if (dx >= 12 || kx < 0 || kx >= 9) return 0.f;
+    return mode == 8 ? w[(((long)o * 64 + ci) * 9 + ky) * 9 + kx] : w[(((long)ci * 4 + o) * 9 + (8 - ky)) * 9 + (8 - kx)];
+}
+static inline long repack_total(int Cout, int Cin, int KH, int KW, int mode) {
+    return mode >= 8 ? 9L * 64 * 16 * 20 : (long)Cout * Cin * KH * KW;
+}
 __global__ void repack_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin,
                                      int KH, int KW, int mode) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (mode >= 8) {
+        if (idx < 9 * 64 * 16 * 20) out[idx] = toeplitz9(w, idx, mode);
+        return;
+    }
     int total = Cout * Cin * KH * KW;
     if (idx >= total) return;
     // idx enumerates the OUTPUT
@@ -902,7 +918,8 @@ __global__ void repack_weight_kernel(const float* __restrict__ w, float* __restr
 }
 TATT_API int tatt_repack_conv_weight(const float* w_oihw, float* out, int Cout, int Cin, int KH, int KW,
                                      int mode, hipStream_t st) {
-    int total = Cout * Cin * KH * KW;
+    if (mode >= 8 && !(KH == 9 && KW == 9 && ((mode == 8 && Cout == 4 && Cin == 64) || (mode == 9 && Cout == 64 && Cin == 4)))) return 1;
+    long total = repack_total(Cout, Cin, KH, KW, mode);
     hipLaunchKernelGGL(repack_weight_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w_oihw, out, Cout, Cin,
                        KH, KW, mode);
     return LAUNCH_CHECK();
@@ -918,6 +935,10 @@ __global__ void repack_batch_kernel(RepackTable t) {
     while (k + 1 < t.n && (int)blockIdx.x >= t.e[k + 1].block0) ++k;          // wave-uniform walk over <= 96 entries
     const RepackEntry& e = t.e[k];
     const int idx = ((int)blockIdx.x - e.block0) * blockDim.x + threadIdx.x;
+    if (e.mode >= 8) {
+        if (idx < 9 * 64 * 16 * 20) e.out[idx] = toeplitz9(e.w, idx, e.mode);
+        return;
+    }
     const int total = e.Cout * e.Cin * e.KH * e.KW;
     if (idx >= total) return;
     const int T = e.KH * e.KW, Cout = e.Cout, Cin = e.Cin;
@@ -952,7 +973,7 @@ TATT_API int tatt_repack_conv_weight_batch(const float* const* ws, float* const*
         for (int k = 0; k < t.n; ++k) {
             const int* d = dims + (long)(base + k) * 5;
             t.e[k] = {ws[base + k], outs[base + k], d[0], d[1], d[2], d[3], d[4], blocks};
-            blocks += cdiv((long)d[0] * d[1] * d[2] * d[3], 256);
+            blocks += cdiv(repack_total(d[0], d[1], d[2], d[3], d[4]), 256);
         }
         hipLaunchKernelGGL(repack_batch_kernel, dim3(blocks), dim3(256), 0, st, t);
     }

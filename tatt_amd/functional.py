@@ -127,6 +127,41 @@ class _DeferredParamGrads:
 SIDE = _DeferredParamGrads()
 
 
+class _ForwardFork:
+    """A short parallel branch in the FORWARD pass: work that depends on parameters only (the query GRU: 48 dependent launches)
+    is issued on a second stream behind an event and joined right before its first consumer, so that it runs beside the STN head,
+    the first convolution and the text encoder.  Inside the step's hipGraph this is a parallel branch (the executor overlaps short
+    branches, tools/graph_sched_probe.py).  The branch reads parameters only and its outputs are first read after the join, so no
+    tensor crosses the streams unordered.  Enabled by the Trainer together with its second stream."""
+
+    def __init__(self):
+        self.enabled = False
+        self._streams = {}
+        self._dirty = set()
+
+    def run(self, ref, fn):
+        if not (self.enabled and ref.is_cuda):
+            return fn()
+        k = str(ref.device)
+        if k not in self._streams:
+            self._streams[k] = torch.cuda.Stream(device=ref.device)
+        side, main = self._streams[k], torch.cuda.current_stream(ref.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            out = fn()
+        self._dirty.add(k)
+        return out
+
+    def join(self, device):
+        k = str(device)
+        if k in self._dirty:
+            torch.cuda.current_stream(device).wait_stream(self._streams[k])
+            self._dirty.discard(k)
+
+
+FWD_FORK = _ForwardFork()
+
+
 def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
@@ -618,6 +653,11 @@ class QueryGruFn(Function):
 
     @staticmethod
     def forward(ctx, emb, wih0, whh0, bih0, bhh0, wih1, whh1, bih1, bhh1, B, H, W):
+        # parameters only: may run as a parallel branch of the forward pass -- the CALLER joins (FWD_FORK.join) before the first use
+        return FWD_FORK.run(emb, lambda: QueryGruFn._forward(ctx, emb, wih0, whh0, bih0, bhh0, wih1, whh1, bih1, bhh1, B, H, W))
+
+    @staticmethod
+    def _forward(ctx, emb, wih0, whh0, bih0, bhh0, wih1, whh1, bih1, bhh1, B, H, W):
         ctx.leaves = (emb, wih0, whh0, bih0, bhh0, wih1, whh1, bih1, bhh1)
         C = emb.shape[1]
         HID = whh0.shape[1]

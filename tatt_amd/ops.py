@@ -156,6 +156,11 @@ def colsum(x2, *, out=None, scale=1.0, beta=0.0):
 # --------------------------------------------------------------------------------------------------
 # convolution (x given as a (B,H,W,C)-indexed tensor with arbitrary strides)
 # --------------------------------------------------------------------------------------------------
+def _packed_numel(shape, mode):
+    Cout, Cin, KH, KW = shape
+    return 9 * 64 * 16 * 20 if mode >= 8 else KH * KW * Cin * Cout
+
+
 class _PackedFilters:
     """Packed copies of convolution filters (the layouts the conv kernels want, see tatt_repack_conv_weight), kept per
     (parameter storage, layout) instead of being rebuilt at every use -- 39 launches of a training step.
@@ -175,7 +180,7 @@ class _PackedFilters:
         Cout, Cin, KH, KW = w.shape
         if e is None and len(self.entries) >= 1024:          # entries pin their parameter's storage: bound what a long-lived
             self.entries.clear()                             # process that keeps building models can accumulate
-        out = e[0] if e is not None else torch.empty(KH * KW * Cin * Cout, device=w.device, dtype=torch.float32)
+        out = e[0] if e is not None else torch.empty(_packed_numel(w.shape, mode), device=w.device, dtype=torch.float32)
         call("tatt_repack_conv_weight", P(w), P(out), Cout, Cin, KH, KW, mode, stream())
         self.entries[key] = (out, w._version, w.detach())
         return out
@@ -203,7 +208,7 @@ def repack_weight(w_oihw, mode, cache=True):
     if cache and w_oihw.is_leaf and w_oihw.is_contiguous():
         return PACKED.get(w_oihw, mode)
     Cout, Cin, KH, KW = w_oihw.shape
-    out = new(w_oihw, KH * KW * Cin * Cout)
+    out = new(w_oihw, _packed_numel(w_oihw.shape, mode))
     call("tatt_repack_conv_weight", P(w_oihw), P(out), Cout, Cin, KH, KW, mode, stream())
     return out
 
@@ -244,9 +249,21 @@ _CONV3_WS = CONV3_WS != "0"
 _WS_ENTRY, _WS_FWD_MODE, _WS_DGRAD_MODE = (("tatt_conv3_c64_fwd_ws16", 6, 7) if CONV3_WS == "16" else ("tatt_conv3_c64_fwd_ws", 4, 5))
 
 
+CONV9_MFMA = os.environ.get("TATT_CONV9_MFMA", "1") != "0"       # A/B switch: 0 -> vector-ALU 9x9 kernel
+
+
+def _conv9_mfma_ok(x_bhwc):
+    return CONV9_MFMA and x_bhwc.is_contiguous() and x_bhwc.shape[1] % 8 == 0 and x_bhwc.shape[2] % 64 == 0 and x_bhwc.shape[3] == 64
+
+
 def conv2d_forward(x_bhwc, weight_oihw, bias, act=ACT_NONE):
     """y = act(conv(x, W) + b) from the reference-layout (OIHW) filter: picks the kernel and the filter packing it wants."""
     Cout, Cin, KH, KW = weight_oihw.shape
+    if KH == 9 and KW == 9 and Cout == 4 and Cin == 64 and act == ACT_NONE and _conv9_mfma_ok(x_bhwc):
+        B, H, W, _ = x_bhwc.shape
+        y = new(x_bhwc, B, H, W, 4)
+        call("tatt_conv9_c64_to_c4_mfma", P(x_bhwc), P(repack_weight(weight_oihw, 8)), P(bias), P(y), B, H, W, stream())
+        return y
     if _conv3_fast_ok(x_bhwc, Cin, Cout, KH, KW):
         B, H, W, _ = x_bhwc.shape
         y = new(x_bhwc, B, H, W, Cout)
@@ -263,6 +280,11 @@ def conv2d_forward(x_bhwc, weight_oihw, bias, act=ACT_NONE):
 def conv2d_dgrad(dy_bhwc, weight_oihw):
     """dx = conv(dy, flip(W)^T): the data gradient as a forward convolution with Cout input / Cin output channels."""
     Cout, Cin, KH, KW = weight_oihw.shape
+    if KH == 9 and KW == 9 and Cout == 64 and Cin == 4 and _conv9_mfma_ok(dy_bhwc):
+        B, H, W, _ = dy_bhwc.shape
+        dx = new(dy_bhwc, B, H, W, 4)
+        call("tatt_conv9_c64_to_c4_mfma", P(dy_bhwc), P(repack_weight(weight_oihw, 9)), None, P(dx), B, H, W, stream())
+        return dx
     if _conv3_fast_ok(dy_bhwc, Cout, Cin, KH, KW):
         B, H, W, _ = dy_bhwc.shape
         dx = new(dy_bhwc, B, H, W, Cin)

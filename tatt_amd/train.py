@@ -278,6 +278,7 @@ class Trainer:
     def _main_lane(self, k, x=None, tp=None, hr=None):
         """Stage 0: forward + loss + backward from the loss; stage k > 0: the part of the backward `stages[k]` names."""
         Fh.SIDE.enabled = self.defer
+        Fh.FWD_FORK.enabled = self.two_lanes
         try:
             if k == 0:
                 for p in self.params:
@@ -299,6 +300,7 @@ class Trainer:
                 self.cuts.run(self.stages[k])
         finally:
             Fh.SIDE.enabled = False
+            Fh.FWD_FORK.enabled = False
         if k == len(self.stages) - 1 and hasattr(self.model, "block"):
             self.model.block = None                  # do not keep the autograd graph of this step alive
 

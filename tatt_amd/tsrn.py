@@ -330,6 +330,7 @@ def _tp_interpreter(feat, tp, ig: TPInterpreter, training, qpos=None):
     memory = Fh.layer_norm(src, Fh.dropout(f, enc.p, drop, 5), enc.norm2)
     # decoder: cross-attention only (self-attention commented out upstream, :817-819)
     kmem = add_pos(memory, pos)
+    Fh.FWD_FORK.join(feat.device)              # the query embedding may have been a parallel branch until here
     outs, wts = [], None
     for li, dec in enumerate(tr.decoder.layers):
         s0 = 10 + 10 * li

@@ -593,3 +593,29 @@ def test_semantic_loss_and_psnr_kernels(dev):
     a_nhwc = a.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)                 # the generator's output layout
     assert abs(float(calculate_psnr(a_nhwc, b)) - float(z["psnr"])) < 1e-4
     assert float(calculate_psnr(a, a)) == float("inf")
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 32, 128), (3, 16, 64), (1, 8, 64), (5, 64, 256)])
+def test_conv9_mfma_toeplitz(dev, B, H, W):
+    """tatt_conv9_c64_to_c4_mfma (4 pixels x 4 channels per MFMA column block, Toeplitz-expanded filter): the 64->4 reconstruction
+    convolution (repack mode 8) and the data gradient of a 4->64 convolution (mode 9) against F.conv2d in fp64."""
+    from tatt_amd import ops
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(B, H, W, 64, generator=g)
+    w = torch.randn(4, 64, 9, 9, generator=g) * 0.02
+    b = torch.randn(4, generator=g)
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), padding=4).permute(0, 2, 3, 1)
+    xd, wd, bd = x.to(dev), w.to(dev), b.to(dev)
+    y = ops.conv2d_forward(xd, wd, bd)
+    check_close("conv9_mfma_fwd", y, ref.float(), 2e-4, 2e-4)
+    # data gradient of block1 (4 -> 64): dx = conv_transpose(dy, w1)
+    w1 = (torch.randn(64, 4, 9, 9, generator=g) * 0.02)
+    xin = torch.randn(B, 4, H, W, generator=g, dtype=torch.float64).requires_grad_(True)
+    dy = torch.randn(B, H, W, 64, generator=g)
+    torch.nn.functional.conv2d(xin, w1.double(), None, padding=4).backward(dy.permute(0, 3, 1, 2).double())
+    dyd, w1d = dy.to(dev), w1.to(dev)
+    dx = ops.conv2d_dgrad(dyd, w1d)
+    check_close("conv9_mfma_dgrad", dx, xin.grad.permute(0, 2, 3, 1).float(), 2e-4, 2e-4)
+    # the packed-filter cache follows an in-place update of the weights
+    wd.mul_(2.0)
+    check_close("conv9_mfma_fwd_after_update", ops.conv2d_forward(xd, wd, bd), (2 * (ref - b.double()) + b.double()).float(), 4e-4, 4e-4)

@@ -89,6 +89,10 @@ wp99 = ops.repack_weight(w99, 0)
 yhr = torch.empty(B, 32, 128, 4, device=dev)
 f99 = 2.0 * B * 4096 * 5184 * 4
 timeit("conv9_fwd_64_4_hr", lambda: ops.conv_fwd(xhr, wp99, None, 4, 9, 9, out=yhr), f99)
+timeit("conv9_fwd_mfma_64_4_hr", lambda: ops.conv2d_forward(xhr, w99, None), f99)
+ylr4 = R(B, 16, 64, 64)
+w14 = R(64, 4, 9, 9) * 0.02
+timeit("conv9_dgrad_mfma_64_4_lr", lambda: ops.conv2d_dgrad(ylr4, w14), f99 / 4)
 timeit("conv9_wgrad_64_4_hr", lambda: ops.conv_wgrad(xhr, yhr, 4, 9, 9), f99)
 wd99 = ops.repack_weight(w99, 1)       # [81][4][64]: dgrad 4 -> 64 (generic kernel)
 timeit("conv9_dgrad_4_64_hr", lambda: ops.conv_fwd(yhr, wd99, None, 64, 9, 9, out=xhr), f99)
