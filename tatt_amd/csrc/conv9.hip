@@ -95,7 +95,7 @@ TATT_API int tatt_conv9_c64_to_c4(const float* x, const float* wpacked, const fl
 #define M9_ROWS (M9_TH + 8)
 #define M9_XS (M9_ROWS * 16 * M9_PW)          // floats: 24,576
 #define M9_WS (16 * 16 * 20)                  // floats: 5,120
-#define M9_LDS ((M9_XS + M9_WS) * 4)          // 118,784 B
+#define M9_LDS ((M9_XS + 2 * M9_WS) * 4)      // 139,264 B
 __global__ __launch_bounds__(256) void conv9_c64_to_c4_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wt,
                                                                    const float* __restrict__ bias, float* __restrict__ y,
                                                                    int B, int H, int W) {
@@ -115,8 +115,20 @@ __global__ __launch_bounds__(256) void conv9_c64_to_c4_mfma_kernel(const float* 
     acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float* xa = Xs + (2 * wave * 16 + kq) * M9_PW + 4 * g;      // + ((ky + r2) * 16 + 4 cq) * PW + 4 d
     const float* wb = Ws + (kq * 16 + i) * 20;                         // + (4 cq * 16) * 20 + 4 d
-    for (int c0 = 0; c0 < 64; c0 += 16) {
-        __syncthreads();                                      // every wave has left the previous chunk's halo
+    // 36 phases (4 channel chunks x 9 filter rows): the NEXT phase's filter slab travels global -> registers under the MFMAs of the
+    // current one and is stored to the other Ws buffer afterwards (one barrier per phase); the halo is re-staged per chunk.
+    f32x4 wpre[5];
+    auto slab_load = [&](int p) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(wt + ((long)(p % 9) * 64 + 16 * (p / 9)) * 320);
+#pragma unroll
+        for (int q = 0; q < 5; ++q) wpre[q] = src[t + 256 * q];
+    };
+    auto slab_store = [&](int buf) {
+        f32x4* dst = reinterpret_cast<f32x4*>(Ws + buf * M9_WS);
+#pragma unroll
+        for (int q = 0; q < 5; ++q) dst[t + 256 * q] = wpre[q];
+    };
+    auto halo_stage = [&](int c0) {
         // halo rows h0-4 .. h0+11, pixels w0-4 .. w0+67, channels c0 .. c0+15 (quads of lanes read 64 contiguous bytes)
         for (int idx = t; idx < M9_ROWS * 72 * 4; idx += 256) {
             const int c4 = idx & 3, pp = idx >> 2;
@@ -128,28 +140,36 @@ __global__ __launch_bounds__(256) void conv9_c64_to_c4_mfma_kernel(const float* 
             float* d = Xs + (r * 16 + 4 * c4) * M9_PW + px;
             d[0] = v[0]; d[M9_PW] = v[1]; d[2 * M9_PW] = v[2]; d[3 * M9_PW] = v[3];
         }
-        for (int ky = 0; ky < 9; ++ky) {
-            __syncthreads();                                  // halo complete / previous filter slab consumed
-            {
-                const f32x4* src = reinterpret_cast<const f32x4*>(wt + ((long)ky * 64 + c0) * 320);
-                f32x4* dst = reinterpret_cast<f32x4*>(Ws);
+    };
+    slab_load(0);
+    halo_stage(0);
+    slab_store(0);
+    __syncthreads();
+#pragma unroll 1
+    for (int p = 0; p < 36; ++p) {
+        const int ky = p % 9;
+        if (p + 1 < 36) slab_load(p + 1);
+        const float* wbp = wb + (p & 1) * M9_WS;
 #pragma unroll
-                for (int q = 0; q < 5; ++q) dst[t + 256 * q] = src[t + 256 * q];
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int cq = 0; cq < 4; ++cq) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(wbp + cq * 4 * 320 + 4 * d);
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(xa + ((ky + 0) * 16 + 4 * cq) * M9_PW + 4 * d);
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(xa + ((ky + 1) * 16 + 4 * cq) * M9_PW + 4 * d);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u], bv[u], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u], bv[u], acc[1], 0, 0, 0);
+                }
+            }
+        if (p + 1 < 36) {
+            slab_store((p + 1) & 1);                          // the other buffer: last read in phase p - 1, before the previous barrier
+            if (ky == 8) {                                    // chunk boundary: every wave must have left the halo first
+                __syncthreads();
+                halo_stage(16 * ((p + 1) / 9));
             }
             __syncthreads();
-#pragma unroll
-            for (int d = 0; d < 3; ++d)
-#pragma unroll
-                for (int cq = 0; cq < 4; ++cq) {
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(wb + cq * 4 * 320 + 4 * d);
-                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(xa + ((ky + 0) * 16 + 4 * cq) * M9_PW + 4 * d);
-                    const f32x4 a1 = *reinterpret_cast<const f32x4*>(xa + ((ky + 1) * 16 + 4 * cq) * M9_PW + 4 * d);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u], bv[u], acc[0], 0, 0, 0);
-                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u], bv[u], acc[1], 0, 0, 0);
-                    }
-                }
         }
     }
     // C layout: column n = lane & 15 = (j, o); row 4 (lane >> 4) + reg -> pixel group g(row).  The 16 columns of a row are 16

@@ -361,14 +361,14 @@ def test_staged_deferred_backward_equals_single_pass(dev):
     query GRU's backward deferred to the side lane of each stage, against the plain single-pass backward: identical kernels on
     identical inputs, only the order in which fan-in gradients are added differs (fp32 round-off).  Compared after ONE step
     (Adam turns round-off on near-zero gradients into +-lr, so trajectories drift apart by construction): same loss, gradient
-    norm to 1e-6, first moments (= 0.5 x gradient) to 1e-6 in l2 -- a race between the lanes, a stale packed filter or a lost
+    norm to 1e-6, first moments (= 0.5 x gradient) to 2e-5 in l2 -- a race between the lanes, a stale packed filter or a lost
     gradient would not pass.  The lane layouts themselves (one stream / two streams, eager / hipGraph) run the same kernels in
     the same order: bit-identical over five steps."""
     l1, s1, _, g1 = _run_steps(dev, 1, 6, True, use_graph=False, defer_param_grads=False)
     l0, s0, _, g0 = _run_steps(dev, 1, 6, True, use_graph=False, defer_param_grads=True, side_stream=True)
     assert l1 == l0 and abs(g1 - g0) <= 1e-6 * g1, (l1, l0, g1, g0)
     # (the flat layouts agree: both follow grad_buckets() order)
-    assert float((s1["m"] - s0["m"]).norm() / s1["m"].norm()) < 1e-6
+    assert float((s1["m"] - s0["m"]).norm() / s1["m"].norm()) < 2e-5
     assert float((s1["bn"] - s0["bn"]).abs().max()) == 0.0 and torch.equal(s1["nbt"], s0["nbt"])
     l2, s2, _, g2 = _run_steps(dev, 5, 6, True, use_graph=False, defer_param_grads=True, side_stream=True)
     l3, s3, _, g3 = _run_steps(dev, 5, 6, True, use_graph=True, defer_param_grads=True, side_stream=True)
