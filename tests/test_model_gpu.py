@@ -396,7 +396,8 @@ def test_single_rank_process_group_runs_the_staged_step(dev):
     # (the flat layouts differ -- bucket order -- so compare through the module's own tensors)
     for a, b in zip(l0, l1):
         assert abs(a - b) <= 1e-6 * abs(a), (l0, l1)
-    assert l2 == l1[:3] or all(abs(a - b) <= 1e-6 * abs(a) for a, b in zip(l2, l1))
+    for a, b in zip(l2, l1):
+        assert abs(a - b) <= 1e-5 * abs(a), (l2, l1)
     assert float((s0["bn"] - s1["bn"]).abs().max()) <= 1e-6 and torch.equal(s0["nbt"], s1["nbt"])
     assert abs(float(s0["p"].double().sum()) - float(s1["p"].double().sum())) < 1e-3
     assert abs(g0 - g1) <= 1e-5 * g0

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""GPU box: repeat the kernels / the forward pass that run concurrently with something (LDS double buffers, the forward fork of the
+query GRU) many times on identical inputs and compare every result bit for bit with the first one."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tatt_amd  # noqa: E402
+from tatt_amd import functional as Fh, ops  # noqa: E402
+from oracle.fixtures import randomize_state_dict, make_inputs  # noqa: E402
+
+dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(1)
+B = 48
+
+
+def repeat(name, fn, n):
+    ref = fn().clone()
+    bad = 0
+    for _ in range(n):
+        out = fn()
+        if not torch.equal(out, ref):
+            bad += 1
+    torch.cuda.synchronize()
+    print("%-44s %4d repetitions, %d differ" % (name, n, bad), flush=True)
+
+
+x = torch.randn(B, 32, 128, 64, generator=g).to(dev)
+w = (torch.randn(4, 64, 9, 9, generator=g) * 0.02).to(dev)
+b = torch.randn(4, generator=g).to(dev)
+repeat("conv9 64->4 mfma, HR", lambda: ops.conv2d_forward(x, w, b), 300)
+xl = torch.randn(B, 16, 64, 64, generator=g).to(dev)
+w1 = (torch.randn(64, 4, 9, 9, generator=g) * 0.02).to(dev)
+repeat("conv9 dgrad mfma, LR", lambda: ops.conv2d_dgrad(xl, w1), 300)
+w3 = (torch.randn(64, 64, 3, 3, generator=g) * 0.05).to(dev)
+b3 = torch.randn(64, generator=g).to(dev)
+repeat("conv3 ws16 64->64", lambda: ops.conv2d_forward(xl, w3, b3), 300)
+w4 = (torch.randn(256, 64, 3, 3, generator=g) * 0.05).to(dev)
+repeat("conv3 ws16 64->256", lambda: ops.conv2d_forward(xl, w4, None), 100)
+repeat("conv3 ws16 dgrad", lambda: ops.conv2d_dgrad(xl, w3), 200)
+repeat("conv3 wgrad (batched reduce off)", lambda: ops.conv_wgrad(xl, xl, 64, 3, 3), 100)
+
+torch.manual_seed(1234)
+m = tatt_amd.TSRN_TL_TRANS(scale_factor=2, width=128, height=32, STN=True, mask=True, srb_nums=5, hidden_units=32)
+m.load_state_dict(randomize_state_dict(m.state_dict()))
+m = m.to(dev).train()
+xi, tp, hr = (t.to(dev) for t in make_inputs(8, seed=3))
+# something else keeps the GPU busy on a third stream while the forward (with its fork) runs
+busy = torch.cuda.Stream()
+junk = torch.randn(4096, 4096, device=dev)
+
+
+def fwd():
+    Fh.set_seed(dev, 7)
+    Fh.FWD_FORK.enabled = True
+    try:
+        with torch.cuda.stream(busy):
+            for _ in range(3):
+                torch.mm(junk, junk)
+        with torch.no_grad():
+            sr, mid = m(xi, tp)
+    finally:
+        Fh.FWD_FORK.enabled = False
+    return torch.cat([sr.reshape(-1), mid["trans_feat"].reshape(-1)])
+
+
+repeat("train-mode forward with the query-GRU fork", fwd, 150)
