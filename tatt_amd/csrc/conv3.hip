@@ -13,6 +13,7 @@
 // prefetch 54 us; 8 waves / loader-wave variants 55-61 us; 16-byte LDS operand reads (v5) 52 us; weight-stationary 4 waves
 // 45 us; weight-stationary 8 waves (two waves per SIMD) 39 us.  Only the last two designs are kept.
 #include "common.h"
+#include <mutex>
 #include <stdlib.h>
 
 #define C3_PX 64
@@ -196,16 +197,15 @@ TATT_API int tatt_conv3_c64_fwd_t(const float* x, const float* wt, const float* 
                                   int Cout, int act, float beta, hipStream_t st) {
     if (Cin % 64 || Cout % 64 || W % C3_PX) return 1;
     Conv3P p = {x, wt, bias, y, B, H, W, Cin, Cout, act, beta};
-    static bool attr_set = false;
     static int ck = 32;
-    if (!attr_set) {
+    static std::once_flag attr_once;                 // C++11 call_once: safe if several host threads launch
+    std::call_once(attr_once, [&] {
 #define C5_ATTR(CKV) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_fwd_v5_kernel<CKV>), \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, C5<CKV>::LDS);
         C5_ATTR(64) C5_ATTR(32) C5_ATTR(16)
         const char* e = getenv("TATT_CONV3_CK");   // 64: one work-group per CU; 32 (default): two per CU; 16: three per CU
         if (e) ck = atoi(e);
-        attr_set = true;
-    }
+    });
     const int ntiles = B * H * (W / C3_PX) * (Cout / 64);
     const int per_cu = ck == 64 ? 1 : (ck == 16 ? 3 : 2);
     const int G = ntiles < 256 * per_cu ? ntiles : 256 * per_cu;
@@ -357,11 +357,10 @@ TATT_API int tatt_conv3_c64_fwd_ws(const float* x, const float* wl, const float*
                                    int Cout, int act, float beta, hipStream_t st) {
     if (Cout % 64 || W % C3_PX) return 1;
     Conv3P p = {x, wl, bias, y, B, H, W, 64, Cout, act, beta};
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::once_flag attr_once;                 // C++11 call_once: safe if several host threads launch
+    std::call_once(attr_once, [&] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS);
-        attr_set = true;
-    }
+    });
     const int cob = Cout / 64, npt = B * H * (W / C3_PX);
     int per = 256 / cob;
     if (per > npt) per = npt;
@@ -491,11 +490,10 @@ TATT_API int tatt_conv3_c64_fwd_ws16(const float* x, const float* wl, const floa
                                      int Cout, int act, float beta, hipStream_t st) {
     if (Cout % 64 || W % C3_PX) return 1;
     Conv3P p = {x, wl, bias, y, B, H, W, 64, Cout, act, beta};
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::once_flag attr_once;                 // C++11 call_once: safe if several host threads launch
+    std::call_once(attr_once, [&] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_ws16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W16_LDS);
-        attr_set = true;
-    }
+    });
     const int cob = Cout / 64, npt = B * H * (W / C3_PX);
     int per = 256 / cob;
     if (per > npt) per = npt;
@@ -661,12 +659,11 @@ TATT_API int tatt_conv3_c64_wgrad_partial(const float* x, const float* dy, float
     if (Cin % 64 || Cout % 64 || W % C3_PX) return 1;
     const int nseg = B * H * (W / C3_PX);
     Conv3WP p = {x, dy, part, B, H, W, Cin, Cout, nseg};
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::once_flag attr_once;                 // C++11 call_once: safe if several host threads launch
+    std::call_once(attr_once, [&] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   C3_WG_LDS);
-        attr_set = true;
-    }
+    });
     hipLaunchKernelGGL(conv3_c64_wgrad_kernel, dim3(G, (Cin / 64) * (Cout / 64)), dim3(512), C3_WG_LDS, st, p);
     return LAUNCH_CHECK();
 }

@@ -10,6 +10,7 @@
 // input channels is staged in LDS channel-quad-major ([c4][row][col] float4: lanes read consecutive 16 B), and the
 // filter -- uniform across the wave -- is read through the scalar cache (s_load) straight into SGPR operands.
 #include "common.h"
+#include <mutex>
 
 #define T9_H 8
 #define T9_W 32
@@ -189,11 +190,10 @@ __global__ __launch_bounds__(256) void conv9_c64_to_c4_mfma_kernel(const float* 
 TATT_API int tatt_conv9_c64_to_c4_mfma(const float* x, const float* wt, const float* bias, float* y, int B, int H, int W,
                                        hipStream_t st) {
     if (H % M9_TH || W % M9_TW) return 1;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::once_flag attr_once;                 // C++11 call_once: safe if several host threads launch
+    std::call_once(attr_once, [&] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv9_c64_to_c4_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, M9_LDS);
-        attr_set = true;
-    }
+    });
     hipLaunchKernelGGL(conv9_c64_to_c4_mfma_kernel, dim3(B * (H / M9_TH) * (W / M9_TW)), dim3(256), M9_LDS, st, x, wt, bias, y, B, H, W);
     return LAUNCH_CHECK();
 }
