@@ -285,10 +285,13 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline and a.arch != "tatt_tpg":
             out["cpu_baseline"] = cpu_baseline(a.arch, a.cpu_batch if a.tile == "std" else min(a.cpu_batch, a.batch), a.tile)
-        print(json.dumps(out))
+        line = json.dumps(out)
     if pg is not None:
         torch.distributed.barrier()
-        torch.distributed.destroy_process_group()
+        torch.distributed.destroy_process_group()      # (RCCL prints its version banner when the communicator goes away)
+    if rank == 0:
+        sys.stdout.flush()
+        print(line, flush=True)                          # the ONE JSON line: last thing on stdout
 
 
 if __name__ == "__main__":

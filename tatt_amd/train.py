@@ -80,10 +80,12 @@ class TextPriorSR(torch.nn.Module):
     def block(self, v):
         self.sr.block = v
 
-    # -- Trainer protocol: buckets follow the SR generator's, the recogniser's parameters close the last one -------------
+    # -- Trainer protocol: the SR generator's stages, then one more for the recogniser --------------------------------------
     def grad_buckets(self):
+        """The student receives gradient from two places -- the distillation loss (first backward stage) and the SR generator's
+        text encoder (stage "tp") -- so its own backward is a last stage, "tpg", fed by the sum of both (forward() cuts there)."""
         b = [(n, list(ps)) for n, ps in self.sr.grad_buckets()]
-        b[-1][1].extend(self.tpg.parameters())
+        b.append(("tpg", list(self.tpg.parameters())))
         return b
 
     def set_grad_cuts(self, cuts):
@@ -107,8 +109,11 @@ class TextPriorSR(torch.nn.Module):
 
     def forward(self, x):
         probs = self._probs(self.tpg, x)
-        self._student_probs = probs
-        prior = probs.permute(1, 0, 2).unsqueeze(1).permute(0, 3, 1, 2)           # (B, 37, 1, T)
+        cuts = getattr(self.sr, "_grad_cuts", None) if self.training else None
+        # staged backward: both consumers of the prior continue on their own detached copy; stage "tpg" adds their gradients up
+        self._student_probs = cuts.cut("tpg", probs) if cuts else probs
+        p_sr = cuts.cut("tpg", probs) if cuts else probs
+        prior = p_sr.permute(1, 0, 2).unsqueeze(1).permute(0, 3, 1, 2)            # (B, 37, 1, T)
         return self.sr(x, prior)
 
     def extra_loss(self, hr):

@@ -203,3 +203,43 @@ def test_sr_loss_trains_the_prior_generator(dev):
               "cnn.conv6.weight", "cnn.batchnorm6.weight"):
         assert params[k].grad is not None, k
         assert rel_err(params[k].grad.cpu(), req[k].grad) < 5e-3, (k, rel_err(params[k].grad.cpu(), req[k].grad))
+
+
+@pytest.mark.gpu
+def test_text_prior_sr_with_teacher_through_the_trainer(dev):
+    """The student recogniser receives gradient from the distillation loss AND from the SR generator's text encoder; in the staged
+    backward both arrive at stage "tpg" (TextPriorSR.forward cuts there).  One step through the Trainer, eager and as a hipGraph:
+    first loss = image loss + distillation term of a plain forward; gradient of a recogniser weight = the single-pass one."""
+    import tatt_amd
+    from oracle.fixtures import make_inputs
+    from tatt_amd.train import TextPriorSR, Trainer, image_loss_mean
+    kw = dict(scale_factor=2, width=128, height=32, STN=False, mask=True, srb_nums=5, hidden_units=32)
+
+    def build():
+        torch.manual_seed(1234)
+        sr_m = tatt_amd.TSRN_TL_TRANS(**kw)
+        sr_m.load_state_dict(randomize_state_dict(sr_m.state_dict()))
+        tpg = tatt_amd.CRNN(32, 1, 37, 256)
+        tpg.load_state_dict(_sd())
+        teacher = tatt_amd.CRNN(32, 1, 37, 256)
+        teacher.load_state_dict(randomize_state_dict(teacher.state_dict(), seed=5))
+        m = TextPriorSR(sr_m, tpg, teacher=teacher).to(dev).train()
+        sr_m.infoGen.dropout_on = False
+        return m
+    x, _, hr = make_inputs(3, seed=11)
+    x, hr = x.to(dev), hr.to(dev)
+    m = build()
+    sr, _ = m(x)
+    loss = image_loss_mean(sr, hr, scale=100.0) + m.extra_loss(hr)
+    loss.backward()                                              # single pass, no staging
+    want, g_ref = float(loss), m.tpg.rnn[1].embedding.weight.grad.clone()
+    m = build()
+    tr = Trainer(m, use_graph=False)
+    assert tr.stages[-1] == "tpg" and tr.groups[1][2] == 0.0
+    got = float(tr.step(x, None, hr))
+    assert abs(got - want) < 1e-6 * abs(want), (got, want)
+    assert rel_err(m.tpg.rnn[1].embedding.weight.grad, g_ref) < 1e-5
+    m = build()
+    tr = Trainer(m, use_graph=True, warmup_eager=2)
+    ls = [float(tr.step(x, None, hr)) for _ in range(5)]
+    assert abs(ls[0] - want) < 1e-6 * abs(want) and all(l == l for l in ls) and ls[-1] < ls[0]
