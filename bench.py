@@ -292,6 +292,12 @@ def main():
     if rank == 0:
         sys.stdout.flush()
         print(line, flush=True)                          # the ONE JSON line: last thing on stdout
+    if pg is not None:
+        # RCCL 2.26 prints a version banner to stdout from a destructor at interpreter teardown -- after the JSON line.  Everything
+        # is flushed and the process group is gone: leave without running the teardown handlers.
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":
