@@ -71,21 +71,52 @@ class _DeferredParamGrads:
 
     def __init__(self):
         self.enabled = False
+        self.fork_stream = None          # set (by the Trainer, for the LAST backward stage): issue at once on this stream instead
+        self.long_stream = None          # set (by the Trainer): closures marked `long` go out at once on this third stream
         self._pending = []
         self._keep = []
 
-    def submit(self, params, fn, *keep):
+    @staticmethod
+    def _run(fn):
+        r = fn()
+        if hasattr(r, "send"):                       # generator closure: nothing to wait for, run it through
+            try:
+                while True:
+                    next(r)
+            except StopIteration as stop:
+                r = stop.value
+        return r
+
+    @staticmethod
+    def _assign(params, grads):
+        for p, g in zip(params, grads):
+            if p is not None and g is not None:
+                p.grad = g if p.grad is None else p.grad + g
+
+    def submit(self, params, fn, *keep, long=False):
         """params: tuple of leaf tensors (or None); fn() -> tuple of their gradients (or None), same order (or a generator that
-        yields once between its split-K GEMMs and their consumer and returns the tuple)."""
+        yields once between its split-K GEMMs and their consumer and returns the tuple).  long: a chain of many dependent launches
+        (the query GRU's backward: 47 of them) -- it gets a stream of its own and runs from now until the end of the backward pass
+        instead of holding up the join of one stage's side lane."""
         if not self.enabled or any(p is not None and not p.is_leaf for p in params):
-            r = fn()
-            if hasattr(r, "send"):
-                try:
-                    while True:
-                        next(r)
-                except StopIteration as stop:
-                    r = stop.value
-            return r
+            return self._run(fn)
+        ref = next((p for p in params if p is not None), None)
+        if long and self.long_stream is not None and ref is not None and ref.is_cuda:
+            main = torch.cuda.current_stream(ref.device)
+            self.long_stream.wait_stream(main)
+            with torch.cuda.stream(self.long_stream):
+                self._assign(params, self._run(fn))
+            self._keep.append(keep)
+            return (None,) * len(params)
+        if self.fork_stream is not None and ref is not None and ref.is_cuda:
+            # last stage of the backward: there is no later main lane to hide behind, so the kernels go out now, on the side
+            # stream, behind an event -- a short branch per operator, joined by the Trainer at the end of the pass
+            main = torch.cuda.current_stream(ref.device)
+            self.fork_stream.wait_stream(main)
+            with torch.cuda.stream(self.fork_stream):
+                self._assign(params, self._run(fn))
+            self._keep.append(keep)
+            return (None,) * len(params)
         self._pending.append((params, fn))
         self._keep.append(keep)
         return (None,) * len(params)
@@ -115,9 +146,7 @@ class _DeferredParamGrads:
                     raise RuntimeError("a deferred gradient closure may yield only once")
                 except StopIteration as stop:
                     r = stop.value
-            for p, g in zip(params, r):
-                if p is not None and g is not None:
-                    p.grad = g if p.grad is None else p.grad + g
+            self._assign(params, r)
 
     def release(self):
         assert not self._pending, "deferred parameter gradients were never flushed"
@@ -691,7 +720,7 @@ class QueryGruFn(Function):
         # every output of this backward is a parameter gradient (the embedding depends on parameters only): all of it is deferrable
         dq = _c(dq)
         saved = ctx.saved_tensors
-        return tuple(SIDE.submit(ctx.leaves, lambda: QueryGruFn._backward(ctx, saved, dq), dq, saved)) + (None, None, None)
+        return tuple(SIDE.submit(ctx.leaves, lambda: QueryGruFn._backward(ctx, saved, dq), dq, saved, long=True)) + (None, None, None)
 
     @staticmethod
     def _backward(ctx, saved, dq):

@@ -362,24 +362,26 @@ class _TrainPathMixin:
     def set_grad_cuts(self, cuts):
         object.__setattr__(self, "_grad_cuts", cuts)
 
-    def grad_buckets(self):
+    def grad_buckets(self, long_lane=False):
         """[(stage name, [parameters])] in backward-completion order; stage names match the `cuts.cut(name, ...)` calls of the
         forward: "trunk" (block7 + up-sampler: what the loss back-propagates into directly), "srb4" ... "srb0" (the residual
-        blocks, last to first), "tp" (TP interpreter), "first" (block1 + STN head)."""
+        blocks, last to first), "tp" (TP interpreter), "first" (block1 + STN head).  long_lane: the query GRU's parameters
+        (their gradient chain runs on a stream of its own until the end of the backward pass) form a last bucket "long"."""
         k = self.srb_nums
-        groups = {"trunk": [], "tp": [], "first": []}
+        groups = {"trunk": [], "tp": [], "first": [], "long": []}
         groups.update({"srb%d" % i: [] for i in range(k)})
         for name, p in self.named_parameters():
             top = name.split(".", 1)[0]
             if top == "infoGen":
-                groups["tp"].append(p)
+                is_q = name.startswith("infoGen.transformer.gru_encoding.") or name.startswith("infoGen.init_factor.")
+                groups["long" if (long_lane and is_q) else "tp"].append(p)
             elif top.startswith("block") and 2 <= int(top[5:]) <= k + 1:
                 groups["srb%d" % (int(top[5:]) - 2)].append(p)
             elif top.startswith("block") and int(top[5:]) > k + 1:
                 groups["trunk"].append(p)
             else:                                  # block1, stn_head, (TBSRN's unused conv / bn)
                 groups["first"].append(p)
-        order = ["trunk"] + ["srb%d" % i for i in range(k - 1, -1, -1)] + ["tp", "first"]
+        order = ["trunk"] + ["srb%d" % i for i in range(k - 1, -1, -1)] + ["tp", "first", "long"]
         return [(n, groups[n]) for n in order if groups[n]]
 
     def _bn_on_path(self):

@@ -317,7 +317,10 @@ def test_width_not_a_multiple_of_64(dev):
 # ---- the published number's own configuration: hipGraph replay, the second stream, B = 48 ---------------------------------------
 def _flat_state(m, tr):
     sd = m.state_dict()
-    return {"p": tr.flat_p.clone(), "m": tr.flat_m.clone(), "v": tr.flat_v.clone(),
+
+    def canon(buf):                  # parameters in the MODULE's order, whatever bucket layout the trainer chose
+        return torch.cat([buf[o:o + k] for o, k in (tr.flat.offsets[id(p)] for p in m.parameters())])
+    return {"p": canon(tr.flat_p), "m": canon(tr.flat_m), "v": canon(tr.flat_v),
             "bn": torch.cat([v.reshape(-1).float() for k, v in sd.items() if k.endswith(("running_mean", "running_var"))]),
             "nbt": torch.stack([v.reshape(()) for k, v in sd.items() if k.endswith("num_batches_tracked")])}
 
