@@ -281,6 +281,7 @@ class Trainer:
         # the last stage that computes anything ("long" has no main lane): its parameter-gradient kernels fork off at once
         self._last_compute = max(i for i, n in enumerate(self.stages) if n != "long")
         self._fork_last = os.environ.get("TATT_FORK_LAST", "0") == "1"
+        self._long_active = False
         self.gnorms = [torch.zeros(1, device=dev) for _ in self.groups]
         self.gnorm = self.gnorms[0]
         self.step_count = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -301,7 +302,12 @@ class Trainer:
         # (forking the LAST stage's parameter-gradient kernels operator by operator -- it has no later main lane to hide behind --
         #  was measured: 9.03 vs 8.59 ms per step; many tiny branches cost more than the 0.26 ms tail they hide.  TATT_FORK_LAST=1)
         Fh.SIDE.fork_stream = self.side if (self._fork_last and self.two_lanes and k == self._last_compute and k > 0) else None
-        Fh.SIDE.long_stream = self.long
+        if k == 0 and x is not None:
+            # The query GRU's backward is B - 1 dependent launches.  On its own stream it overlaps well when the chain is short and
+            # its kernels heavy (large tile, B = 16: 10.66 -> 10.35 ms per step); as 47 small launches (B = 48) the graph executor
+            # handles the long thin branch badly (8.49 -> 8.73 ms), so there it stays in its stage's side lane.
+            self._long_active = self.long is not None and x.shape[0] <= 24
+        Fh.SIDE.long_stream = self.long if self._long_active else None
         try:
             if k == 0:
                 for p in self.params:
