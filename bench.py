@@ -246,6 +246,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = tr.step(x, tp, hr)
+    t_issue = time.perf_counter() - t0             # host time to ISSUE the steps (graph launches); the GPU may still be running
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -273,7 +274,7 @@ def main():
                        if a.arch == "tatt" else "%s train step, batch %d/GPU" % (a.arch.upper(), a.batch),
                        "global_batch": a.batch * world, "parallelism": "dp%d" % world + (" (self-test: RCCL group of one rank)" if a.dp_selftest else ""),
                        "launch": ("hipGraph replay" if graph_ok else "eager") + ("" if a.no_defer else ", staged backward" + ("" if a.no_side_stream else " on 2 streams")), "final_loss": round(loss_v, 5),
-                       "known_answer": kat,
+                       "host_issue_ms_per_step": round(t_issue / a.steps * 1e3, 3), "known_answer": kat,
                        "whole_step_tflops": round(ips * tile["flop_per_image"] / 1e12, 2) if a.arch == "tatt" else None},
             "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),

@@ -197,13 +197,14 @@ int tatt_adam_step(float* p, const float* g, float* m, float* v, long n, float l
  * token(s,t) = (s / s_in)*stride_hi + (s % s_in)*stride_lo + t*stride_t on the NHWC token grid: vertical scan
  * (gru1): s_in=W, stride_hi=H*W, stride_lo=1, stride_t=W, T=H; horizontal (gru2): s_in=1, stride_hi=W, stride_t=1, T=W. */
 int tatt_gru32_fwd(const float* gi, const float* whh_f, const float* bhh_f, const float* whh_r,
-                   const float* bhh_r, float* out, int nseq, int T, int s_in, long stride_hi, long stride_lo,
-                   long stride_t, hipStream_t st);
-/* BPTT: writes dgi[tok][192], dgh[tok][192] (recurrent-side gate gradients) and hprev[tok][64] */
-int tatt_gru32_bwd(const float* gi, const float* out, const float* dout, const float* whh_f,
-                   const float* bhh_f, const float* whh_r, const float* bhh_r, float* dgi, float* dgh,
-                   float* hprev, int nseq, int T, int s_in, long stride_hi, long stride_lo, long stride_t,
-                   hipStream_t st);
+                   const float* bhh_r, float* out, float* gates, int nseq, int T, int s_in, long stride_hi,
+                   long stride_lo, long stride_t, hipStream_t st);
+/* gates (may be NULL: inference): [tok][256] = per direction {r, z, n, W_hn h + b_hn} x 32, what autograd keeps of
+ * torch.nn.GRU's forward for its backward.
+ * BPTT from those: writes dgi[tok][192], dgh[tok][192] (recurrent-side gate gradients) and hprev[tok][64] */
+int tatt_gru32_bwd(const float* gates, const float* out, const float* dout, const float* whh_f,
+                   const float* whh_r, float* dgi, float* dgh, float* hprev, int nseq, int T, int s_in,
+                   long stride_hi, long stride_lo, long stride_t, hipStream_t st);
 
 /* backward step, fused form: dh = dhseq_next + dhcarry + dgh_cur @ whh, then the gate part of the NEXT step on the same tile:
  * dgi_acc += input-side gate grads, dgh_next = recurrent-side gate grads, dhcarry = dh*z  (whhT = whh transposed) */

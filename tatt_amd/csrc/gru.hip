@@ -27,14 +27,24 @@ __device__ __forceinline__ long seq_base(const SeqGeom& g, int s) {
 // (~1-2 us away), so each group keeps GRU_PF steps of input in flight in a register ring.  A 32-lane group lives inside
 // one wave, so the LDS hand-off of h needs only wave-level ordering -- no work-group barrier couples the 8 groups.
 #define GRU_PF 4
+// Every load is UNCONDITIONAL (step indices clamped into the sequence; groups past the last sequence redo the last one, writing
+// identical values to identical addresses) and nothing loaded lives in a register across the loop's back edge: the inputs of a
+// group of GRU_PF steps are loaded while the group before it computes and are parked in LDS (each lane its own column) at the
+// end of that group.  With a branch around a load, or a register ring carried around the loop, the compiler copies the ring at
+// the back edge behind `s_waitcnt vmcnt(0)`, which drains the prefetch just issued (and, on gfx9, every store since): measured
+// 1.5-2 us per step instead of 0.3-0.5.
+//
+// SAVE: also write gates[tok][dir*128 + {r, z, n, W_hn h + b_hn}*32 + j] for the backward pass (it then needs neither gi nor the
+// 96x32 gate recomputation, which halves its arithmetic and its registers).
+template <bool SAVE>
 __global__ __launch_bounds__(256) void gru32_fwd_kernel(const float* __restrict__ gi,
                                                         const float* __restrict__ whh_f, const float* __restrict__ bhh_f,
                                                         const float* __restrict__ whh_r, const float* __restrict__ bhh_r,
-                                                        float* __restrict__ out, SeqGeom g) {
+                                                        float* __restrict__ out, float* __restrict__ gates, SeqGeom g) {
     __shared__ __attribute__((aligned(16))) float hs[8][32];
+    __shared__ float pf[3 * GRU_PF][256];
     const int t = threadIdx.x, grp = t >> 5, j = t & 31;
-    const int seq = blockIdx.x * 4 + (grp >> 1), dir = grp & 1;
-    const bool valid = seq < g.nseq;
+    const int seq = min((int)blockIdx.x * 4 + (grp >> 1), g.nseq - 1), dir = grp & 1;
     const float* whh = dir ? whh_r : whh_f;
     const float* bhh = dir ? bhh_r : bhh_f;
     float wr[32], wz[32], wn[32];
@@ -45,160 +55,184 @@ __global__ __launch_bounds__(256) void gru32_fwd_kernel(const float* __restrict_
         wn[k] = whh[(2 * 32 + j) * 32 + k];
     }
     const float br = bhh[j], bz = bhh[32 + j], bn = bhh[64 + j];
-    const long base = valid ? seq_base(g, seq) : 0;
-    auto token = [&](int step) { return base + (long)(dir ? g.T - 1 - step : step) * g.stride_t; };
-    float pr[GRU_PF], pz[GRU_PF], pn[GRU_PF];
+    const int T = g.T;
+    const long st_t = dir ? -g.stride_t : g.stride_t;
+    const long tok0 = seq_base(g, seq) + (dir ? (long)(T - 1) * g.stride_t : 0);          // token of step 0
+    const float* gq = gi + dir * 96 + j;
+    float* oq = out + dir * 32 + j;
+    float* sq = gates + dir * 128 + j;
     auto fetch = [&](int step, float& a, float& b, float& c) {
-        a = b = c = 0.f;
-        if (!valid || step >= g.T) return;
-        const float* q = gi + token(step) * 192 + dir * 96 + j;
+        const float* q = gq + (tok0 + (long)min(step, T - 1) * st_t) * 192;
         a = q[0]; b = q[32]; c = q[64];
     };
-#pragma unroll
-    for (int d = 0; d < GRU_PF; ++d) fetch(d, pr[d], pz[d], pn[d]);
     float h = 0.f;
-    for (int s0 = 0; s0 < g.T; s0 += GRU_PF) {
+    auto one_step = [&](int step, float gr, float gz, float gn) {
+        hs[grp][j] = h;
+        wave_lds_sync();
+        float ar = br, az = bz, an = bn;
+        const f32x4* hv = reinterpret_cast<const f32x4*>(hs[grp]);
+#pragma unroll
+        for (int k4 = 0; k4 < 8; ++k4) {
+            f32x4 hh = hv[k4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                ar = fmaf(wr[k4 * 4 + e], hh[e], ar);
+                az = fmaf(wz[k4 * 4 + e], hh[e], az);
+                an = fmaf(wn[k4 * 4 + e], hh[e], an);
+            }
+        }
+        wave_lds_sync();
+        const float r = sigmoid_fast(gr + ar);
+        const float z = sigmoid_fast(gz + az);
+        const float n = tanh_fast(gn + r * an);
+        h = (1.f - z) * n + z * h;
+        const long tok = tok0 + (long)step * st_t;
+        oq[tok * 64] = h;
+        if (SAVE) {
+            float* q = sq + tok * 256;
+            q[0] = r; q[32] = z; q[64] = n; q[96] = an;
+        }
+    };
+    {
+        float a, b, c;
 #pragma unroll
         for (int u = 0; u < GRU_PF; ++u) {
-            const int step = s0 + u;
-            if (step >= g.T) break;
-            const float gr = pr[u], gz = pz[u], gn = pn[u];
-            fetch(step + GRU_PF, pr[u], pz[u], pn[u]);
-            hs[grp][j] = h;
-            wave_lds_sync();
-            float ar = br, az = bz, an = bn;
-            const f32x4* hv = reinterpret_cast<const f32x4*>(hs[grp]);
-#pragma unroll
-            for (int k4 = 0; k4 < 8; ++k4) {
-                f32x4 hh = hv[k4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    ar = fmaf(wr[k4 * 4 + e], hh[e], ar);
-                    az = fmaf(wz[k4 * 4 + e], hh[e], az);
-                    an = fmaf(wn[k4 * 4 + e], hh[e], an);
-                }
-            }
-            wave_lds_sync();
-            const float r = sigmoid_fast(gr + ar);
-            const float z = sigmoid_fast(gz + az);
-            const float n = tanh_fast(gn + r * an);
-            h = (1.f - z) * n + z * h;
-            if (valid) out[token(step) * 64 + dir * 32 + j] = h;
+            fetch(u, a, b, c);
+            pf[u * 3 + 0][t] = a; pf[u * 3 + 1][t] = b; pf[u * 3 + 2][t] = c;
         }
+    }
+    int s0 = 0;
+    for (; s0 + GRU_PF <= T; s0 += GRU_PF) {
+        float nr[GRU_PF], nz[GRU_PF], nn[GRU_PF];
+#pragma unroll
+        for (int u = 0; u < GRU_PF; ++u) fetch(s0 + GRU_PF + u, nr[u], nz[u], nn[u]);
+#pragma unroll
+        for (int u = 0; u < GRU_PF; ++u) one_step(s0 + u, pf[u * 3 + 0][t], pf[u * 3 + 1][t], pf[u * 3 + 2][t]);
+#pragma unroll
+        for (int u = 0; u < GRU_PF; ++u) { pf[u * 3 + 0][t] = nr[u]; pf[u * 3 + 1][t] = nz[u]; pf[u * 3 + 2][t] = nn[u]; }
+    }
+    for (; s0 < T; ++s0) {                                   // T % GRU_PF leftover steps: plain loads
+        float gr, gz, gn;
+        fetch(s0, gr, gz, gn);
+        one_step(s0, gr, gz, gn);
     }
 }
 TATT_API int tatt_gru32_fwd(const float* gi, const float* whh_f, const float* bhh_f, const float* whh_r,
-                            const float* bhh_r, float* out, int nseq, int T, int s_in, long stride_hi, long stride_lo,
-                            long stride_t, hipStream_t st) {
+                            const float* bhh_r, float* out, float* gates, int nseq, int T, int s_in, long stride_hi,
+                            long stride_lo, long stride_t, hipStream_t st) {
+    if (nseq <= 0 || T <= 0) return 0;
     SeqGeom g = {nseq, T, s_in, stride_hi, stride_lo, stride_t};
-    hipLaunchKernelGGL(gru32_fwd_kernel, dim3(cdiv(nseq, 4)), dim3(256), 0, st, gi, whh_f, bhh_f, whh_r, bhh_r, out, g);
+    if (gates)
+        hipLaunchKernelGGL(gru32_fwd_kernel<true>, dim3(cdiv(nseq, 4)), dim3(256), 0, st, gi, whh_f, bhh_f, whh_r, bhh_r, out,
+                           gates, g);
+    else
+        hipLaunchKernelGGL(gru32_fwd_kernel<false>, dim3(cdiv(nseq, 4)), dim3(256), 0, st, gi, whh_f, bhh_f, whh_r, bhh_r, out,
+                           gates, g);
     return LAUNCH_CHECK();
 }
 
 // ------------------------------------------------------------------------------------------------
-// small BiGRU backward (BPTT).  Recomputes the gates from gi and the stored outputs.
+// small BiGRU backward (BPTT) from the gates the forward pass saved.
 // writes dgi [tok][192], dgh [tok][192] (recurrent-side gate grads: n-gate scaled by r) and
 // hprev [tok][64] (the h_{t-1} each step consumed) -- dW_hh = dgh^T hprev, dW_ih = dgi^T x, dx = dgi W_ih
 // are GEMMs issued by the host afterwards.
+// Per step only the chain  dh -> gate gradients -> (LDS) -> dh_{t-1} = dh z + W_hh^T [dr, dz, dn r]  is serial.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gru32_bwd_kernel(const float* __restrict__ gi, const float* __restrict__ out,
+__global__ __launch_bounds__(256) void gru32_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ out,
                                                         const float* __restrict__ dout,
-                                                        const float* __restrict__ whh_f, const float* __restrict__ bhh_f,
-                                                        const float* __restrict__ whh_r, const float* __restrict__ bhh_r,
+                                                        const float* __restrict__ whh_f, const float* __restrict__ whh_r,
                                                         float* __restrict__ dgi, float* __restrict__ dgh,
                                                         float* __restrict__ hprev, SeqGeom g) {
-    __shared__ __attribute__((aligned(16))) float hs[8][32];
     __shared__ __attribute__((aligned(16))) float ds[8][96];
+    __shared__ float pf[6 * GRU_PF][256];
     const int t = threadIdx.x, grp = t >> 5, j = t & 31;
-    const int seq = blockIdx.x * 4 + (grp >> 1), dir = grp & 1;
-    const bool valid = seq < g.nseq;
+    const int seq = min((int)blockIdx.x * 4 + (grp >> 1), g.nseq - 1), dir = grp & 1;
     const float* whh = dir ? whh_r : whh_f;
-    const float* bhh = dir ? bhh_r : bhh_f;
-    float wr[32], wz[32], wn[32], wt[96];
-#pragma unroll
-    for (int k = 0; k < 32; ++k) {
-        wr[k] = whh[(0 * 32 + j) * 32 + k];
-        wz[k] = whh[(1 * 32 + j) * 32 + k];
-        wn[k] = whh[(2 * 32 + j) * 32 + k];
-    }
+    float wt[96];
 #pragma unroll
     for (int row = 0; row < 96; ++row) wt[row] = whh[row * 32 + j];
-    const float br = bhh[j], bz = bhh[32 + j], bn = bhh[64 + j];
-    const long base = valid ? seq_base(g, seq) : 0;
+    const int T = g.T;
+    const long st_t = dir ? -g.stride_t : g.stride_t;
+    const long tok0 = seq_base(g, seq) + (dir ? (long)(T - 1) * g.stride_t : 0);          // token of (forward) step 0
+    const float* sq = gates + dir * 128 + j;
+    const float* oq = out + dir * 32 + j;
+    const float* dq = dout + dir * 32 + j;
     float dhc = 0.f;   // gradient carried to h_{t-1}
-    // register ring: the operands of steps s-1 .. s-GRU_PF (h_{t-1}, gi, dout) are in flight while step s computes
-    auto fetch = [&](int step, float& hp, float& gr, float& gz, float& gn, float& go) {
-        hp = gr = gz = gn = go = 0.f;
-        if (!valid || step < 0) return;
-        const int ti = dir ? g.T - 1 - step : step;
-        const long tok = base + (long)ti * g.stride_t;
-        const long ptok = tok + (dir ? g.stride_t : -g.stride_t);     // token of forward-step (step-1)
-        if (step > 0) hp = out[ptok * 64 + dir * 32 + j];
-        gr = gi[tok * 192 + dir * 96 + j]; gz = gi[tok * 192 + dir * 96 + 32 + j]; gn = gi[tok * 192 + dir * 96 + 64 + j];
-        go = dout[tok * 64 + dir * 32 + j];
+    auto fetch = [&](int step, float& hp, float& r, float& z, float& n, float& an, float& go) {
+        const int sc = max(step, 0);
+        const long tok = tok0 + (long)sc * st_t;
+        hp = oq[(tok0 + (long)max(sc - 1, 0) * st_t) * 64];    // raw: h_{-1} = 0 is selected where the value is used
+        const float* q = sq + tok * 256;
+        r = q[0]; z = q[32]; n = q[64]; an = q[96];
+        go = dq[tok * 64];
     };
-    float p_hp[GRU_PF], p_gr[GRU_PF], p_gz[GRU_PF], p_gn[GRU_PF], p_go[GRU_PF];
+    auto one_step = [&](int step, float hp_raw, float r, float z, float n, float an, float go) {
+        const long tok = tok0 + (long)step * st_t;
+        const float hp = step > 0 ? hp_raw : 0.f;
+        const float dh = dhc + go;
+        const float dn = dh * (1.f - z);
+        const float dz = dh * (hp - n);
+        const float dnp = dn * (1.f - n * n);
+        const float drp = dnp * an * r * (1.f - r);
+        const float dzp = dz * z * (1.f - z);
+        const float dghn = dnp * r;
+        ds[grp][j] = drp; ds[grp][32 + j] = dzp; ds[grp][64 + j] = dghn;
+        wave_lds_sync();
+        {
+            float* a = dgi + tok * 192 + dir * 96 + j;
+            float* b = dgh + tok * 192 + dir * 96 + j;
+            a[0] = drp; a[32] = dzp; a[64] = dnp;
+            b[0] = drp; b[32] = dzp; b[64] = dghn;
+            hprev[tok * 64 + dir * 32 + j] = hp;
+        }
+        // 96-term dot product split over 4 accumulators (a single dependent FMA chain would cost ~96 x 8 cycles per step)
+        float c0 = dh * z, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+        const f32x4* dv = reinterpret_cast<const f32x4*>(ds[grp]);
 #pragma unroll
-    for (int d = 0; d < GRU_PF; ++d) fetch(g.T - 1 - d, p_hp[d], p_gr[d], p_gz[d], p_gn[d], p_go[d]);
-    for (int s0 = g.T - 1; s0 >= 0; s0 -= GRU_PF) {
+        for (int k4 = 0; k4 < 24; ++k4) {
+            f32x4 dd = dv[k4];
+            c0 = fmaf(wt[k4 * 4 + 0], dd[0], c0); c1 = fmaf(wt[k4 * 4 + 1], dd[1], c1);
+            c2 = fmaf(wt[k4 * 4 + 2], dd[2], c2); c3 = fmaf(wt[k4 * 4 + 3], dd[3], c3);
+        }
+        dhc = (c0 + c1) + (c2 + c3);
+        wave_lds_sync();
+    };
+    {
+        float a, b, c, d, e, f;
 #pragma unroll
         for (int u = 0; u < GRU_PF; ++u) {
-            const int step = s0 - u;
-            if (step < 0) break;
-            const int ti = dir ? g.T - 1 - step : step;
-            const long tok = base + (long)ti * g.stride_t;
-            const float hp = p_hp[u], gr = p_gr[u], gz = p_gz[u], gn = p_gn[u];
-            const float dh = dhc + p_go[u];
-            fetch(step - GRU_PF, p_hp[u], p_gr[u], p_gz[u], p_gn[u], p_go[u]);
-            hs[grp][j] = hp;
-            wave_lds_sync();
-            float ar = br, az = bz, an = bn;
-            const f32x4* hv = reinterpret_cast<const f32x4*>(hs[grp]);
-#pragma unroll
-            for (int k4 = 0; k4 < 8; ++k4) {
-                f32x4 hh = hv[k4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    ar = fmaf(wr[k4 * 4 + e], hh[e], ar);
-                    az = fmaf(wz[k4 * 4 + e], hh[e], az);
-                    an = fmaf(wn[k4 * 4 + e], hh[e], an);
-                }
-            }
-            const float r = sigmoid_fast(gr + ar), z = sigmoid_fast(gz + az), n = tanh_fast(gn + r * an);
-            const float dn = dh * (1.f - z);
-            const float dz = dh * (hp - n);
-            const float dnp = dn * (1.f - n * n);
-            const float drp = dnp * an * r * (1.f - r);
-            const float dzp = dz * z * (1.f - z);
-            const float dghn = dnp * r;
-            if (valid) {
-                dgi[tok * 192 + dir * 96 + j] = drp; dgi[tok * 192 + dir * 96 + 32 + j] = dzp; dgi[tok * 192 + dir * 96 + 64 + j] = dnp;
-                dgh[tok * 192 + dir * 96 + j] = drp; dgh[tok * 192 + dir * 96 + 32 + j] = dzp; dgh[tok * 192 + dir * 96 + 64 + j] = dghn;
-                hprev[tok * 64 + dir * 32 + j] = hp;
-            }
-            ds[grp][j] = drp; ds[grp][32 + j] = dzp; ds[grp][64 + j] = dghn;
-            wave_lds_sync();
-            // 96-term dot product split over 4 accumulators (a single dependent FMA chain would cost ~96 x 8 cycles per step)
-            float c0 = dh * z, c1 = 0.f, c2 = 0.f, c3 = 0.f;
-            const f32x4* dv = reinterpret_cast<const f32x4*>(ds[grp]);
-#pragma unroll
-            for (int k4 = 0; k4 < 24; ++k4) {
-                f32x4 dd = dv[k4];
-                c0 = fmaf(wt[k4 * 4 + 0], dd[0], c0); c1 = fmaf(wt[k4 * 4 + 1], dd[1], c1);
-                c2 = fmaf(wt[k4 * 4 + 2], dd[2], c2); c3 = fmaf(wt[k4 * 4 + 3], dd[3], c3);
-            }
-            dhc = (c0 + c1) + (c2 + c3);
-            wave_lds_sync();
+            fetch(T - 1 - u, a, b, c, d, e, f);
+            pf[u * 6 + 0][t] = a; pf[u * 6 + 1][t] = b; pf[u * 6 + 2][t] = c; pf[u * 6 + 3][t] = d; pf[u * 6 + 4][t] = e;
+            pf[u * 6 + 5][t] = f;
         }
     }
+    int s0 = T - 1;
+    for (; s0 >= GRU_PF - 1; s0 -= GRU_PF) {
+        float nx[GRU_PF][6];
+#pragma unroll
+        for (int u = 0; u < GRU_PF; ++u) fetch(s0 - GRU_PF - u, nx[u][0], nx[u][1], nx[u][2], nx[u][3], nx[u][4], nx[u][5]);
+#pragma unroll
+        for (int u = 0; u < GRU_PF; ++u)
+            one_step(s0 - u, pf[u * 6 + 0][t], pf[u * 6 + 1][t], pf[u * 6 + 2][t], pf[u * 6 + 3][t], pf[u * 6 + 4][t],
+                     pf[u * 6 + 5][t]);
+#pragma unroll
+        for (int u = 0; u < GRU_PF; ++u)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) pf[u * 6 + k][t] = nx[u][k];
+    }
+    for (; s0 >= 0; --s0) {                                  // T % GRU_PF leftover steps: plain loads
+        float a, b, c, d, e, f;
+        fetch(s0, a, b, c, d, e, f);
+        one_step(s0, a, b, c, d, e, f);
+    }
 }
-TATT_API int tatt_gru32_bwd(const float* gi, const float* out, const float* dout, const float* whh_f,
-                            const float* bhh_f, const float* whh_r, const float* bhh_r, float* dgi, float* dgh,
-                            float* hprev, int nseq, int T, int s_in, long stride_hi, long stride_lo, long stride_t,
-                            hipStream_t st) {
+TATT_API int tatt_gru32_bwd(const float* gates, const float* out, const float* dout, const float* whh_f,
+                            const float* whh_r, float* dgi, float* dgh, float* hprev, int nseq, int T, int s_in,
+                            long stride_hi, long stride_lo, long stride_t, hipStream_t st) {
+    if (nseq <= 0 || T <= 0) return 0;
     SeqGeom g = {nseq, T, s_in, stride_hi, stride_lo, stride_t};
-    hipLaunchKernelGGL(gru32_bwd_kernel, dim3(cdiv(nseq, 4)), dim3(256), 0, st, gi, out, dout, whh_f, bhh_f, whh_r, bhh_r,
-                       dgi, dgh, hprev, g);
+    hipLaunchKernelGGL(gru32_bwd_kernel, dim3(cdiv(nseq, 4)), dim3(256), 0, st, gates, out, dout, whh_f, whh_r, dgi, dgh, hprev,
+                       g);
     return LAUNCH_CHECK();
 }
 

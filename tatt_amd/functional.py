@@ -71,8 +71,7 @@ class _DeferredParamGrads:
 
     def __init__(self):
         self.enabled = False
-        self.fork_stream = None          # set (by the Trainer, for the LAST backward stage): issue at once on this stream instead
-        self.long_stream = None          # set (by the Trainer): closures marked `long` go out at once on this third stream
+        self.stage = 0                   # index of the backward stage whose main lane is running (set by the Trainer)
         self._pending = []
         self._keep = []
 
@@ -93,46 +92,30 @@ class _DeferredParamGrads:
             if p is not None and g is not None:
                 p.grad = g if p.grad is None else p.grad + g
 
-    def submit(self, params, fn, *keep, long=False):
+    def submit(self, params, fn, *keep, lag=0):
         """params: tuple of leaf tensors (or None); fn() -> tuple of their gradients (or None), same order (or a generator that
-        yields once between its split-K GEMMs and their consumer and returns the tuple).  long: a chain of many dependent launches
-        (the query GRU's backward: 47 of them) -- it gets a stream of its own and runs from now until the end of the backward pass
-        instead of holding up the join of one stage's side lane."""
+        yields once between its split-K GEMMs and their consumer and returns the tuple).  lag: run with the side lane `lag` stages
+        after the current one (the query GRU's backward, 47 dependent launches, is given to the NEXT stage's side lane: side
+        lanes overlap the main lane beside them only while they stay short, see tools/graph_sched_probe.py)."""
         if not self.enabled or any(p is not None and not p.is_leaf for p in params):
             return self._run(fn)
-        ref = next((p for p in params if p is not None), None)
-        if long and self.long_stream is not None and ref is not None and ref.is_cuda:
-            main = torch.cuda.current_stream(ref.device)
-            self.long_stream.wait_stream(main)
-            with torch.cuda.stream(self.long_stream):
-                self._assign(params, self._run(fn))
-            self._keep.append(keep)
-            return (None,) * len(params)
-        if self.fork_stream is not None and ref is not None and ref.is_cuda:
-            # last stage of the backward: there is no later main lane to hide behind, so the kernels go out now, on the side
-            # stream, behind an event -- a short branch per operator, joined by the Trainer at the end of the pass
-            main = torch.cuda.current_stream(ref.device)
-            self.fork_stream.wait_stream(main)
-            with torch.cuda.stream(self.fork_stream):
-                self._assign(params, self._run(fn))
-            self._keep.append(keep)
-            return (None,) * len(params)
-        self._pending.append((params, fn))
+        self._pending.append((self.stage + lag, params, fn))
         self._keep.append(keep)
         return (None,) * len(params)
 
-    def flush(self):
-        """Run the pending closures in submission order on the CURRENT stream; results become / are added to `.grad`.
-        While they run, the split-K reductions behind their weight-gradient GEMMs are only registered and then summed by one
-        launch per 36 (ops.reduce_defer); a closure that consumes such a result itself is a GENERATOR: it yields once after
-        issuing its GEMMs and is resumed after the batched reduction."""
-        pending, self._pending = self._pending, []
+    def flush(self, upto=None):
+        """Run the pending closures due at stage <= `upto` (all of them if None) in submission order on the CURRENT stream;
+        results become / are added to `.grad`.  While they run, the split-K reductions behind their weight-gradient GEMMs are only
+        registered and then summed by one launch per 36 (ops.reduce_defer); a closure that consumes such a result itself is a
+        GENERATOR: it yields once after issuing its GEMMs and is resumed after the batched reduction."""
+        pending = [e for e in self._pending if upto is None or e[0] <= upto]
         if not pending:
             return
+        self._pending = [e for e in self._pending if not (upto is None or e[0] <= upto)]
         results = []
         ops.reduce_defer(True)
         try:
-            for params, fn in pending:
+            for _, params, fn in pending:
                 r = fn()
                 if hasattr(r, "send"):                # generator: run up to its yield
                     next(r)
@@ -333,17 +316,17 @@ class BiGRU32Fn(Function):
         ops.linear_fwd(x2, wih_f, bih_f, out=gi[:, :96])
         ops.linear_fwd(x2, wih_r, bih_r, out=gi[:, 96:])
         geom = ops.seq_geom(B, H, W, vertical)
-        out = ops.gru32_fwd(gi, whh_f, bhh_f, whh_r, bhh_r, geom)
-        ctx.save_for_backward(x, gi, out, wih_f, whh_f, bhh_f, wih_r, whh_r, bhh_r)
+        out, gates = ops.gru32_fwd(gi, whh_f, bhh_f, whh_r, bhh_r, geom, save=any(ctx.needs_input_grad))
+        ctx.save_for_backward(x, gates, out, wih_f, whh_f, wih_r, whh_r)
         ctx.geom = geom
         return out.reshape(B, H, W, 64)
 
     @staticmethod
     def backward(ctx, dout):
-        x, gi, out, wih_f, whh_f, bhh_f, wih_r, whh_r, bhh_r = ctx.saved_tensors
+        x, gates, out, wih_f, whh_f, wih_r, whh_r = ctx.saved_tensors
         C = x.shape[-1]
         x2 = x.reshape(-1, C)
-        dgi, dgh, hprev = ops.gru32_bwd(gi, out, _c(dout).reshape(-1, 64), whh_f, bhh_f, whh_r, bhh_r, ctx.geom)
+        dgi, dgh, hprev = ops.gru32_bwd(gates, out, _c(dout).reshape(-1, 64), whh_f, whh_r, ctx.geom)
         dx = ops.linear_bwd_input(dgi[:, :96], wih_f)
         ops.linear_bwd_input(dgi[:, 96:], wih_r, out=dx, beta=1.0)
         g = []
@@ -386,8 +369,8 @@ class GruBlockFn(Function):
                  ops.P(Wp), ops.P(bp), K, ops.stream())
         gi = ops.linear_fwd(x2, Wp, bp, x2b=xb2)
         geom = ops.seq_geom(B, H, W, vertical)
-        out = ops.gru32_fwd(gi, whh_f, bhh_f, whh_r, bhh_r, geom)
-        ctx.save_for_backward(x, xb, Wc, Wp, gi, out, wih_f, whh_f, bhh_f, wih_r, whh_r, bhh_r, conv_b)
+        out, gates = ops.gru32_fwd(gi, whh_f, bhh_f, whh_r, bhh_r, geom, save=any(ctx.needs_input_grad))
+        ctx.save_for_backward(x, xb, Wc, Wp, gates, out, wih_f, whh_f, wih_r, whh_r, conv_b)
         ctx.geom = geom
         ctx.wshape = conv_w.shape
         ctx.leaves = (conv_w, conv_b, wih_f, whh_f, bih_f, bhh_f, wih_r, whh_r, bih_r, bhh_r)
@@ -395,11 +378,11 @@ class GruBlockFn(Function):
 
     @staticmethod
     def backward(ctx, dout):
-        x, xb, Wc, Wp, gi, out, wih_f, whh_f, bhh_f, wih_r, whh_r, bhh_r, conv_b = ctx.saved_tensors
+        x, xb, Wc, Wp, gates, out, wih_f, whh_f, wih_r, whh_r, conv_b = ctx.saved_tensors
         K1 = x.shape[-1]
         K = Wc.shape[1]
         x2 = x.reshape(-1, K1)
-        dgi, dgh, hprev = ops.gru32_bwd(gi, out, _c(dout).reshape(-1, 64), whh_f, bhh_f, whh_r, bhh_r, ctx.geom)
+        dgi, dgh, hprev = ops.gru32_bwd(gates, out, _c(dout).reshape(-1, 64), whh_f, whh_r, ctx.geom)
         dx = ops.linear_bwd_input(dgi, Wp, col0=0, ncols=K1).reshape(x.shape) if ctx.needs_input_grad[0] else None
         dxb = None
         if xb is not None and ctx.needs_input_grad[1]:
@@ -720,7 +703,7 @@ class QueryGruFn(Function):
         # every output of this backward is a parameter gradient (the embedding depends on parameters only): all of it is deferrable
         dq = _c(dq)
         saved = ctx.saved_tensors
-        return tuple(SIDE.submit(ctx.leaves, lambda: QueryGruFn._backward(ctx, saved, dq), dq, saved, long=True)) + (None, None, None)
+        return tuple(SIDE.submit(ctx.leaves, lambda: QueryGruFn._backward(ctx, saved, dq), dq, saved, lag=1)) + (None, None, None)
 
     @staticmethod
     def _backward(ctx, saved, dq):

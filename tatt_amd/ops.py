@@ -484,16 +484,17 @@ def seq_geom(B, H, W, vertical):
     return B * H, W, 1, W, 0, 1
 
 
-def gru32_fwd(gi, whh_f, bhh_f, whh_r, bhh_r, geom):
+def gru32_fwd(gi, whh_f, bhh_f, whh_r, bhh_r, geom, save=False):
+    """-> (out [tok][64], gates [tok][256] or None).  save: keep r, z, n and W_hn h + b_hn of every step for gru32_bwd."""
     out = new(gi, gi.shape[0], 64)
-    call("tatt_gru32_fwd", P(gi), P(whh_f), P(bhh_f), P(whh_r), P(bhh_r), P(out), *geom, stream())
-    return out
+    gates = new(gi, gi.shape[0], 256) if save else None
+    call("tatt_gru32_fwd", P(gi), P(whh_f), P(bhh_f), P(whh_r), P(bhh_r), P(out), P(gates), *geom, stream())
+    return out, gates
 
 
-def gru32_bwd(gi, out, dout, whh_f, bhh_f, whh_r, bhh_r, geom):
-    dgi, dgh, hprev = torch.empty_like(gi), torch.empty_like(gi), torch.empty_like(out)
-    call("tatt_gru32_bwd", P(gi), P(out), P(dout), P(whh_f), P(bhh_f), P(whh_r), P(bhh_r), P(dgi), P(dgh), P(hprev),
-         *geom, stream())
+def gru32_bwd(gates, out, dout, whh_f, whh_r, geom):
+    dgi, dgh, hprev = new(out, out.shape[0], 192), new(out, out.shape[0], 192), torch.empty_like(out)
+    call("tatt_gru32_bwd", P(gates), P(out), P(dout), P(whh_f), P(whh_r), P(dgi), P(dgh), P(hprev), *geom, stream())
     return dgi, dgh, hprev
 
 

@@ -172,6 +172,8 @@ class TBSRN(_TrainPathMixin, nn.Module):
             Fh.begin_training_forward(x.device)                  # fresh dropout masks for this call (and its backward)
         if self.stn and training:
             ctrl = _stn_forward(x, self.stn_head)
+            if cuts:
+                ctrl = cuts.cut("stn", ctrl)
             xin, _ = _tps_forward(x, ctrl, self.tps)
         else:
             xin = x.permute(0, 2, 3, 1)

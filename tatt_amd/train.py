@@ -82,11 +82,11 @@ class TextPriorSR(torch.nn.Module):
         self.sr.block = v
 
     # -- Trainer protocol: the SR generator's stages, then one more for the recogniser --------------------------------------
-    def grad_buckets(self, long_lane=False):
+    def grad_buckets(self):
         """The student receives gradient from two places -- the distillation loss (first backward stage) and the SR generator's
         text encoder (stage "tp") -- so its own backward is a last stage, "tpg", fed by the sum of both (forward() cuts there)."""
-        b = [(n, list(ps)) for n, ps in self.sr.grad_buckets(False)]     # (no separate lane for the query GRU here: the SR model's
-        b.append(("tpg", list(self.tpg.parameters())))                  #  parameters must stay one contiguous clip group)
+        b = [(n, list(ps)) for n, ps in self.sr.grad_buckets()]
+        b.append(("tpg", list(self.tpg.parameters())))
         return b
 
     def set_grad_cuts(self, cuts):
@@ -244,15 +244,7 @@ class Trainer:
         self.defer = bool(defer_param_grads)
         self.two_lanes = self.defer and bool(side_stream) and self.cuda
         staged = (self.dp or self.defer) and hasattr(model, "grad_buckets") and hasattr(model, "set_grad_cuts")
-        # A third stream for the query GRU's backward (47 dependent launches): single GPU only -- under data parallelism its
-        # 19 MB of gradients belong in the "tp" bucket, whose all-reduce hides behind the last stage (A/B: TATT_LONG_LANE=0).
-        use_long = self.two_lanes and staged and not self.dp and os.environ.get("TATT_LONG_LANE", "1") != "0"
-        buckets = None
-        if hasattr(model, "grad_buckets"):
-            try:
-                buckets = model.grad_buckets(long_lane=use_long)
-            except TypeError:                            # a model that does not know the long lane
-                buckets, use_long = model.grad_buckets(), False
+        buckets = model.grad_buckets() if hasattr(model, "grad_buckets") else None
         if buckets is not None and not staged:           # one stage: one bucket, same parameter ORDER as the staged layout
             buckets = [("all", [p for _, ps in buckets for p in ps])]
         self.flat = FlatParams(model, buckets)
@@ -276,12 +268,6 @@ class Trainer:
             if self.dp or dropout_seed is not None:
                 Fh.set_seed(dev, rank_dropout_seed(base, self.rank) if self.dp else base)
         self.side = torch.cuda.Stream(device=dev) if self.two_lanes else None
-        use_long = use_long and "long" in self.stages
-        self.long = torch.cuda.Stream(device=dev) if use_long else None
-        # the last stage that computes anything ("long" has no main lane): its parameter-gradient kernels fork off at once
-        self._last_compute = max(i for i, n in enumerate(self.stages) if n != "long")
-        self._fork_last = os.environ.get("TATT_FORK_LAST", "0") == "1"
-        self._long_active = False
         self.gnorms = [torch.zeros(1, device=dev) for _ in self.groups]
         self.gnorm = self.gnorms[0]
         self.step_count = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -299,15 +285,7 @@ class Trainer:
         """Stage 0: forward + loss + backward from the loss; stage k > 0: the part of the backward `stages[k]` names."""
         Fh.SIDE.enabled = self.defer
         Fh.FWD_FORK.enabled = self.two_lanes
-        # (forking the LAST stage's parameter-gradient kernels operator by operator -- it has no later main lane to hide behind --
-        #  was measured: 9.03 vs 8.59 ms per step; many tiny branches cost more than the 0.26 ms tail they hide.  TATT_FORK_LAST=1)
-        Fh.SIDE.fork_stream = self.side if (self._fork_last and self.two_lanes and k == self._last_compute and k > 0) else None
-        if k == 0 and x is not None:
-            # The query GRU's backward is B - 1 dependent launches.  On its own stream it overlaps well when the chain is short and
-            # its kernels heavy (large tile, B = 16: 10.66 -> 10.35 ms per step); as 47 small launches (B = 48) the graph executor
-            # handles the long thin branch badly (8.49 -> 8.73 ms), so there it stays in its stage's side lane.
-            self._long_active = self.long is not None and x.shape[0] <= 24
-        Fh.SIDE.long_stream = self.long if self._long_active else None
+        Fh.SIDE.stage = k
         try:
             if k == 0:
                 for p in self.params:
@@ -329,15 +307,14 @@ class Trainer:
                 self.cuts.run(self.stages[k])
         finally:
             Fh.SIDE.enabled = False
-            Fh.SIDE.fork_stream = None
-            Fh.SIDE.long_stream = None
             Fh.FWD_FORK.enabled = False
         if k == len(self.stages) - 1 and hasattr(self.model, "block"):
             self.model.block = None                  # do not keep the autograd graph of this step alive
 
     def _side_lane(self, k):
-        """The deferred parameter-gradient kernels of stage k, then bucket k of the flat gradient buffer."""
-        Fh.SIDE.flush()
+        """The deferred parameter-gradient kernels due by stage k (everything left at the last stage), then bucket k of the flat
+        gradient buffer."""
+        Fh.SIDE.flush(None if k == len(self.stages) - 1 else k)
         self.flat.gather_grads(k)
 
     def _pass(self, k, x=None, tp=None, hr=None):
@@ -346,8 +323,6 @@ class Trainer:
         parallel branch, which the hipGraph executor does overlap (tools/graph_sched_probe.py); otherwise it simply runs first."""
         nst = len(self.stages)
         main = torch.cuda.current_stream(self.dev) if self.cuda else None
-        if k == nst and self.long is not None:
-            main.wait_stream(self.long)              # the query GRU's backward has had the rest of the backward pass; its bucket is next
         if k >= 1:
             if self.two_lanes:
                 self.side.wait_stream(main)

@@ -362,26 +362,29 @@ class _TrainPathMixin:
     def set_grad_cuts(self, cuts):
         object.__setattr__(self, "_grad_cuts", cuts)
 
-    def grad_buckets(self, long_lane=False):
-        """[(stage name, [parameters])] in backward-completion order; stage names match the `cuts.cut(name, ...)` calls of the
-        forward: "trunk" (block7 + up-sampler: what the loss back-propagates into directly), "srb4" ... "srb0" (the residual
-        blocks, last to first), "tp" (TP interpreter), "first" (block1 + STN head).  long_lane: the query GRU's parameters
-        (their gradient chain runs on a stream of its own until the end of the backward pass) form a last bucket "long"."""
+    def grad_buckets(self):
+        """[(stage name, [parameters])] in the order the parameters' gradients are complete; stage names match the
+        `cuts.cut(name, ...)` calls of the forward: "trunk" (block7 + up-sampler: what the loss back-propagates into directly),
+        "srb4" ... "srb0" (the residual blocks, last to first), "tp" (TP interpreter), "first" (block1 + TPS sampler; also the
+        query GRU's parameters -- their gradient chain runs in this stage's side lane, one stage after it is registered),
+        "stn" (STN head)."""
         k = self.srb_nums
-        groups = {"trunk": [], "tp": [], "first": [], "long": []}
+        groups = {"trunk": [], "tp": [], "first": [], "stn": []}
         groups.update({"srb%d" % i: [] for i in range(k)})
         for name, p in self.named_parameters():
             top = name.split(".", 1)[0]
             if top == "infoGen":
                 is_q = name.startswith("infoGen.transformer.gru_encoding.") or name.startswith("infoGen.init_factor.")
-                groups["long" if (long_lane and is_q) else "tp"].append(p)
+                groups["first" if is_q else "tp"].append(p)
             elif top.startswith("block") and 2 <= int(top[5:]) <= k + 1:
                 groups["srb%d" % (int(top[5:]) - 2)].append(p)
             elif top.startswith("block") and int(top[5:]) > k + 1:
                 groups["trunk"].append(p)
-            else:                                  # block1, stn_head, (TBSRN's unused conv / bn)
+            elif top == "stn_head":
+                groups["stn"].append(p)
+            else:                                  # block1, (TBSRN's unused conv / bn)
                 groups["first"].append(p)
-        order = ["trunk"] + ["srb%d" % i for i in range(k - 1, -1, -1)] + ["tp", "first", "long"]
+        order = ["trunk"] + ["srb%d" % i for i in range(k - 1, -1, -1)] + ["tp", "first", "stn"]
         return [(n, groups[n]) for n in order if groups[n]]
 
     def _bn_on_path(self):
@@ -460,6 +463,8 @@ class _GeneratorBase(_TrainPathMixin, nn.Module):
             qpos = _query_pos(self.infoGen, x.shape[0], x.shape[2], x.shape[3])
         if self.stn and training:
             ctrl = _stn_forward(x, self.stn_head, False)
+            if cuts:
+                ctrl = cuts.cut("stn", ctrl)                     # the STN head's backward is a stage of its own
             xin, _ = _tps_forward(x, ctrl, self.tps)             # NHWC
         else:
             xin = x.permute(0, 2, 3, 1)                          # NHWC-indexed view, read through strides

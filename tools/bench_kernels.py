@@ -132,9 +132,9 @@ whh, bhh = R(96, 32) * 0.2, R(96) * 0.1
 for vert in (True, False):
     geom = ops.seq_geom(B, 16, 64, vert)
     nm = "v" if vert else "h"
-    timeit("gru32_fwd_" + nm, lambda: ops.gru32_fwd(gi, whh, bhh, whh, bhh, geom), 0, M * 256 * 4)
-    out = ops.gru32_fwd(gi, whh, bhh, whh, bhh, geom)
-    timeit("gru32_bwd_" + nm, lambda: ops.gru32_bwd(gi, out, t64, whh, bhh, whh, bhh, geom), 0, M * (192 * 3 + 64 * 3) * 4)
+    timeit("gru32_fwd_" + nm, lambda: ops.gru32_fwd(gi, whh, bhh, whh, bhh, geom, save=True), 0, M * (192 + 64 + 256) * 4)
+    out, gates = ops.gru32_fwd(gi, whh, bhh, whh, bhh, geom, save=True)
+    timeit("gru32_bwd_" + nm, lambda: ops.gru32_bwd(gates, out, t64, whh, whh, geom), 0, M * (256 + 64 * 2 + 192 * 2 + 64) * 4)
 
 # ---- attention core ----
 seed = torch.zeros(1, dtype=torch.int64, device=dev)
