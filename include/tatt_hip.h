@@ -65,9 +65,10 @@ int tatt_repack_conv_weight(const float* w_oihw, float* out, int Cout, int Cin, 
 int tatt_repack_conv_weight_batch(const float* const* ws, float* const* outs, const int* dims, int n, hipStream_t st);
 
 /* C = sum over S partial (M x N) slabs (+ beta*C); remap_cin > 0: row i = tap*remap_cin + ci, col j = co is scattered to
- * the OIHW filter layout dW[co][ci][tap] */
+ * the OIHW filter layout dW[co][ci][tap].  vec (may be NULL): additionally vec[i] = sum over S partial vectors of vec_len
+ * floats stored behind the S slabs (the bias-gradient partials of tatt_conv3_c64_wgrad_partial) */
 int tatt_splitk_reduce(const float* partial, float* C, int M, int N, int S, int remap_cin, int remap_taps,
-                       float beta, hipStream_t st);
+                       float beta, float* vec, int vec_len, hipStream_t st);
 /* on != 0: split-K reductions issued from now on (tatt_gemm / tatt_conv2d_wgrad with splitk > 1, tatt_splitk_reduce) are only
  * REGISTERED -- their partial slabs must stay allocated -- and are summed by one launch per 36 entries at tatt_reduce_flush or
  * tatt_reduce_defer(0): the 70 small reduction launches behind the weight-gradient GEMMs of a training step become 6.  Results
@@ -90,10 +91,11 @@ int tatt_conv3_c64_fwd_ws(const float* x, const float* wl, const float* bias, fl
  * whole 9 x 64 contraction (v_mfma_f32_16x16x4_f32), no partial sums to exchange; wl = tatt_repack_conv_weight mode 6 / mode 7 */
 int tatt_conv3_c64_fwd_ws16(const float* x, const float* wl, const float* bias, float* y, int B, int H, int W,
                             int Cout, int act, float beta, hipStream_t st);
-/* weight-gradient partials part[G][9*Cin][Cout] (G persistent work-groups, G <= B*H*W/64); finish with
- * tatt_splitk_reduce(part, dw_oihw, 9*Cin, Cout, G, Cin, 9, beta) */
-int tatt_conv3_c64_wgrad_partial(const float* x, const float* dy, float* part, int B, int H, int W, int Cin,
-                                 int Cout, int G, hipStream_t st);
+/* weight-gradient partials part[G][9*Cin][Cout] (G persistent work-groups, G <= B*H*W/64) and, if pdb != NULL, bias-gradient
+ * partials pdb[G][Cout] (the column sums of dy the kernel streams anyway; nn.Conv2d's bias gradient); finish with
+ * tatt_splitk_reduce(part, dw_oihw, 9*Cin, Cout, G, Cin, 9, beta, db, Cout) where pdb = part + G*9*Cin*Cout */
+int tatt_conv3_c64_wgrad_partial(const float* x, const float* dy, float* part, float* pdb, int B, int H, int W,
+                                 int Cin, int Cout, int G, hipStream_t st);
 
 /* 9x9 convolution 64 -> 4 channels (fp32 vector ALU; filter through the scalar cache): the final reconstruction conv
  * (model/tsrn.py:623) and, with the mode-1 packed filter, the data gradient of block1 (model/tsrn.py:597).

@@ -512,16 +512,19 @@ TATT_API int tatt_conv3_c64_fwd_ws16(const float* x, const float* wl, const floa
 struct Conv3WP {
     const float* x; const float* dy; float* part;
     int B, H, W, Cin, Cout, nseg;
+    float* pdb;      // per-work-group partial bias gradient [gridDim.x][Cout] (column sums of dy), or null
 };
 #define WG_HALO (3 * C3_HW * 64)                     // floats: x halo [3][66][64 ci]
 #define WG_BUF (WG_HALO + 64 * 64)                   // + dy tile [64 px][64 co]
 #define C3_WG_LDS (2 * WG_BUF * 4)                   // 133.9 KB
 #define WG_F4 (WG_BUF / 4)                           // float4 per buffer: 3168 + 1024 = 4192
 
+// dbacc: running sum of the B operands (dy values) this lane feeds to the MFMAs -- over a launch that is the column sum of dy
+// for output channel (lane & 31) of the wave's half over the pixels of parity lane >> 5: the bias gradient, at one add per k-step.
 template <int T0, int NT>
 __device__ __forceinline__ void wgrad_segment(f32x16 (&acc)[5], const float* __restrict__ acol, const float* __restrict__ bcol,
                                               const Conv3WP& p, bool has_next, int nn, int nh, int nw0, int ci0, int co0,
-                                              float* __restrict__ nbuf, int t) {
+                                              float* __restrict__ nbuf, int t, float& dbacc) {
     // float4 #idx of the next segment's buffer: [0, 3168) halo (c4 = idx & 15, pixel = idx >> 4), then the dy tile
     auto fetch = [&](int idx) -> f32x4 {
         f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -556,6 +559,7 @@ __device__ __forceinline__ void wgrad_segment(f32x16 (&acc)[5], const float* __r
 #pragma unroll
         for (int tp = 0; tp < NT; ++tp)
             acc[tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[cur][tp], wb[cur], acc[tp], 0, 0, 0);
+        if (T0 == 0) dbacc += wb[cur];
         __builtin_amdgcn_sched_barrier(0);
         if (has_next && k % 6 == 4 && k / 6 < 9) {
             const int idx = t + 512 * (k / 6);
@@ -581,6 +585,7 @@ __global__ __launch_bounds__(512, 1) void conv3_c64_wgrad_kernel(Conv3WP p) {
         const int seg = s % segs; s /= segs;
         h = s % p.H; n = s / p.H; w0 = seg * C3_PX;
     };
+    float dbacc = 0.f;
     int s = blockIdx.x;
     if (s < p.nseg) {
         int n, h, w0;
@@ -623,13 +628,17 @@ __global__ __launch_bounds__(512, 1) void conv3_c64_wgrad_kernel(Conv3WP p) {
             const int kq = lane >> 5;
             const float* acol = cur + kq * 64 + qi * 32 + (lane & 31);
             const float* bcol = cur + WG_HALO + kq * 64 + qo * 32 + (lane & 31);
-            if (tg == 0) wgrad_segment<0, 5>(acc, acol, bcol, p, has_next, nn, nh, nw0, ci0, co0, nxt, t);
-            else wgrad_segment<5, 4>(acc, acol, bcol, p, has_next, nn, nh, nw0, ci0, co0, nxt, t);
+            if (tg == 0) wgrad_segment<0, 5>(acc, acol, bcol, p, has_next, nn, nh, nw0, ci0, co0, nxt, t, dbacc);
+            else wgrad_segment<5, 4>(acc, acol, bcol, p, has_next, nn, nh, nw0, ci0, co0, nxt, t, dbacc);
             __syncthreads();                               // next buffer published; everyone is done with the current one
             if (!has_next) break;
             s = sn;
             buf ^= 1;
         }
+    }
+    if (p.pdb && cib == 0 && tg == 0 && qi == 0) {           // bias gradient partial of this work-group: both pixel parities
+        const float v = dbacc + __shfl_xor(dbacc, 32, 64);
+        if (lane < 32) p.pdb[(long)blockIdx.x * p.Cout + co0 + qo * 32 + lane] = v;
     }
     // ---- partial[blockIdx.x][(tap*Cin + ci)][Cout]: each 32 ci x 32 co accumulator is transposed through a per-wave LDS tile
     // (the segment buffers are free now) and leaves as 4 sixteen-byte stores per lane ----
@@ -654,11 +663,11 @@ __global__ __launch_bounds__(512, 1) void conv3_c64_wgrad_kernel(Conv3WP p) {
     }
 }
 // partials: part[G][9*Cin][Cout] with G work-groups along x (<= 256 / blocks); reduce with the split-K reducer
-TATT_API int tatt_conv3_c64_wgrad_partial(const float* x, const float* dy, float* part, int B, int H, int W, int Cin,
-                                          int Cout, int G, hipStream_t st) {
+TATT_API int tatt_conv3_c64_wgrad_partial(const float* x, const float* dy, float* part, float* pdb, int B, int H, int W,
+                                          int Cin, int Cout, int G, hipStream_t st) {
     if (Cin % 64 || Cout % 64 || W % C3_PX) return 1;
     const int nseg = B * H * (W / C3_PX);
-    Conv3WP p = {x, dy, part, B, H, W, Cin, Cout, nseg};
+    Conv3WP p = {x, dy, part, B, H, W, Cin, Cout, nseg, pdb};
     static std::once_flag attr_once;                 // C++11 call_once: safe if several host threads launch
     std::call_once(attr_once, [&] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -628,6 +628,7 @@ struct ReduceArgs {
     int M, N, S, Z;
     float alpha, beta;
     int act, remap_cin, remap_taps, block0;
+    int RM;     // length of the row-sum vector (0: M)
 };
 __device__ __forceinline__ void splitk_reduce_body(const ReduceArgs& a, long block) {
     __shared__ float sh[4][64];
@@ -641,11 +642,12 @@ __device__ __forceinline__ void splitk_reduce_body(const ReduceArgs& a, long blo
     if (a.rowsum && idx >= total64) {
         // trailing blocks: row sums of A, partial slabs [S][M] stored behind the S (M x N) slabs  (Z == 1)
         const long i2 = idx - total64;
+        const int rm = a.RM > 0 ? a.RM : M;
         float r = 0.f;
-        if (i2 < M) for (int k = ty; k < S; k += 4) r += partial[(long)S * M * N + (long)k * M + i2];
+        if (i2 < rm) for (int k = ty; k < S; k += 4) r += partial[(long)S * M * N + (long)k * rm + i2];
         sh[ty][tx] = r;
         __syncthreads();
-        if (ty == 0 && i2 < M) a.rowsum[i2] = a.alpha * ((sh[0][tx] + sh[1][tx]) + (sh[2][tx] + sh[3][tx]));
+        if (ty == 0 && i2 < rm) a.rowsum[i2] = a.alpha * ((sh[0][tx] + sh[1][tx]) + (sh[2][tx] + sh[3][tx]));
         return;
     }
     const bool ok = idx < total;
@@ -700,7 +702,7 @@ static ReduceArgs g_reduce_pending[REDUCE_MAX];
 static int g_reduce_n = 0;
 static long reduce_blocks(const ReduceArgs& a) {
     long total = (long)a.Z * a.M * a.N;
-    if (a.rowsum) total = (long)cdiv(total, 64) * 64 + a.M;       // extra thread range (64-aligned start) for the row sums of A
+    if (a.rowsum) total = (long)cdiv(total, 64) * 64 + (a.RM > 0 ? a.RM : a.M);   // extra thread range (64-aligned start) for the row sums
     return cdiv(total, 64);
 }
 static int reduce_flush(hipStream_t st) {
@@ -762,7 +764,7 @@ static int launch_gemm(const GemmP& p, int Z, bool ak, bool bk, hipStream_t st) 
 
 static int finish_splitk(const GemmP& p, int Z, int remap_cin, int remap_taps, hipStream_t st) {
     ReduceArgs a = {p.partial, p.C, p.bias, p.rowsum, p.scm, p.scn, p.bsC, p.bsBias, p.M, p.N, p.splitk, Z, p.alpha, p.beta,
-                    p.act, remap_cin, remap_taps, 0};
+                    p.act, remap_cin, remap_taps, 0, 0};
     return reduce_submit(a, st);
 }
 
@@ -984,7 +986,8 @@ TATT_API int tatt_repack_conv_weight_batch(const float* const* ws, float* const*
 // i = tap*remap_cin + ci, column j = co to the OIHW filter layout dW[co][ci][tap] (used by the specialised conv
 // weight-gradient kernels of conv3.hip).
 TATT_API int tatt_splitk_reduce(const float* partial, float* C, int M, int N, int S, int remap_cin, int remap_taps,
-                                float beta, hipStream_t st) {
-    ReduceArgs a = {partial, C, nullptr, nullptr, (long)N, 1L, 0L, 0L, M, N, S, 1, 1.f, beta, (int)ACT_NONE, remap_cin, remap_taps, 0};
+                                float beta, float* vec, int vec_len, hipStream_t st) {
+    ReduceArgs a = {partial, C, nullptr, vec, (long)N, 1L, 0L, 0L, M, N, S, 1, 1.f, beta, (int)ACT_NONE, remap_cin, remap_taps, 0,
+                    vec ? vec_len : 0};
     return reduce_submit(a, st);
 }

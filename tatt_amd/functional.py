@@ -206,6 +206,8 @@ class Conv2dFn(Function):
         want_dw, want_db = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
 
         def param_grads():
+            if want_dw and want_db:
+                return ops.conv_wgrad(x, dy, Cout, KH, KW, want_db=True)
             dw = ops.conv_wgrad(x, dy, Cout, KH, KW) if want_dw else None
             db = ops.colsum(dy.reshape(-1, Cout)) if want_db else None
             return dw, db

@@ -298,7 +298,9 @@ def conv2d_dgrad(dy_bhwc, weight_oihw):
     return conv_fwd(dy_bhwc, repack_weight(weight_oihw, 1), None, Cin, KH, KW)
 
 
-def conv_wgrad(x_bhwc, dy_bhwc, Cout, KH, KW):
+def conv_wgrad(x_bhwc, dy_bhwc, Cout, KH, KW, want_db=False):
+    """-> dw (OIHW), or (dw, db) with want_db: the bias gradient (column sums of dy) comes out of the 3x3 64-channel kernel for
+    free (it streams dy anyway); the other paths add a column-sum pass."""
     B, H, W, Cin = x_bhwc.shape
     sn, sh, sw, sc = x_bhwc.stride()
     dw = new(x_bhwc, Cout, Cin, KH, KW)
@@ -306,10 +308,21 @@ def conv_wgrad(x_bhwc, dy_bhwc, Cout, KH, KW):
     if contig and KH == 3 and KW == 3 and Cin % 64 == 0 and Cout % 64 == 0 and W % 64 == 0:
         nseg = B * H * (W // 64)
         G = min(nseg, max(1, 256 // ((Cin // 64) * (Cout // 64))))
-        part = _split_ws(new(x_bhwc, G * 9 * Cin * Cout))
-        call("tatt_conv3_c64_wgrad_partial", P(x_bhwc), P(dy_bhwc), P(part), B, H, W, Cin, Cout, G, stream())
-        call("tatt_splitk_reduce", P(part), P(dw), 9 * Cin, Cout, G, Cin, 9, 0.0, stream())
-        return dw
+        n = G * 9 * Cin * Cout
+        part = _split_ws(new(x_bhwc, n + (G * Cout if want_db else 0)))
+        db = new(x_bhwc, Cout) if want_db else None
+        call("tatt_conv3_c64_wgrad_partial", P(x_bhwc), P(dy_bhwc), P(part), P(part[n:]) if want_db else None, B, H, W, Cin,
+             Cout, G, stream())
+        call("tatt_splitk_reduce", P(part), P(dw), 9 * Cin, Cout, G, Cin, 9, 0.0, P(db), Cout, stream())
+        return (dw, db) if want_db else dw
+    if want_db:
+        return _conv_wgrad_general(x_bhwc, dy_bhwc, dw, Cout, KH, KW, contig), colsum(dy_bhwc.reshape(-1, Cout))
+    return _conv_wgrad_general(x_bhwc, dy_bhwc, dw, Cout, KH, KW, contig)
+
+
+def _conv_wgrad_general(x_bhwc, dy_bhwc, dw, Cout, KH, KW, contig):
+    B, H, W, Cin = x_bhwc.shape
+    sn, sh, sw, sc = x_bhwc.stride()
     if contig and KH == 9 and KW == 9 and Cout == 4 and Cin == 64 and H % 8 == 0 and W % 32 == 0:
         G = min(B * (H // 8) * (W // 32), 256)
         part = new(x_bhwc, G * 81 * 64 * 4)
