@@ -323,6 +323,11 @@ class Trainer:
         parallel branch, which the hipGraph executor does overlap (tools/graph_sched_probe.py); otherwise it simply runs first."""
         nst = len(self.stages)
         main = torch.cuda.current_stream(self.dev) if self.cuda else None
+        # Single GPU: the LAST stage's own parameter-gradient kernels follow its main lane on the main stream, beside the side lane
+        # of the stage before it (the query GRU's 47-launch chain is still running there) -- there is no pass of its own for them.
+        merge_last = self.two_lanes and not self.dp and nst >= 2
+        if merge_last and k == nst:
+            return
         if k >= 1:
             if self.two_lanes:
                 self.side.wait_stream(main)
@@ -332,6 +337,8 @@ class Trainer:
                 self._side_lane(k - 1)
         if k < nst:
             self._main_lane(k, x, tp, hr)
+        if merge_last and k == nst - 1:
+            self._side_lane(k)
         if k >= 1 and self.two_lanes:
             main.wait_stream(self.side)
 
