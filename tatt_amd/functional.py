@@ -72,6 +72,7 @@ class _DeferredParamGrads:
     def __init__(self):
         self.enabled = False
         self.stage = 0                   # index of the backward stage whose main lane is running (set by the Trainer)
+        self.due_of = {}                 # id(parameter) -> index of the stage (= gradient bucket) its gradient belongs to
         self._pending = []
         self._keep = []
 
@@ -94,12 +95,17 @@ class _DeferredParamGrads:
 
     def submit(self, params, fn, *keep, lag=0):
         """params: tuple of leaf tensors (or None); fn() -> tuple of their gradients (or None), same order (or a generator that
-        yields once between its split-K GEMMs and their consumer and returns the tuple).  lag: run with the side lane `lag` stages
-        after the current one (the query GRU's backward, 47 dependent launches, is given to the NEXT stage's side lane: side
-        lanes overlap the main lane beside them only while they stay short, see tools/graph_sched_probe.py)."""
+        yields once between its split-K GEMMs and their consumer and returns the tuple).  The closure runs with the side lane of
+        the current stage, or of a later one: `lag` stages later, and not before the stage whose gradient bucket holds its
+        parameters (`due_of`, from the model's grad_buckets(): the query GRU's 47 dependent launches and the 9x9 output
+        convolution's 0.4 ms weight gradient are filed under later buckets, where the main lane beside them has room)."""
         if not self.enabled or any(p is not None and not p.is_leaf for p in params):
             return self._run(fn)
-        self._pending.append((self.stage + lag, params, fn))
+        due = self.stage + lag
+        for p in params:                 # a parameter filed under a LATER bucket: its kernels run with that stage's side lane
+            if p is not None:
+                due = max(due, self.due_of.get(id(p), 0))
+        self._pending.append((due, params, fn))
         self._keep.append(keep)
         return (None,) * len(params)
 
@@ -705,7 +711,7 @@ class QueryGruFn(Function):
         # every output of this backward is a parameter gradient (the embedding depends on parameters only): all of it is deferrable
         dq = _c(dq)
         saved = ctx.saved_tensors
-        return tuple(SIDE.submit(ctx.leaves, lambda: QueryGruFn._backward(ctx, saved, dq), dq, saved, lag=1)) + (None, None, None)
+        return tuple(SIDE.submit(ctx.leaves, lambda: QueryGruFn._backward(ctx, saved, dq), dq, saved)) + (None, None, None)
 
     @staticmethod
     def _backward(ctx, saved, dq):

@@ -249,6 +249,9 @@ class Trainer:
             buckets = [("all", [p for _, ps in buckets for p in ps])]
         self.flat = FlatParams(model, buckets)
         self.stages = self.flat.bucket_names             # stage k fills bucket k; stage 0 is the backward from the loss
+        # id(parameter) -> its bucket: a deferred weight-gradient closure runs with the side lane of that stage (or of the stage
+        # that produced it, whichever is later), so that the bucket is complete when that side lane gathers it
+        self._due = {id(p): k for k, (_, ps) in enumerate(buckets or []) for p in ps}
         self.cuts = GradCuts() if staged and len(self.stages) > 1 else None
         if hasattr(model, "set_grad_cuts"):
             model.set_grad_cuts(self.cuts)
@@ -286,6 +289,7 @@ class Trainer:
         Fh.SIDE.enabled = self.defer
         Fh.FWD_FORK.enabled = self.two_lanes
         Fh.SIDE.stage = k
+        Fh.SIDE.due_of = self._due
         try:
             if k == 0:
                 for p in self.params:
@@ -340,7 +344,8 @@ class Trainer:
         if merge_last and k == nst - 1:
             self._side_lane(k)
         if k >= 1 and self.two_lanes:
-            main.wait_stream(self.side)
+            main.wait_stream(self.side)          # (without this per-pass join the side lanes form one long branch, which the
+                                                 #  hipGraph executor does not overlap with the main lane: 8.98 ms instead of 7.86)
 
     def _optim(self):
         self.step_count += 1

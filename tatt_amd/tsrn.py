@@ -365,9 +365,11 @@ class _TrainPathMixin:
     def grad_buckets(self):
         """[(stage name, [parameters])] in the order the parameters' gradients are complete; stage names match the
         `cuts.cut(name, ...)` calls of the forward: "trunk" (block7 + up-sampler: what the loss back-propagates into directly),
-        "srb4" ... "srb0" (the residual blocks, last to first), "tp" (TP interpreter), "first" (block1 + TPS sampler; also the
-        query GRU's parameters -- their gradient chain runs in this stage's side lane, one stage after it is registered),
-        "stn" (STN head)."""
+        "srb4" ... "srb0" (the residual blocks, last to first), "tp" (TP interpreter), "first" (block1 + TPS sampler), "stn" (STN
+        head).  A parameter may be filed under a LATER bucket than the stage that produces its gradient: its weight-gradient
+        kernels then run with that later stage's side lane (tatt_amd.functional.SIDE.due_of).  Two are: the query GRU (47 dependent
+        launches, "first": beside the STN head's backward) and, with a TP interpreter, the 9x9 output convolution (0.4 ms of
+        weight gradient, "srb0": beside the TP interpreter's long, launch-bound backward instead of the first residual block's)."""
         k = self.srb_nums
         groups = {"trunk": [], "tp": [], "first": [], "stn": []}
         groups.update({"srb%d" % i: [] for i in range(k)})
@@ -379,7 +381,8 @@ class _TrainPathMixin:
             elif top.startswith("block") and 2 <= int(top[5:]) <= k + 1:
                 groups["srb%d" % (int(top[5:]) - 2)].append(p)
             elif top.startswith("block") and int(top[5:]) > k + 1:
-                groups["trunk"].append(p)
+                out_conv = int(top[5:]) == k + 3 and name.split(".")[1] == str(len(getattr(self, top)) - 1)
+                groups["srb0" if (out_conv and hasattr(self, "infoGen") and k > 0) else "trunk"].append(p)
             elif top == "stn_head":
                 groups["stn"].append(p)
             else:                                  # block1, (TBSRN's unused conv / bn)
