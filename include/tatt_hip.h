@@ -136,13 +136,17 @@ int tatt_bn_bwd(const float* X, long ldx, const float* dY, long lddy, float* dX,
 /* Y = LayerNorm(A + Bres) * gamma + beta over the last axis (C <= 256), stats[M][2] = (mean, 1/denominator).
  * mode 0 = nn.LayerNorm (biased variance, eps inside the sqrt); mode 1 = the TBSRN variant's own LayerNorm
  * (model/tbsrn.py:23-36: unbiased std, eps added to the std).
- * nn.LayerNorm + the residual add in front of it (model/transformer_v2.py:478-483,826-832,380-387). */
+ * nn.LayerNorm + the residual add in front of it (model/transformer_v2.py:478-483,826-832,380-387).
+ * pdrop > 0: Bres goes through nn.Dropout(pdrop) first (mask = tatt_dropout's for the same seed word, site and flat index):
+ * LayerNorm(A + Dropout(Bres)) in one pass. */
 int tatt_ln_fwd(const float* A, const float* Bres, float* Y, float* stats, int M, int C,
-                const float* gamma, const float* beta, float eps, int mode, hipStream_t st);
-/* dX = d(A+Bres); part >= ceil(M/64)*2*C floats; ws >= 256*2*C doubles */
-int tatt_ln_bwd(const float* A, const float* Bres, const float* dY, const float* stats, float* dX, int M,
+                const float* gamma, const float* beta, float eps, int mode, float pdrop,
+                const unsigned long long* seed, unsigned site, hipStream_t st);
+/* dX = d(A + Dropout(Bres)) (the gradient of A); dB (pdrop > 0 only) = the gradient of Bres = Dropout'(dX);
+ * part >= ceil(M/64)*2*C floats; ws >= 256*2*C doubles */
+int tatt_ln_bwd(const float* A, const float* Bres, const float* dY, const float* stats, float* dX, float* dB, int M,
                 int C, const float* gamma, float* dgamma, float* dbeta, float* part, double* ws, float eps, int mode,
-                hipStream_t st);
+                float pdrop, const unsigned long long* seed, unsigned site, hipStream_t st);
 
 /* ---- element-wise ------------------------------------------------------------------------------------ */
 

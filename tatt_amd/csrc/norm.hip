@@ -478,19 +478,30 @@ TATT_API int tatt_bn_bwd(const float* X, long ldx, const float* dY, long lddy, f
 
 // mode 0: nn.LayerNorm  y = (x-mu)/sqrt(biased var + eps)*g + b;   mode 1: the TBSRN variant's own LayerNorm
 // (reference model/tbsrn.py:23-36)  y = g*(x-mu)/(UNBIASED std + eps) + b.  stats = (mu, 1/denominator) in both modes.
+// pdrop > 0: Bres passes through nn.Dropout(pdrop) on the way in (the mask of tatt_dropout for the same seed word / site / flat
+// index row*C + c, so fused and separate forms agree bit for bit): LayerNorm(a + Dropout(b)), transformer_v2.py:478-483,826-832
+__device__ __forceinline__ float ln_residual(const float* __restrict__ Bres, long idx, float pdrop, uint64_t seedv, unsigned site,
+                                             uint32_t th) {
+    const float b = Bres[idx];
+    if (pdrop <= 0.f) return b;
+    return dropout_keep(seedv, site, (uint64_t)idx, th) ? b * (1.f / (1.f - pdrop)) : 0.f;
+}
 __global__ void ln_fwd_kernel(const float* __restrict__ A, const float* __restrict__ Bres, float* __restrict__ Y,
                               float* __restrict__ stats, int M, int C, const float* __restrict__ gamma,
-                              const float* __restrict__ beta, float eps, int mode) {
+                              const float* __restrict__ beta, float eps, int mode, float pdrop,
+                              const unsigned long long* __restrict__ seed, unsigned site) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= M) return;
+    const uint64_t seedv = pdrop > 0.f ? seed[0] : 0;
+    const uint32_t th = dropout_thresh(pdrop);
     float v[LN_MAXPER];
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < LN_MAXPER; ++k) {
         int c = lane + 64 * k;
         float x = 0.f;
-        if (c < C) { x = A[row * C + c]; if (Bres) x += Bres[row * C + c]; }
+        if (c < C) { x = A[row * C + c]; if (Bres) x += ln_residual(Bres, row * C + c, pdrop, seedv, site, th); }
         v[k] = x; s += x;
     }
     float mu = wave_sum(s) / C;
@@ -507,9 +518,12 @@ __global__ void ln_fwd_kernel(const float* __restrict__ A, const float* __restri
     if (lane == 0 && stats) { stats[row * 2] = mu; stats[row * 2 + 1] = rs; }
 }
 TATT_API int tatt_ln_fwd(const float* A, const float* Bres, float* Y, float* stats, int M, int C,
-                         const float* gamma, const float* beta, float eps, int mode, hipStream_t st) {
+                         const float* gamma, const float* beta, float eps, int mode, float pdrop,
+                         const unsigned long long* seed, unsigned site, hipStream_t st) {
     if (C > 64 * LN_MAXPER) return 1;
-    hipLaunchKernelGGL(ln_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, A, Bres, Y, stats, M, C, gamma, beta, eps, mode);
+    if (pdrop > 0.f && (!Bres || !seed)) return 2;
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, A, Bres, Y, stats, M, C, gamma, beta, eps, mode,
+                       pdrop, seed, site);
     return LAUNCH_CHECK();
 }
 
@@ -517,9 +531,12 @@ TATT_API int tatt_ln_fwd(const float* A, const float* Bres, float* Y, float* sta
 #define LN_BWD_ROWS 64   // rows per wave-loop block (4 waves x 16 rows)
 __global__ void ln_bwd_kernel(const float* __restrict__ A, const float* __restrict__ Bres,
                               const float* __restrict__ dY, const float* __restrict__ stats, float* __restrict__ dX,
-                              int M, int C, const float* __restrict__ gamma, float* __restrict__ part, float eps, int mode) {
+                              float* __restrict__ dB, int M, int C, const float* __restrict__ gamma, float* __restrict__ part,
+                              float eps, int mode, float pdrop, const unsigned long long* __restrict__ seed, unsigned site) {
     __shared__ float sh[4][2][64 * LN_MAXPER];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t seedv = pdrop > 0.f ? seed[0] : 0;
+    const uint32_t th = dropout_thresh(pdrop);
     float dg[LN_MAXPER], db[LN_MAXPER];
 #pragma unroll
     for (int k = 0; k < LN_MAXPER; ++k) { dg[k] = 0.f; db[k] = 0.f; }
@@ -535,7 +552,7 @@ __global__ void ln_bwd_kernel(const float* __restrict__ A, const float* __restri
             int c = lane + 64 * k;
             xh[k] = 0.f; dxh[k] = 0.f;
             if (c < C) {
-                float x = A[row * C + c]; if (Bres) x += Bres[row * C + c];
+                float x = A[row * C + c]; if (Bres) x += ln_residual(Bres, row * C + c, pdrop, seedv, site, th);
                 float dy = dY[row * C + c];
                 xh[k] = (x - mu) * rs;
                 dxh[k] = dy * gamma[c];
@@ -549,7 +566,11 @@ __global__ void ln_bwd_kernel(const float* __restrict__ A, const float* __restri
 #pragma unroll
         for (int k = 0; k < LN_MAXPER; ++k) {
             int c = lane + 64 * k;
-            if (c < C) dX[row * C + c] = rs * (dxh[k] - s1) - xh[k] * c2;
+            if (c < C) {
+                const float d = rs * (dxh[k] - s1) - xh[k] * c2;
+                dX[row * C + c] = d;
+                if (dB) dB[row * C + c] = dropout_keep(seedv, site, (uint64_t)(row * C + c), th) ? d * (1.f / (1.f - pdrop)) : 0.f;
+            }
         }
     }
 #pragma unroll
@@ -563,12 +584,16 @@ __global__ void ln_bwd_kernel(const float* __restrict__ A, const float* __restri
     }
 }
 // part: cdiv(M,64)*2*C floats;  ws: doubles for the colsum (cdiv(G,256)*2*C)
-TATT_API int tatt_ln_bwd(const float* A, const float* Bres, const float* dY, const float* stats, float* dX, int M,
+// dB (with pdrop > 0): the gradient of the residual input in front of its dropout, Dropout'(dX); without dropout it equals dX
+TATT_API int tatt_ln_bwd(const float* A, const float* Bres, const float* dY, const float* stats, float* dX, float* dB, int M,
                          int C, const float* gamma, float* dgamma, float* dbeta, float* part, double* ws, float eps,
-                         int mode, hipStream_t st) {
+                         int mode, float pdrop, const unsigned long long* seed, unsigned site, hipStream_t st) {
     if (C > 64 * LN_MAXPER) return 1;
+    if (pdrop > 0.f && (!Bres || !seed || !dB)) return 2;
+    if (pdrop <= 0.f) dB = nullptr;
     int G = cdiv(M, LN_BWD_ROWS);
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(G), dim3(256), 0, st, A, Bres, dY, stats, dX, M, C, gamma, part, eps, mode);
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(G), dim3(256), 0, st, A, Bres, dY, stats, dX, dB, M, C, gamma, part, eps, mode, pdrop,
+                       seed, site);
     // part viewed as (G, 2C) -> column sums give [dgamma | dbeta]
     int G2 = cs_groups(G);
     int rpb = cdiv(G, G2);

@@ -554,12 +554,15 @@ class Permute4dFn(Function):
 
 
 class LayerNormFn(Function):
-    """LayerNorm(a + b) over the last axis (b optional)."""
+    """LayerNorm(a + b) over the last axis (b optional); with p > 0: LayerNorm(a + Dropout_p(b)), the dropout (site `site` of this
+    forward's seed) applied while b is read -- same mask as `dropout(b, p, True, site)`."""
 
     @staticmethod
-    def forward(ctx, a, b, gamma, beta, eps, mode):
+    def forward(ctx, a, b, gamma, beta, eps, mode, p, site):
         C = a.shape[-1]
-        y, stats = ops.ln_fwd(a.reshape(-1, C), None if b is None else b.reshape(-1, C), gamma, beta, eps, mode)
+        ctx.p, ctx.site = float(p), site
+        ctx.seed = current_seed(a.device) if p > 0.0 else None
+        y, stats = ops.ln_fwd(a.reshape(-1, C), None if b is None else b.reshape(-1, C), gamma, beta, eps, mode, ctx.p, ctx.seed, site)
         ctx.save_for_backward(a, b, stats, gamma)
         ctx.eps, ctx.mode = eps, mode
         return y.reshape(a.shape)
@@ -568,14 +571,15 @@ class LayerNormFn(Function):
     def backward(ctx, dy):
         a, b, stats, gamma = ctx.saved_tensors
         C = a.shape[-1]
-        dx, dg, db = ops.ln_bwd(a.reshape(-1, C), None if b is None else b.reshape(-1, C), _c(dy).reshape(-1, C), stats,
-                                gamma, ctx.eps, ctx.mode)
-        dx = dx.reshape(a.shape)
-        return dx, (dx if b is not None else None), dg, db, None, None
+        dx, db2, dg, db = ops.ln_bwd(a.reshape(-1, C), None if b is None else b.reshape(-1, C), _c(dy).reshape(-1, C), stats,
+                                     gamma, ctx.eps, ctx.mode, ctx.p, ctx.seed, ctx.site)
+        return dx.reshape(a.shape), (db2.reshape(a.shape) if b is not None else None), dg, db, None, None, None, None
 
 
-def layer_norm(a, b, ln):
-    return LayerNormFn.apply(_c(a), None if b is None else _c(b), ln.weight, ln.bias, ln.eps, 0)
+def layer_norm(a, b, ln, p=0.0, training=False, site=0):
+    """LayerNorm(a + b); with training and p > 0: LayerNorm(a + Dropout_p(b)) in one kernel."""
+    p = p if (training and b is not None) else 0.0
+    return LayerNormFn.apply(_c(a), None if b is None else _c(b), ln.weight, ln.bias, ln.eps, 0, p, site)
 
 
 class DropoutFn(Function):

@@ -371,23 +371,29 @@ def bn_bwd(x2, dy2, mean, rstd, gamma, beta, act, training):
     return dx, dgamma, dbeta
 
 
-def ln_fwd(a2, b2, gamma, beta, eps=1e-5, mode=0):
+def ln_fwd(a2, b2, gamma, beta, eps=1e-5, mode=0, pdrop=0.0, seed=None, site=0):
+    """LayerNorm(a2 + b2), or LayerNorm(a2 + Dropout_pdrop(b2)) with the mask of `dropout(b2, pdrop, seed, site)`."""
     M, C = a2.shape
     y, stats = new(a2, M, C), new(a2, M, 2)
-    call("tatt_ln_fwd", P(a2), P(b2), P(y), P(stats), M, C, P(gamma), P(beta), eps, mode, stream())
+    call("tatt_ln_fwd", P(a2), P(b2), P(y), P(stats), M, C, P(gamma), P(beta), eps, mode, float(pdrop), P(seed), int(site),
+         stream())
     return y, stats
 
 
-def ln_bwd(a2, b2, dy2, stats, gamma, eps=1e-5, mode=0):
+def ln_bwd(a2, b2, dy2, stats, gamma, eps=1e-5, mode=0, pdrop=0.0, seed=None, site=0):
+    """-> dx (gradient of a2), db2 (gradient of b2: dx itself without dropout, None if there is no b2), dgamma, dbeta"""
     M, C = a2.shape
     dx, dgb = new(a2, M, C), new(a2, 2 * C)
+    db2 = new(a2, M, C) if (pdrop > 0.0 and b2 is not None) else None
     dgamma, dbeta = dgb[:C], dgb[C:]              # adjacent: the kernel finishes both with one launch
     G = cdiv(M, 64)
     part = new(a2, G * 2 * C)
     ws = new(a2, 256 * 2 * C, dtype=torch.float64)
-    call("tatt_ln_bwd", P(a2), P(b2), P(dy2), P(stats), P(dx), M, C, P(gamma), P(dgamma), P(dbeta), P(part), P(ws),
-         eps, mode, stream())
-    return dx, dgamma, dbeta
+    call("tatt_ln_bwd", P(a2), P(b2), P(dy2), P(stats), P(dx), P(db2), M, C, P(gamma), P(dgamma), P(dbeta), P(part), P(ws),
+         eps, mode, float(pdrop), P(seed), int(site), stream())
+    if db2 is None and b2 is not None:
+        db2 = dx
+    return dx, db2, dgamma, dbeta
 
 
 # --------------------------------------------------------------------------------------------------

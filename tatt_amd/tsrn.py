@@ -325,9 +325,9 @@ def _tp_interpreter(feat, tp, ig: TPInterpreter, training, qpos=None):
     src = Fh.ScaleFn.apply(x, 2.0)
     qk = add_pos(src, pos)
     a, _ = Fh.multihead_attention(qk, qk, src, enc.self_attn, drop, 2)
-    src = Fh.layer_norm(src, Fh.dropout(a, enc.p, drop, 3), enc.norm1)
+    src = Fh.layer_norm(src, a, enc.norm1, enc.p, drop, 3)
     f = _ffn(src, enc, drop, 4)
-    memory = Fh.layer_norm(src, Fh.dropout(f, enc.p, drop, 5), enc.norm2)
+    memory = Fh.layer_norm(src, f, enc.norm2, enc.p, drop, 5)
     # decoder: cross-attention only (self-attention commented out upstream, :817-819)
     kmem = add_pos(memory, pos)
     Fh.FWD_FORK.join(feat.device)              # the query embedding may have been a parallel branch until here
@@ -335,9 +335,9 @@ def _tp_interpreter(feat, tp, ig: TPInterpreter, training, qpos=None):
     for li, dec in enumerate(tr.decoder.layers):
         s0 = 10 + 10 * li
         a, wts = Fh.multihead_attention(Fh.add(tgt, qpos), kmem, memory, dec.multihead_attn, drop, s0)
-        tgt = Fh.layer_norm(tgt, Fh.dropout(a, dec.p, drop, s0 + 1), dec.norm2)
+        tgt = Fh.layer_norm(tgt, a, dec.norm2, dec.p, drop, s0 + 1)
         f = _ffn(tgt, dec, drop, s0 + 2)
-        tgt = Fh.layer_norm(tgt, Fh.dropout(f, dec.p, drop, s0 + 3), dec.norm3)
+        tgt = Fh.layer_norm(tgt, f, dec.norm3, dec.p, drop, s0 + 3)
         outs.append(Fh.layer_norm(tgt, None, tr.decoder.norm))
     tp_tok = Fh.MeanOf2Fn.apply(outs[0], outs[1]) if len(outs) == 2 else sum(outs) / len(outs)
     return tp_tok.reshape(B, H, W, C), wts

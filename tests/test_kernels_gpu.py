@@ -224,9 +224,9 @@ def test_layernorm(dev):
     from tatt_amd import functional as Fh
     a, b, g, be = R(3, 100, 64), R(3, 100, 64, seed=1), 1 + 0.1 * R(64, seed=2), 0.1 * R(64, seed=3)
     ln = torch.nn.LayerNorm(64)
-    compare_fn("ln_res", lambda a, b, g, be: Fh.LayerNormFn.apply(a, b, g, be, 1e-5, 0),
+    compare_fn("ln_res", lambda a, b, g, be: Fh.LayerNormFn.apply(a, b, g, be, 1e-5, 0, 0.0, 0),
                lambda a, b, g, be: O.layer_norm(a + b, g, be), [a, b, g, be], dev)
-    compare_fn("ln", lambda a, g, be: Fh.LayerNormFn.apply(a, None, g, be, 1e-5, 0),
+    compare_fn("ln", lambda a, g, be: Fh.LayerNormFn.apply(a, None, g, be, 1e-5, 0, 0.0, 0),
                lambda a, g, be: O.layer_norm(a, g, be), [a, g, be], dev)
 
 
@@ -247,6 +247,29 @@ def test_prelu_pixelshuffle_maxpool_tanh(dev):
     compare_fn("add", Fh.add, lambda a, b: a + b, [a, b], dev)
     compare_fn("mean2", Fh.MeanOf2Fn.apply, lambda a, b: 0.5 * (a + b), [a, b], dev)
     compare_fn("permute", lambda a: Fh.Permute4dFn.apply(a, (0, 3, 1, 2)), lambda a: a.permute(0, 3, 1, 2), [a], dev)
+
+
+def test_layernorm_fused_dropout_equals_separate(dev):
+    """LayerNorm(a + Dropout(b)) in one kernel (tatt_ln_fwd / tatt_ln_bwd with pdrop) == dropout kernel followed by the plain
+    LayerNorm, bit for bit: same mask (seed word, site, flat index), same arithmetic; gradients of a, b, gamma, beta included."""
+    from tatt_amd import functional as Fh
+    Fh.set_seed(dev, 11)
+    Fh.begin_training_forward(dev)
+    ln = torch.nn.LayerNorm(64).to(dev)
+    outs = []
+    for fused in (True, False):
+        a = R(5, 77, 64).to(dev).requires_grad_()
+        b = R(5, 77, 64, seed=1).to(dev).requires_grad_()
+        ln.zero_grad()
+        if fused:
+            y = Fh.layer_norm(a, b, ln, 0.1, True, 9)
+        else:
+            y = Fh.layer_norm(a, Fh.dropout(b, 0.1, True, 9), ln)
+        (y * R(5, 77, 64, seed=2).to(dev)).sum().backward()
+        outs.append([t.detach().cpu().clone() for t in (y, a.grad, b.grad, ln.weight.grad, ln.bias.grad)])
+    for u, v in zip(*outs):
+        assert torch.equal(u, v)
+    assert (outs[0][2] == 0).float().mean() > 0.05          # the mask did drop something
 
 
 def test_dropout_mask_consistency(dev):
@@ -462,7 +485,7 @@ def test_tbsrn_layer_norm_mode1(dev):
     g = torch.Generator().manual_seed(11)
     a, b = torch.randn(3, 50, 128, generator=g), torch.randn(3, 50, 128, generator=g)
     ga, be = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g)
-    compare_fn("tbsrn_ln", lambda a, b, g_, be_: Fh.LayerNormFn.apply(a, b, g_, be_, 1e-6, 1),
+    compare_fn("tbsrn_ln", lambda a, b, g_, be_: Fh.LayerNormFn.apply(a, b, g_, be_, 1e-6, 1, 0.0, 0),
                lambda a, b, g_, be_: O.tbsrn_layer_norm(a + b, g_, be_), [a, b, ga, be], dev)
 
 
