@@ -161,6 +161,9 @@ int tatt_act_bwd(const float* ref, const float* dy, float* dx, long n, int act, 
                  hipStream_t st);
 /* y = alpha*a + beta*b (b may be NULL) */
 int tatt_axpby(const float* a, const float* b, float* y, float alpha, float beta, long n, hipStream_t st);
+/* y = ((s0 + s1) + s2) + ... : n <= 8 contiguous, 16-byte aligned tensors of numel floats (srcs: HOST array of n device pointers);
+ * the gradient of a tensor with several consumers, which autograd sums with a chain of at::add */
+int tatt_add_n(const float* const* srcs, int n, float* y, long numel, hipStream_t st);
 /* y[m,:] = a[m,:] + b[m % period,:]  (positional embedding broadcast over the batch) */
 int tatt_add_rowbcast(const float* a, const float* b, float* y, long rows, int C, long period,
                       hipStream_t st);

@@ -79,6 +79,38 @@ TATT_API int tatt_axpby(const float* a, const float* b, float* y, float alpha, f
     hipLaunchKernelGGL(axpby_kernel, EW_GRID(n), 0, st, a, b, y, alpha, beta, n);
     return LAUNCH_CHECK();
 }
+// y = ((s0 + s1) + s2) + ... over n <= 8 equally shaped tensors, one launch (gradient contributions of a tensor with several
+// consumers, summed left to right like a chain of binary adds)
+struct AddNP { const float* s[8]; int n; };
+__global__ void add_n_kernel(AddNP p, float* __restrict__ y, long numel) {
+    long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= numel) return;
+    if (i + 4 <= numel) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(p.s[0] + i);
+        for (int k = 1; k < p.n; ++k) {
+            const f32x4 u = *reinterpret_cast<const f32x4*>(p.s[k] + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += u[e];
+        }
+        *reinterpret_cast<f32x4*>(y + i) = v;
+    } else {
+        for (long j = i; j < numel; ++j) {
+            float v = p.s[0][j];
+            for (int k = 1; k < p.n; ++k) v += p.s[k][j];
+            y[j] = v;
+        }
+    }
+}
+TATT_API int tatt_add_n(const float* const* srcs, int n, float* y, long numel, hipStream_t st) {
+    if (n < 1 || n > 8) return 1;
+    AddNP p;
+    for (int k = 0; k < 8; ++k) p.s[k] = k < n ? srcs[k] : nullptr;
+    p.n = n;
+    for (int k = 0; k < n; ++k) if (((uintptr_t)srcs[k]) & 15) return 2;
+    if (((uintptr_t)y) & 15) return 2;
+    hipLaunchKernelGGL(add_n_kernel, dim3(cdiv(cdiv(numel, 4), 256)), dim3(256), 0, st, p, y, numel);
+    return LAUNCH_CHECK();
+}
 // y[m, :] = a[m, :] + b[(m % period), :]   (row-broadcast add: positional / query embeddings)
 __global__ void add_rowbcast_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y,
                                     long rows, int C, long period) {

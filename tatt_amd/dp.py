@@ -105,10 +105,16 @@ class GradCuts:
     def run(self, stage: str):
         outs, grads = [], []
         for orig, copies in self._stages.pop(stage, {}).values():
+            gs = [d.grad for d in reversed(copies) if d.grad is not None]   # later consumers first, like the single-pass engine
             g = None
-            for d in reversed(copies):               # later consumers deliver their gradient first, like the single-pass engine
-                if d.grad is not None:
-                    g = d.grad if g is None else g + d.grad
+            if gs:
+                if len(gs) > 2 and gs[0].is_cuda and len(gs) <= 8 and gs[0].dtype == torch.float32:
+                    from . import ops
+                    g = ops.add_n(gs)                # one launch, same left-to-right order as the chain of adds below
+                else:
+                    g = gs[0]
+                    for t in gs[1:]:
+                        g = g + t
             if g is not None and orig.requires_grad:
                 outs.append(orig)
                 grads.append(g)

@@ -391,10 +391,14 @@ class GruBlockFn(Function):
         K = Wc.shape[1]
         x2 = x.reshape(-1, K1)
         dgi, dgh, hprev = ops.gru32_bwd(gates, out, _c(dout).reshape(-1, 64), whh_f, whh_r, ctx.geom)
-        dx = ops.linear_bwd_input(dgi, Wp, col0=0, ncols=K1).reshape(x.shape) if ctx.needs_input_grad[0] else None
         dxb = None
-        if xb is not None and ctx.needs_input_grad[1]:
-            dxb = ops.linear_bwd_input(dgi, Wp, col0=K1, ncols=K - K1).reshape(xb.shape)
+        if xb is not None and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and K == 2 * K1:
+            dx, dxb = ops.linear_bwd_input_halves(dgi, Wp)          # both halves of the concatenated input: one launch
+            dx, dxb = dx.reshape(x.shape), dxb.reshape(xb.shape)
+        else:
+            dx = ops.linear_bwd_input(dgi, Wp, col0=0, ncols=K1).reshape(x.shape) if ctx.needs_input_grad[0] else None
+            if xb is not None and ctx.needs_input_grad[1]:
+                dxb = ops.linear_bwd_input(dgi, Wp, col0=K1, ncols=K - K1).reshape(xb.shape)
 
         def param_grads():
             # weight-gradient GEMMs over the tokens; the bias gradients (column sums of dgi / dgh) ride along as a virtual ones column

@@ -131,6 +131,18 @@ def linear_bwd_input(dy, W, *, col0=0, ncols=None, alpha=1.0, out=None, beta=0.0
     return dx
 
 
+def linear_bwd_input_halves(dy, W):
+    """(dy @ W[:, :K/2], dy @ W[:, K/2:]) as two contiguous (M, K/2) tensors from ONE launch (a 2-batch GEMM that shares A): the
+    input gradients of a linear layer over the concatenation of two equally wide sources (GruBlock over cat[x, tp_map])."""
+    M, N = dy.shape
+    K = W.shape[1]
+    h = K // 2
+    assert K == 2 * h
+    buf = new(dy, 2, M, h)
+    gemm(dy, dy.stride(0), dy.stride(1), W, K, 1, buf, h, 1, M, h, N, Z=2, bsA=0, bsB=h, bsC=M * h)
+    return buf[0], buf[1]
+
+
 def linear_bwd_weight(dy, x2, *, alpha=1.0, out=None, out_ld=None, beta=0.0, rowsum=None):
     """dW (N,K) = alpha * dy^T (N,M) @ x2 (M,K); reduction over the M tokens (split-K, deterministic).
     rowsum: optional (N,) tensor that receives alpha * dy.sum(0) -- the bias gradient -- from the same pass."""
@@ -430,6 +442,16 @@ def axpby(a, b, alpha=1.0, beta=1.0):
     _check_dev(a)
     y = torch.empty_like(a)
     call("tatt_axpby", P(a), P(b), P(y), alpha, beta, a.numel(), stream())
+    return y
+
+
+def add_n(ts):
+    """((t0 + t1) + t2) + ... in one launch (2 <= len(ts) <= 8, equal shapes)."""
+    ts = [t if t.is_contiguous() else t.contiguous() for t in ts]
+    _check_dev(ts[0])
+    y = torch.empty_like(ts[0])
+    srcs = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    call("tatt_add_n", srcs, len(ts), P(y), y.numel(), stream())
     return y
 
 
