@@ -249,6 +249,38 @@ def test_prelu_pixelshuffle_maxpool_tanh(dev):
     compare_fn("permute", lambda a: Fh.Permute4dFn.apply(a, (0, 3, 1, 2)), lambda a: a.permute(0, 3, 1, 2), [a], dev)
 
 
+def test_add_n_equals_chain_of_adds(dev):
+    """tatt_add_n: ((s0 + s1) + s2) + ... in one launch, bit-identical to the chain of binary adds (any size, incl. a ragged tail)."""
+    from tatt_amd import ops
+    for shape in [(48, 16, 64, 64), (3, 7, 5), (1, 9)]:
+        ts = [R(*shape, seed=k).to(dev) for k in range(5)]
+        want = ts[0]
+        for t in ts[1:]:
+            want = want + t
+        assert torch.equal(ops.add_n(ts), want)
+        assert torch.equal(ops.add_n(ts[:2]), ts[0] + ts[1])
+
+
+def test_linear_bwd_input_halves(dev):
+    """One 2-batch GEMM for both halves of a concatenated input's gradient == the two separate column-range GEMMs."""
+    from tatt_amd import ops
+    dy, W = R(1024, 192).to(dev), R(192, 128, seed=1).to(dev)
+    a, b = ops.linear_bwd_input_halves(dy, W)
+    assert a.is_contiguous() and b.is_contiguous()
+    assert torch.equal(a, ops.linear_bwd_input(dy, W, col0=0, ncols=64))
+    assert torch.equal(b, ops.linear_bwd_input(dy, W, col0=64, ncols=64))
+    check_close("halves", torch.cat([a, b], 1), dy.cpu() @ W.cpu(), rtol=1e-4, atol=1e-4)
+
+
+def test_conv3_wgrad_bias_gradient(dev):
+    """The 3x3 64-channel weight-gradient kernel's bias gradient (sum of the dy operands it streams) against dy.sum over pixels."""
+    from tatt_amd import ops
+    x, dy = R(3, 16, 64, 64).to(dev), R(3, 16, 64, 128, seed=1).to(dev)
+    dw, db = ops.conv_wgrad(x, dy, 128, 3, 3, want_db=True)
+    check_close("db", db, dy.cpu().double().sum((0, 1, 2)).float(), rtol=1e-5, atol=1e-4)
+    assert torch.equal(dw, ops.conv_wgrad(x, dy, 128, 3, 3))
+
+
 def test_layernorm_fused_dropout_equals_separate(dev):
     """LayerNorm(a + Dropout(b)) in one kernel (tatt_ln_fwd / tatt_ln_bwd with pdrop) == dropout kernel followed by the plain
     LayerNorm, bit for bit: same mask (seed word, site, flat index), same arithmetic; gradients of a, b, gamma, beta included."""
