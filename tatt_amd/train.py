@@ -271,6 +271,8 @@ class Trainer:
             if self.dp or dropout_seed is not None:
                 Fh.set_seed(dev, rank_dropout_seed(base, self.rank) if self.dp else base)
         self.side = torch.cuda.Stream(device=dev) if self.two_lanes else None
+        self._merge_last = self.two_lanes and len(self.stages) >= 2
+        self._npass = len(self.stages) + (0 if self._merge_last else 1)
         self.gnorms = [torch.zeros(1, device=dev) for _ in self.groups]
         self.gnorm = self.gnorms[0]
         self.step_count = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -327,9 +329,9 @@ class Trainer:
         parallel branch, which the hipGraph executor does overlap (tools/graph_sched_probe.py); otherwise it simply runs first."""
         nst = len(self.stages)
         main = torch.cuda.current_stream(self.dev) if self.cuda else None
-        # Single GPU: the LAST stage's own parameter-gradient kernels follow its main lane on the main stream, beside the side lane
-        # of the stage before it (the query GRU's 47-launch chain is still running there) -- there is no pass of its own for them.
-        merge_last = self.two_lanes and not self.dp and nst >= 2
+        # The LAST stage's own parameter-gradient kernels follow its main lane on the main stream, beside the side lane of the
+        # stage before it (the query GRU's 47-launch chain is still running there) -- there is no pass of its own for them.
+        merge_last = self._merge_last
         if merge_last and k == nst:
             return
         if k >= 1:
@@ -396,13 +398,15 @@ class Trainer:
         if graphs is not None and "step" in graphs:
             graphs["step"].replay()                  # single GPU: the whole step is one graph
             return self.last_loss.clone()            # (the captured tensor is overwritten by the next replay)
-        for k in range(nst + 1):
+        for k in range(self._npass):
             if graphs is None:
                 self._pass(k, x, tp, hr)
             else:
                 graphs["pass"][k].replay()
             if k >= 1:
                 self._reduce(k - 1)                  # bucket k-1 is complete: on the wire while pass k+1 computes
+        if self._merge_last:
+            self._reduce(nst - 1)                    # (the last pass completed two buckets)
         self._wait_reduces()
         if graphs is None:
             Fh.SIDE.release()
@@ -420,7 +424,7 @@ class Trainer:
         if not self.dp:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                for k in range(nst + 1):
+                for k in range(self._npass):
                     self._pass(k, sx, stp, shr)
                 Fh.SIDE.release()
                 self._optim()
@@ -432,7 +436,7 @@ class Trainer:
         pool = torch.cuda.graph_pool_handle()
         kw = dict(pool=pool, capture_error_mode="thread_local")
         graphs = {"pass": []}
-        for k in range(nst + 1):
+        for k in range(self._npass):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, **kw):
                 self._pass(k, sx, stp, shr)
