@@ -203,14 +203,15 @@ class Trainer:
     """One training step per `step()` call: forward, ImageLoss.mean()*100, backward, [all-reduce], clip, Adam.
 
     The backward runs in the stages the model announces (`grad_buckets` / `set_grad_cuts`: up-sampler + block7, the five SRBs one
-    by one, the TP interpreter, block1 + STN head).  Each stage has two lanes:
+    by one, the TP interpreter, block1 + TPS sampler, the STN head).  Each stage has two lanes:
       * main lane: the activation-gradient chain of the stage; weight / bias gradients and the query GRU's backward -- a third of
         the step's kernel time that nothing on that chain waits for -- are only REGISTERED while it runs (`defer_param_grads`,
         tatt_amd.functional.SIDE);
-      * side lane: those registered kernels (their split-K reductions batched into one launch), then the gather of the stage's
-        gradients into its bucket of the flat buffer.
+      * side lane: the registered kernels that are due (their split-K reductions batched into one launch) -- those of this stage
+        and those the model filed under this stage's bucket although an earlier stage produced them -- then the gather of the
+        stage's gradients into its bucket of the flat buffer.
     Pass k of a step runs main lane k beside side lane k-1: with `side_stream` the side lane is a short branch forked onto a
-    second HIP stream and joined at the end of the pass.  (Data parallel) bucket k-1 is complete after pass k and its asynchronous
+    second HIP stream and joined at the end of the pass; the last stage's side lane follows its main lane on the main stream.  (Data parallel) bucket k-1 is complete after pass k and its asynchronous
     sum all-reduce over RCCL travels while pass k+1 computes.
     `use_graph`: after `warmup_eager` eager steps the step is captured and replayed: ONE hipGraph for the whole step on a single
     GPU (the forks and joins become parallel branches), one per pass + one for the optimiser under data parallelism (the
