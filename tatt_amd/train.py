@@ -272,7 +272,7 @@ class Trainer:
             if self.dp or dropout_seed is not None:
                 Fh.set_seed(dev, rank_dropout_seed(base, self.rank) if self.dp else base)
         self.side = torch.cuda.Stream(device=dev) if self.two_lanes else None
-        self._merge_last = self.two_lanes and len(self.stages) >= 2
+        self._merge_last = len(self.stages) >= 2         # (also without a second stream: one pass structure everywhere)
         self._npass = len(self.stages) + (0 if self._merge_last else 1)
         self.gnorms = [torch.zeros(1, device=dev) for _ in self.groups]
         self.gnorm = self.gnorms[0]
