@@ -270,6 +270,46 @@ int tatt_softmax_rows_fwd(float* S, float* Pd, long rows, int L, float pdrop, co
 int tatt_softmax_rows_bwd(const float* P, float* dP, long rows, int L, float pdrop, const unsigned long long* seed,
                           unsigned site, hipStream_t st);
 
+/* ---- one TP-interpreter transformer layer as ONE kernel (csrc/tplayer.hip) --------------------------------- */
+
+/* Reference TransformerDecoderLayer_TP.forward_post (model/transformer_v2.py:806-833: cross-attention over the S <= 32 projected
+ * keys / values of the text prior -> +residual -> LayerNorm -> FFN -> +residual -> LayerNorm; the self-attention is commented
+ * out upstream) and TransformerEncoderLayer.forward_post (:470-484), E = 64, 4 heads, dim_ff = 64:
+ *   q    = ((x + qpos) in_w[0:64]^T + in_b[0:64]) / 4          qpos: (B,L,64) [qbs = L*64] or (L,64) broadcast [qbs = 0]
+ *   ctx  = dropout_{p_attn}(softmax(q K^T)) V per head,        wavg (B,L,S; nullable) = head mean of the dropped probabilities
+ *   x1   = LN_A(x + dropout_{p_res}(ctx out_w^T + out_b))
+ *   xout = LN_B(x1 + dropout_{p_res}(w2 dropout_{p_ffn}(relu(w1 x1 + b1)) + b2))                        (nullable)
+ *   fin  = fin_scale * (LN_F(x) [if fin_both] + LN_F(xout))   when lnF_w != NULL: the stacked final norms of
+ *          TransformerDecoder.forward (:380-390) averaged as TPInterpreter does (model/tsrn.py:218)       (nullable)
+ * K, V: (B,S,64) = the key / value rows of the packed in-projection applied beforehand.  Dropout sites site0 .. site0+3 draw the
+ * masks of tatt_attn_fwd / tatt_ln_fwd / tatt_dropout / tatt_ln_fwd for the same seed word and flat element index. */
+int tatt_tplayer_fwd(const float* x, const float* qpos, long qbs, const float* K, const float* V, const float* in_w,
+                     const float* in_b, const float* out_w, const float* out_b, const float* w1, const float* b1,
+                     const float* w2, const float* b2, const float* lnA_w, const float* lnA_b, const float* lnB_w,
+                     const float* lnB_b, const float* lnF_w, const float* lnF_b, float fin_scale, int fin_both, float* xout,
+                     float* fin, float* wavg, int B, int L, int S, float p_attn, float p_res, float p_ffn,
+                     const unsigned long long* seed, unsigned site0, float eps, hipStream_t st);
+/* Backward of the layer, recomputed from x (the forward saves nothing else): upstream gradients dxout (of xout), dfin (of fin;
+ * required when lnF_w != NULL), dwavg (of wavg) -- each nullable; dqacc (nullable) is added to dqpos (the next layer's dqpos).
+ * Writes dx (B,L,64), dqpos (B,L,64; nullable), and partial records: kvpart (dK / dV per work-group and sample) and ppart
+ * (parameter gradients per work-group) -- sizes from tatt_tplayer_geom -- to be summed by the two reducers. */
+int tatt_tplayer_bwd(const float* x, const float* qpos, long qbs, const float* K, const float* V, const float* in_w,
+                     const float* in_b, const float* out_w, const float* out_b, const float* w1, const float* b1,
+                     const float* w2, const float* b2, const float* lnA_w, const float* lnA_b, const float* lnB_w,
+                     const float* lnB_b, const float* lnF_w, const float* lnF_b, float fin_scale, int fin_both,
+                     const float* dxout, const float* dfin, const float* dwavg, const float* dqacc, float* dx,
+                     float* dqpos, float* kvpart, float* ppart, int B, int L, int S, float p_attn, float p_res,
+                     float p_ffn, const unsigned long long* seed, unsigned site0, float eps, hipStream_t st);
+/* host-side: out[0] = work-groups, out[1] = dK/dV records per work-group, out[2] = floats of kvpart, out[3] = floats of ppart */
+int tatt_tplayer_geom(int B, int L, int* out);
+/* dK, dV (B,S,64) = sums of the kvpart records */
+int tatt_tplayer_reduce_kv(const float* kvpart, float* dK, float* dV, int B, int L, int S, hipStream_t st);
+/* parameter gradients = sums of the ppart records: d_in_w receives 64x64 (the query rows of the packed in-projection), d_in_b 64;
+ * any destination may be NULL; betaF = 1 accumulates into d_lnF_w / d_lnF_b */
+int tatt_tplayer_reduce_params(const float* ppart, int B, int L, float* d_in_w, float* d_in_b, float* d_out_w, float* d_out_b,
+                               float* d_w1, float* d_b1, float* d_w2, float* d_b2, float* d_lnA_w, float* d_lnA_b,
+                               float* d_lnB_w, float* d_lnB_b, float* d_lnF_w, float* d_lnF_b, float betaF, hipStream_t st);
+
 /* ---- TPS rectification ---------------------------------------------------------------------------------- */
 
 /* src[b,p,:] = repr[p,:] @ (inv @ [ctrl[b]; pad])  (model/tps_spatial_transformer.py:103-105); N ctrl points, P pixels */

@@ -675,6 +675,123 @@ def multihead_attention(q_in, k_in, v_in, mha, training, site):
 
 
 # --------------------------------------------------------------------------------------------------
+class TPStackCfg:
+    """Static description of a fused stack (see TPStackFn): dropout sites per layer, probabilities, final norm, outputs."""
+
+    def __init__(self, sites, p_attn, p_res, p_ffn, fin, need_wavg, shared_mem, eps):
+        self.sites, self.p_attn, self.p_res, self.p_ffn = tuple(sites), float(p_attn), float(p_res), float(p_ffn)
+        self.fin, self.need_wavg, self.shared_mem, self.eps = bool(fin), bool(need_wavg), bool(shared_mem), float(eps)
+        self.n = len(self.sites)
+        assert 1 <= self.n <= 2 and not (self.shared_mem and self.n != 1)
+
+
+class TPStackFn(Function):
+    """One or two transformer layers of the TP interpreter over one memory, each layer ONE kernel (csrc/tplayer.hip):
+
+        layer:  x <- LN_B(x1 + Drop(FFN(x1))),  x1 = LN_A(x + Drop(MHA(q = x + qpos, k = mem + pos, v = mem)))
+        out  =  mean over the layers of LN_F(layer output)   (cfg.fin: reference TransformerDecoder.forward,
+                model/transformer_v2.py:380-390, averaged by TPInterpreter, model/tsrn.py:218)   or the last layer's output
+
+    = reference TransformerDecoderLayer_TP.forward_post (:806-833) for the decoder, TransformerEncoderLayer.forward_post (:470-484)
+    for the encoder (x is mem: cfg.shared_mem).  The K / V rows of each layer's packed in-projection are applied here (two small
+    GEMMs per layer over the S <= 32 memory tokens).  Nothing but the layer inputs is saved: the backward kernel recomputes.
+    params: per layer (in_proj_weight, in_proj_bias, out_proj.weight, out_proj.bias, linear1.weight, linear1.bias, linear2.weight,
+    linear2.bias, norm_A.weight, norm_A.bias, norm_B.weight, norm_B.bias), then (norm_F.weight, norm_F.bias) with cfg.fin."""
+
+    @staticmethod
+    def forward(ctx, x, qpos, mem, pos, cfg, *params):
+        n = cfg.n
+        lps = [params[12 * l:12 * l + 12] for l in range(n)]
+        lnF = tuple(params[12 * n:12 * n + 2]) if cfg.fin else None
+        B, L, E = x.shape
+        S = mem.shape[1]
+        drop = cfg.p_attn > 0.0 or cfg.p_res > 0.0 or cfg.p_ffn > 0.0
+        seed = current_seed(x.device) if drop else None
+        kin = ops.axpby(mem, pos, 1.0, 1.0) if pos.dim() == 3 else ops.add_rowbcast(mem, pos, pos.shape[0])
+        kin2, mem2 = kin.reshape(-1, E), mem.reshape(-1, E)
+        xs, Ks, Vs = [x], [], []
+        out = wavg = None
+        for l, lp in enumerate(lps):
+            in_w, in_b = lp[0], lp[1]
+            K = ops.linear_fwd(kin2, in_w[E:2 * E], in_b[E:2 * E]).reshape(B, S, E)
+            V = ops.linear_fwd(mem2, in_w[2 * E:], in_b[2 * E:]).reshape(B, S, E)
+            last = l == n - 1
+            fin_here = cfg.fin and last
+            xout, fin, w = ops.tplayer_fwd(xs[l], qpos, K, V, lp, lnF if fin_here else None, 1.0 / n, int(n == 2), cfg.p_attn,
+                                           cfg.p_res, cfg.p_ffn, seed, cfg.sites[l], cfg.eps, not fin_here,
+                                           cfg.need_wavg and last)
+            if last:
+                out, wavg = (fin if fin_here else xout), w
+            else:
+                xs.append(xout)
+            Ks.append(K)
+            Vs.append(V)
+        ctx.save_for_backward(qpos, mem, kin, *xs, *Ks, *Vs, *params)
+        ctx.cfg, ctx.seed = cfg, seed
+        return out, wavg
+
+    @staticmethod
+    def backward(ctx, dout, dwavg):
+        cfg = ctx.cfg
+        n = cfg.n
+        sv = ctx.saved_tensors
+        qpos, mem, kin = sv[0], sv[1], sv[2]
+        xs, Ks, Vs = sv[3:3 + n], sv[3 + n:3 + 2 * n], sv[3 + 2 * n:3 + 3 * n]
+        params = sv[3 + 3 * n:]
+        lps = [params[12 * l:12 * l + 12] for l in range(n)]
+        lnF = tuple(params[12 * n:12 * n + 2]) if cfg.fin else None
+        B, L, E = xs[0].shape
+        S = mem.shape[1]
+        kin2, mem2 = kin.reshape(-1, E), mem.reshape(-1, E)
+        up = _c(dout) if dout is not None else torch.zeros_like(xs[0])
+        dwavg = _c(dwavg) if dwavg is not None else None
+        want_dq = ctx.needs_input_grad[1]
+        want_dmem = ctx.needs_input_grad[2] or (cfg.shared_mem and ctx.needs_input_grad[0])
+        dmem2 = dq = None
+        pgrads = [None] * len(params)
+        for l in range(n - 1, -1, -1):
+            lp = lps[l]
+            last = l == n - 1
+            fin_here = cfg.fin and last
+            dx, dq, kvpart, ppart = ops.tplayer_bwd(xs[l], qpos, Ks[l], Vs[l], lp, lnF if fin_here else None, 1.0 / n, int(n == 2),
+                                                    cfg.p_attn, cfg.p_res, cfg.p_ffn, ctx.seed, cfg.sites[l], cfg.eps,
+                                                    None if fin_here else up, up if fin_here else None, dwavg if last else None,
+                                                    dq, want_dq)
+            dK, dV = ops.tplayer_reduce_kv(kvpart, B, L, S)
+            dK2, dV2 = dK.reshape(-1, E), dV.reshape(-1, E)
+            in_w = lp[0]
+            if want_dmem:
+                if dmem2 is None:
+                    if cfg.shared_mem:                       # x is the memory itself (encoder): its gradients add up in dx
+                        dmem2 = dx.reshape(-1, E)
+                        ops.linear_bwd_input(dK2, in_w[E:2 * E], out=dmem2, beta=1.0)
+                    else:
+                        dmem2 = ops.linear_bwd_input(dK2, in_w[E:2 * E])
+                else:
+                    ops.linear_bwd_input(dK2, in_w[E:2 * E], out=dmem2, beta=1.0)
+                ops.linear_bwd_input(dV2, in_w[2 * E:], out=dmem2, beta=1.0)
+
+            def param_grads(lp=lp, ppart=ppart, dK2=dK2, dV2=dV2, fin_here=fin_here):
+                g = [ops.new(dK2, *t.shape) for t in lp]
+                gF = [ops.new(dK2, *t.shape) for t in lnF] if fin_here else [None, None]
+                ops.tplayer_reduce_params(ppart, B, L, [g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], g[9], g[10], g[11],
+                                                        gF[0], gF[1]])
+                ops.linear_bwd_weight(dK2, kin2, out=g[0][E:2 * E], out_ld=E, rowsum=g[1][E:2 * E])
+                ops.linear_bwd_weight(dV2, mem2, out=g[0][2 * E:], out_ld=E, rowsum=g[1][2 * E:])
+                return tuple(g) + (tuple(gF) if fin_here else ())
+            leaves = tuple(lp) + (tuple(lnF) if fin_here else ())
+            got = SIDE.submit(leaves, param_grads, ppart, dK2, dV2, kin2, mem2)
+            pgrads[12 * l:12 * l + 12] = got[:12]
+            if fin_here:
+                pgrads[12 * n:12 * n + 2] = got[12:14]
+            up = dx
+        dmem = None
+        if want_dmem and not cfg.shared_mem:
+            dmem = dmem2.reshape(mem.shape)
+        return (up, dq if want_dq else None, dmem, None, None) + tuple(pgrads)
+
+
+# --------------------------------------------------------------------------------------------------
 class QueryGruFn(Function):
     """Query positional embedding: init_factor (H*W, C) -> BiGRU(C*H -> C*H/2 per direction) whose TIME axis is
     the sample axis (reference quirk) -> (B, H, W, C)."""

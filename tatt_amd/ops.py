@@ -560,6 +560,64 @@ def attn_bwd(Q, K, V, dctx, dwavg, pdrop, seed, site):
     return dQ, dK, dV
 
 
+# --------------------------------------------------------------------------------------------------
+# fused TP-interpreter layer (csrc/tplayer.hip)
+# --------------------------------------------------------------------------------------------------
+def tplayer_geom(B, L):
+    """-> (work-groups, dK/dV records per work-group, floats of kvpart, floats of ppart) of a fused-layer launch."""
+    out = (ctypes.c_int * 4)()
+    call("tatt_tplayer_geom", int(B), int(L), out)
+    return out[0], out[1], out[2], out[3]
+
+
+def _tpl_weights(lp, lnF):
+    """Pointer list shared by tatt_tplayer_fwd / _bwd: lp = (in_w, in_b, out_w, out_b, w1, b1, w2, b2, lnA_w, lnA_b, lnB_w, lnB_b)."""
+    return [P(t) for t in lp] + [P(lnF[0]) if lnF else None, P(lnF[1]) if lnF else None]
+
+
+def tplayer_fwd(x, qpos, K, V, lp, lnF, fin_scale, fin_both, p_attn, p_res, p_ffn, seed, site0, eps, want_xout, want_wavg):
+    """One fused transformer layer (see tatt_tplayer_fwd).  x (B,L,64); qpos (B,L,64) or (L,64); K, V (B,S,64).
+    -> (xout or None, fin or None, wavg or None)"""
+    _check_dev(x)
+    B, L, E = x.shape
+    S = K.shape[1]
+    assert E == 64 and K.shape == (B, S, 64) and V.shape == K.shape and x.is_contiguous() and qpos.is_contiguous()
+    qbs = L * 64 if qpos.dim() == 3 else 0
+    xout = torch.empty_like(x) if want_xout else None
+    fin = torch.empty_like(x) if lnF else None
+    wavg = new(x, B, L, S) if want_wavg else None
+    call("tatt_tplayer_fwd", P(x), P(qpos), qbs, P(K), P(V), *_tpl_weights(lp, lnF), float(fin_scale), int(fin_both), P(xout), P(fin),
+         P(wavg), B, L, S, float(p_attn), float(p_res), float(p_ffn), P(seed), int(site0), float(eps), stream())
+    return xout, fin, wavg
+
+
+def tplayer_bwd(x, qpos, K, V, lp, lnF, fin_scale, fin_both, p_attn, p_res, p_ffn, seed, site0, eps, dxout, dfin, dwavg, dqacc,
+                want_dqpos):
+    """-> dx, dqpos (or None), kvpart, ppart (partial records for tplayer_reduce_kv / tplayer_reduce_params)"""
+    B, L, E = x.shape
+    S = K.shape[1]
+    qbs = L * 64 if qpos.dim() == 3 else 0
+    _, _, nkv, npp = tplayer_geom(B, L)
+    dx = torch.empty_like(x)
+    dqpos = torch.empty_like(x) if want_dqpos else None
+    kvpart, ppart = new(x, nkv), new(x, npp)
+    call("tatt_tplayer_bwd", P(x), P(qpos), qbs, P(K), P(V), *_tpl_weights(lp, lnF), float(fin_scale), int(fin_both), P(dxout), P(dfin),
+         P(dwavg), P(dqacc), P(dx), P(dqpos), P(kvpart), P(ppart), B, L, S, float(p_attn), float(p_res), float(p_ffn), P(seed),
+         int(site0), float(eps), stream())
+    return dx, dqpos, kvpart, ppart
+
+
+def tplayer_reduce_kv(kvpart, B, L, S):
+    dK, dV = new(kvpart, B, S, 64), new(kvpart, B, S, 64)
+    call("tatt_tplayer_reduce_kv", P(kvpart), P(dK), P(dV), B, L, S, stream())
+    return dK, dV
+
+
+def tplayer_reduce_params(ppart, B, L, dsts, betaF=0.0):
+    """dsts: 14 tensors or None in the order of tatt_tplayer_reduce_params."""
+    call("tatt_tplayer_reduce_params", P(ppart), B, L, *[P(t) for t in dsts], float(betaF), stream())
+
+
 def tps_grid_fwd(ctrl, inv, pad, repr_):
     B, N, _ = ctrl.shape
     Pn = repr_.shape[0]

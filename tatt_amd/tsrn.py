@@ -299,6 +299,36 @@ def _query_pos(ig: TPInterpreter, B, H, W):
     return Fh.query_embedding(ig.init_factor.weight, ig.transformer.gru_encoding, B, H, W).reshape(B, H * W, C)
 
 
+def _enc_params(enc):
+    sa = enc.self_attn
+    return (sa.in_proj_weight, sa.in_proj_bias, sa.out_proj.weight, sa.out_proj.bias, enc.linear1.weight, enc.linear1.bias,
+            enc.linear2.weight, enc.linear2.bias, enc.norm1.weight, enc.norm1.bias, enc.norm2.weight, enc.norm2.bias)
+
+
+def _dec_params(dec):
+    ca = dec.multihead_attn
+    return (ca.in_proj_weight, ca.in_proj_bias, ca.out_proj.weight, ca.out_proj.bias, dec.linear1.weight, dec.linear1.bias,
+            dec.linear2.weight, dec.linear2.bias, dec.norm2.weight, dec.norm2.bias, dec.norm3.weight, dec.norm3.bias)
+
+
+TP_FUSED = True          # test hook: False walks the operator-by-operator path for every geometry (tests compare the two)
+
+
+def _tp_fusable(ig: TPInterpreter, L):
+    """The one-kernel-per-layer path (csrc/tplayer.hip) covers the geometry the reference instantiates (model/tsrn.py:175-182):
+    d_model 64, 4 heads, dim_feedforward 64, one encoder layer, one or two decoder layers, at most 32 prior steps."""
+    tr = ig.transformer
+    enc, decs = tr.encoder.layers, tr.decoder.layers
+    if not TP_FUSED:
+        return False
+    if len(enc) != 1 or not 1 <= len(decs) <= 2 or L > 32:
+        return False
+    for m, att in [(enc[0], enc[0].self_attn)] + [(d, d.multihead_attn) for d in decs]:
+        if att.embed_dim != 64 or att.num_heads != 4 or tuple(m.linear1.weight.shape) != (64, 64):
+            return False
+    return True
+
+
 def _tp_interpreter(feat, tp, ig: TPInterpreter, training, qpos=None):
     """TPInterpreter.forward (model/tsrn.py:194-224) + InfoTransformer.forward (model/transformer_v2.py:198-244).
     feat (B,H,W,C) NHWC block1 output; tp (B,37,1,26).  Returns tp_map (B,H,W,C), pr_weights (B,H*W,26)."""
@@ -313,16 +343,37 @@ def _tp_interpreter(feat, tp, ig: TPInterpreter, training, qpos=None):
     if drop:
         # pe(zeros) passes through Dropout(0.1) per sample (model/tsrn.py:214; transformer_v2.py:39-42)
         pos = Fh.dropout(pe.unsqueeze(0).expand(B, L, C).contiguous(), ig.pe.p, True, 1)
-        add_pos = Fh.add
     else:
         pos = pe
-        add_pos = Fh.AddRowBcastFn.apply
     if qpos is None:
         qpos = _query_pos(ig, B, H, W)
     tgt = feat.reshape(B, H * W, C)
-    # encoder: one layer fed with output + src = 2*src (transformer_v2.py:274)
+    src = Fh.ScaleFn.apply(x, 2.0)               # the encoder layer is fed with output + src = 2*src (transformer_v2.py:274)
+    if not _tp_fusable(ig, L):
+        return _tp_layers_unfused(src, pos, tgt, qpos, tr, drop, (B, H, W, C))
     enc = tr.encoder.layers[0]
-    src = Fh.ScaleFn.apply(x, 2.0)
+    pd = lambda v: float(v) if drop else 0.0
+    cfg = Fh.TPStackCfg((2,), pd(enc.self_attn.dropout), pd(enc.p), pd(enc.p), False, False, True, enc.norm1.eps)
+    memory, _ = Fh.TPStackFn.apply(_cc(src), _cc(pos), src, pos, cfg, *_enc_params(enc))
+    Fh.FWD_FORK.join(feat.device)              # the query embedding may have been a parallel branch until here
+    decs = list(tr.decoder.layers)
+    d0 = decs[0]
+    cfg = Fh.TPStackCfg([10 + 10 * i for i in range(len(decs))], pd(d0.multihead_attn.dropout), pd(d0.p), pd(d0.p), True, True,
+                        False, tr.decoder.norm.eps)
+    dparams = [t for d in decs for t in _dec_params(d)] + [tr.decoder.norm.weight, tr.decoder.norm.bias]
+    tp_tok, wts = Fh.TPStackFn.apply(_cc(tgt), _cc(qpos), memory, pos, cfg, *dparams)
+    return tp_tok.reshape(B, H, W, C), wts
+
+
+def _cc(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _tp_layers_unfused(src, pos, tgt, qpos, tr, drop, shape):
+    """The encoder / decoder layers operator by operator (any width, head count, depth): ~14 launches per layer."""
+    B, H, W, C = shape
+    add_pos = Fh.add if pos.dim() == 3 else Fh.AddRowBcastFn.apply
+    enc = tr.encoder.layers[0]
     qk = add_pos(src, pos)
     a, _ = Fh.multihead_attention(qk, qk, src, enc.self_attn, drop, 2)
     src = Fh.layer_norm(src, a, enc.norm1, enc.p, drop, 3)
@@ -330,7 +381,7 @@ def _tp_interpreter(feat, tp, ig: TPInterpreter, training, qpos=None):
     memory = Fh.layer_norm(src, f, enc.norm2, enc.p, drop, 5)
     # decoder: cross-attention only (self-attention commented out upstream, :817-819)
     kmem = add_pos(memory, pos)
-    Fh.FWD_FORK.join(feat.device)              # the query embedding may have been a parallel branch until here
+    Fh.FWD_FORK.join(tgt.device)              # the query embedding may have been a parallel branch until here
     outs, wts = [], None
     for li, dec in enumerate(tr.decoder.layers):
         s0 = 10 + 10 * li
