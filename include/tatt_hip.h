@@ -91,6 +91,14 @@ int tatt_conv3_c64_fwd_ws(const float* x, const float* wl, const float* bias, fl
  * whole 9 x 64 contraction (v_mfma_f32_16x16x4_f32), no partial sums to exchange; wl = tatt_repack_conv_weight mode 6 / mode 7 */
 int tatt_conv3_c64_fwd_ws16(const float* x, const float* wl, const float* bias, float* y, int B, int H, int W,
                             int Cout, int act, float beta, hipStream_t st);
+/* tatt_conv3_c64_fwd_ws16 with BatchNorm folded in on either side (reference model/tsrn.py:877-886: conv -> bn -> mish -> conv -> bn):
+ * in_scale / in_shift (64 floats, nullable): input pixels pass through in_act(x * in_scale[c] + in_shift[c]) while the halo is
+ * staged (the producer's BatchNorm + activation; zero padding pads the transformed map); stats (nullable; Cout == 64, act none,
+ * beta 0): [min(256, B*H*W/64)][2][64] doubles, per-work-group sum and sum of squares of the output per channel = the stage-1
+ * partials tatt_bn_stats_finish turns into mean / rstd / running statistics. */
+int tatt_conv3_c64_fwd_ws16_bn(const float* x, const float* wl, const float* bias, float* y, int B, int H, int W,
+                               int Cout, int act, float beta, const float* in_scale, const float* in_shift, int in_act,
+                               double* stats, hipStream_t st);
 /* weight-gradient partials part[G][9*Cin][Cout] (G persistent work-groups, G <= B*H*W/64) and, if pdb != NULL, bias-gradient
  * partials pdb[G][Cout] (the column sums of dy the kernel streams anyway; nn.Conv2d's bias gradient); finish with
  * tatt_splitk_reduce(part, dw_oihw, 9*Cin, Cout, G, Cin, 9, beta, db, Cout) where pdb = part + G*9*Cin*Cout */
@@ -122,6 +130,11 @@ int tatt_colsum(const float* X, long ld, int M, int C, float* out, float scale, 
  * ws >= 256*2*C doubles */
 int tatt_bn_stats(const float* X, long ld, int M, int C, float eps, float momentum, float* mean,
                   float* rstd, float* running_mean, float* running_var, double* ws, hipStream_t st);
+/* stage 2 of tatt_bn_stats alone: part [G][2][C] doubles (per-block sum, sum of squares; e.g. from tatt_conv3_c64_fwd_ws16_bn) ->
+ * mean, rstd, running statistics; scale / shift (nullable): gamma * rstd and beta - mean * gamma * rstd, the folded affine map */
+int tatt_bn_stats_finish(const double* part, int G, int C, int M, float eps, float momentum, const float* gamma,
+                         const float* beta, float* mean, float* rstd, float* running_mean, float* running_var, float* scale,
+                         float* shift, hipStream_t st);
 /* eval mode: rstd = 1/sqrt(running_var + eps) */
 int tatt_bn_rstd(const float* var, float* rstd, int C, float eps, hipStream_t st);
 /* Y = act((X - mean) * rstd * gamma + beta) */

@@ -23,6 +23,9 @@ struct Conv3P {
     const float* x; const float* w; const float* bias; float* y;
     int B, H, W, Cin, Cout, act;
     float beta;
+    // ws16 kernel only: BatchNorm folded into the convolution on either side (reference model/tsrn.py:877-886: conv -> bn -> mish -> conv -> bn)
+    const float* in_scale; const float* in_shift; int in_act;    // input pixels pass through act(x * scale[c] + shift[c]) while the halo is staged
+    double* stats;                                               // [work-group][2][64]: sum / sum of squares of the output per channel
 };
 // ---- filter re-staged through LDS per tap (any multiple of 64 input channels) ------------------------------------------------
 // Persistent work-groups; the [co][CK ci] filter slice of each tap and 1/9 of the next halo are prefetched global -> registers
@@ -397,8 +400,19 @@ __global__ __launch_bounds__(512, 1) void conv3_c64_ws16_kernel(Conv3P p) {
         cb = x % cob;
         pt = (x / cob) * (stride / xg) + m;
     }
-    if (pt >= npt) return;
+    __shared__ float st_red[2][2][64];                       // [pixel half][sum, sum of squares][channel]
+    if (pt >= npt) {
+        if (p.stats && t < 128) p.stats[(long)blockIdx.x * 128 + t] = 0.0;
+        return;
+    }
     const int co0 = cb * 64 + cq * 16;
+    // BatchNorm + activation of the PRODUCER applied while the halo is staged: this thread always stages channels 4 (t & 15) ..
+    f32x4 isc = (f32x4){1.f, 1.f, 1.f, 1.f}, ish = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (p.in_scale) {
+        isc = *reinterpret_cast<const f32x4*>(p.in_scale + 4 * (t & 15));
+        ish = *reinterpret_cast<const f32x4*>(p.in_shift + 4 * (t & 15));
+    }
+    float st_s = 0.f, st_q = 0.f;                            // statistics of output channel co0 + (lane & 15) over this lane's pixels
     f32x4 wq[36];                                             // [tap * 4 + g][u]: input channel 16 g + 4 (lane >> 4) + u, output channel co0 + (lane & 15)
     {
         const f32x4* wsrc = reinterpret_cast<const f32x4*>(p.w) + (long)(cb * 4 + cq) * 36 * 64 + lane;
@@ -414,8 +428,16 @@ __global__ __launch_bounds__(512, 1) void conv3_c64_ws16_kernel(Conv3P p) {
         const int pix = idx >> 4, r = pix / C3_HW, px = pix - r * C3_HW;
         const int hh = h + r - 1, ww = w0 + px - 1;
         f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (idx < 3 * C3_HW * 16 && hh >= 0 && hh < p.H && ww >= 0 && ww < p.W)
+        if (idx < 3 * C3_HW * 16 && hh >= 0 && hh < p.H && ww >= 0 && ww < p.W) {
             v = *reinterpret_cast<const f32x4*>(p.x + (((long)n * p.H + hh) * p.W + ww) * 64 + 4 * (idx & 15));
+            if (p.in_scale) {                                // (the zero padding stays zero: it pads the TRANSFORMED map)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float u = fmaf(v[e], isc[e], ish[e]);
+                    v[e] = p.in_act == ACT_MISH ? mish_f(u) : (p.in_act == ACT_RELU ? fmaxf(u, 0.f) : u);
+                }
+            }
+        }
         return v;
     };
     auto halo_store = [&](float* Xs, int idx, f32x4 v) {
@@ -476,6 +498,7 @@ __global__ __launch_bounds__(512, 1) void conv3_c64_ws16_kernel(Conv3P p) {
                     float v = apply_act(acc[m][r] + bj, p.act);
                     if (p.beta != 0.f) v += p.beta * *dst;
                     *dst = v;
+                    st_s += v; st_q += v * v;
                 }
         }
         if (!has_next) break;
@@ -483,13 +506,36 @@ __global__ __launch_bounds__(512, 1) void conv3_c64_ws16_kernel(Conv3P p) {
         pt = npt_next; n = nn; h = nh; w0 = nw0;
         xbuf ^= 1;
     }
+    if (p.stats) {
+        // per-channel sum / sum of squares of everything this work-group wrote: lanes of a channel, then the two pixel halves
+        st_s += __shfl_xor(st_s, 16, 64); st_s += __shfl_xor(st_s, 32, 64);
+        st_q += __shfl_xor(st_q, 16, 64); st_q += __shfl_xor(st_q, 32, 64);
+        if (lane < 16) { st_red[pxh][0][cq * 16 + lane] = st_s; st_red[pxh][1][cq * 16 + lane] = st_q; }
+        __syncthreads();
+        if (t < 128) p.stats[(long)blockIdx.x * 128 + t] = (double)st_red[0][t >> 6][t & 63] + (double)st_red[1][t >> 6][t & 63];
+    }
 }
 
+TATT_API int tatt_conv3_c64_fwd_ws16_bn(const float* x, const float* wl, const float* bias, float* y, int B, int H, int W,
+                                        int Cout, int act, float beta, const float* in_scale, const float* in_shift, int in_act,
+                                        double* stats, hipStream_t st);
 // wl = filter from tatt_repack_conv_weight mode 6 (forward) / mode 7 (data gradient of a 64-output-channel convolution)
 TATT_API int tatt_conv3_c64_fwd_ws16(const float* x, const float* wl, const float* bias, float* y, int B, int H, int W,
                                      int Cout, int act, float beta, hipStream_t st) {
+    return tatt_conv3_c64_fwd_ws16_bn(x, wl, bias, y, B, H, W, Cout, act, beta, nullptr, nullptr, 0, nullptr, st);
+}
+// The same convolution with BatchNorm folded in on either side:
+//   in_scale / in_shift (64 floats each, nullable): every input pixel passes through in_act(x * in_scale[c] + in_shift[c]) first
+//     (BatchNorm + activation of the producing layer, applied while the halo is staged; zero padding pads the transformed map);
+//   stats (nullable; Cout == 64, act == none, beta == 0): [grid][2][64] doubles -- per work-group sum and sum of squares of the
+//     output per channel, the stage-1 partials of tatt_bn_stats_finish; grid = min(256, B*H*W/64) work-groups.
+TATT_API int tatt_conv3_c64_fwd_ws16_bn(const float* x, const float* wl, const float* bias, float* y, int B, int H, int W,
+                                        int Cout, int act, float beta, const float* in_scale, const float* in_shift, int in_act,
+                                        double* stats, hipStream_t st) {
     if (Cout % 64 || W % C3_PX) return 1;
-    Conv3P p = {x, wl, bias, y, B, H, W, 64, Cout, act, beta};
+    if (stats && (Cout != 64 || act != ACT_NONE || beta != 0.f)) return 2;
+    if (in_scale && (!in_shift || in_act == ACT_TANH)) return 3;
+    Conv3P p = {x, wl, bias, y, B, H, W, 64, Cout, act, beta, in_scale, in_shift, in_act, stats};
     static std::once_flag attr_once;                 // C++11 call_once: safe if several host threads launch
     std::call_once(attr_once, [&] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_ws16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W16_LDS);

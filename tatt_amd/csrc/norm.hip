@@ -195,7 +195,10 @@ __global__ __launch_bounds__(256) void bn_stats_stage1_v4(const float* __restric
 // stage 2: mean / rstd (biased var) + running-stat update (unbiased var, momentum) -- one thread per channel
 __global__ __launch_bounds__(64 * S2_L) void bn_stats_stage2(const double* __restrict__ part, int G, int C, int M, float eps,
                                                              float momentum, float* __restrict__ mean, float* __restrict__ rstd,
-                                                             float* __restrict__ running_mean, float* __restrict__ running_var) {
+                                                             float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                             const float* __restrict__ gamma = nullptr,
+                                                             const float* __restrict__ beta = nullptr,
+                                                             float* __restrict__ scale = nullptr, float* __restrict__ shift = nullptr) {
     __shared__ double sh[2][S2_L][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + tx;
@@ -214,6 +217,11 @@ __global__ __launch_bounds__(64 * S2_L) void bn_stats_stage2(const double* __res
     if (var < 0.0) var = 0.0;
     mean[c] = (float)mu;
     rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (scale) {                                             // the affine map a consumer folds into its input staging
+        const float sc = gamma[c] * rstd[c];
+        scale[c] = sc;
+        shift[c] = beta[c] - mean[c] * sc;
+    }
     if (running_mean) {
         double unb = M > 1 ? var * ((double)M / (M - 1)) : var;
         running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
@@ -229,6 +237,14 @@ TATT_API int tatt_bn_stats(const float* X, long ld, int M, int C, float eps, flo
     else hipLaunchKernelGGL(bn_stats_stage1, dim3(G), dim3(256), 0, st, X, ld, M, C, rpb, ws);
     hipLaunchKernelGGL(bn_stats_stage2, dim3(cdiv(C, 64)), dim3(64 * S2_L), 0, st, ws, G, C, M, eps, momentum, mean, rstd,
                        running_mean, running_var);
+    return LAUNCH_CHECK();
+}
+TATT_API int tatt_bn_stats_finish(const double* part, int G, int C, int M, float eps, float momentum, const float* gamma,
+                                  const float* beta, float* mean, float* rstd, float* running_mean, float* running_var,
+                                  float* scale, float* shift, hipStream_t st) {
+    if (scale && (!gamma || !beta || !shift)) return 1;
+    hipLaunchKernelGGL(bn_stats_stage2, dim3(cdiv(C, 64)), dim3(64 * S2_L), 0, st, part, G, C, M, eps, momentum, mean, rstd,
+                       running_mean, running_var, gamma, beta, scale, shift);
     return LAUNCH_CHECK();
 }
 // eval mode: rstd from running_var

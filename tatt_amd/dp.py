@@ -133,6 +133,10 @@ def broadcast_model(flat: FlatParams, model: torch.nn.Module, group=None, src: i
             t = b.contiguous()
             dist.broadcast(t, src, group=group)
             b.copy_(t)
+    if flat.p.is_cuda:
+        # the weights changed behind torch's version counters (writes through the flat buffer): packed filter copies are stale
+        from . import ops
+        ops.PACKED.refresh(flat.p.device)
 
 
 def allreduce_bucket(flat: FlatParams, k: int, group=None, async_op: bool = False):

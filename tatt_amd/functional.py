@@ -261,6 +261,98 @@ def batch_norm_act(x, bn, act=ACT_NONE, count=True):
 
 
 # --------------------------------------------------------------------------------------------------
+class ConvBnFn(Function):
+    """3x3 convolution 64 -> 64 with BatchNorm (train mode) folded in on both sides (reference RecurrentResidualBlock:
+    conv1 -> bn1 -> mish -> conv2 -> bn2, model/tsrn.py:877-886,896-903; block7, :609-614):
+
+      * input side (`in_*` given): x is the PRE-BatchNorm output of the producing convolution; in_act(x * in_scale + in_shift) is
+        applied while the kernel stages its halo, so the normalised + activated map is never written to HBM;
+      * output side: the per-channel sum / sum of squares of y leave the convolution's epilogue as per-work-group partials and one
+        small launch turns them into mean / rstd / running statistics and the folded (scale, shift) of THIS layer's BatchNorm.
+
+    Returns y (raw convolution output) and mean, rstd, scale, shift of its BatchNorm (not differentiable: whoever applies the
+    BatchNorm -- the next ConvBnFn through `in_*`, or BatchNormApplyFn -- back-propagates through the statistics).
+    conv | stats1 | stats2 | apply | conv | ...  ->  conv(+stats) | finish | conv(+apply, +stats) | finish."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, momentum, eps,
+                in_mean, in_rstd, in_gamma, in_beta, in_scale, in_shift, in_act):
+        B, H, W, C = x.shape
+        y, part, G = ops.conv3_bn_forward(x, weight, bias, in_scale, in_shift, in_act, True)
+        mean, rstd, scale, shift = ops.bn_stats_finish(part, G, 64, B * H * W, eps, momentum, gamma, beta, running_mean, running_var)
+        folded = in_scale is not None
+        ctx.save_for_backward(x, weight, in_mean, in_rstd, in_gamma, in_beta)
+        ctx.folded, ctx.in_act, ctx.has_bias = folded, in_act, bias is not None
+        ctx.leaves = (weight, bias)
+        ctx.mark_non_differentiable(mean, rstd, scale, shift)
+        return y, mean, rstd, scale, shift
+
+    @staticmethod
+    def backward(ctx, dy, *_):
+        x, weight, in_mean, in_rstd, in_gamma, in_beta = ctx.saved_tensors
+        dy = _c(dy)
+        x2 = x.reshape(-1, 64)
+        dx = dgi = dbi = None
+        need_in = ctx.folded and (ctx.needs_input_grad[0] or ctx.needs_input_grad[11] or ctx.needs_input_grad[12])
+        if ctx.needs_input_grad[0] or need_in:
+            dr = ops.conv2d_dgrad(dy, weight)
+            if ctx.folded:
+                dx, dgi, dbi = ops.bn_bwd(x2, dr.reshape(-1, 64), in_mean, in_rstd, in_gamma, in_beta, ctx.in_act, True)
+                dx = dx.reshape(x.shape)
+            else:
+                dx = dr
+        want_dw, want_db = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+
+        def param_grads():
+            # the convolution's actual input (normalised + activated) is rebuilt here, off the critical path
+            xin = x if not ctx.folded else ops.bn_apply(x2, in_mean, in_rstd, in_gamma, in_beta, ctx.in_act).reshape(x.shape)
+            if want_dw and want_db:
+                return ops.conv_wgrad(xin, dy, 64, 3, 3, want_db=True)
+            dw = ops.conv_wgrad(xin, dy, 64, 3, 3) if want_dw else None
+            db = ops.colsum(dy.reshape(-1, 64)) if want_db else None
+            return dw, db
+        dw, db = SIDE.submit(ctx.leaves, param_grads, x, dy)
+        return (dx, dw, db) + (None,) * 8 + (dgi, dbi, None, None, None)
+
+
+class BatchNormApplyFn(Function):
+    """y = act((x - mean) * rstd * gamma + beta) for statistics computed elsewhere (ConvBnFn); the backward is the full train-mode
+    BatchNorm backward (the dependence of mean / rstd on x included)."""
+
+    @staticmethod
+    def forward(ctx, x, mean, rstd, gamma, beta, act):
+        C = x.shape[-1]
+        y = ops.bn_apply(x.reshape(-1, C), mean, rstd, gamma, beta, act).reshape(x.shape)
+        ctx.save_for_backward(x, mean, rstd, gamma, beta)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd, gamma, beta = ctx.saved_tensors
+        C = x.shape[-1]
+        dx, dg, db = ops.bn_bwd(x.reshape(-1, C), _c(dy).reshape(-1, C), mean, rstd, gamma, beta, ctx.act, True)
+        return dx.reshape(x.shape), None, None, dg, db, None
+
+
+def conv_bn(x, conv, bn, prev=None):
+    """conv: nn.Conv2d(64, 64, 3, padding=1), bn: its nn.BatchNorm2d (train mode), both parameter holders.
+    prev = (y_prev's ConvBnFn statistics tuple, bn_prev, act): fold bn_prev + act of the producing layer into this convolution.
+    -> (y, stats) with stats = (mean, rstd, scale, shift) of `bn` over y."""
+    if prev is None:
+        ins = (None,) * 6 + (ACT_NONE,)
+    else:
+        (pm, pr, ps, psh), pbn, pact = prev
+        ins = (pm, pr, pbn.weight, pbn.bias, ps, psh, pact)
+    out = ConvBnFn.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, *ins)
+    return out[0], tuple(out[1:])
+
+
+def bn_apply_stats(y, stats, bn, act=ACT_NONE):
+    return BatchNormApplyFn.apply(y, stats[0], stats[1], bn.weight, bn.bias, act)
+
+
+# --------------------------------------------------------------------------------------------------
 class LinearFn(Function):
     """y = act(alpha*(x @ W^T + b)); optional second input concatenated along the feature axis."""
 

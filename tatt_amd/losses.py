@@ -28,8 +28,7 @@ class ImageLoss(nn.Module):
         self.loss_weight = list(loss_weight)
 
     def forward(self, out_images, target_images, grad_mask=None):
-        if grad_mask is not None:
-            raise NotImplementedError("tatt_amd.losses.ImageLoss: grad_mask is not on the TATT recipe's path")
+        # grad_mask: accepted and ignored, exactly as the reference does (loss/image_loss.py:19-23 never reads it)
         w1 = float(self.loss_weight[1]) if self.gradient else 0.0
         return image_loss(out_images, target_images, (float(self.loss_weight[0]), w1))
 
@@ -43,7 +42,8 @@ class _SsimBase(nn.Module):
     def __init__(self, window_size=11, size_average=True):
         super().__init__()
         if window_size != 11:
-            raise NotImplementedError("the HIP SSIM kernels implement the recipe's 11x11 window")
+            # documented limit: every call site of the reference constructs SSIM() / TRI_SSIM() with the default
+            raise NotImplementedError("the HIP SSIM kernels implement the 11x11 window every reference call site uses")
         self.window_size, self.size_average = window_size, size_average
 
     def _reduce(self, per_sample):

@@ -191,7 +191,10 @@ class _PackedFilters:
             return e[0]
         Cout, Cin, KH, KW = w.shape
         if e is None and len(self.entries) >= 1024:          # entries pin their parameter's storage: bound what a long-lived
-            self.entries.clear()                             # process that keeps building models can accumulate
+            # process that keeps building models can accumulate.  Buffers may be baked into captured hipGraphs: never evicted
+            # silently -- the owner of the old models calls clear() when their graphs are gone.
+            raise RuntimeError("tatt_amd.ops.PACKED holds 1024 packed filters; call tatt_amd.ops.PACKED.clear() once the models "
+                               "(and hipGraphs) that own them are released")
         out = e[0] if e is not None else torch.empty(_packed_numel(w.shape, mode), device=w.device, dtype=torch.float32)
         call("tatt_repack_conv_weight", P(w), P(out), Cout, Cin, KH, KW, mode, stream())
         self.entries[key] = (out, w._version, w.detach())
@@ -243,7 +246,7 @@ def conv_fwd(x_bhwc, wpacked, bias, Cout, KH, KW, *, act=ACT_NONE, out=None, bet
     if tiles < 128 and nchunks >= 32:
         splitk = max(1, min(256 // tiles, nchunks // 8))
         if splitk > 1:
-            ws = new(x_bhwc, splitk * M * Cout)
+            ws = _split_ws(new(x_bhwc, splitk * M * Cout))       # (must outlive a deferred reduction, like every split-K slab)
     call("tatt_conv2d_fwd", P(x_bhwc), sn, sh, sw, sc, P(wpacked), P(bias), P(y), Cout, B, H, W, Cin, Cout, KH, KW,
          act, beta, splitk, P(ws), stream())
     return y
@@ -287,6 +290,35 @@ def conv2d_forward(x_bhwc, weight_oihw, bias, act=ACT_NONE):
         call("tatt_conv3_c64_fwd_t", P(x_bhwc), P(wt), P(bias), P(y), B, H, W, Cin, Cout, act, 0.0, stream())
         return y
     return conv_fwd(x_bhwc, repack_weight(weight_oihw, 0), bias, Cout, KH, KW, act=act)
+
+
+def conv3_bn_fusable(x_bhwc, weight_oihw):
+    """The 3x3 64 -> 64 convolutions of the residual blocks / block7 on a contiguous NHWC map whose width is a multiple of 64: the
+    weight-stationary kernel can fold the producer's BatchNorm into its input staging and emit this layer's batch statistics."""
+    return (_CONV3_WS and CONV3_WS == "16" and tuple(weight_oihw.shape) == (64, 64, 3, 3) and x_bhwc.is_contiguous()
+            and x_bhwc.shape[3] == 64 and x_bhwc.shape[2] % 64 == 0)
+
+
+def conv3_bn_forward(x_bhwc, weight_oihw, bias, in_scale=None, in_shift=None, in_act=ACT_NONE, want_stats=True):
+    """y = conv3x3(in_act(x * in_scale + in_shift)) + bias (no transform without in_scale) and, with want_stats, the stage-1
+    partials of y's per-channel batch statistics ([G][2][64] doubles) -> (y, part, G)."""
+    _check_dev(x_bhwc)
+    B, H, W, _ = x_bhwc.shape
+    y = new(x_bhwc, B, H, W, 64)
+    G = min(256, B * H * (W // 64))
+    part = new(x_bhwc, G * 128, dtype=torch.float64) if want_stats else None
+    call("tatt_conv3_c64_fwd_ws16_bn", P(x_bhwc), P(repack_weight(weight_oihw, 6)), P(bias), P(y), B, H, W, 64, ACT_NONE, 0.0,
+         P(in_scale), P(in_shift), int(in_act), P(part), stream())
+    return y, part, G
+
+
+def bn_stats_finish(part, G, C, M, eps, momentum, gamma, beta, running_mean, running_var):
+    """stage-1 partials -> mean, rstd, and the folded affine map scale = gamma * rstd, shift = beta - mean * scale; updates the
+    running statistics (reference nn.BatchNorm2d in train mode)."""
+    mean, rstd, scale, shift = new(gamma, C), new(gamma, C), new(gamma, C), new(gamma, C)
+    call("tatt_bn_stats_finish", P(part), G, C, M, float(eps), float(momentum), P(gamma), P(beta), P(mean), P(rstd),
+         P(running_mean), P(running_var), P(scale), P(shift), stream())
+    return mean, rstd, scale, shift
 
 
 def conv2d_dgrad(dy_bhwc, weight_oihw):

@@ -173,11 +173,20 @@ class TssimRecipe:
         with torch.no_grad():
             x_rot, hr_rot = rot(x, self.theta_pos), rot(hr, self.theta_pos)
             x_ret = rot(x_rot, self.theta_neg)
-        sr = model(x_rot, tp)[0]
-        sr_ret = model(x_ret, tp)[0]
+        # generators that take no external prior (TSRN, TBSRN, TextPriorSR: its student recogniser reads the rotated LR image, as the
+        # reference's loop does, interfaces/super_resolution.py:786-815) are called with the image alone
+        fwd = (lambda im: model(im, tp)) if tp is not None else model
+        out = fwd(x_rot)
+        sr = out[0] if isinstance(out, tuple) else out
+        # the distillation term belongs to the FIRST forward (student prior on x_rot vs teacher prior on hr_rot, :767,879); it has to be
+        # taken before the second forward overwrites the model's cached student prior
+        extra = model.extra_loss(hr_rot) if hasattr(model, "extra_loss") else None
+        out = fwd(x_ret)
+        sr_ret = out[0] if isinstance(out, tuple) else out
         l_img = image_loss_mean(sr, hr_rot, scale=100.0)
         l_tssim = (1.0 - TRI_SSIM()(rot(sr_ret, self.theta_pos), sr, hr_rot)) * 10.0
-        return l_img + l_tssim
+        loss = l_img + l_tssim
+        return loss if extra is None else loss + extra
 
 
 class HipStepKernels:
@@ -253,9 +262,9 @@ class Trainer:
         # id(parameter) -> its bucket: a deferred weight-gradient closure runs with the side lane of that stage (or of the stage
         # that produced it, whichever is later), so that the bucket is complete when that side lane gathers it
         self._due = {id(p): k for k, (_, ps) in enumerate(buckets or []) for p in ps}
+        # installed on the model only while a step's forward runs (_main_lane): a forward made outside the Trainer -- a plain
+        # loss.backward() loop, a gradient check -- sees an ordinary, uncut graph
         self.cuts = GradCuts() if staged and len(self.stages) > 1 else None
-        if hasattr(model, "set_grad_cuts"):
-            model.set_grad_cuts(self.cuts)
         self.params = self.flat.params
         self.n = self.flat.n
         self.flat_p, self.flat_g = self.flat.p, self.flat.g
@@ -299,6 +308,7 @@ class Trainer:
                     p.grad = None
                 if self.cuts is not None:
                     self.cuts.reset()
+                    self.model.set_grad_cuts(self.cuts)
                 if self.recipe is not None:
                     loss = self.recipe.loss(self.model, x, tp, hr)
                 else:
@@ -315,6 +325,8 @@ class Trainer:
         finally:
             Fh.SIDE.enabled = False
             Fh.FWD_FORK.enabled = False
+            if k == 0 and self.cuts is not None:
+                self.model.set_grad_cuts(None)
         if k == len(self.stages) - 1 and hasattr(self.model, "block"):
             self.model.block = None                  # do not keep the autograd graph of this step alive
 

@@ -279,10 +279,17 @@ def _gru_block(x, blk: GruBlock, vertical, x_cat=None):
 
 def _srb(x, tp_map, blk: RecurrentResidualBlock):
     """RecurrentResidualBlock[TL].forward (model/tsrn.py:862-871, 892-910).  (num_batches_tracked: bumped by the generator.)"""
-    r = Fh.conv2d(x, blk.conv1.weight, blk.conv1.bias)
-    r = Fh.batch_norm_act(r, blk.bn1, ACT_MISH, False)
-    r = Fh.conv2d(r, blk.conv2.weight, blk.conv2.bias)
-    r = Fh.batch_norm_act(r, blk.bn2, ACT_NONE, False)
+    if blk.bn1.training and blk.bn2.training and ops.conv3_bn_fusable(x, blk.conv1.weight) and ops.conv3_bn_fusable(x, blk.conv2.weight):
+        # conv(+stats) | finish | conv(+bn1, mish on the way in, +stats) | finish | apply bn2: 5 launches instead of 8, and the
+        # normalised + activated map between the two convolutions never exists in HBM
+        y1, st1 = Fh.conv_bn(x, blk.conv1, blk.bn1)
+        y2, st2 = Fh.conv_bn(y1, blk.conv2, blk.bn2, prev=(st1, blk.bn1, ACT_MISH))
+        r = Fh.bn_apply_stats(y2, st2, blk.bn2, ACT_NONE)
+    else:
+        r = Fh.conv2d(x, blk.conv1.weight, blk.conv1.bias)
+        r = Fh.batch_norm_act(r, blk.bn1, ACT_MISH, False)
+        r = Fh.conv2d(r, blk.conv2.weight, blk.conv2.bias)
+        r = Fh.batch_norm_act(r, blk.bn2, ACT_NONE, False)
     r = _gru_block(r, blk.gru1, True, x_cat=tp_map)
     return _gru_block(Fh.add(x, r), blk.gru2, False)
 
@@ -545,8 +552,12 @@ class _GeneratorBase(_TrainPathMixin, nn.Module):
         if cuts and k > 0:
             h = cuts.cut("srb%d" % (k - 1), h)
         b7 = getattr(self, "block%d" % (k + 2))
-        h = Fh.conv2d(h, b7[0].weight, b7[0].bias)
-        h = Fh.batch_norm_act(h, b7[1], ACT_NONE, False)
+        if b7[1].training and ops.conv3_bn_fusable(h, b7[0].weight):
+            y7, st7 = Fh.conv_bn(_cc(h), b7[0], b7[1])
+            h = Fh.bn_apply_stats(y7, st7, b7[1], ACT_NONE)
+        else:
+            h = Fh.conv2d(h, b7[0].weight, b7[0].bias)
+            h = Fh.batch_norm_act(h, b7[1], ACT_NONE, False)
         feats[str(k + 2)] = h
         b8 = getattr(self, "block%d" % (k + 3))
         u = Fh.add(b1_trunk, h)

@@ -243,3 +243,65 @@ def test_text_prior_sr_with_teacher_through_the_trainer(dev):
     tr = Trainer(m, use_graph=True, warmup_eager=2)
     ls = [float(tr.step(x, None, hr)) for _ in range(5)]
     assert abs(ls[0] - want) < 1e-6 * abs(want) and all(l == l for l in ls) and ls[-1] < ls[0]
+
+
+@pytest.mark.gpu
+def test_tssim_recipe_with_text_prior_generator_and_plain_tsrn(dev):
+    """The shipped configuration (train_TATT.sh: --use_distill --tssim_loss --rotate_train=5): the student recogniser reads the
+    ROTATED LR image and the distillation term (student prior on x_rot vs teacher prior on hr_rot, x100) is added to the recipe's
+    loss (reference interfaces/super_resolution.py:786-815,879,910-914).  Trainer step (staged) == the same composition written
+    out with plain forwards and a single-pass backward; the recipe also drives generators that take no prior (TSRN)."""
+    import tatt_amd
+    from oracle.fixtures import make_inputs
+    from tatt_amd import functional as Fh
+    from tatt_amd.losses import TRI_SSIM
+    from tatt_amd.train import TextPriorSR, Trainer, TssimRecipe, image_loss_mean
+    kw = dict(scale_factor=2, width=128, height=32, STN=False, mask=True, srb_nums=5, hidden_units=32)
+
+    def build():
+        torch.manual_seed(1234)
+        sr_m = tatt_amd.TSRN_TL_TRANS(**kw)
+        sr_m.load_state_dict(randomize_state_dict(sr_m.state_dict()))
+        tpg = tatt_amd.CRNN(32, 1, 37, 256)
+        tpg.load_state_dict(_sd())
+        teacher = tatt_amd.CRNN(32, 1, 37, 256)
+        teacher.load_state_dict(randomize_state_dict(teacher.state_dict(), seed=5))
+        m = TextPriorSR(sr_m, tpg, teacher=teacher).to(dev).train()
+        sr_m.infoGen.dropout_on = False
+        return m
+    x, _, hr = make_inputs(3, seed=11)
+    x, hr = x.to(dev), hr.to(dev)
+    # written out: same angles as the recipe will draw
+    rec = TssimRecipe(5.0, seed=4)
+    rec.new_step(x)
+    rot = Fh.AffineSampleFn.apply
+    m = build()
+    with torch.no_grad():
+        x_rot, hr_rot = rot(x, rec.theta_pos), rot(hr, rec.theta_pos)
+        x_ret = rot(x_rot, rec.theta_neg)
+    sr = m(x_rot)[0]
+    dist = m.extra_loss(hr_rot)
+    sr_ret = m(x_ret)[0]
+    loss = image_loss_mean(sr, hr_rot, scale=100.0) + (1.0 - TRI_SSIM()(rot(sr_ret, rec.theta_pos), sr, hr_rot)) * 10.0 + dist
+    loss.backward()
+    want, g_ref = float(loss), m.tpg.rnn[1].embedding.weight.grad.clone()
+    assert float(dist) > 0.0
+    for use_graph in (False, True):
+        m = build()
+        tr = Trainer(m, use_graph=use_graph, warmup_eager=2, recipe=TssimRecipe(5.0, seed=4))
+        got = float(tr.step(x, None, hr))
+        assert abs(got - want) < 2e-6 * abs(want), (use_graph, got, want)
+        if not use_graph:
+            assert rel_err(m.tpg.rnn[1].embedding.weight.grad, g_ref) < 1e-4
+        ls = [float(tr.step(x, None, hr)) for _ in range(4)]
+        assert all(l == l for l in ls)
+    # a generator without a prior under the recipe
+    torch.manual_seed(1)
+    t = tatt_amd.TSRN(**kw).to(dev).train()
+    tr = Trainer(t, use_graph=False, recipe=TssimRecipe(5.0, seed=2))
+    l0 = float(tr.step(x, None, hr))
+    assert l0 == l0 and l0 > 0.0
+    # and the Trainer leaves the model uncut: a plain forward/backward reaches every stage's parameters
+    out = t(x)
+    out.sum().backward()
+    assert t.block1[0].weight.grad is not None and float(t.block1[0].weight.grad.abs().max()) > 0.0

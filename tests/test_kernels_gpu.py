@@ -674,3 +674,48 @@ def test_conv9_mfma_toeplitz(dev, B, H, W):
     # the packed-filter cache follows an in-place update of the weights
     wd.mul_(2.0)
     check_close("conv9_mfma_fwd_after_update", ops.conv2d_forward(xd, wd, bd), (2 * (ref - b.double()) + b.double()).float(), 4e-4, 4e-4)
+
+
+# ------------------------------------------------------------------------------------------- conv + BatchNorm folding
+@pytest.mark.parametrize("B,H,W", [(2, 16, 64), (5, 3, 128)])
+def test_conv_bn_folded_equals_operator_chain(dev, B, H, W):
+    """conv -> bn -> mish -> conv -> bn with the statistics taken from the convolution's epilogue and bn + mish applied while the
+    next convolution stages its input (ConvBnFn / BatchNormApplyFn) == the operator chain conv2d | batch_norm_act | conv2d |
+    batch_norm_act (reference model/tsrn.py:877-886): outputs, running statistics, every gradient."""
+    from tatt_amd import functional as Fh
+    from tatt_amd.tsrn import RecurrentResidualBlock
+    from tatt_amd.ops import ACT_MISH, ACT_NONE
+    torch.manual_seed(5)
+    res = []
+    for folded in (True, False):
+        torch.manual_seed(5)
+        blk = RecurrentResidualBlock(64, 0).to(dev).train()
+        with torch.no_grad():
+            for bn in (blk.bn1, blk.bn2):
+                bn.weight.add_(0.3 * R(64).to(dev))
+                bn.bias.add_(0.3 * R(64, seed=1).to(dev))
+        x = (R(B, H, W, 64, seed=2) + 0.5).to(dev).requires_grad_(True)
+        if folded:
+            y1, st1 = Fh.conv_bn(x, blk.conv1, blk.bn1)
+            y2, st2 = Fh.conv_bn(y1, blk.conv2, blk.bn2, prev=(st1, blk.bn1, ACT_MISH))
+            out = Fh.bn_apply_stats(y2, st2, blk.bn2, ACT_NONE)
+        else:
+            r = Fh.conv2d(x, blk.conv1.weight, blk.conv1.bias)
+            r = Fh.batch_norm_act(r, blk.bn1, ACT_MISH, False)
+            r = Fh.conv2d(r, blk.conv2.weight, blk.conv2.bias)
+            out = Fh.batch_norm_act(r, blk.bn2, ACT_NONE, False)
+        (out * R(B, H, W, 64, seed=3).to(dev)).sum().backward()
+        d = {"out": out, "dx": x.grad}
+        for n in ("conv1.weight", "conv1.bias", "conv2.weight", "conv2.bias", "bn1.weight", "bn1.bias", "bn2.weight", "bn2.bias"):
+            d["g." + n] = blk.get_parameter(n).grad
+        for n in ("bn1.running_mean", "bn1.running_var", "bn2.running_mean", "bn2.running_var"):
+            d[n] = blk.get_buffer(n)
+        res.append({k: v.detach().float().cpu().clone() for k, v in d.items()})
+    bad = []
+    for k in res[0]:
+        ref = float(res[1][k].abs().max()) + 1e-12
+        noise = k in ("g.conv1.bias", "g.conv2.bias")          # mathematically zero (a bias in front of a BatchNorm): round-off only
+        err = float((res[0][k] - res[1][k]).abs().max()) / (1.0 if noise else ref)
+        if not err < (1e-3 if noise else 2e-4):
+            bad.append("%s: %.3e" % (k, err))
+    assert not bad, "\n".join(bad)

@@ -427,16 +427,17 @@ def case_train_large(ref, report):
     np.savez_compressed(os.path.join(OUT, "large_train_b2.npz"), **save)
 
 
-def case_fp64_error_bars(ref, report):
+def case_fp64_error_bars(ref, report, B=4, fname="fp64_error_bars.npz", seed=None):
     """How far is the REFERENCE's own fp32 gradient from the fp64 gradient of the same graph?  The tatt_train_b4 case again (same seed,
     weights and inputs): reference fp32 backward vs the oracle evaluated in fp64.  Stores, per parameter tensor,
     ||g_ref32 - g_64|| / ||g_64|| -- the yardstick tests/test_model_gpu.py::test_gradients_vs_fp64 holds the HIP gradients to
-    (the fp64 gradients themselves are recomputed by the oracle on the test host: 60 MB would be too much to commit)."""
+    (the fp64 gradients themselves are recomputed by the oracle on the test host: 60 MB would be too much to commit).
+    B = 48 (`fp64_error_bars_b48.npz`, inputs make_inputs(48, seed=48)): the same yardstick at the benchmarked batch, STN on."""
     m = build_ref(ref, "TSRN_TL_TRANS", scale_factor=2, width=128, height=32, STN=True, mask=True, srb_nums=5, hidden_units=32)
     m.train()
     set_dropout_eval(m)
     sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
-    x, tp, hr = make_inputs(4)
+    x, tp, hr = make_inputs(B) if seed is None else make_inputs(B, seed=seed)
     loss = ref_image_loss()(m(x, tp)[0], hr).mean() * 100
     m.zero_grad()
     loss.backward()
@@ -452,9 +453,9 @@ def case_fp64_error_bars(ref, report):
         ref_err.append(float((g.double() - d).norm()) / den)
         ora_err.append(float((o32[k].double() - d).norm()) / den)
     i = int(np.argmax(ref_err))
-    report.append("fp64 yardstick loss fp64 %.7f (ref fp32 %.6f); worst ||g_ref32 - g_64||/||g_64|| = %.3e (%s); oracle fp32: %.3e"
-                  % (float(l64), float(loss), ref_err[i], keys[i], max(ora_err)))
-    np.savez_compressed(os.path.join(OUT, "fp64_error_bars.npz"), keys=np.array(keys), ref32_err=np.array(ref_err),
+    report.append("fp64 yardstick B=%d loss fp64 %.7f (ref fp32 %.6f); worst ||g_ref32 - g_64||/||g_64|| = %.3e (%s); oracle fp32: %.3e"
+                  % (B, float(l64), float(loss), ref_err[i], keys[i], max(ora_err)))
+    np.savez_compressed(os.path.join(OUT, fname), keys=np.array(keys), ref32_err=np.array(ref_err),
                         oracle32_err=np.array(ora_err), loss64=np.float64(float(l64)), scale=np.float64(scale))
 
 
@@ -488,6 +489,12 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     ref = import_reference()
     report = ["golden vectors generated from /root/reference (torch %s, CPU fp32)" % torch.__version__]
+    if "--only-fp64-b48" in sys.argv:            # one case alone (appends its line to REPORT.txt)
+        case_fp64_error_bars(ref, report, B=48, fname="fp64_error_bars_b48.npz", seed=48)
+        with open(os.path.join(OUT, "REPORT.txt"), "a") as f:
+            f.write(report[-1] + "\n")
+        print(report[-1])
+        return
     case_kat(ref, report)
     std = dict(scale_factor=2, width=128, height=32, STN=True, mask=True, srb_nums=5, hidden_units=32)
     case_eval(ref, "tatt_eval_b2", "TSRN_TL_TRANS", 2, True, report, **std)
@@ -503,6 +510,7 @@ def main():
     case_losses(ref, report)
     case_train_large(ref, report)
     case_fp64_error_bars(ref, report)
+    case_fp64_error_bars(ref, report, B=48, fname="fp64_error_bars_b48.npz", seed=48)
     case_bench_losses(ref, report)
     with open(os.path.join(OUT, "REPORT.txt"), "w") as f:
         f.write("\n".join(report) + "\n")
