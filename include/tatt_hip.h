@@ -69,10 +69,13 @@ int tatt_repack_conv_weight_batch(const float* const* ws, float* const* outs, co
  * floats stored behind the S slabs (the bias-gradient partials of tatt_conv3_c64_wgrad_partial) */
 int tatt_splitk_reduce(const float* partial, float* C, int M, int N, int S, int remap_cin, int remap_taps,
                        float beta, float* vec, int vec_len, hipStream_t st);
-/* on != 0: split-K reductions issued from now on (tatt_gemm / tatt_conv2d_wgrad with splitk > 1, tatt_splitk_reduce) are only
- * REGISTERED -- their partial slabs must stay allocated -- and are summed by one launch per 36 entries at tatt_reduce_flush or
- * tatt_reduce_defer(0): the 70 small reduction launches behind the weight-gradient GEMMs of a training step become 6.  Results
- * are undefined until the flush.  Accumulating reductions (beta != 0) flush and run immediately.  Host-side state: one thread. */
+/* on != 0: split-K reductions issued ON STREAM st from now on (tatt_gemm / tatt_conv2d_wgrad with splitk > 1, tatt_splitk_reduce)
+ * are only REGISTERED -- their partial slabs must stay allocated -- and are summed by one launch per 36 entries at
+ * tatt_reduce_flush(st) or tatt_reduce_defer(0, st): the 70 small reduction launches behind the weight-gradient GEMMs of a training
+ * step become 6.  Results are undefined until the flush.  Accumulating reductions (beta != 0) flush and run immediately.
+ * This is the ONLY host-side state the library keeps: one registration table per stream, guarded by a mutex -- callers that drive
+ * different streams (several trainers, several host threads) do not interact; calls on ONE stream must come from one thread at a
+ * time, as for any stream-ordered API. */
 int tatt_reduce_defer(int on, hipStream_t st);
 int tatt_reduce_flush(hipStream_t st);
 
@@ -240,6 +243,9 @@ int tatt_qgru_bwd_fused(const float* dgh_cur0, const float* dgh_cur1, const floa
  * bp (192) = [wih_f; wih_r] bc + [bih_f; bih_r]  (reference GruBlock.forward, model/tsrn.py:1075-1081) */
 int tatt_gru_compose(const float* wih_f, const float* wih_r, const float* bih_f, const float* bih_r,
                      const float* Wc, const float* bc, float* Wp, float* bp, int K, hipStream_t st);
+/* tatt_gru_compose for n GruBlocks in one launch (a generator composes all of its blocks once per forward): ptrs = HOST array of
+ * n x 8 device pointers (wih_f, wih_r, bih_f, bih_r, Wc, bc, Wp, bp), Ks = HOST array of the n conv input widths */
+int tatt_gru_compose_batch(const float* const* ptrs, const int* Ks, int n, hipStream_t st);
 /* ... and map the gradients of the composed projection back: dwih_d (96,64) = dWp_d Wc^T + dbp_d bc^T,
  * dWc (64,K) = sum_d wih_d^T dWp_d, dbc (64) = sum_d wih_d^T dbp_d; dwhh_d (96,32) = d-th diagonal block of dWhh (192,64) */
 int tatt_gru_tail(const float* dWp, const float* dbp, const float* Wc, const float* bc, const float* wih_f,

@@ -58,7 +58,11 @@ __device__ __forceinline__ float act_grad(float u, int act) {
 // ---- counter-based RNG for dropout ---------------------------------------------------------
 // keep-mask for element `idx` of dropout site `site`; `seed` is read from DEVICE memory so that a
 // captured hipGraph draws fresh masks on every replay (the host bumps the word between replays).
-__device__ __forceinline__ uint32_t mix32(uint64_t z) {
+// 32-bit counter hash: the murmur3 finaliser (a bijection of 2^32 with full avalanche) over the element index, keyed by the
+// (seed, site) pair before the first and between the two multiplies -- 3 integer multiplies + 9 simple ops per element.  (Round 2
+// used two 64-bit splitmix rounds: ~12 quarter-rate multiplies per element, a third of the instructions of the fused
+// transformer-layer kernel.)  The keys depend on (seed, site) only: wave-uniform, computed on the scalar unit.
+__device__ __forceinline__ uint32_t mix32(uint64_t z) {            // (key derivation / host-visible seed mixing)
     z += 0x9E3779B97F4A7C15ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
@@ -66,9 +70,33 @@ __device__ __forceinline__ uint32_t mix32(uint64_t z) {
     return (uint32_t)(z >> 32);
 }
 __device__ __forceinline__ bool dropout_keep(uint64_t seed, uint32_t site, uint64_t idx, uint32_t thresh) {
-    return mix32(seed ^ ((uint64_t)site << 40) ^ idx * 0xD1342543DE82EF95ull) >= thresh;
+    const uint32_t k0 = (uint32_t)seed ^ (site * 0x9E3779B9u);
+    const uint32_t k1 = (uint32_t)(seed >> 32) + site * 0x85EBCA77u;
+    uint32_t h = ((uint32_t)idx ^ k0) + (uint32_t)(idx >> 32) * 0x27D4EB2Fu;
+    h ^= h >> 16; h *= 0x85EBCA6Bu;
+    h += k1;
+    h ^= h >> 13; h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h >= thresh;
 }
 __device__ __forceinline__ uint32_t dropout_thresh(float p) { return (uint32_t)((double)p * 4294967296.0); }
+
+// ---- DPP lane exchanges (VALU rate; __shfl_xor compiles to ds_bpermute_b32, an LDS-pipe instruction) ------------------------
+// row = 16 consecutive lanes.  DPP_ROR(n): lane i of a row reads lane (i - n) mod 16 of its row; DPP_QXOR1 / 2: lane ^ 1 / ^ 2.
+#define DPP_ROR(n) (0x120 + (n))
+#define DPP_QXOR1 0xB1
+#define DPP_QXOR2 0x4E
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+// sum over the 16 lanes of a row, result in every lane
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_f<DPP_ROR(1)>(v); v += dpp_f<DPP_ROR(2)>(v); v += dpp_f<DPP_ROR(4)>(v); v += dpp_f<DPP_ROR(8)>(v);
+    return v;
+}
+__device__ __forceinline__ float quad_sum(float v) { v += dpp_f<DPP_QXOR1>(v); v += dpp_f<DPP_QXOR2>(v); return v; }
+__device__ __forceinline__ float quad_max(float v) { v = fmaxf(v, dpp_f<DPP_QXOR1>(v)); v = fmaxf(v, dpp_f<DPP_QXOR2>(v)); return v; }
 
 // ---- wave / block reductions -----------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

@@ -11,6 +11,8 @@
 // MFMA operand read  lane -> (row = lane&31, k = lane>>5)  is bank-conflict free).
 // Split-K (grid.y) writes raw partial tiles that tatt_splitk_reduce sums deterministically.
 #include "common.h"
+#include <mutex>
+#include <unordered_map>
 #include <stdlib.h>
 
 #define BM 64
@@ -697,43 +699,60 @@ __global__ __launch_bounds__(256) void splitk_reduce_batch_kernel(ReduceTable t)
     while (k + 1 < t.n && (int)blockIdx.x >= t.e[k + 1].block0) ++k;
     splitk_reduce_body(t.e[k], (long)blockIdx.x - t.e[k].block0);
 }
-static bool g_reduce_defer = false;
-static ReduceArgs g_reduce_pending[REDUCE_MAX];
-static int g_reduce_n = 0;
+// Host-side state of the deferred reductions, ONE RECORD PER STREAM (guarded by a mutex): hosts driving different streams -- two
+// trainers, two threads, the two lanes of one training step -- never see each other's registrations.
+struct ReduceState { bool defer = false; int n = 0; ReduceArgs pending[REDUCE_MAX]; };
+static std::mutex g_reduce_mu;
+static std::unordered_map<hipStream_t, ReduceState> g_reduce_states;
 static long reduce_blocks(const ReduceArgs& a) {
     long total = (long)a.Z * a.M * a.N;
     if (a.rowsum) total = (long)cdiv(total, 64) * 64 + (a.RM > 0 ? a.RM : a.M);   // extra thread range (64-aligned start) for the row sums
     return cdiv(total, 64);
 }
-static int reduce_flush(hipStream_t st) {
-    if (g_reduce_n == 0) return 0;
+static int reduce_flush_locked(ReduceState& rs, hipStream_t st) {
+    if (rs.n == 0) return 0;
     ReduceTable t;
-    t.n = g_reduce_n;
+    t.n = rs.n;
     int blocks = 0;
     for (int k = 0; k < t.n; ++k) {
-        t.e[k] = g_reduce_pending[k];
+        t.e[k] = rs.pending[k];
         t.e[k].block0 = blocks;
         blocks += (int)reduce_blocks(t.e[k]);
     }
-    g_reduce_n = 0;
+    rs.n = 0;
     hipLaunchKernelGGL(splitk_reduce_batch_kernel, dim3(blocks), dim3(256), 0, st, t);
     return LAUNCH_CHECK();
 }
+static int reduce_flush(hipStream_t st) {
+    std::lock_guard<std::mutex> lock(g_reduce_mu);
+    auto it = g_reduce_states.find(st);
+    return it == g_reduce_states.end() ? 0 : reduce_flush_locked(it->second, st);
+}
 static int reduce_submit(const ReduceArgs& a, hipStream_t st) {
-    if (!g_reduce_defer || a.beta != 0.f) {                       // an accumulating reduce must see earlier ones: flush, then run it
-        int rc = reduce_flush(st);
-        if (rc) return rc;
+    std::lock_guard<std::mutex> lock(g_reduce_mu);
+    auto it = g_reduce_states.find(st);
+    if (it == g_reduce_states.end() || !it->second.defer || a.beta != 0.f) {   // an accumulating reduce must see earlier ones: flush, then run it
+        if (it != g_reduce_states.end()) {
+            int rc = reduce_flush_locked(it->second, st);
+            if (rc) return rc;
+        }
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)reduce_blocks(a)), dim3(256), 0, st, a);
         return LAUNCH_CHECK();
     }
-    g_reduce_pending[g_reduce_n++] = a;
-    return g_reduce_n == REDUCE_MAX ? reduce_flush(st) : 0;
+    ReduceState& rs = it->second;
+    rs.pending[rs.n++] = a;
+    return rs.n == REDUCE_MAX ? reduce_flush_locked(rs, st) : 0;
 }
 // on != 0: split-K reductions issued from now on are only registered (their workspaces must stay allocated);
-// on == 0 (or tatt_reduce_flush): everything registered is reduced by one launch per 36 entries.  Host-side state, one thread.
+// on == 0 (or tatt_reduce_flush): everything registered ON THAT STREAM is reduced by one launch per 36 entries.
 TATT_API int tatt_reduce_defer(int on, hipStream_t st) {
-    g_reduce_defer = on != 0;
-    return on ? 0 : reduce_flush(st);
+    std::lock_guard<std::mutex> lock(g_reduce_mu);
+    if (on) { g_reduce_states[st].defer = true; return 0; }
+    auto it = g_reduce_states.find(st);
+    if (it == g_reduce_states.end()) return 0;
+    const int rc = reduce_flush_locked(it->second, st);
+    g_reduce_states.erase(it);
+    return rc;
 }
 TATT_API int tatt_reduce_flush(hipStream_t st) { return reduce_flush(st); }
 

@@ -511,6 +511,44 @@ TATT_API int tatt_gru_compose(const float* wih_f, const float* wih_r, const floa
                        bc, Wp, bp, K);
     return LAUNCH_CHECK();
 }
+// The same for up to GC_MAX GruBlocks in ONE launch (all ten of a generator, once per forward: the compositions depend on parameters only)
+#define GC_MAX 16
+struct GCEntry { const float* wih_f; const float* wih_r; const float* bih_f; const float* bih_r; const float* Wc; const float* bc;
+                 float* Wp; float* bp; int K; int block0; };
+struct GCTable { GCEntry e[GC_MAX]; int n; };
+__global__ void gru_compose_batch_kernel(GCTable t) {
+    int k = 0;
+    while (k + 1 < t.n && (int)blockIdx.x >= t.e[k + 1].block0) ++k;
+    const GCEntry& e = t.e[k];
+    const int K = e.K;
+    const int idx = ((int)blockIdx.x - e.block0) * blockDim.x + threadIdx.x;
+    if (idx >= 192 * (K + 1)) return;
+    const int row = idx / (K + 1), col = idx - row * (K + 1);
+    const float* w = (row < 96 ? e.wih_f : e.wih_r) + (row % 96) * 64;
+    float s0 = 0.f, s1 = 0.f;
+    if (col < K) {
+        for (int c = 0; c < 64; c += 2) { s0 = fmaf(w[c], e.Wc[c * K + col], s0); s1 = fmaf(w[c + 1], e.Wc[(c + 1) * K + col], s1); }
+        e.Wp[row * K + col] = s0 + s1;
+    } else {
+        for (int c = 0; c < 64; c += 2) { s0 = fmaf(w[c], e.bc[c], s0); s1 = fmaf(w[c + 1], e.bc[c + 1], s1); }
+        e.bp[row] = s0 + s1 + (row < 96 ? e.bih_f : e.bih_r)[row % 96];
+    }
+}
+// ptrs: HOST array of n x 8 device pointers (wih_f, wih_r, bih_f, bih_r, Wc, bc, Wp, bp per block); Ks: HOST array of n ints
+TATT_API int tatt_gru_compose_batch(const float* const* ptrs, const int* Ks, int n, hipStream_t st) {
+    for (int base = 0; base < n; base += GC_MAX) {
+        GCTable t;
+        t.n = n - base < GC_MAX ? n - base : GC_MAX;
+        int blocks = 0;
+        for (int k = 0; k < t.n; ++k) {
+            const float* const* q = ptrs + (long)(base + k) * 8;
+            t.e[k] = {q[0], q[1], q[2], q[3], q[4], q[5], const_cast<float*>(q[6]), const_cast<float*>(q[7]), Ks[base + k], blocks};
+            blocks += cdiv(192 * (Ks[base + k] + 1), 256);
+        }
+        hipLaunchKernelGGL(gru_compose_batch_kernel, dim3(blocks), dim3(256), 0, st, t);
+    }
+    return LAUNCH_CHECK();
+}
 // dW_ih_d (96x64) = dW'_d W_c^T + db'_d b_c^T ;  dW_c (64xK) = sum_d W_ih_d^T dW'_d ;  db_c (64) = sum_d W_ih_d^T db'_d ;
 // dW_hh_d (96x32) = the d-th diagonal block of dWhh (192x64) = dgh^T hprev
 __global__ void gru_tail_kernel(const float* __restrict__ dWp, const float* __restrict__ dbp,

@@ -49,10 +49,7 @@ struct TLP {
     float* dx; float* dqpos; float* kvpart; float* ppart; int span;
 };
 
-__device__ __forceinline__ float tl_sum16(float v) {
-    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-    return v;
-}
+__device__ __forceinline__ float tl_sum16(float v) { return row16_sum(v); }      // the 16 lanes of a token = one DPP row
 __device__ __forceinline__ f32x4 tl_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void tl_st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
@@ -194,7 +191,7 @@ __global__ __launch_bounds__(TL_NT, 1) void tplayer_kernel(TLP p) {
         const float mean = tl_sum16((v[0] + v[1]) + (v[2] + v[3])) * (1.f / 64.f);
         f32x4 d = v - mean;
         const float var = tl_sum16((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) * (1.f / 64.f);
-        rstd = 1.f / sqrtf(var + p.eps);
+        rstd = __builtin_amdgcn_rsqf(var + p.eps);
         xh = d * rstd;
     };
     // LayerNorm backward of a row quad: g = upstream gradient, xh = normalised row, gam = gamma quad -> gradient of the LN input
@@ -273,14 +270,12 @@ __global__ __launch_bounds__(TL_NT, 1) void tplayer_kernel(TLP p) {
                 pr[i] = s < p.S ? a : -INFINITY;
                 mx = fmaxf(mx, pr[i]);
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+            mx = quad_max(mx);                              // the four key lanes of a (token, head) are one quad
             float sum = 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) { pr[i] = (4 * i + au) < p.S ? __expf(pr[i] - mx) : 0.f; sum += pr[i]; }
-            sum += __shfl_xor(sum, 1, 64);
-            sum += __shfl_xor(sum, 2, 64);
-            const float inv = 1.f / sum;
+            sum = quad_sum(sum);
+            const float inv = __builtin_amdgcn_rcpf(sum);
             float* PS = T5 + (rt * 4 + ah) * TL_PSP;         // forward exchange buffer: T5..T6
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -292,7 +287,10 @@ __global__ __launch_bounds__(TL_NT, 1) void tplayer_kernel(TLP p) {
             }
             wave_lds_sync();
             f32x4 c4 = z4;
-            for (int s = 0; s < p.S; ++s) c4 += tl_ld4(Vs + s * TL_P + rc) * PS[s];
+            for (int s = 0; s < p.S; s += 2) {               // (rows / probabilities beyond S are zero)
+                const float2 pp = *reinterpret_cast<const float2*>(PS + s);
+                c4 += tl_ld4(Vs + s * TL_P + rc) * pp.x + tl_ld4(Vs + (s + 1) * TL_P + rc) * pp.y;
+            }
             tl_st4(T1 + rt * TL_P + rc, c4);                 // (every wave finished reading x + qpos at S2)
             if (!BWD && p.wavg) {
                 const float* P0 = T5 + (rt * 4) * TL_PSP;
@@ -480,8 +478,7 @@ __global__ __launch_bounds__(TL_NT, 1) void tplayer_kernel(TLP p) {
                 ds[i] = d;
                 dot = fmaf(pr[i], d, dot);
             }
-            dot += __shfl_xor(dot, 1, 64);
-            dot += __shfl_xor(dot, 2, 64);
+            dot = quad_sum(dot);
 #pragma unroll
             for (int i = 0; i < 8; ++i) ds[i] = pr[i] * (ds[i] - dot);
         }
@@ -499,7 +496,10 @@ __global__ __launch_bounds__(TL_NT, 1) void tplayer_kernel(TLP p) {
             tl_kvgrad(PSb, T2, wave & 3, wave >> 2, am, kq, accK);
             const float* PS = PSb + (rt * 4 + ah) * TL_PSP;
             f32x4 dq = z4;
-            for (int s = 0; s < p.S; ++s) dq += tl_ld4(Ks + s * TL_P + rc) * PS[s];
+            for (int s = 0; s < p.S; s += 2) {
+                const float2 pp = *reinterpret_cast<const float2*>(PS + s);
+                dq += tl_ld4(Ks + s * TL_P + rc) * pp.x + tl_ld4(Ks + (s + 1) * TL_P + rc) * pp.y;
+            }
             dq *= 0.25f;
             tl_st4(T5 + rt * TL_P + rc, dq);
             f32x4 xq = z4;                                   // x + qpos again (L2-resident; cheaper than 8 registers held all tile)

@@ -142,7 +142,29 @@ class _DeferredParamGrads:
         self._keep.clear()
 
 
-SIDE = _DeferredParamGrads()
+class _PerThread:
+    """One instance of `cls` per host thread behind a module-level name: the schedulers below carry the state of the training step
+    in flight (pending closures, the stage being run, dirty streams), and two trainers driven from two host threads must not see
+    each other's.  (Two trainers in ONE thread take turns: every step leaves the state clean.)"""
+
+    def __init__(self, cls):
+        object.__setattr__(self, "_cls", cls)
+        object.__setattr__(self, "_tls", __import__("threading").local())
+
+    def _get(self):
+        inst = getattr(self._tls, "inst", None)
+        if inst is None:
+            inst = self._tls.inst = self._cls()
+        return inst
+
+    def __getattr__(self, name):
+        return getattr(self._get(), name)
+
+    def __setattr__(self, name, value):
+        setattr(self._get(), name, value)
+
+
+SIDE = _PerThread(_DeferredParamGrads)
 
 
 class _ForwardFork:
@@ -177,7 +199,7 @@ class _ForwardFork:
             self._dirty.discard(k)
 
 
-FWD_FORK = _ForwardFork()
+FWD_FORK = _PerThread(_ForwardFork)
 
 
 def _c(t):
@@ -285,11 +307,14 @@ class ConvBnFn(Function):
         ctx.folded, ctx.in_act, ctx.has_bias = folded, in_act, bias is not None
         ctx.leaves = (weight, bias)
         ctx.mark_non_differentiable(mean, rstd, scale, shift)
+        ctx.set_materialize_grads(False)          # (otherwise autograd zero-fills a gradient for each of the four statistics: 4 launches)
         return y, mean, rstd, scale, shift
 
     @staticmethod
     def backward(ctx, dy, *_):
         x, weight, in_mean, in_rstd, in_gamma, in_beta = ctx.saved_tensors
+        if dy is None:
+            return (None,) * 16
         dy = _c(dy)
         x2 = x.reshape(-1, 64)
         dx = dgi = dbi = None
@@ -446,6 +471,37 @@ def bigru32(x, gru, vertical):
 
 
 # --------------------------------------------------------------------------------------------------
+class _Precomposed:
+    """Composed GruBlock projections (W_ih W_c, W_ih b_c + b_ih) of the forward in flight, keyed by the block's conv weight: a
+    generator composes all of its blocks with ONE launch at the start of its forward (`gru_precompose`) instead of one tiny launch
+    in front of every block's GEMM (10 dependent launches per TATT forward); GruBlockFn.forward pops its entry."""
+
+    def __init__(self):
+        self.table = {}
+
+
+_PRE = _PerThread(_Precomposed)
+
+
+def gru_precompose(blocks):
+    """blocks: GruBlock parameter holders (conv1 = 1x1 conv, gru = nn.GRU(64, 32, bidirectional)) on one device."""
+    import ctypes
+    blocks = [b for b in blocks if b.conv1.weight.is_cuda]
+    _PRE.table = {}
+    if not blocks:
+        return
+    ptrs, Ks, outs = [], [], {}
+    for b in blocks:
+        g, Wc = b.gru, b.conv1.weight
+        K = Wc.numel() // Wc.shape[0]
+        Wp, bp = ops.new(Wc, 192, K), ops.new(Wc, 192)
+        ptrs += [t.data_ptr() for t in (g.weight_ih_l0, g.weight_ih_l0_reverse, g.bias_ih_l0, g.bias_ih_l0_reverse, Wc, b.conv1.bias, Wp, bp)]
+        Ks.append(K)
+        outs[Wc.data_ptr()] = (Wp, bp, Wc._version)
+    ops.call("tatt_gru_compose_batch", (ctypes.c_void_p * len(ptrs))(*ptrs), (ctypes.c_int * len(Ks))(*Ks), len(Ks), ops.stream())
+    _PRE.table = outs
+
+
 class GruBlockFn(Function):
     """reference GruBlock (model/tsrn.py:1067-1084) as ONE operator: 1x1 conv (optionally over cat[x, xb]) -> BiGRU(64 -> 2x32)
     along image columns (vertical) or rows.
@@ -463,10 +519,14 @@ class GruBlockFn(Function):
         K = Wc.shape[1]
         x2 = x.reshape(-1, K1)
         xb2 = xb.reshape(-1, K - K1) if xb is not None else None
-        Wp = ops.new(x, 192, K)                                  # composed projection  [W_ih_f; W_ih_r] @ W_c
-        bp = ops.new(x, 192)
-        ops.call("tatt_gru_compose", ops.P(wih_f), ops.P(wih_r), ops.P(bih_f), ops.P(bih_r), ops.P(Wc), ops.P(conv_b),
-                 ops.P(Wp), ops.P(bp), K, ops.stream())
+        pre = _PRE.table.pop(conv_w.data_ptr(), None)           # composed at the start of this forward (gru_precompose)?
+        if pre is not None and pre[2] == conv_w._version and pre[0].device == x.device:
+            Wp, bp = pre[0], pre[1]
+        else:
+            Wp = ops.new(x, 192, K)                              # composed projection  [W_ih_f; W_ih_r] @ W_c
+            bp = ops.new(x, 192)
+            ops.call("tatt_gru_compose", ops.P(wih_f), ops.P(wih_r), ops.P(bih_f), ops.P(bih_r), ops.P(Wc), ops.P(conv_b),
+                     ops.P(Wp), ops.P(bp), K, ops.stream())
         gi = ops.linear_fwd(x2, Wp, bp, x2b=xb2)
         geom = ops.seq_geom(B, H, W, vertical)
         out, gates = ops.gru32_fwd(gi, whh_f, bhh_f, whh_r, bhh_r, geom, save=any(ctx.needs_input_grad))
@@ -703,6 +763,7 @@ class AttnCoreFn(Function):
         c, w = ops.attn_fwd(Q, K, V, pdrop, seed, site, True)
         ctx.save_for_backward(Q, K, V)
         ctx.pdrop, ctx.site, ctx.seed = pdrop, site, seed
+        ctx.set_materialize_grads(False)
         return c, w
 
     @staticmethod
@@ -820,6 +881,7 @@ class TPStackFn(Function):
             Vs.append(V)
         ctx.save_for_backward(qpos, mem, kin, *xs, *Ks, *Vs, *params)
         ctx.cfg, ctx.seed = cfg, seed
+        ctx.set_materialize_grads(False)          # an unused `wavg` must not cost a zero-filled (B,L,S) gradient
         return out, wavg
 
     @staticmethod

@@ -54,29 +54,35 @@ def new(ref: torch.Tensor, *shape, dtype=torch.float32):
 # --------------------------------------------------------------------------------------------------
 # GEMM family
 # --------------------------------------------------------------------------------------------------
-_REDUCE_DEFER = False
-_REDUCE_KEEP = []
+_REDUCE_KEEP = {}          # stream handle -> split-K workspaces registered on that stream (present <=> the stream is deferring)
+
+
+def _skey():
+    return torch.cuda.current_stream().cuda_stream
 
 
 def reduce_defer(on: bool):
-    """Split-K reductions behind the GEMMs / convolution weight gradients issued from now on are batched into one launch per 36
-    (tatt_reduce_defer); `reduce_defer(False)` (or `reduce_flush`) runs them.  Until then their outputs are undefined."""
-    global _REDUCE_DEFER
-    _REDUCE_DEFER = bool(on)
+    """Split-K reductions behind the GEMMs / convolution weight gradients issued ON THE CURRENT STREAM from now on are batched into
+    one launch per 36 (tatt_reduce_defer); `reduce_defer(False)` (or `reduce_flush`) runs them.  Until then their outputs are
+    undefined.  The state is per stream, here and in the library: lanes / trainers on other streams are not affected."""
     call("tatt_reduce_defer", int(bool(on)), stream())
-    if not on:
-        _REDUCE_KEEP.clear()
+    if on:
+        _REDUCE_KEEP.setdefault(_skey(), [])
+    else:
+        _REDUCE_KEEP.pop(_skey(), None)
 
 
 def reduce_flush():
     call("tatt_reduce_flush", stream())
-    _REDUCE_KEEP.clear()
+    if _skey() in _REDUCE_KEEP:
+        _REDUCE_KEEP[_skey()] = []
 
 
 def _split_ws(t):
     """A split-K workspace: must outlive a deferred reduction."""
-    if _REDUCE_DEFER and t is not None:
-        _REDUCE_KEEP.append(t)
+    keep = _REDUCE_KEEP.get(_skey())
+    if keep is not None and t is not None:
+        keep.append(t)
     return t
 
 

@@ -518,6 +518,10 @@ class _GeneratorBase(_TrainPathMixin, nn.Module):
         if training:
             Fh.begin_training_forward(x.device)                  # fresh dropout masks for this call (and its backward)
             self._bump_bn_counters()
+        if k > 0 and isinstance(getattr(self, "block2").gru1, GruBlock):
+            # the composed 1x1-conv x GRU-input projections of every residual block: parameters only, one launch for all of them
+            Fh.gru_precompose([g for i in range(k) for g in (getattr(self, "block%d" % (i + 2)).gru1,
+                                                             getattr(self, "block%d" % (i + 2)).gru2)])
         if use_tp:
             if text_emb is None:
                 text_emb = torch.zeros(1, 37, 1, 26, device=x.device)     # reference :653-654
