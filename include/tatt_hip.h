@@ -57,7 +57,9 @@ int tatt_conv2d_wgrad(const float* x, long xsn, long xsh, long xsw, long xsc, co
  * mode 2: [KH][KW][Cout][Cin]; mode 3: [KH][KW][Cin][Cout], taps flipped -- forward / data-gradient filters with the
  * contraction axis contiguous, for tatt_conv3_c64_fwd_t; modes 4 / 5: the same two 3x3 filters (64 contraction channels) in the
  * per-lane register order of tatt_conv3_c64_fwd_ws; modes 6 / 7: in the register order of tatt_conv3_c64_fwd_ws16;
- * modes 8 / 9: the Toeplitz-expanded 9x9 filter [9][64][16][20] of tatt_conv9_c64_to_c4_mfma (out needs 184,320 floats) */
+ * modes 8 / 9: the Toeplitz-expanded 9x9 filter [9][64][16][20] of tatt_conv9_c64_to_c4_mfma (out needs 184,320 floats);
+ * modes 10 / 11: the split-bf16 (hi / lo) forward / data-gradient operand of tatt_conv3_c64_fwd_sb (3x3, channel counts multiples
+ * of 64; Cout*Cin*9 32-bit words of two bf16, one chunk per 64 contraction channels) */
 int tatt_repack_conv_weight(const float* w_oihw, float* out, int Cout, int Cin, int KH, int KW,
                             int mode, hipStream_t st);
 /* the same for n filters in one launch (all packed layouts of a model, refreshed once per optimiser step): ws / outs are HOST arrays
@@ -102,6 +104,14 @@ int tatt_conv3_c64_fwd_ws16(const float* x, const float* wl, const float* bias, 
 int tatt_conv3_c64_fwd_ws16_bn(const float* x, const float* wl, const float* bias, float* y, int B, int H, int W,
                                int Cout, int act, float beta, const float* in_scale, const float* in_shift, int in_act,
                                double* stats, hipStream_t st);
+/* The same 3x3 convolution on the bf16 matrix cores by operand splitting: a = hi + lo (hi = bf16(a), lo = bf16(a - hi)),
+ * a*b ~ hi hi + hi lo + lo hi accumulated in fp32 (the dropped lo*lo term is 2^-16 relative; measured effect on the network:
+ * profiles/r03_split_bf16_probe.txt).  x holds cin_total >= 64 channels per pixel; the 64-channel slice starting at ci0 is
+ * contracted with the matching chunk of a mode-10 / mode-11 packed filter (chunk c starts c*Cout*576 words in); wider inputs are
+ * chunked by the caller with beta = 1.  BatchNorm folding arguments as tatt_conv3_c64_fwd_ws16_bn. */
+int tatt_conv3_c64_fwd_sb(const float* x, int cin_total, int ci0, const float* wl, const float* bias, float* y, int B, int H,
+                          int W, int Cout, int act, float beta, const float* in_scale, const float* in_shift, int in_act,
+                          double* stats, hipStream_t st);
 /* weight-gradient partials part[G][9*Cin][Cout] (G persistent work-groups, G <= B*H*W/64) and, if pdb != NULL, bias-gradient
  * partials pdb[G][Cout] (the column sums of dy the kernel streams anyway; nn.Conv2d's bias gradient); finish with
  * tatt_splitk_reduce(part, dw_oihw, 9*Cin, Cout, G, Cin, 9, beta, db, Cout) where pdb = part + G*9*Cin*Cout */

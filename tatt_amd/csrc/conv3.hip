@@ -547,6 +547,189 @@ TATT_API int tatt_conv3_c64_fwd_ws16_bn(const float* x, const float* wl, const f
     return LAUNCH_CHECK();
 }
 
+// ---- weight-stationary forward on the bf16 matrix cores: split-bf16 (hi + lo), three products per fp32 product -------------------
+// bf16 MFMA runs at 16x the fp32-MFMA rate on gfx950.  Every fp32 operand is split a = hi + lo, hi = bf16(a), lo = bf16(a - hi)
+// (16 mantissa bits kept), and  a * b  is evaluated as  hi_a hi_b + (hi_a lo_b + lo_a hi_b)  with fp32 accumulation: the dropped
+// lo_a lo_b term is 2^-16 relative.  Measured on the CPU oracle (tools/split_bf16_probe.py, profiles/r03_split_bf16_probe.txt): the
+// eval SR moves by 1.1e-6 (fp32 itself is 2.6e-7 from fp64; parity bar 1e-3, test bound 2e-5) and every training gradient stays inside
+// the fp64 yardstick (worst ratio 0.18 of the test limit).  Same organisation as conv3_c64_ws16_kernel: wave (pxh, cq) owns 32 px x 16 co,
+// the filter (hi and lo, 144 registers per lane again) lives in registers, activations stream through a double-buffered LDS halo that
+// is split into a hi and a lo bf16 image while it is staged (two v_cvt_pk_bf16_f32 + one subtraction per pair of values).
+//   v_mfma_f32_16x16x32_bf16: lane (i = lane & 15, kq = lane >> 4) supplies 8 consecutive k of row i; k-step ks = (tap, half):
+//   input channels 32 half + 8 kq .. + 7 of pixel i  =  ONE ds_read_b128 per operand image.
+//   halo pitch 160 B per pixel (128 B of channels + 32): pixel i -> 16-byte slot 10 i, k-slot kq -> + kq: the lane groups a
+//   ds_read_b128 is served in touch 16 distinct slots (conflict-free).
+// Handles a 64-channel slice [ci0, ci0 + 64) of a wider input (cin_total): wider contractions are chunked by the host (beta = 1).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define SB_PW 40                                             // halo pitch in 32-bit words (two bf16 each)
+#define SB_IMG (3 * C3_HW * SB_PW)                           // words of one image (hi or lo) of one halo buffer: 7920
+#define SB_LDS (4 * SB_IMG * 4)                              // two buffers x (hi, lo): 126,720 B
+struct Conv3SB { Conv3P c; int cin_total, ci0; };
+__device__ __forceinline__ void sb_split(f32x4 v, uint2& hi, uint2& lo) {
+    const bf16x2 h0 = __builtin_convertvector((f32x2){v[0], v[1]}, bf16x2), h1 = __builtin_convertvector((f32x2){v[2], v[3]}, bf16x2);
+    const f32x2 r0 = (f32x2){v[0], v[1]} - __builtin_convertvector(h0, f32x2), r1 = (f32x2){v[2], v[3]} - __builtin_convertvector(h1, f32x2);
+    const bf16x2 l0 = __builtin_convertvector(r0, bf16x2), l1 = __builtin_convertvector(r1, bf16x2);
+    hi = make_uint2(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1));
+    lo = make_uint2(__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1));
+}
+__global__ __launch_bounds__(512, 1) void conv3_c64_sb_kernel(Conv3SB q) {
+    const Conv3P& p = q.c;
+    extern __shared__ __attribute__((aligned(16))) unsigned smem_u[];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int cq = wave & 3, pxh = wave >> 2;
+    const int segs = p.W / C3_PX, cob = p.Cout / 64;
+    const int npt = p.B * p.H * segs;
+    const int stride = gridDim.x / cob;
+    int cb = blockIdx.x % cob, pt = blockIdx.x / cob;
+    if (gridDim.x % 8 == 0 && 8 % cob == 0 && stride % (8 / cob) == 0) {      // XCD-aware tile order (see conv3_c64_ws_kernel)
+        const int x = blockIdx.x & 7, m = blockIdx.x >> 3, xg = 8 / cob;
+        cb = x % cob;
+        pt = (x / cob) * (stride / xg) + m;
+    }
+    __shared__ float st_red[2][2][64];
+    if (pt >= npt) {
+        if (p.stats && t < 128) p.stats[(long)blockIdx.x * 128 + t] = 0.0;
+        return;
+    }
+    const int co0 = cb * 64 + cq * 16;
+    f32x4 isc = (f32x4){1.f, 1.f, 1.f, 1.f}, ish = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (p.in_scale) {
+        isc = *reinterpret_cast<const f32x4*>(p.in_scale + 4 * (t & 15));
+        ish = *reinterpret_cast<const f32x4*>(p.in_shift + 4 * (t & 15));
+    }
+    float st_s = 0.f, st_q = 0.f;
+    f32x4 wq[36];                                            // [kstep * 2 + {hi, lo}]: 8 bf16 = input channels 32 half + 8 (lane >> 4) .. of output channel co0 + (lane & 15)
+    {
+        const f32x4* wsrc = reinterpret_cast<const f32x4*>(p.w) + (long)(cb * 4 + cq) * 36 * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < 36; ++k) wq[k] = wsrc[k * 64];
+    }
+    auto decode = [&](int tile, int& n, int& h, int& w0) {
+        const int seg = tile % segs; tile /= segs;
+        h = tile % p.H; n = tile / p.H; w0 = seg * C3_PX;
+    };
+    auto halo_load = [&](int n, int h, int w0, int idx) -> f32x4 {
+        const int pix = idx >> 4, r = pix / C3_HW, px = pix - r * C3_HW;
+        const int hh = h + r - 1, ww = w0 + px - 1;
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (idx < 3 * C3_HW * 16 && hh >= 0 && hh < p.H && ww >= 0 && ww < p.W) {
+            v = *reinterpret_cast<const f32x4*>(p.x + (((long)n * p.H + hh) * p.W + ww) * q.cin_total + q.ci0 + 4 * (idx & 15));
+            if (p.in_scale) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float u = fmaf(v[e], isc[e], ish[e]);
+                    v[e] = p.in_act == ACT_MISH ? mish_f(u) : (p.in_act == ACT_RELU ? fmaxf(u, 0.f) : u);
+                }
+            }
+        }
+        return v;
+    };
+    auto halo_store = [&](unsigned* Xs, int idx, f32x4 v) {    // Xs: hi image; the lo image follows SB_IMG words later
+        if (idx < 3 * C3_HW * 16) {
+            uint2 hi, lo;
+            sb_split(v, hi, lo);
+            unsigned* d = Xs + (idx >> 4) * SB_PW + 2 * (idx & 15);
+            *reinterpret_cast<uint2*>(d) = hi;
+            *reinterpret_cast<uint2*>(d + SB_IMG) = lo;
+        }
+    };
+    int n, h, w0;
+    decode(pt, n, h, w0);
+    {
+        f32x4 hp[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) hp[k] = halo_load(n, h, w0, t + 512 * k);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) halo_store(smem_u, t + 512 * k, hp[k]);
+    }
+    __syncthreads();
+    const int abase = (pxh * 32 + (lane & 15)) * SB_PW + 4 * (lane >> 4);
+    const float bj = p.bias ? p.bias[co0 + (lane & 15)] : 0.f;
+    int xbuf = 0;
+    while (true) {
+        const int npt_next = pt + stride;
+        const bool has_next = npt_next < npt;
+        int nn = n, nh = h, nw0 = w0;
+        if (has_next) decode(npt_next, nn, nh, nw0);
+        const unsigned* Xs = smem_u + xbuf * 2 * SB_IMG + abase;
+        unsigned* XsN = smem_u + (xbuf ^ 1) * 2 * SB_IMG;
+        f32x4 accM[2], accC[2];                              // hi*hi products; cross products (hi*lo + lo*hi), summed separately
+#pragma unroll
+        for (int m = 0; m < 2; ++m) { accM[m] = (f32x4){0.f, 0.f, 0.f, 0.f}; accC[m] = accM[m]; }
+        f32x4 va[2][4];                                      // ring: [.][2 m + {hi, lo}]; reads of k-step ks + 1 are issued before the MFMAs of ks
+        f32x4 hq = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // k-step ks = tap * 2 + half; M-tile m: pixels pxh * 32 + 16 m + i
+#define SB_AOFF(ks, m) ((((ks) >> 1) / 3 * C3_HW + ((ks) >> 1) % 3 + 16 * (m)) * SB_PW + 16 * ((ks) & 1))
+#define SB_LD(ks) va[(ks) % 2][0] = *reinterpret_cast<const f32x4*>(Xs + SB_AOFF(ks, 0)); \
+                  va[(ks) % 2][1] = *reinterpret_cast<const f32x4*>(Xs + SB_AOFF(ks, 0) + SB_IMG); \
+                  va[(ks) % 2][2] = *reinterpret_cast<const f32x4*>(Xs + SB_AOFF(ks, 1)); \
+                  va[(ks) % 2][3] = *reinterpret_cast<const f32x4*>(Xs + SB_AOFF(ks, 1) + SB_IMG);
+        SB_LD(0)
+#pragma unroll
+        for (int ks = 0; ks < 18; ++ks) {
+            if (ks % 2 == 0 && ks / 2 < 7 && has_next) hq = halo_load(nn, nh, nw0, t + 512 * (ks / 2));
+            if (ks + 1 < 18) { SB_LD(ks + 1) }
+            __builtin_amdgcn_sched_barrier(0);
+            const bf16x8 wh = __builtin_bit_cast(bf16x8, wq[2 * ks]), wl = __builtin_bit_cast(bf16x8, wq[2 * ks + 1]);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const bf16x8 ah = __builtin_bit_cast(bf16x8, va[ks % 2][2 * m]), al = __builtin_bit_cast(bf16x8, va[ks % 2][2 * m + 1]);
+                accM[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wh, accM[m], 0, 0, 0);
+                accC[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wl, accC[m], 0, 0, 0);
+                accC[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wh, accC[m], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks % 2 == 1 && ks / 2 < 7 && has_next) halo_store(XsN, t + 512 * (ks / 2), hq);
+        }
+        {
+            const long rowbase = ((long)n * p.H + h) * p.W + w0 + pxh * 32 + 4 * (lane >> 4);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float* dst = p.y + (rowbase + 16 * m + r) * p.Cout + co0 + (lane & 15);
+                    float v = apply_act((accM[m][r] + accC[m][r]) + bj, p.act);
+                    if (p.beta != 0.f) v += p.beta * *dst;
+                    *dst = v;
+                    st_s += v; st_q += v * v;
+                }
+        }
+        if (!has_next) break;
+        __syncthreads();
+        pt = npt_next; n = nn; h = nh; w0 = nw0;
+        xbuf ^= 1;
+    }
+    if (p.stats) {
+        st_s += __shfl_xor(st_s, 16, 64); st_s += __shfl_xor(st_s, 32, 64);
+        st_q += __shfl_xor(st_q, 16, 64); st_q += __shfl_xor(st_q, 32, 64);
+        if (lane < 16) { st_red[pxh][0][cq * 16 + lane] = st_s; st_red[pxh][1][cq * 16 + lane] = st_q; }
+        __syncthreads();
+        if (t < 128) p.stats[(long)blockIdx.x * 128 + t] = (double)st_red[0][t >> 6][t & 63] + (double)st_red[1][t >> 6][t & 63];
+    }
+}
+// Split-bf16 3x3 convolution (see the kernel): x holds cin_total >= 64 channels per pixel, the 64-channel slice starting at ci0 is
+// contracted; wl = the matching 64-input-channel chunk of the filter from tatt_repack_conv_weight mode 10 (forward) / mode 11 (data
+// gradient): chunk c of a mode-10/11 buffer starts c * Cout * 576 words in.  BatchNorm folding arguments as tatt_conv3_c64_fwd_ws16_bn.
+TATT_API int tatt_conv3_c64_fwd_sb(const float* x, int cin_total, int ci0, const float* wl, const float* bias, float* y, int B, int H,
+                                   int W, int Cout, int act, float beta, const float* in_scale, const float* in_shift, int in_act,
+                                   double* stats, hipStream_t st) {
+    if (Cout % 64 || W % C3_PX || cin_total % 4 || ci0 % 4 || ci0 + 64 > cin_total) return 1;
+    if (stats && (Cout != 64 || act != ACT_NONE || beta != 0.f)) return 2;
+    if (in_scale && (!in_shift || in_act == ACT_TANH)) return 3;
+    Conv3SB q = {{x, wl, bias, y, B, H, W, 64, Cout, act, beta, in_scale, in_shift, in_act, stats}, cin_total, ci0};
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [&] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_sb_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SB_LDS);
+    });
+    const int cob = Cout / 64, npt = B * H * (W / C3_PX);
+    int per = 256 / cob;
+    if (per > npt) per = npt;
+    hipLaunchKernelGGL(conv3_c64_sb_kernel, dim3(per * cob), dim3(512), SB_LDS, st, q);
+    return LAUNCH_CHECK();
+}
+
 // ---- weight gradient -------------------------------------------------------------------------------------------------
 // dW[tap][ci][co] = sum over pixels x[pixel + tap][ci] * dy[pixel][co]: the pixels are the contraction axis.  Persistent
 // work-groups of 8 waves walk 64-pixel row segments; wave w owns the (ci half, co half) quadrant w & 3 of one 64 ci x 64 co

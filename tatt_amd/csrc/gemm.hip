@@ -893,11 +893,37 @@ __device__ __forceinline__ float toeplitz9(const float* __restrict__ w, int idx,
     return mode == 8 ? w[(((long)o * 64 + ci) * 9 + ky) * 9 + kx] : w[(((long)ci * 4 + o) * 9 + (8 - ky)) * 9 + (8 - kx)];
 }
 static inline long repack_total(int Cout, int Cin, int KH, int KW, int mode) {
-    return mode >= 8 ? 9L * 64 * 16 * 20 : (long)Cout * Cin * KH * KW;
+    return (mode == 8 || mode == 9) ? 9L * 64 * 16 * 20 : (long)Cout * Cin * KH * KW;
+}
+// modes 10 / 11: the split-bf16 B operand of tatt_conv3_c64_fwd_sb (3x3; conv input channels a multiple of 64, output channels of 16):
+// 32-bit words of two bf16 with consecutive input channels,
+//   word[((((chunk * nblk + blk) * 18 + ks) * 2 + hl) * 64 + lane) * 4 + e2],  ks = tap * 2 + half, hl = 0: hi = bf16(v), 1: lo = bf16(v - hi),
+//   conv output channel o = 16 blk + (lane & 15), conv input channel i = 64 chunk + 32 half + 8 (lane >> 4) + 2 e2 + {0, 1};
+//   mode 10: v = filter[o][i][tap] (forward);  mode 11: v = filter[i][o][8 - tap] (data gradient: o = ci, i = co of the OIHW filter)
+typedef __bf16 rp_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float rp_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float repack_sb(const float* __restrict__ w, long idx, int Cout, int Cin, int mode) {
+    const int e2 = (int)(idx & 3), lane = (int)((idx >> 2) & 63), hl = (int)((idx >> 8) & 1);
+    long r = idx >> 9;
+    const int ks = (int)(r % 18); r /= 18;
+    const int nblk = (mode == 10 ? Cout : Cin) / 16;
+    const int blk = (int)(r % nblk), chunk = (int)(r / nblk);
+    const int tap = ks >> 1, half = ks & 1;
+    const int o = 16 * blk + (lane & 15), i = 64 * chunk + 32 * half + 8 * (lane >> 4) + 2 * e2;
+    rp_f32x2 v;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) v[u] = mode == 10 ? w[((long)o * Cin + (i + u)) * 9 + tap] : w[((long)(i + u) * Cin + o) * 9 + (8 - tap)];
+    const rp_bf16x2 hi = __builtin_convertvector(v, rp_bf16x2);
+    const rp_bf16x2 lo = __builtin_convertvector(v - __builtin_convertvector(hi, rp_f32x2), rp_bf16x2);
+    return __builtin_bit_cast(float, hl ? lo : hi);
 }
 __global__ void repack_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin,
                                      int KH, int KW, int mode) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (mode >= 10) {
+        if (idx < Cout * Cin * 9) out[idx] = repack_sb(w, idx, Cout, Cin, mode);
+        return;
+    }
     if (mode >= 8) {
         if (idx < 9 * 64 * 16 * 20) out[idx] = toeplitz9(w, idx, mode);
         return;
@@ -939,7 +965,8 @@ __global__ void repack_weight_kernel(const float* __restrict__ w, float* __restr
 }
 TATT_API int tatt_repack_conv_weight(const float* w_oihw, float* out, int Cout, int Cin, int KH, int KW,
                                      int mode, hipStream_t st) {
-    if (mode >= 8 && !(KH == 9 && KW == 9 && ((mode == 8 && Cout == 4 && Cin == 64) || (mode == 9 && Cout == 64 && Cin == 4)))) return 1;
+    if ((mode == 8 || mode == 9) && !(KH == 9 && KW == 9 && ((mode == 8 && Cout == 4 && Cin == 64) || (mode == 9 && Cout == 64 && Cin == 4)))) return 1;
+    if (mode >= 10 && !(mode <= 11 && KH == 3 && KW == 3 && Cout % 64 == 0 && Cin % 64 == 0)) return 1;
     long total = repack_total(Cout, Cin, KH, KW, mode);
     hipLaunchKernelGGL(repack_weight_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w_oihw, out, Cout, Cin,
                        KH, KW, mode);
@@ -956,6 +983,10 @@ __global__ void repack_batch_kernel(RepackTable t) {
     while (k + 1 < t.n && (int)blockIdx.x >= t.e[k + 1].block0) ++k;          // wave-uniform walk over <= 96 entries
     const RepackEntry& e = t.e[k];
     const int idx = ((int)blockIdx.x - e.block0) * blockDim.x + threadIdx.x;
+    if (e.mode >= 10) {
+        if (idx < e.Cout * e.Cin * 9) e.out[idx] = repack_sb(e.w, idx, e.Cout, e.Cin, e.mode);
+        return;
+    }
     if (e.mode >= 8) {
         if (idx < 9 * 64 * 16 * 20) e.out[idx] = toeplitz9(e.w, idx, e.mode);
         return;

@@ -142,29 +142,11 @@ class _DeferredParamGrads:
         self._keep.clear()
 
 
-class _PerThread:
-    """One instance of `cls` per host thread behind a module-level name: the schedulers below carry the state of the training step
-    in flight (pending closures, the stage being run, dirty streams), and two trainers driven from two host threads must not see
-    each other's.  (Two trainers in ONE thread take turns: every step leaves the state clean.)"""
-
-    def __init__(self, cls):
-        object.__setattr__(self, "_cls", cls)
-        object.__setattr__(self, "_tls", __import__("threading").local())
-
-    def _get(self):
-        inst = getattr(self._tls, "inst", None)
-        if inst is None:
-            inst = self._tls.inst = self._cls()
-        return inst
-
-    def __getattr__(self, name):
-        return getattr(self._get(), name)
-
-    def __setattr__(self, name, value):
-        setattr(self._get(), name, value)
-
-
-SIDE = _PerThread(_DeferredParamGrads)
+# One scheduler per PROCESS, on purpose: torch runs every backward node of a device in its autograd worker thread while the forward
+# and the Trainer run in the caller's thread, so the state of the step in flight (pending closures, stage, dirty streams) must be
+# visible across threads -- a thread-local would be empty exactly where it is read.  A process therefore drives ONE training step at
+# a time (several trainers take turns: every step leaves the state clean); one process per GPU is the deployment model anyway.
+SIDE = _DeferredParamGrads()
 
 
 class _ForwardFork:
@@ -199,7 +181,7 @@ class _ForwardFork:
             self._dirty.discard(k)
 
 
-FWD_FORK = _PerThread(_ForwardFork)
+FWD_FORK = _ForwardFork()
 
 
 def _c(t):
@@ -480,7 +462,7 @@ class _Precomposed:
         self.table = {}
 
 
-_PRE = _PerThread(_Precomposed)
+_PRE = _Precomposed()
 
 
 def gru_precompose(blocks):

@@ -7,6 +7,7 @@ stream (so the calls are hipGraph-capturable).  There is no CPU fallback: a non-
 from __future__ import annotations
 
 import ctypes
+import weakref
 from typing import Optional
 
 import os
@@ -193,26 +194,29 @@ class _PackedFilters:
     def get(self, w, mode):
         key = (w.data_ptr(), tuple(w.shape), mode, str(w.device))
         e = self.entries.get(key)
-        if e is not None and e[1] == w._version and e[2].data_ptr() == w.data_ptr():
+        if e is not None and e[1] == w._version and e[2]() is w:
             return e[0]
         Cout, Cin, KH, KW = w.shape
-        if e is None and len(self.entries) >= 1024:          # entries pin their parameter's storage: bound what a long-lived
-            # process that keeps building models can accumulate.  Buffers may be baked into captured hipGraphs: never evicted
-            # silently -- the owner of the old models calls clear() when their graphs are gone.
-            raise RuntimeError("tatt_amd.ops.PACKED holds 1024 packed filters; call tatt_amd.ops.PACKED.clear() once the models "
-                               "(and hipGraphs) that own them are released")
+        if e is not None and e[2]() is not w:                # the address was recycled by another tensor: a fresh buffer (the old
+            e = None                                         # one may be baked into a hipGraph of the model that owned it)
+        if e is None and len(self.entries) >= 1024:
+            # entries hold only a WEAK reference to their parameter: those of models that no longer exist are dropped here; buffers
+            # of live models are never evicted (their pointers may be baked into captured hipGraphs)
+            self.entries = {k: v for k, v in self.entries.items() if v[2]() is not None}
+            if len(self.entries) >= 1024:
+                raise RuntimeError("tatt_amd.ops.PACKED holds 1024 packed filters of live parameters")
         out = e[0] if e is not None else torch.empty(_packed_numel(w.shape, mode), device=w.device, dtype=torch.float32)
         call("tatt_repack_conv_weight", P(w), P(out), Cout, Cin, KH, KW, mode, stream())
-        self.entries[key] = (out, w._version, w.detach())
+        self.entries[key] = (out, w._version, weakref.ref(w))
         return out
 
     def refresh(self, device=None):
         """Rebuild every cached layout from the current weights (one launch per 96 entries)."""
-        ent = [(k, e) for k, e in self.entries.items() if device is None or k[3] == str(device)]
+        ent = [(k, e) for k, e in self.entries.items() if (device is None or k[3] == str(device)) and e[2]() is not None]
         if not ent:
             return
         n = len(ent)
-        ws = (ctypes.c_void_p * n)(*[e[2].data_ptr() for _, e in ent])
+        ws = (ctypes.c_void_p * n)(*[k[0] for k, _ in ent])
         outs = (ctypes.c_void_p * n)(*[e[0].data_ptr() for _, e in ent])
         dims = (ctypes.c_int * (5 * n))(*[v for k, _ in ent for v in (k[1][0], k[1][1], k[1][2], k[1][3], k[2])])
         call("tatt_repack_conv_weight_batch", ws, outs, dims, n, stream())
@@ -271,6 +275,26 @@ _WS_ENTRY, _WS_FWD_MODE, _WS_DGRAD_MODE = (("tatt_conv3_c64_fwd_ws16", 6, 7) if 
 
 
 CONV9_MFMA = os.environ.get("TATT_CONV9_MFMA", "1") != "0"       # A/B switch: 0 -> vector-ALU 9x9 kernel
+# The 3x3 convolutions between multiples of 64 channels on the bf16 matrix cores by operand splitting (tatt_conv3_c64_fwd_sb: three
+# bf16 products per fp32 product, fp32 accumulation; measured effect on SR 1e-6, profiles/r03_split_bf16_probe.txt).  Test / A-B hook:
+# False -> the exact-fp32 MFMA kernels.
+CONV3_SB = True
+
+
+def _conv3_sb(x_bhwc, w_oihw, mode, bias, act=ACT_NONE, in_scale=None, in_shift=None, in_act=ACT_NONE, stats=None):
+    """3x3 'same' convolution through tatt_conv3_c64_fwd_sb; mode 10: forward (Cin = w.shape[1]), mode 11: data gradient of w
+    (input channels = w.shape[0], output channels = w.shape[1]).  Contractions wider than 64 channels are chunked (beta = 1)."""
+    B, H, W, cin = x_bhwc.shape
+    cout = w_oihw.shape[0] if mode == 10 else w_oihw.shape[1]
+    assert cin == (w_oihw.shape[1] if mode == 10 else w_oihw.shape[0])
+    wl = repack_weight(w_oihw, mode)
+    y = new(x_bhwc, B, H, W, cout)
+    nchunk = cin // 64
+    assert nchunk == 1 or (act == ACT_NONE and stats is None)
+    for c in range(nchunk):
+        call("tatt_conv3_c64_fwd_sb", P(x_bhwc), cin, 64 * c, P(wl[c * cout * 576:]), P(bias) if c == 0 else None, P(y), B, H, W, cout,
+             act, 0.0 if c == 0 else 1.0, P(in_scale), P(in_shift), int(in_act), P(stats), stream())
+    return y
 
 
 def _conv9_mfma_ok(x_bhwc):
@@ -287,6 +311,8 @@ def conv2d_forward(x_bhwc, weight_oihw, bias, act=ACT_NONE):
         return y
     if _conv3_fast_ok(x_bhwc, Cin, Cout, KH, KW):
         B, H, W, _ = x_bhwc.shape
+        if CONV3_SB and (Cin == 64 or act == ACT_NONE):
+            return _conv3_sb(x_bhwc, weight_oihw, 10, bias, act)
         y = new(x_bhwc, B, H, W, Cout)
         if Cin == 64 and _CONV3_WS:                              # weight-stationary kernel: the filter lives in registers
             wl = repack_weight(weight_oihw, _WS_FWD_MODE)
@@ -310,9 +336,11 @@ def conv3_bn_forward(x_bhwc, weight_oihw, bias, in_scale=None, in_shift=None, in
     partials of y's per-channel batch statistics ([G][2][64] doubles) -> (y, part, G)."""
     _check_dev(x_bhwc)
     B, H, W, _ = x_bhwc.shape
-    y = new(x_bhwc, B, H, W, 64)
     G = min(256, B * H * (W // 64))
     part = new(x_bhwc, G * 128, dtype=torch.float64) if want_stats else None
+    if CONV3_SB:
+        return _conv3_sb(x_bhwc, weight_oihw, 10, bias, ACT_NONE, in_scale, in_shift, in_act, part), part, G
+    y = new(x_bhwc, B, H, W, 64)
     call("tatt_conv3_c64_fwd_ws16_bn", P(x_bhwc), P(repack_weight(weight_oihw, 6)), P(bias), P(y), B, H, W, 64, ACT_NONE, 0.0,
          P(in_scale), P(in_shift), int(in_act), P(part), stream())
     return y, part, G
@@ -337,6 +365,8 @@ def conv2d_dgrad(dy_bhwc, weight_oihw):
         return dx
     if _conv3_fast_ok(dy_bhwc, Cout, Cin, KH, KW):
         B, H, W, _ = dy_bhwc.shape
+        if CONV3_SB:
+            return _conv3_sb(dy_bhwc, weight_oihw, 11, None)
         dx = new(dy_bhwc, B, H, W, Cin)
         if Cout == 64 and _CONV3_WS:
             wl = repack_weight(weight_oihw, _WS_DGRAD_MODE)

@@ -719,3 +719,55 @@ def test_conv_bn_folded_equals_operator_chain(dev, B, H, W):
         if not err < (1e-3 if noise else 2e-4):
             bad.append("%s: %.3e" % (k, err))
     assert not bad, "\n".join(bad)
+
+
+# ------------------------------------------------------------------------------------------- split-bf16 3x3 convolution
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 16, 64, 64, 64), (3, 5, 128, 64, 256), (2, 16, 64, 256, 64), (1, 1, 64, 128, 128)])
+def test_conv3_split_bf16_vs_fp64(dev, B, H, W, Cin, Cout):
+    """tatt_conv3_c64_fwd_sb (bf16 matrix cores, hi/lo operand split, three products, fp32 accumulation) against the fp64 convolution:
+    forward and data gradient, also for contractions wider than 64 channels (chunked).  Error model: operands keep 16 mantissa bits,
+    so each product is 2^-16 = 1.5e-5 relative at worst and the sum of K = 9 Cin random-sign terms lands around 1e-6 of the output
+    scale -- the exact-fp32 kernel sits at 1e-7; both far inside the parity budget (tools/split_bf16_probe.py)."""
+    from tatt_amd import ops
+    x = R(B, H, W, Cin, seed=1)
+    w = R(Cout, Cin, 3, 3, seed=2) * (1.0 / math.sqrt(9 * Cin))
+    b = R(Cout, seed=3)
+    dy = R(B, H, W, Cout, seed=4)
+    ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), b.double(), padding=1).permute(0, 2, 3, 1)
+    ref_dx = torch.nn.grad.conv2d_input((B, Cin, H, W), w.double(), dy.double().permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
+    res = {}
+    for sb in (True, False):
+        ops.CONV3_SB = sb
+        try:
+            y = ops.conv2d_forward(x.to(dev), w.to(dev), b.to(dev))
+            dx = ops.conv2d_dgrad(dy.to(dev), w.to(dev))
+        finally:
+            ops.CONV3_SB = True
+        res[sb] = (float((y.cpu().double() - ref).abs().max() / ref.abs().max()), float((dx.cpu().double() - ref_dx).abs().max() / ref_dx.abs().max()))
+    print("conv3 %dx%dx%d %d->%d: split-bf16 rel-max err fwd %.2e dgrad %.2e | fp32 MFMA fwd %.2e dgrad %.2e" % (
+        B, H, W, Cin, Cout, res[True][0], res[True][1], res[False][0], res[False][1]))
+    assert res[True][0] < 1e-5 and res[True][1] < 1e-5, res
+    assert res[False][0] < 2e-6 and res[False][1] < 2e-6, res
+
+
+def test_conv3_split_bf16_bn_folding(dev):
+    """The split-bf16 kernel with the producer's BatchNorm + mish folded into its input staging and the batch statistics of its own
+    output taken from the epilogue == the same through the exact-fp32 kernel (to the split's 1e-5)."""
+    from tatt_amd import ops
+    B, H, W = 3, 16, 64
+    x, w, b = R(B, H, W, 64, seed=1).to(dev), (R(64, 64, 3, 3, seed=2) / 24).to(dev), R(64, seed=3).to(dev)
+    sc, sh = (1.0 + 0.3 * R(64, seed=4)).to(dev), (0.2 * R(64, seed=5)).to(dev)
+    out = {}
+    for sb in (True, False):
+        ops.CONV3_SB = sb
+        try:
+            y, part, G = ops.conv3_bn_forward(x, w, b, sc, sh, ops.ACT_MISH, True)
+        finally:
+            ops.CONV3_SB = True
+        out[sb] = (y.cpu(), part.reshape(G, 2, 64).sum(0).cpu())
+    ref = F.conv2d(F.mish(x.cpu() * sc.cpu() + sh.cpu()).permute(0, 3, 1, 2), w.cpu(), b.cpu(), padding=1).permute(0, 2, 3, 1)
+    for sb in (True, False):
+        y, st = out[sb]
+        assert float((y - ref).abs().max() / ref.abs().max()) < (2e-5 if sb else 3e-6), sb
+        check_close("stats.sum", st[0].float(), y.double().reshape(-1, 64).sum(0).float(), rtol=1e-5, atol=1e-3)
+        check_close("stats.sq", st[1].float(), (y.double() ** 2).reshape(-1, 64).sum(0).float(), rtol=1e-5, atol=1e-3)
