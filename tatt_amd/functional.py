@@ -318,7 +318,9 @@ class ConvBnFn(Function):
             dw = ops.conv_wgrad(xin, dy, 64, 3, 3) if want_dw else None
             db = ops.colsum(dy.reshape(-1, 64)) if want_db else None
             return dw, db
-        dw, db = SIDE.submit(ctx.leaves, param_grads, x, dy)
+        # everything the deferred closure reads must outlive this node (autograd frees saved tensors when the node is done, and a block
+        # freed on the main stream is reused there at once, beside the side lane that still reads it)
+        dw, db = SIDE.submit(ctx.leaves, param_grads, x, dy, in_mean, in_rstd, in_gamma, in_beta, weight)
         return (dx, dw, db) + (None,) * 8 + (dgi, dbi, None, None, None)
 
 

@@ -7,15 +7,24 @@
   directory, with or without the 'state_dict_G' wrapper, `module.`-prefixed keys of DataParallel checkpoints accepted in both
   directions.
 * `evaluate` is the metric part of the reference's eval loop (interfaces/super_resolution.py:1409-1420,1454-1455): PSNR and SSIM
-  of the SR images against HR on the first three channels, averaged over batches -- computed by the HIP kernels.
+  of the SR images against HR on the first three channels, averaged over batches -- computed by the HIP kernels -- and, given a
+  CRNN recogniser and the label strings, the recognition accuracies of the SR / LR / HR images (:1374-1396,1527-1558,1662-1664;
+  greedy CTC decoding = utils/metrics.py:71-92, string filter = utils/util.py:12-32).
+* `collate_labels` / `collate_batch` produce the batch tuple the reference's loaders hand to the loop
+  (dataset/dataset.py:1966-2077, alignCollate_realWTLAMask.__call__): images stacked, labels stretched to 26 steps and one-hot
+  encoded as the (B, 37, 1, 26) text prior, the per-character class list and the blank flags.  Image decoding / resizing / mask
+  synthesis (PIL, cv2, lmdb) stay outside: the adapter takes tensors that are already resized.
 torch.save / torch.load are file-format plumbing; all arithmetic stays in the HIP path.
 """
 from __future__ import annotations
 
 import os
+import string
 from typing import Iterable, Optional, Sequence
 
 import torch
+
+ALPHABET = "0123456789abcdefghijklmnopqrstuvwxyz"          # class 0 is the CTC blank "-" (reference utils/metrics.py:71)
 
 
 def _unwrap(m):
@@ -71,25 +80,116 @@ def load_generator(model: torch.nn.Module, resume: str, iter_: int = 0, strict: 
     return blob.get("info") if isinstance(blob, dict) and "state_dict_G" in blob else None
 
 
+def stretch_label(word: str, max_len: int = 26) -> str:
+    """The reference's label layout (dataset/dataset.py:2015-2034): lower-cased; words of 2..25 characters are spread over the
+    26 prior steps by inserting int((26 - len) / (len - 1)) blanks between neighbouring characters; longer words are cut."""
+    word = word.lower()
+    if len(word) <= 1:
+        return word
+    if len(word) < max_len:
+        pad = int((max_len - len(word)) / (len(word) - 1))
+        return word[0] + "".join("-" * pad + ch for ch in word[1:])
+    return word[:max_len]
+
+
+def collate_labels(label_strs: Sequence[str], alphabet: str = ALPHABET, max_len: int = 26):
+    """-> (label_vecs (B, len(alphabet)+1, 1, max_len) one-hot float, weighted_mask (sum of label lengths,) long, weighted_tics (B,) long)
+    exactly as alignCollate_realWTLAMask builds them (dataset/dataset.py:2009-2063): characters outside the alphabet are dropped, a
+    word with no valid character becomes a single blank (class 0) with tic 0."""
+    d2a = "-" + alphabet
+    a2d = {ch: i for i, ch in enumerate(d2a)}
+    alsize = len(d2a)
+    out = torch.zeros(len(label_strs), max_len, alsize)
+    masks, tics = [], []
+    for b, word in enumerate(label_strs):
+        ids = [a2d[ch] for ch in stretch_label(word, max_len) if ch in a2d]
+        if ids:
+            masks.extend(ids)
+            out[b, torch.arange(len(ids)), torch.tensor(ids)] = 1.0
+            tics.append(1)
+        else:
+            masks.append(0)
+            out[b, 0, 0] = 1.0
+            tics.append(0)
+    return out.unsqueeze(1).permute(0, 3, 1, 2).contiguous(), torch.tensor(masks).long(), torch.tensor(tics)
+
+
+def collate_batch(samples, device=None, alphabet: str = ALPHABET):
+    """samples: iterable of (img_HR, img_lr, img_HRy, img_lry, label_str) with the images already tensors of their final size
+    ((4 or 3, H, W) float in [0, 1]) -> the tuple of the reference's collate function (dataset/dataset.py:2077):
+    (images_HR, images_pseudoLR = None, images_lr, images_HRy, images_lry, label_strs, label_vecs, weighted_mask, weighted_tics),
+    image stacks and label_vecs on `device` (the loop's `.to(self.device)`, interfaces/super_resolution.py:700-707)."""
+    hr, lr, hry, lry, labels = zip(*samples)
+    st = lambda ts: torch.stack([torch.as_tensor(t) for t in ts], 0).to(device) if device is not None else torch.stack(
+        [torch.as_tensor(t) for t in ts], 0)
+    vecs, masks, tics = collate_labels(labels, alphabet)
+    return st(hr), None, st(lr), st(hry), st(lry), tuple(labels), (vecs.to(device) if device is not None else vecs), masks, tics
+
+
+def ctc_greedy_decode(logits: torch.Tensor, alphabet: str = ALPHABET) -> list:
+    """(T, B, C) recogniser outputs -> B strings: arg-max per step, repeats merged, blanks dropped (reference get_string_crnn,
+    utils/metrics.py:71-92).  The arg-max is an index operation on a (T, B) grid; the strings are built on the host."""
+    d2a = "-" + alphabet
+    idx = logits.detach().permute(1, 0, 2).argmax(2).cpu().tolist()
+    out = []
+    for row in idx:
+        s, last = "", ""
+        for i in row:
+            if d2a[i] != last:
+                if i != 0:
+                    s += d2a[i]
+                    last = d2a[i]
+                else:
+                    last = ""
+        out.append(s)
+    return out
+
+
+def str_filt(s: str, voc_type: str = "lower") -> str:
+    """reference utils/util.py:12-32 for the Latin vocabularies ('digit', 'lower', 'upper', 'all')."""
+    alpha = {"digit": string.digits, "lower": string.digits + string.ascii_lowercase, "upper": string.digits + string.ascii_letters,
+             "all": string.digits + string.ascii_letters + string.punctuation}[voc_type]
+    if voc_type == "lower":
+        s = s.lower()
+    return "".join(ch for ch in s if ch in alpha)
+
+
 @torch.no_grad()
-def evaluate(model: torch.nn.Module, batches: Iterable, prior_fn=None):
-    """Metric part of the reference's eval loop: for every (images_lr, images_hr[, text_prior]) batch run the generator in eval
-    mode and accumulate calculate_psnr / SSIM of SR vs HR on the first three channels (interfaces/super_resolution.py:1454-1455),
-    plus the same for the LR input when its size matches HR.  Returns {'psnr', 'ssim', 'n_batches'} (python floats)."""
+def evaluate(model: torch.nn.Module, batches: Iterable, prior_fn=None, recognizer=None, voc_type: str = "lower"):
+    """Metric part of the reference's eval loop: for every (images_lr, images_hr[, text_prior[, label_strs]]) batch run the
+    generator in eval mode and accumulate calculate_psnr / SSIM of SR vs HR on the first three channels
+    (interfaces/super_resolution.py:1454-1455).  With a `recognizer` (tatt_amd.CRNN, the reference's --test_model CRNN) and label
+    strings in the batch, also the recognition accuracies of the SR, LR and HR images (:1374-1396,1527-1558,1662-1664).
+    Returns {'psnr', 'ssim', 'n_batches'[, 'accuracy', 'accuracy_lr', 'accuracy_hr', 'n_images']} (python floats)."""
     from .losses import SSIM, calculate_psnr
+    from .crnn import parse_crnn_data
     was_training = model.training
     model.eval()
     ssim = SSIM()
     psnr_sum = torch.zeros((), device=next(model.parameters()).device)
     ssim_sum = torch.zeros_like(psnr_sum)
     n = 0
+    correct = {"sr": 0, "lr": 0, "hr": 0}
+    n_img = 0
+    if recognizer is not None:
+        recognizer.eval()
     for batch in batches:
         lr, hr = batch[0], batch[1]
-        tp = batch[2] if len(batch) > 2 else (prior_fn(lr) if prior_fn is not None else None)
+        tp = batch[2] if len(batch) > 2 and batch[2] is not None else (prior_fn(lr) if prior_fn is not None else None)
+        labels = batch[3] if len(batch) > 3 else None
         out = model(lr, tp) if tp is not None else model(lr)
         sr = out[0] if isinstance(out, tuple) else out
         psnr_sum += calculate_psnr(sr[:, :3], hr[:, :3])
         ssim_sum += ssim(sr[:, :3], hr[:, :3])
         n += 1
+        if recognizer is not None and labels is not None:
+            for name, img in (("sr", sr), ("lr", lr), ("hr", hr)):
+                pred = ctc_greedy_decode(recognizer(parse_crnn_data(img[:, :3].contiguous())))
+                correct[name] += sum(str_filt(p, voc_type) == str_filt(t, voc_type) for p, t in zip(pred, labels))
+            n_img += len(labels)
     model.train(was_training)
-    return {"psnr": float(psnr_sum) / max(n, 1), "ssim": float(ssim_sum) / max(n, 1), "n_batches": n}
+    res = {"psnr": float(psnr_sum) / max(n, 1), "ssim": float(ssim_sum) / max(n, 1), "n_batches": n}
+    if n_img:
+        res.update(accuracy=round(correct["sr"] / n_img, 4), accuracy_lr=round(correct["lr"] / n_img, 4),
+                   accuracy_hr=round(correct["hr"] / n_img, 4), n_images=n_img)
+    return res

@@ -180,49 +180,89 @@ def _packed_numel(shape, mode):
     return 9 * 64 * 16 * 20 if mode >= 8 else KH * KW * Cin * Cout
 
 
-class _PackedFilters:
-    """Packed copies of convolution filters (the layouts the conv kernels want, see tatt_repack_conv_weight), kept per
-    (parameter storage, layout) instead of being rebuilt at every use -- 39 launches of a training step.
-
-    An entry is valid while the parameter's torch version counter is unchanged; in-place updates torch does not see (the
-    Trainer's Adam kernel writes through raw pointers) are followed by `refresh()`: ONE launch that rebuilds every entry
-    (captured into the optimiser's hipGraph; the buffers are persistent, so the captured pointers stay valid)."""
+class _PackedHolder:
+    """Packed layouts of ONE filter: {mode: (buffer, torch version counter at packing time)}.  Owned by the parameter object."""
+    __slots__ = ("bufs", "key", "__weakref__")
 
     def __init__(self):
-        self.entries = {}
+        self.bufs, self.key = {}, None
+
+
+class _PackedFilters:
+    """Packed copies of convolution filters (the layouts the conv kernels want, see tatt_repack_conv_weight), kept per
+    (parameter, layout) instead of being rebuilt at every use -- 39 launches of a training step.
+
+    Lifetime: the buffers of a filter live in a holder that the PARAMETER OBJECT owns (attribute `_tatt_packed`); this registry
+    maps (address, shape, device) -> weak reference to the holder, so that aliases of the parameter (the tensors autograd hands
+    back from `saved_tensors` are new Python objects over the same storage) find them.  When a model is released its holders go
+    with it -- nothing is ever evicted while its parameter is alive (buffer pointers are baked into captured hipGraphs), and a
+    long-lived process that keeps building models does not accumulate them.
+    An entry is valid while the parameter's torch version counter is unchanged; in-place updates torch does not see (the Trainer's
+    Adam kernel writes through raw pointers, a broadcast into the flat buffer) are followed by `refresh()`: ONE launch that rebuilds
+    every live entry (captured into the optimiser's hipGraph; the buffers are persistent, so the captured pointers stay valid)."""
+
+    def __init__(self):
+        self.reg = {}
+
+    def _holder(self, w):
+        key = (w.data_ptr(), tuple(w.shape), str(w.device))
+        r = self.reg.get(key)
+        h = r() if r is not None else None
+        if h is None:
+            h = getattr(w, "_tatt_packed", None)         # re-homed parameter (FlatParams moves .data): same owner, new address
+            if h is None:
+                h = _PackedHolder()
+                w._tatt_packed = h
+            elif h.key is not None and h.key != key:
+                self.reg.pop(h.key, None)                # the old address is no longer this filter's
+                h.bufs = {}
+            h.key = key
+            if len(self.reg) >= 4096:
+                self.reg = {k: v for k, v in self.reg.items() if v() is not None}
+            self.reg[key] = weakref.ref(h)
+        return h
 
     def get(self, w, mode):
-        key = (w.data_ptr(), tuple(w.shape), mode, str(w.device))
-        e = self.entries.get(key)
-        if e is not None and e[1] == w._version and e[2]() is w:
+        h = self._holder(w)
+        e = h.bufs.get(mode)
+        if e is not None and e[1] == w._version:
             return e[0]
         Cout, Cin, KH, KW = w.shape
-        if e is not None and e[2]() is not w:                # the address was recycled by another tensor: a fresh buffer (the old
-            e = None                                         # one may be baked into a hipGraph of the model that owned it)
-        if e is None and len(self.entries) >= 1024:
-            # entries hold only a WEAK reference to their parameter: those of models that no longer exist are dropped here; buffers
-            # of live models are never evicted (their pointers may be baked into captured hipGraphs)
-            self.entries = {k: v for k, v in self.entries.items() if v[2]() is not None}
-            if len(self.entries) >= 1024:
-                raise RuntimeError("tatt_amd.ops.PACKED holds 1024 packed filters of live parameters")
         out = e[0] if e is not None else torch.empty(_packed_numel(w.shape, mode), device=w.device, dtype=torch.float32)
         call("tatt_repack_conv_weight", P(w), P(out), Cout, Cin, KH, KW, mode, stream())
-        self.entries[key] = (out, w._version, weakref.ref(w))
+        h.bufs[mode] = (out, w._version)
         return out
+
+    def _live(self, device=None):
+        for key, r in list(self.reg.items()):
+            h = r()
+            if h is None:
+                del self.reg[key]
+            elif device is None or key[2] == str(device):
+                for mode, (out, _) in h.bufs.items():
+                    yield key, mode, out
 
     def refresh(self, device=None):
         """Rebuild every cached layout from the current weights (one launch per 96 entries)."""
-        ent = [(k, e) for k, e in self.entries.items() if (device is None or k[3] == str(device)) and e[2]() is not None]
+        ent = list(self._live(device))
         if not ent:
             return
         n = len(ent)
-        ws = (ctypes.c_void_p * n)(*[k[0] for k, _ in ent])
-        outs = (ctypes.c_void_p * n)(*[e[0].data_ptr() for _, e in ent])
-        dims = (ctypes.c_int * (5 * n))(*[v for k, _ in ent for v in (k[1][0], k[1][1], k[1][2], k[1][3], k[2])])
+        ws = (ctypes.c_void_p * n)(*[k[0] for k, _, _ in ent])
+        outs = (ctypes.c_void_p * n)(*[o.data_ptr() for _, _, o in ent])
+        dims = (ctypes.c_int * (5 * n))(*[v for k, m, _ in ent for v in (k[1][0], k[1][1], k[1][2], k[1][3], m)])
         call("tatt_repack_conv_weight_batch", ws, outs, dims, n, stream())
 
     def clear(self):
-        self.entries.clear()
+        for r in self.reg.values():
+            h = r()
+            if h is not None:
+                h.bufs = {}
+        self.reg = {}
+
+    @property
+    def entries(self):                                   # (diagnostics / tests)
+        return {(k[0], k[1], m, k[2]): o for k, m, o in self._live()}
 
 
 PACKED = _PackedFilters()

@@ -64,3 +64,61 @@ def test_eval_loop_metrics(dev):
     got = evaluate(m, batches)
     assert got["n_batches"] == 2 and m.training
     assert abs(got["psnr"] - want_p) < 1e-3 and abs(got["ssim"] - want_s) < 1e-5, (got, want_p, want_s)
+
+
+def test_collate_labels_follow_the_reference_layout():
+    """dataset/dataset.py:2009-2063 (alignCollate_realWTLAMask.__call__): lower-case, spread over 26 steps with
+    int((26 - len) / (len - 1)) blanks between characters, characters outside the alphabet dropped, one-hot (B, 37, 1, 26)."""
+    from tatt_amd import io
+    assert io.stretch_label("ab") == "a" + "-" * 24 + "b"
+    assert io.stretch_label("Hello") == "h-----e-----l-----l-----o"
+    assert io.stretch_label("x") == "x" and io.stretch_label("") == ""
+    assert io.stretch_label("abcdefghijklmnopqrstuvwxyz0123") == "abcdefghijklmnopqrstuvwxyz"
+    vecs, masks, tics = io.collate_labels(["Hello", "", "a!b", "zz9"])
+    assert tuple(vecs.shape) == (4, 37, 1, 26) and vecs.dtype == torch.float32
+    d2a = "-" + io.ALPHABET
+    dec = lambda b, n: "".join(d2a[int(vecs[b, :, 0, t].argmax())] for t in range(n))
+    assert dec(0, 25) == "h-----e-----l-----l-----o" and float(vecs[0, :, 0, 25].sum()) == 0.0
+    assert float(vecs[1].sum()) == 1.0 and float(vecs[1, 0, 0, 0]) == 1.0          # empty word: one blank, tic 0
+    # "a!b" -> "a" + 11 blanks + "!" + 11 blanks + "b" (25 steps), the "!" is dropped AFTER stretching: 24 one-hot columns
+    assert dec(2, 24) == "a" + "-" * 22 + "b" and float(vecs[2].sum()) == 24.0
+    assert tics.tolist() == [1, 0, 1, 1]
+    assert masks.numel() == 25 + 1 + 24 + 25 and masks.dtype == torch.int64
+    batch = io.collate_batch([(torch.rand(4, 32, 128), torch.rand(4, 16, 64), torch.rand(1, 32, 128), torch.rand(1, 16, 64), w)
+                              for w in ("ab", "text")])
+    assert len(batch) == 9 and batch[1] is None and tuple(batch[0].shape) == (2, 4, 32, 128) and tuple(batch[2].shape) == (2, 4, 16, 64)
+    assert batch[5] == ("ab", "text") and tuple(batch[6].shape) == (2, 37, 1, 26)
+
+
+def test_ctc_greedy_decode_and_filter():
+    """utils/metrics.py:71-92 (get_string_crnn) and utils/util.py:12-32 (str_filt)."""
+    from tatt_amd import io
+    T, B = 7, 3
+    lg = torch.full((T, B, 37), -5.0)
+    seqs = [[11, 11, 0, 11, 12, 12, 0], [0, 0, 0, 0, 0, 0, 0], [1, 0, 1, 36, 36, 0, 36]]
+    for b, sq in enumerate(seqs):
+        for t, c in enumerate(sq):
+            lg[t, b, c] = 3.0
+    assert io.ctc_greedy_decode(lg) == ["aab", "", "00zz"]
+    assert io.str_filt("Ab-C!9", "lower") == "abc9" and io.str_filt("Ab-C!9", "upper") == "AbC9" and io.str_filt("a1", "digit") == "1"
+
+
+@pytest.mark.gpu
+def test_evaluate_reports_recognition_accuracy(dev):
+    """The eval loop with a CRNN recogniser: accuracy of SR / LR / HR = fraction of images whose greedy-decoded, filtered string
+    equals the filtered label (reference interfaces/super_resolution.py:1527-1558,1662-1664) -- checked against the same
+    decode done by hand on the recogniser's own outputs."""
+    import tatt_amd
+    from tatt_amd import io
+    from tatt_amd.crnn import parse_crnn_data
+    torch.manual_seed(3)
+    m = tatt_amd.TSRN(scale_factor=2, width=128, height=32, STN=False, mask=True, srb_nums=2, hidden_units=32).to(dev).eval()
+    rec = tatt_amd.CRNN(32, 1, 37, 256).to(dev).eval()
+    g = torch.Generator().manual_seed(0)
+    lr, hr = torch.rand(4, 4, 16, 64, generator=g).to(dev), torch.rand(4, 4, 32, 128, generator=g).to(dev)
+    with torch.no_grad():
+        hr_strings = io.ctc_greedy_decode(rec(parse_crnn_data(hr[:, :3].contiguous())))
+    labels = [hr_strings[0], hr_strings[1].upper(), "definitely-not-it", hr_strings[3] + "!"]
+    res = io.evaluate(m, [(lr, hr, None, labels)], recognizer=rec)
+    assert res["n_images"] == 4 and res["accuracy_hr"] == 0.75          # case and punctuation are filtered ('lower'), the third differs
+    assert 0.0 <= res["accuracy"] <= 1.0 and 0.0 <= res["accuracy_lr"] <= 1.0 and res["psnr"] > 0.0

@@ -15,6 +15,11 @@ from tests.util import max_err, rel_err, compare_param_grads, STRUCTURAL_ZERO_GR
 pytestmark = pytest.mark.gpu
 STD = dict(scale_factor=2, width=128, height=32, STN=True, mask=True, srb_nums=5, hidden_units=32)
 SR_TOL = 1e-3
+# Train-mode SR without the STN against the oracle / reference vectors.  Round 2 (exact-fp32 MFMA convolutions) measured <= 1.5e-5 and
+# asserted 2e-5; the split-bf16 3x3 convolutions (16 mantissa bits per operand, tatt_conv3_c64_fwd_sb) measure 2.1e-5 / 2.2e-5 on the
+# same cases -- batch statistics re-normalise every convolution output, so its 1e-6-relative error is carried through ten
+# BatchNorms.  The eval forwards stay at 2e-5; the stated bar of the path is 1e-3 (north_star).
+SR_TRAIN_TOL = 5e-5
 
 
 def build(cls, dev, randomize=True, **kw):
@@ -144,7 +149,7 @@ def test_train_step_without_stn_is_tight(dev):
     loss = image_loss(sr, hr.to(dev)).mean() * 100
     loss.backward()
     o_loss, o_grads, _, _, o_out, _ = O.train_step(sd0, x, tp, hr, tatt=True, stn=False)
-    assert max_err(sr, o_out["sr"]) < 2e-5, max_err(sr, o_out["sr"])
+    assert max_err(sr, o_out["sr"]) < SR_TRAIN_TOL, max_err(sr, o_out["sr"])
     assert max_err(mid["trans_feat"], o_out["tp_map"]) < 2e-5
     assert max_err(mid["pr_weights"], o_out["pr_weights"]) < 1e-6
     worst = compare_param_grads(m.named_parameters(), o_grads, rtol=2e-3)
@@ -466,7 +471,7 @@ def test_large_tile_train_golden(dev):
     loss = image_loss(sr, hr.to(dev)).mean() * 100
     loss.backward()
     assert tuple(sr.shape) == (2, 4, 64, 256)
-    assert max_err(sr, torch.from_numpy(z["sr"])) < 2e-5, max_err(sr, torch.from_numpy(z["sr"]))
+    assert max_err(sr, torch.from_numpy(z["sr"])) < SR_TRAIN_TOL, max_err(sr, torch.from_numpy(z["sr"]))
     assert abs(float(loss.detach()) - float(z["loss"])) < 1e-5 * float(z["loss"])
     assert max_err(mid["pr_weights"][:, ::16], torch.from_numpy(z["pr_weights"])) < 1e-5
     assert max_err(mid["trans_feat"][:, :4], torch.from_numpy(z["tp_map"])) < 2e-5

@@ -89,12 +89,15 @@ def main():
         print("  split-bf16 (%d products) 3x3 convs: max|SR - SR_fp32| = %.3e, vs fp64 %.3e" % (
             terms, float((sr_s - sr32).abs().max()), float((sr_s.double() - sr64).abs().max())))
 
+    # Gradients: with the STN off.  (With it on, the bilinear sampler amplifies ANY last-bit change of the 20 control points -- DESIGN.md
+    # section 2 -- and the STN head's gradients of two fp32 runs already differ by ~1e-2: the reference's own fp32 gradient is 5e-3 ..
+    # 8e-3 from fp64 there.  That conditioning noise would drown what this probe measures.)
     def grads(patch, dtype=torch.float32):
         p = {k: (v.to(dtype) if v.is_floating_point() else v).clone().requires_grad_(O.is_param(k)) for k, v in sd.items()}
         if patch:
             patch.__enter__()
         try:
-            out = O.generator_forward(p, x.to(dtype), tp.to(dtype), training=True, drop_on=False)
+            out = O.generator_forward(p, x.to(dtype), tp.to(dtype), training=True, drop_on=False, stn=False)
             loss = O.image_loss(out["sr"], hr.to(dtype)).mean() * 100.0
             loss.backward()
         finally:
@@ -103,7 +106,7 @@ def main():
         return float(loss.detach()), {k: v.grad.double() for k, v in p.items() if v.grad is not None}
     l64, g64 = grads(None, torch.float64)
     l32, g32 = grads(None)
-    print("train step (dropout off): loss fp64 %.7f, fp32 %.7f" % (l64, l32))
+    print("train step (dropout off, STN off): loss fp64 %.7f, fp32 %.7f" % (l64, l32))
     scale = max(float(g.abs().max()) for g in g64.values())
     for terms in (3, 4):
         ls, gs = grads(Patch(terms))
