@@ -22,7 +22,9 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_FP32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_FP32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0       # same guide: bf16 MFMA, dense (the sparse figure is never used)
+PEAK_HBM_GBPS = 8000.0               # same guide: HBM3E spec peak (6.3 TB/s measured achievable)
 # SURVEY.md 8d (FlopCounterMode on the reference graph): forward + backward FLOPs per LR image
 TILES = {"std": dict(H=16, W=64, batch=48, flop_per_image=7.613e9, stn=True, loss_key="tatt_b48_16x64"),           # configs[1]/[2]
          "large": dict(H=32, W=128, batch=16, flop_per_image=36.66e9, stn=False, loss_key="tatt_b16_32x128")}     # configs[4]
@@ -77,31 +79,20 @@ def first_step_loss(model, x, tp, hr):
     return loss
 
 
-def dominant_kernel_traffic(key):
+def dominant_kernel_traffic(key, kernel):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/conv3_ws_pmc.json: 2 x FETCH_SIZE -- the
-    gfx950 correction for 16-byte coalesced reads, MI355X_MICROARCH.md -- + WRITE_SIZE), or None if that shape was not profiled."""
+    gfx950 correction for 16-byte coalesced reads, MI355X_MICROARCH.md -- + WRITE_SIZE), or None if that kernel / shape was not
+    profiled (counters cannot be collected from inside a timed run: separate rocprofv3 --pmc passes, tools/pmc_collect.sh)."""
     try:
-        return json.load(open(PMC_FILE))["shapes"][key]["traffic_bytes"]
+        return json.load(open(PMC_FILE))["kernels"][kernel][key]["traffic_bytes"]
     except (OSError, KeyError, ValueError):
         return None
 
 
-def time_dominant_kernel(dev, B, H=16, W=64):
-    """Average duration of the dominant kernel -- conv3_c64_ws_kernel, the 3x3 convolution 64->64 channels on B x H x W
-    pixels (22 forward/data-gradient launches of this exact shape per training step) -- measured with HIP events on the
-    stream it is launched on.  Algorithmic FLOPs per launch = 2 * pixels * (3*3*64) * 64."""
-    from tatt_amd import ops
-    x = torch.randn(B, H, W, 64, device=dev)
-    w = torch.randn(64, 64, 3, 3, device=dev) * 0.05
-    b = torch.zeros(64, device=dev)
-    wl = ops.repack_weight(w, ops._WS_FWD_MODE)
-    y = torch.empty(B, H, W, 64, device=dev)
-
-    def run():
-        ops.call(ops._WS_ENTRY, ops.P(x), ops.P(wl), ops.P(b), ops.P(y), B, H, W, 64, 0, 0.0, ops.stream())
-    for _ in range(5):
+def _timed_ms(run, n=50, warm=5):
+    """Average duration of `run` (one launch) with HIP events on the stream it launches on (torch's current stream)."""
+    for _ in range(warm):
         run()
-    n = 50
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
@@ -109,9 +100,83 @@ def time_dominant_kernel(dev, B, H=16, W=64):
         run()
     e1.record()
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / n
-    flops = 2.0 * B * H * W * 576 * 64
-    return ms, flops
+    return e0.elapsed_time(e1) / n
+
+
+def time_dominant_kernel(dev, B, H=16, W=64):
+    """Average duration of the dominant kernel of the TATT / TSRN step -- the 3x3 convolution 64->64 channels on B x H x W pixels
+    (22 forward / data-gradient launches of this exact shape per training step; conv3_c64_sb_kernel: split-bf16 on the bf16 matrix
+    cores, or conv3_c64_ws16_kernel with tatt_amd.ops.CONV3_SB = False) -- measured with HIP events on the stream it is launched on.
+    Algorithmic FLOPs per launch = 2 * pixels * (3*3*64) * 64 (the fp32 convolution); the split executes three bf16 products each."""
+    from tatt_amd import ops
+    x = torch.randn(B, H, W, 64, device=dev)
+    w = torch.randn(64, 64, 3, 3, device=dev) * 0.05
+    b = torch.zeros(64, device=dev)
+    if ops.CONV3_SB:
+        wl = ops.repack_weight(w, 10)
+        y = torch.empty(B, H, W, 64, device=dev)
+        run = lambda: ops.call("tatt_conv3_c64_fwd_sb", ops.P(x), 64, 0, ops.P(wl), ops.P(b), ops.P(y), B, H, W, 64, 0, 0.0, None, None, 0,
+                               None, ops.stream())
+    else:
+        wl = ops.repack_weight(w, ops._WS_FWD_MODE)
+        y = torch.empty(B, H, W, 64, device=dev)
+        run = lambda: ops.call(ops._WS_ENTRY, ops.P(x), ops.P(wl), ops.P(b), ops.P(y), B, H, W, 64, 0, 0.0, ops.stream())
+    return _timed_ms(run), 2.0 * B * H * W * 576 * 64
+
+
+def time_tp_layer(dev, B, L, S=26):
+    """The attention path: one fused TP-interpreter decoder layer (csrc/tplayer.hip; last layer: final norms + attention weights out),
+    forward and backward, dropout on, at the benchmark's token count -- fp32 MFMA (16x16x4) for the four 64x64 projections and the
+    weight / key / value gradients, vector ALU for the 26-key softmax.  -> dict for the bench line (`roofline_attn`)."""
+    from tatt_amd import ops, functional as Fh
+    g = torch.Generator().manual_seed(0)
+    r = lambda *s: (torch.randn(*s, generator=g) * 0.3).to(dev)
+    x, qpos, K, V, up = r(B, L, 64), r(B, L, 64), r(B, S, 64), r(B, S, 64), r(B, L, 64)
+    lp = (r(192, 64), r(192), r(64, 64), r(64), r(64, 64), r(64), r(64, 64), r(64), r(64) + 1, r(64), r(64) + 1, r(64))
+    lnF = (r(64) + 1, r(64))
+    seed = Fh.seed_tensor(dev)
+    tf = _timed_ms(lambda: ops.tplayer_fwd(x, qpos, K, V, lp, lnF, 0.5, 1, 0.1, 0.1, 0.1, seed, 10, 1e-5, False, True), 30, 3)
+    tb = _timed_ms(lambda: ops.tplayer_bwd(x, qpos, K, V, lp, lnF, 0.5, 1, 0.1, 0.1, 0.1, seed, 10, 1e-5, None, up, None, None, True), 30, 3)
+    tok = B * L
+    f_fwd = tok * (4 * 2 * 64 * 64)                      # MFMA work only: the four projections (Q, out, FFN 1, FFN 2)
+    f_bwd = tok * (12 * 2 * 64 * 64 + 2 * 2 * S * 64)    # recompute + data gradients + weight gradients + dK / dV
+    b_fwd = tok * (64 * 4 * 3 + S * 4)                   # x, qpos in; the layer's output map + the (L, S) attention weights out
+    b_bwd = tok * 64 * 4 * 5                             # x, qpos, upstream gradient in; dx, dqpos out
+    ach = (f_fwd + f_bwd) / ((tf + tb) * 1e-3) / 1e12
+    return {"kernel": "tplayer_kernel<fwd> + <bwd> (fused cross-attention + LayerNorm + FFN layer, %d x %d query tokens, %d keys)" % (B, L, S),
+            "bound": "mfma", "unit": "TFLOP/s", "peak": PEAK_FP32_MFMA_TFLOPS, "achieved": round(ach, 2),
+            "mfma_util": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "fwd_ms": round(tf, 4), "bwd_ms": round(tb, 4),
+            "hbm_gbps": round((b_fwd + b_bwd) / ((tf + tb) * 1e-3) / 1e9, 1),
+            "hbm_frac": round((b_fwd + b_bwd) / ((tf + tb) * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
+            "launches_per_step": "2 decoder layers + 1 encoder layer, forward and backward"}
+
+
+def time_tbsrn_attention(dev, B, P=1024, h=4, d=32):
+    """The dominant kernels of the TBSRN step (configs[3]): the score-free self-attention of one FeatureEnhancer (csrc/sattn.hip,
+    fp32 MFMA 16x16x4): forward (QK^T and PV: 4 B h P^2 d FLOPs) and backward (D; dK, dV; dQ: seven P x P x d products = 14 B h P^2 d),
+    dropout on.  -> (ms forward + backward, FLOPs, algorithmic HBM bytes: Q, K, V, O in / out, their gradients)."""
+    from tatt_amd import ops, functional as Fh
+    E = h * d
+    Q, K, V, dO = (torch.randn(B, P, E, device=dev) for _ in range(4))
+    O, lse, ws = torch.empty_like(Q), torch.empty(B, h, P, device=dev), torch.empty(B, h, P, device=dev)
+    dQ, dK, dV = torch.empty_like(Q), torch.empty_like(Q), torch.empty_like(Q)
+    seed = Fh.seed_tensor(dev)
+    sc = d ** -0.5
+    fwd = lambda: ops.call("tatt_sattn_fwd", ops.P(Q), ops.P(K), ops.P(V), ops.P(O), ops.P(lse), B, P, h, sc, 0.1, ops.P(seed), 100, ops.stream())
+    bwd = lambda: ops.call("tatt_sattn_bwd", ops.P(Q), ops.P(K), ops.P(V), ops.P(O), ops.P(lse), ops.P(dO), ops.P(dQ), ops.P(dK), ops.P(dV),
+                           ops.P(ws), B, P, h, sc, 0.1, ops.P(seed), 100, ops.stream())
+    tf, tb = _timed_ms(fwd, 10, 2), _timed_ms(bwd, 10, 2)
+    return tf, tb, 4.0 * B * h * P * P * d, 14.0 * B * h * P * P * d, 11.0 * B * P * E * 4
+
+
+def executed_flop_per_image(tile, B):
+    """FLOPs the build executes per LR image: the reference graph's count minus the query GRU's input projection, which the build
+    hoists out of the recurrence (identical maths: the input is the same at every step).  As written the
+    reference spends 2 * W * (64 H) * (3 * 32 H) * 2 directions per image in the forward (x3 with the backward); hoisted it runs once
+    per step, i.e. 1/B of that per image."""
+    H, W = tile["H"], tile["W"]
+    proj = 3.0 * 2.0 * W * (64 * H) * (96 * H) * 2
+    return tile["flop_per_image"] - proj * (1.0 - 1.0 / B)
 
 
 def make_model(arch, tile="std"):
@@ -259,9 +324,42 @@ def main():
     if rank == 0:
         ms = dt / a.steps * 1e3
         ips = a.batch * world * a.steps / dt
-        kms, kflops = time_dominant_kernel(dev, a.batch, tile["H"], tile["W"])
-        from tatt_amd.ops import CONV3_WS as ops_variant
-        ach = kflops / (kms * 1e-3) / 1e12
+        from tatt_amd import ops as _ops
+        shape_key = "B%d_%dx%d" % (a.batch, tile["H"], tile["W"])
+        if a.arch == "tbsrn":
+            tf, tb, ff, fb, kbytes = time_tbsrn_attention(dev, a.batch, tile["H"] * tile["W"])
+            kms, kflops = tf + tb, ff + fb
+            ach = kflops / (kms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None, "algorithmic_bytes": kbytes,
+                    "hbm_gbps": round(kbytes / (kms * 1e-3) / 1e9, 1),
+                    "kernel": "sattn_fwd_kernel + sattn_bwd_kv_kernel + sattn_bwd_q_kernel: score-free self-attention of one FeatureEnhancer "
+                              "(B = %d, P = %d, 4 heads x 32; fp32 MFMA 16x16x4, online softmax, dropout on); 5 per step" % (
+                                  a.batch, tile["H"] * tile["W"]),
+                    "kernel_ms": round(kms, 4), "fwd_ms": round(tf, 4), "bwd_ms": round(tb, 4), "flops_per_launch": kflops,
+                    "fwd_tflops": round(ff / (tf * 1e-3) / 1e12, 2), "bwd_tflops": round(fb / (tb * 1e-3) / 1e12, 2)}
+        else:
+            kms, kflops = time_dominant_kernel(dev, a.batch, tile["H"], tile["W"])
+            alg_bytes = 2 * a.batch * tile["H"] * tile["W"] * 64 * 4 + 9 * 64 * 64 * 4
+            if _ops.CONV3_SB:          # three bf16 products per fp32 product on the bf16 matrix cores
+                ach = 3.0 * kflops / (kms * 1e-3) / 1e12
+                roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4),
+                        "traffic": dominant_kernel_traffic(shape_key, "conv3_c64_sb_kernel"), "algorithmic_bytes": alg_bytes,
+                        "fp32_equivalent_tflops": round(kflops / (kms * 1e-3) / 1e12, 2),
+                        "hbm_gbps": round(alg_bytes / (kms * 1e-3) / 1e9, 1), "hbm_frac": round(alg_bytes / (kms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
+                        "kernel": "conv3_c64_sb_kernel (3x3 conv, 64->64 ch, %d x%dx%d px; fp32 in/out, split-bf16 hi+lo operands, 3 bf16 "
+                                  "MFMA products per fp32 product, fp32 accumulation)" % (a.batch, tile["H"], tile["W"]),
+                        "kernel_ms": round(kms, 4), "flops_per_launch": kflops, "executed_bf16_flops_per_launch": 3.0 * kflops}
+            else:
+                ach = kflops / (kms * 1e-3) / 1e12
+                roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+                        "traffic": dominant_kernel_traffic(shape_key, "conv3_c64_ws16_kernel"), "algorithmic_bytes": alg_bytes,
+                        "hbm_gbps": round(alg_bytes / (kms * 1e-3) / 1e9, 1), "hbm_frac": round(alg_bytes / (kms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
+                        "kernel": "conv3_c64_ws16_kernel (3x3 conv, 64->64 ch, %d x%dx%d px, fp32 MFMA)" % (a.batch, tile["H"], tile["W"]),
+                        "kernel_ms": round(kms, 4), "flops_per_launch": kflops}
+        attn = time_tp_layer(dev, a.batch, tile["H"] * tile["W"]) if a.arch in ("tatt", "tatt_tpg") else None
         out = {
             "metric": "LR images/s (train fwd+bwd+clip+Adam) at %dx%d->%dx%d" % (tile["H"], tile["W"], 2 * tile["H"], 2 * tile["W"]),
             "value": round(ips, 2), "unit": "LR images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -275,15 +373,18 @@ def main():
                        "global_batch": a.batch * world, "parallelism": "dp%d" % world + (" (self-test: RCCL group of one rank)" if a.dp_selftest else ""),
                        "launch": ("hipGraph replay" if graph_ok else "eager") + ("" if a.no_defer else ", staged backward" + ("" if a.no_side_stream else " on 2 streams")), "final_loss": round(loss_v, 5),
                        "host_issue_ms_per_step": round(t_issue / a.steps * 1e3, 3), "known_answer": kat,
-                       "whole_step_tflops": round(ips * tile["flop_per_image"] / 1e12, 2) if a.arch == "tatt" else None},
-            "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
-                         "traffic": dominant_kernel_traffic("B%d_%dx%d" % (a.batch, tile["H"], tile["W"])),
-                         "algorithmic_bytes": 2 * a.batch * tile["H"] * tile["W"] * 64 * 4 + 9 * 64 * 64 * 4,
-                         "kernel": "%s (3x3 conv, 64->64 ch, %d x%dx%d px, fp32 MFMA)" % (
-                             "conv3_c64_ws16_kernel" if ops_variant == "16" else "conv3_c64_ws_kernel", a.batch, tile["H"], tile["W"]),
-                         "kernel_ms": round(kms, 4), "flops_per_launch": kflops},
+                       "arithmetic": "fp32 storage, accumulation and results throughout (the reference's arithmetic)"
+                                     + ("; the 3x3 convolutions evaluate every fp32 product as three bf16 matrix-core products of hi/lo operand "
+                                        "halves (2^-16 relative, measured 1e-6 on SR: profiles/r03_split_bf16_probe.txt)" if _ops.CONV3_SB else ""),
+                       # algorithmic = the reference graph's FLOP count; executed = minus the query-GRU input projection
+                       # the build hoists out of the recurrence
+                       "whole_step_tflops": ({"algorithmic": round(ips * tile["flop_per_image"] / 1e12, 2),
+                                              "executed": round(ips * executed_flop_per_image(tile, a.batch) / 1e12, 2)}
+                                             if a.arch == "tatt" else None)},
+            "roofline": roof,
         }
+        if attn is not None:
+            out["roofline_attn"] = attn
         if world == 1 and not a.no_cpu_baseline and a.arch != "tatt_tpg":
             out["cpu_baseline"] = cpu_baseline(a.arch, a.cpu_batch if a.tile == "std" else min(a.cpu_batch, a.batch), a.tile)
         line = json.dumps(out)

@@ -299,6 +299,19 @@ int tatt_softmax_rows_fwd(float* S, float* Pd, long rows, int L, float pdrop, co
 int tatt_softmax_rows_bwd(const float* P, float* dP, long rows, int L, float pdrop, const unsigned long long* seed,
                           unsigned site, hipStream_t st);
 
+/* ---- score-free self-attention of the TBSRN FeatureEnhancer (csrc/sattn.hip) ---------------------------------- */
+
+/* O (B,P,E) = dropout_{pdrop}(softmax(Q K^T * scale)) V per head of 32 channels (E = 32 h, P a multiple of 64): reference
+ * `attention` / MultiHeadedAttention (model/tbsrn.py:96-151) without materialising the (B,h,P,P) scores; lse (B,h,P) receives the
+ * log-sum-exp of the scaled scores per query (the only thing the backward needs besides Q, K, V, O).  Dropout masks = those of
+ * tatt_softmax_rows_fwd for the same seed word and site (flat index ((b h + head) P + q) P + key). */
+int tatt_sattn_fwd(const float* Q, const float* K, const float* V, float* O, float* lse, int B, int P, int h, float scale,
+                   float pdrop, const unsigned long long* seed, unsigned site, hipStream_t st);
+/* gradients of the same (probabilities recomputed tile by tile, no atomics: deterministic); Dws: workspace of B*h*P floats */
+int tatt_sattn_bwd(const float* Q, const float* K, const float* V, const float* O, const float* lse, const float* dO,
+                   float* dQ, float* dK, float* dV, float* Dws, int B, int P, int h, float scale, float pdrop,
+                   const unsigned long long* seed, unsigned site, hipStream_t st);
+
 /* ---- one TP-interpreter transformer layer as ONE kernel (csrc/tplayer.hip) --------------------------------- */
 
 /* Reference TransformerDecoderLayer_TP.forward_post (model/transformer_v2.py:806-833: cross-attention over the S <= 32 projected

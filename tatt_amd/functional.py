@@ -1136,6 +1136,47 @@ class SelfAttnCoreFn(Function):
         return dQ, dK, dV, None, None, None
 
 
+class SelfAttnFlashFn(Function):
+    """The same attention as SelfAttnCoreFn without the (B, h, P, P) tensors: csrc/sattn.hip (online softmax forward; backward
+    recomputes the probabilities tile by tile from Q, K and the saved per-query log-sum-exp).  d_k = 32, P a multiple of 64."""
+
+    @staticmethod
+    def forward(ctx, Q, K, V, h, pdrop, site):
+        B, Pn, E = Q.shape
+        scale = 1.0 / math.sqrt(E // h)
+        seed = current_seed(Q.device) if pdrop > 0.0 else None
+        O, lse = torch.empty_like(Q), ops.new(Q, B, h, Pn)
+        ops.call("tatt_sattn_fwd", ops.P(Q), ops.P(K), ops.P(V), ops.P(O), ops.P(lse), B, Pn, h, scale, float(pdrop), ops.P(seed),
+                 int(site), ops.stream())
+        ctx.save_for_backward(Q, K, V, O, lse)
+        ctx.cfg = (h, float(pdrop), int(site), seed, scale)
+        return O
+
+    @staticmethod
+    def backward(ctx, dO):
+        Q, K, V, O, lse = ctx.saved_tensors
+        h, pdrop, site, seed, scale = ctx.cfg
+        B, Pn, E = Q.shape
+        dO = _c(dO)
+        dQ, dK, dV = torch.empty_like(Q), torch.empty_like(K), torch.empty_like(V)
+        ws = ops.new(Q, B, h, Pn)
+        ops.call("tatt_sattn_bwd", ops.P(Q), ops.P(K), ops.P(V), ops.P(O), ops.P(lse), ops.P(dO), ops.P(dQ), ops.P(dK), ops.P(dV),
+                 ops.P(ws), B, Pn, h, scale, pdrop, ops.P(seed), site, ops.stream())
+        return dQ, dK, dV, None, None, None
+
+
+def self_attention(Q, K, V, h, pdrop, site):
+    """Multi-head self-attention core over (B, P, E) projected tensors: the score-free kernels when they apply, else the
+    materialised path (any head width / ragged P)."""
+    B, Pn, E = Q.shape
+    if E == 32 * h and Pn % 64 == 0 and SATTN_FLASH:
+        return SelfAttnFlashFn.apply(_c(Q), _c(K), _c(V), h, pdrop, site)
+    return SelfAttnCoreFn.apply(Q, K, V, h, pdrop, site)
+
+
+SATTN_FLASH = True          # test / A-B hook: False -> materialised scores (SelfAttnCoreFn)
+
+
 class CatPEFn(Function):
     """tokens (B,P,C) ++ positional table (P,Cp) broadcast over the batch -> (B,P,C+Cp)  (reference model/tbsrn.py:84-87)."""
 

@@ -114,7 +114,7 @@ def _feature_enhancer(r, fe: FeatureEnhancer, training, dropout_on, site0):
     q = Fh.linear(x, mh.linears[0].weight, mh.linears[0].bias)
     k = Fh.linear(x, mh.linears[1].weight, mh.linears[1].bias)
     v = Fh.linear(x, mh.linears[2].weight, mh.linears[2].bias)
-    a = Fh.SelfAttnCoreFn.apply(q, k, v, mh.h, mh.p if drop else 0.0, site0)
+    a = Fh.self_attention(q, k, v, mh.h, mh.p if drop else 0.0, site0)
     a = Fh.linear(a, mh.linears[3].weight, mh.linears[3].bias)
     ln1, ln3 = fe.mul_layernorm1, fe.mul_layernorm3
     x = Fh.LayerNormFn.apply(x, a, ln1.a_2, ln1.b_2, ln1.eps, 1, 0.0, 0)

@@ -771,3 +771,38 @@ def test_conv3_split_bf16_bn_folding(dev):
         assert float((y - ref).abs().max() / ref.abs().max()) < (2e-5 if sb else 3e-6), sb
         check_close("stats.sum", st[0].float(), y.double().reshape(-1, 64).sum(0).float(), rtol=1e-5, atol=1e-3)
         check_close("stats.sq", st[1].float(), (y.double() ** 2).reshape(-1, 64).sum(0).float(), rtol=1e-5, atol=1e-3)
+
+
+# ------------------------------------------------------------------------------------------- score-free self-attention (TBSRN)
+@pytest.mark.parametrize("B,Pn", [(2, 256), (1, 1024), (3, 64), (2, 4096)])
+def test_flash_self_attention_vs_reference(dev, B, Pn):
+    """csrc/sattn.hip (online-softmax forward, recomputing backward; no (B,h,P,P) tensor) against plain torch attention
+    (reference model/tbsrn.py:130-151), dropout off: values and the three input gradients."""
+    from tatt_amd import functional as Fh
+    g = torch.Generator().manual_seed(12 + Pn)
+    q, k, v = (torch.randn(B, Pn, 128, generator=g) for _ in range(3))
+    compare_fn("flash_self_attn", lambda q, k, v: Fh.SelfAttnFlashFn.apply(q, k, v, 4, 0.0, 0),
+               lambda q, k, v: _ref_self_attn(q, k, v, 4), [q, k, v], dev, grtol=1e-3)
+
+
+@pytest.mark.parametrize("B,Pn", [(2, 128), (1, 1024)])
+def test_flash_self_attention_equals_materialised_path_with_dropout(dev, B, Pn):
+    """Dropout ON: the score-free kernels draw the masks of the materialised path (tatt_softmax_rows_fwd: same seed word, site and
+    flat index), so outputs and gradients agree to accumulation-order round-off -- forward and both backward kernels included."""
+    from tatt_amd import functional as Fh
+    Fh.set_seed(dev, 5)
+    Fh.begin_training_forward(dev)
+    g = torch.Generator().manual_seed(3)
+    base = [torch.randn(B, Pn, 128, generator=g) for _ in range(3)]
+    w = torch.randn(B, Pn, 128, generator=g).to(dev)
+    res = []
+    for fn in (Fh.SelfAttnFlashFn, Fh.SelfAttnCoreFn):
+        q, k, v = (t.clone().to(dev).requires_grad_(True) for t in base)
+        out = fn.apply(q, k, v, 4, 0.1, 77)
+        (out * w).sum().backward()
+        res.append([t.detach().cpu() for t in (out, q.grad, k.grad, v.grad)])
+    for name, a, b in zip(("out", "dq", "dk", "dv"), *res):
+        err = float((a - b).abs().max()) / (float(b.abs().max()) + 1e-12)
+        assert err < 2e-5, (name, err)
+    out0 = Fh.SelfAttnFlashFn.apply(*(t.to(dev) for t in base), 4, 0.0, 77)
+    assert float((res[0][0] - out0.cpu()).abs().max()) > 1e-3          # masks were applied

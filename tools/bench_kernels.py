@@ -18,6 +18,8 @@ ap.add_argument("--only", default="")
 ap.add_argument("--match", default="", help="substring filter on the kernel name")
 ap.add_argument("--iters", type=int, default=30)
 ap.add_argument("--batch", type=int, default=48)
+ap.add_argument("--H", type=int, default=16, help="LR height for the conv3_fwd_sb / tplayer entries (large tile: 32)")
+ap.add_argument("--W", type=int, default=64, help="LR width (large tile: 128)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 B = a.batch
@@ -64,6 +66,11 @@ timeit("conv3_fwd_ws_64_64", lambda: ops.call("tatt_conv3_c64_fwd_ws", ops.P(x64
 wl16 = ops.repack_weight(w33, 6)
 timeit("conv3_fwd_ws16_64_64", lambda: ops.call("tatt_conv3_c64_fwd_ws16", ops.P(x64), ops.P(wl16), ops.P(b64), ops.P(y64), B, 16, 64, 64,
                                                  0, 0.0, ops.stream()), f33)
+wsb = ops.repack_weight(w33, 10)
+xs_ = R(B, a.H, a.W, 64)
+ys_ = torch.empty_like(xs_)
+timeit("conv3_fwd_sb_64_64", lambda: ops.call("tatt_conv3_c64_fwd_sb", ops.P(xs_), 64, 0, ops.P(wsb), ops.P(b64), ops.P(ys_), B, a.H, a.W, 64, 0, 0.0,
+                                               None, None, 0, None, ops.stream()), 2.0 * B * a.H * a.W * 576 * 64, 2.0 * B * a.H * a.W * 64 * 4)
 timeit("conv3_wgrad_64_64", lambda: ops.conv_wgrad(x64, y64, 64, 3, 3), f33)
 xs = x64.permute(0, 3, 1, 2).contiguous().permute(0, 2, 3, 1)       # strided view -> generic implicit-GEMM kernel
 timeit("conv3_generic_64_64", lambda: ops.conv_fwd(xs, wp, b64, 64, 3, 3, out=y64), f33)
@@ -141,3 +148,15 @@ seed = torch.zeros(1, dtype=torch.int64, device=dev)
 Q, K, V = R(B, 1024, 64), R(B, 26, 64), R(B, 26, 64)
 timeit("attn_fwd", lambda: ops.attn_fwd(Q, K, V, 0.1, seed, 1), 2.0 * B * 1024 * 26 * 64 * 2, M * 64 * 4 * 2)
 timeit("attn_bwd", lambda: ops.attn_bwd(Q, K, V, Q, None, 0.1, seed, 1), 2.0 * B * 1024 * 26 * 64 * 5, M * 64 * 4 * 3)
+
+# ---- fused TP-interpreter layer (csrc/tplayer.hip) ----
+from tatt_amd import functional as Fh  # noqa: E402
+L = a.H * a.W
+tx, tq, tK, tV, tup = R(B, L, 64) * 0.3, R(B, L, 64) * 0.3, R(B, 26, 64) * 0.3, R(B, 26, 64) * 0.3, R(B, L, 64) * 0.3
+lp = tuple(R(*sh) * 0.3 for sh in ((192, 64), (192,), (64, 64), (64,), (64, 64), (64,), (64, 64), (64,), (64,), (64,), (64,), (64,)))
+lnF = (R(64) * 0.3 + 1, R(64) * 0.3)
+sd = Fh.seed_tensor(dev)
+timeit("tplayer_fwd", lambda: ops.tplayer_fwd(tx, tq, tK, tV, lp, lnF, 0.5, 1, 0.1, 0.1, 0.1, sd, 10, 1e-5, False, True),
+       B * L * 4 * 2 * 64 * 64, B * L * (64 * 4 * 3 + 26 * 4))
+timeit("tplayer_bwd", lambda: ops.tplayer_bwd(tx, tq, tK, tV, lp, lnF, 0.5, 1, 0.1, 0.1, 0.1, sd, 10, 1e-5, None, tup, None, None, True),
+       B * L * (12 * 2 * 64 * 64 + 2 * 2 * 26 * 64), B * L * 64 * 4 * 5)
