@@ -23,7 +23,7 @@ import torch
 
 from . import functional as Fh
 from . import ops
-from .dp import FlatParams, GradCuts, broadcast_model, allreduce_bucket, rank_dropout_seed
+from .dp import FlatParams, GradCuts, broadcast_model, rank_dropout_seed
 
 
 def image_loss(sr, hr, weights=(1.0, 1e-4)):
@@ -82,10 +82,10 @@ class TextPriorSR(torch.nn.Module):
         self.sr.block = v
 
     # -- Trainer protocol: the SR generator's stages, then one more for the recogniser --------------------------------------
-    def grad_buckets(self):
+    def grad_buckets(self, dp=False):
         """The student receives gradient from two places -- the distillation loss (first backward stage) and the SR generator's
         text encoder (stage "tp") -- so its own backward is a last stage, "tpg", fed by the sum of both (forward() cuts there)."""
-        b = [(n, list(ps)) for n, ps in self.sr.grad_buckets()]
+        b = [(n, list(ps)) for n, ps in self.sr.grad_buckets(dp)]
         b.append(("tpg", list(self.tpg.parameters())))
         return b
 
@@ -254,7 +254,11 @@ class Trainer:
         self.defer = bool(defer_param_grads)
         self.two_lanes = self.defer and bool(side_stream) and self.cuda
         staged = (self.dp or self.defer) and hasattr(model, "grad_buckets") and hasattr(model, "set_grad_cuts")
-        buckets = model.grad_buckets() if hasattr(model, "grad_buckets") else None
+        buckets = None
+        if hasattr(model, "grad_buckets"):
+            import inspect
+            takes_dp = "dp" in inspect.signature(model.grad_buckets).parameters
+            buckets = model.grad_buckets(dp=self.dp) if takes_dp else model.grad_buckets()
         if buckets is not None and not staged:           # one stage: one bucket, same parameter ORDER as the staged layout
             buckets = [("all", [p for _, ps in buckets for p in ps])]
         self.flat = FlatParams(model, buckets)
@@ -294,6 +298,14 @@ class Trainer:
         self._nsteps = 0
         self._works = []
         self.last_loss = None
+        # Data parallel: the passes run in at most three groups, each followed by ONE all-reduce of the (contiguous) buckets it
+        # completed -- [passes 0 .. n-3] -> the trunk / residual-block buckets, [pass n-2] -> the bucket of stage n-3 (TATT: the TP
+        # interpreter with the query GRU, 19 MB), [pass n-1] -> the last two.  With `use_graph` a group is one hipGraph: four graph
+        # launches and three collectives per step instead of ten and ten.
+        n = self._npass
+        groups = [list(range(0, n - 2)), [n - 2], [n - 1]] if n >= 3 else [[k] for k in range(n)]
+        self._groups = [g for g in groups if g]
+        self.reduce_log = []                         # [(last pass of the group, first bucket, last bucket)] of the latest step
 
     # -- pieces ----------------------------------------------------------------------------------
     def _main_lane(self, k, x=None, tp=None, hr=None):
@@ -373,11 +385,20 @@ class Trainer:
         if hasattr(self.kernels, "after_update"):
             self.kernels.after_update(self.dev)
 
-    def _reduce(self, k):
-        """Data parallel: asynchronous sum all-reduce of bucket k, ordered behind the work already issued on the current stream
-        (RCCL runs it on its own stream: it overlaps the stages launched next)."""
-        if self.dp:
-            self._works.append(allreduce_bucket(self.flat, k, self.pg, async_op=True))
+    def _reduce(self, lo, hi, after_pass):
+        """Data parallel: ONE asynchronous sum all-reduce of buckets lo .. hi (adjacent in the flat buffer), ordered behind the
+        work already issued on the current stream (RCCL runs it on its own stream: it overlaps the passes launched next)."""
+        if self.dp and hi >= lo:
+            self.reduce_log.append((after_pass, lo, hi))
+            s, e = self.flat.ranges[lo][0], self.flat.ranges[hi][1]
+            self._works.append(torch.distributed.all_reduce(self.flat.g[s:e], op=torch.distributed.ReduceOp.SUM, group=self.pg,
+                                                            async_op=True))
+
+    def _buckets_done_by(self, k):
+        """Index of the last bucket that is complete once pass k has run (-1: none): pass k gathers bucket k - 1; the last pass
+        gathers its own bucket too."""
+        nst = len(self.stages)
+        return nst - 1 if (self._merge_last and k >= nst - 1) else min(k - 1, nst - 1)
 
     def _wait_reduces(self):
         """The current stream waits for the collectives (device-side waits; the host does not block on a GPU)."""
@@ -411,15 +432,17 @@ class Trainer:
         if graphs is not None and "step" in graphs:
             graphs["step"].replay()                  # single GPU: the whole step is one graph
             return self.last_loss.clone()            # (the captured tensor is overwritten by the next replay)
-        for k in range(self._npass):
+        self.reduce_log = []
+        sent = -1                                    # last bucket already on the wire
+        for gi, group in enumerate(self._groups):
             if graphs is None:
-                self._pass(k, x, tp, hr)
+                for k in group:
+                    self._pass(k, x, tp, hr)
             else:
-                graphs["pass"][k].replay()
-            if k >= 1:
-                self._reduce(k - 1)                  # bucket k-1 is complete: on the wire while pass k+1 computes
-        if self._merge_last:
-            self._reduce(nst - 1)                    # (the last pass completed two buckets)
+                graphs["pass"][gi].replay()
+            done = self._buckets_done_by(group[-1])
+            self._reduce(sent + 1, done, group[-1])  # what this group completed: on the wire while the next group computes
+            sent = max(sent, done)
         self._wait_reduces()
         if graphs is None:
             Fh.SIDE.release()
@@ -449,10 +472,11 @@ class Trainer:
         pool = torch.cuda.graph_pool_handle()
         kw = dict(pool=pool, capture_error_mode="thread_local")
         graphs = {"pass": []}
-        for k in range(self._npass):
+        for group in self._groups:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, **kw):
-                self._pass(k, sx, stp, shr)
+                for k in group:
+                    self._pass(k, sx, stp, shr)
             graphs["pass"].append(g)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, **kw):

@@ -420,14 +420,17 @@ class _TrainPathMixin:
     def set_grad_cuts(self, cuts):
         object.__setattr__(self, "_grad_cuts", cuts)
 
-    def grad_buckets(self):
+    def grad_buckets(self, dp=False):
         """[(stage name, [parameters])] in the order the parameters' gradients are complete; stage names match the
         `cuts.cut(name, ...)` calls of the forward: "trunk" (block7 + up-sampler: what the loss back-propagates into directly),
         "srb4" ... "srb0" (the residual blocks, last to first), "tp" (TP interpreter), "first" (block1 + TPS sampler), "stn" (STN
         head).  A parameter may be filed under a LATER bucket than the stage that produces its gradient: its weight-gradient
         kernels then run with that later stage's side lane (tatt_amd.functional.SIDE.due_of).  Two are: the query GRU (47 dependent
         launches, "first": beside the STN head's backward) and, with a TP interpreter, the 9x9 output convolution (0.4 ms of
-        weight gradient, "srb0": beside the TP interpreter's long, launch-bound backward instead of the first residual block's)."""
+        weight gradient, "srb0": beside the TP interpreter's long, launch-bound backward instead of the first residual block's).
+        `dp` (data parallel): the query GRU -- 18.9 of the model's 30.4 MB -- is filed under "tp" instead, the stage that completes its
+        upstream gradient: its backward then runs beside block1's and its all-reduce travels while the STN head back-propagates; only
+        the last bucket (block1 + STN head, 7.5 MB) is left with nothing to hide behind."""
         k = self.srb_nums
         groups = {"trunk": [], "tp": [], "first": [], "stn": []}
         groups.update({"srb%d" % i: [] for i in range(k)})
@@ -435,7 +438,7 @@ class _TrainPathMixin:
             top = name.split(".", 1)[0]
             if top == "infoGen":
                 is_q = name.startswith("infoGen.transformer.gru_encoding.") or name.startswith("infoGen.init_factor.")
-                groups["first" if is_q else "tp"].append(p)
+                groups["first" if (is_q and not dp) else "tp"].append(p)
             elif top.startswith("block") and 2 <= int(top[5:]) <= k + 1:
                 groups["srb%d" % (int(top[5:]) - 2)].append(p)
             elif top.startswith("block") and int(top[5:]) > k + 1:

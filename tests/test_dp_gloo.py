@@ -68,6 +68,9 @@ def _worker(rank, world, port, q):
     g = torch.Generator().manual_seed(rank_seed(0, rank))
     x, y = torch.rand(3, 4, 8, 8, generator=g), torch.rand(3, 4, 8, 8, generator=g)
     losses = [float(tr.step(x, None, y)) for _ in range(2)]
+    # buckets go on the wire in completion order, each exactly once, the first ones BEFORE the last pass has run:
+    # (last pass of the group, first bucket, last bucket)
+    assert tr.reduce_log == [(1, 0, 0), (2, 1, 2)], tr.reduce_log
     # parameters start on 64-byte boundaries inside the flat buffers; the padding stays zero through the updates
     used = torch.zeros(tr.flat.n, dtype=torch.bool)
     for prm in tr.flat.params:
