@@ -318,6 +318,12 @@ def _dec_params(dec):
             dec.linear2.weight, dec.linear2.bias, dec.norm2.weight, dec.norm2.bias, dec.norm3.weight, dec.norm3.bias)
 
 
+# Data parallel: file the query GRU (18.9 of 30.4 MB) with the TP interpreter's bucket so that its all-reduce travels while the STN
+# head back-propagates?  Measured on one GPU against an RCCL group of one rank (bench.py --dp-selftest, same box, round 3): 7.28 ms
+# per step with it, 6.81 without (6.59 without a process group): the 47-launch backward chain of the query GRU then sits beside
+# block1's short backward and lengthens that pass by 0.47 ms -- more than the ~0.3 ms the 19 MB all-reduce costs when it trails the
+# last pass.  Off by default; tools/ab_bench.py tatt_amd.tsrn.DP_QGRU_WITH_TP=1 re-measures.
+DP_QGRU_WITH_TP = False
 TP_FUSED = True          # test hook: False walks the operator-by-operator path for every geometry (tests compare the two)
 
 
@@ -428,9 +434,7 @@ class _TrainPathMixin:
         kernels then run with that later stage's side lane (tatt_amd.functional.SIDE.due_of).  Two are: the query GRU (47 dependent
         launches, "first": beside the STN head's backward) and, with a TP interpreter, the 9x9 output convolution (0.4 ms of
         weight gradient, "srb0": beside the TP interpreter's long, launch-bound backward instead of the first residual block's).
-        `dp` (data parallel): the query GRU -- 18.9 of the model's 30.4 MB -- is filed under "tp" instead, the stage that completes its
-        upstream gradient: its backward then runs beside block1's and its all-reduce travels while the STN head back-propagates; only
-        the last bucket (block1 + STN head, 7.5 MB) is left with nothing to hide behind."""
+        `dp` (data parallel) with DP_QGRU_WITH_TP: the query GRU is filed under "tp" instead (measured slower, see the flag)."""
         k = self.srb_nums
         groups = {"trunk": [], "tp": [], "first": [], "stn": []}
         groups.update({"srb%d" % i: [] for i in range(k)})
@@ -438,7 +442,7 @@ class _TrainPathMixin:
             top = name.split(".", 1)[0]
             if top == "infoGen":
                 is_q = name.startswith("infoGen.transformer.gru_encoding.") or name.startswith("infoGen.init_factor.")
-                groups["first" if (is_q and not dp) else "tp"].append(p)
+                groups["first" if (is_q and not (dp and DP_QGRU_WITH_TP)) else "tp"].append(p)
             elif top.startswith("block") and 2 <= int(top[5:]) <= k + 1:
                 groups["srb%d" % (int(top[5:]) - 2)].append(p)
             elif top.startswith("block") and int(top[5:]) > k + 1:
