@@ -299,6 +299,20 @@ int tatt_softmax_rows_fwd(float* S, float* Pd, long rows, int L, float pdrop, co
 int tatt_softmax_rows_bwd(const float* P, float* dP, long rows, int L, float pdrop, const unsigned long long* seed,
                           unsigned site, hipStream_t st);
 
+/* ---- token-matrix projections on the bf16 matrix cores (csrc/tokgemm.hip) ------------------------------------------ */
+
+/* Y (M x N) = [X1 | X2] (M x K) W^T + bias by operand splitting (hi + lo bf16, three products, fp32 accumulation; same arithmetic as
+ * tatt_conv3_c64_fwd_sb): the GRU input projections of the GruBlocks (reference model/tsrn.py:1075-1084) and their data gradients.
+ * Wp = packed operand from tatt_tokgemm_pack (N*K 32-bit words); X1 (M, K1), X2 (M, K - K1) (NULL when K1 == K); output columns
+ * [0, N1) go to Y1 (M, N1), the rest to Y2 (M, N - N1) (NULL when N1 == N).  M a multiple of 64; (N, K) one of (192, 128), (192, 64),
+ * (128, 192), (64, 192), (64, 64), (64, 128). */
+int tatt_tokgemm_sb(const float* X1, const float* X2, int K1, const float* Wp, const float* bias, float* Y1, float* Y2, int N1,
+                    int M, int N, int K, hipStream_t st);
+/* trans = 0: w(n, k) = W[n*ldw + k] (y = x W^T);  trans = 1: w(n, k) = W[k*ldw + n] (dx = dy W).  out: N*K words */
+int tatt_tokgemm_pack(const float* W, float* out, int N, int K, int ldw, int trans, hipStream_t st);
+/* n packs in one launch: ptrs = HOST array of n x 2 device pointers (W, out), dims = HOST array of n x 4 ints (N, K, ldw, trans) */
+int tatt_tokgemm_pack_batch(const float* const* ptrs, const int* dims, int n, hipStream_t st);
+
 /* ---- score-free self-attention of the TBSRN FeatureEnhancer (csrc/sattn.hip) ---------------------------------- */
 
 /* O (B,P,E) = dropout_{pdrop}(softmax(Q K^T * scale)) V per head of 32 channels (E = 32 h, P a multiple of 64): reference

@@ -475,15 +475,37 @@ def gru_precompose(blocks):
     if not blocks:
         return
     ptrs, Ks, outs = [], [], {}
+    pk_ptrs, pk_dims = [], []
     for b in blocks:
         g, Wc = b.gru, b.conv1.weight
         K = Wc.numel() // Wc.shape[0]
         Wp, bp = ops.new(Wc, 192, K), ops.new(Wc, 192)
         ptrs += [t.data_ptr() for t in (g.weight_ih_l0, g.weight_ih_l0_reverse, g.bias_ih_l0, g.bias_ih_l0_reverse, Wc, b.conv1.bias, Wp, bp)]
         Ks.append(K)
-        outs[Wc.data_ptr()] = (Wp, bp, Wc._version)
+        Wfk = Wbk = None
+        if TOKGEMM_SB and K in (64, 128):            # split-bf16 operands of the projection (forward) and of its data gradient
+            Wfk, Wbk = ops.new(Wc, 192 * K), ops.new(Wc, 192 * K)
+            pk_ptrs += [Wp.data_ptr(), Wfk.data_ptr(), Wp.data_ptr(), Wbk.data_ptr()]
+            pk_dims += [192, K, K, 0, K, 192, K, 1]
+        outs[Wc.data_ptr()] = (Wp, bp, Wc._version, Wfk, Wbk)
     ops.call("tatt_gru_compose_batch", (ctypes.c_void_p * len(ptrs))(*ptrs), (ctypes.c_int * len(Ks))(*Ks), len(Ks), ops.stream())
+    if pk_ptrs:
+        ops.call("tatt_tokgemm_pack_batch", (ctypes.c_void_p * len(pk_ptrs))(*pk_ptrs), (ctypes.c_int * len(pk_dims))(*pk_dims),
+                 len(pk_ptrs) // 2, ops.stream())
     _PRE.table = outs
+
+
+TOKGEMM_SB = True          # test / A-B hook: False -> the exact-fp32 MFMA GEMMs for the GRU input projections
+
+
+def _tokgemm(X1, X2, Wpk, bias, N, K, N1=None):
+    """[X1 | X2] (M, K) @ W^T (+ bias) through tatt_tokgemm_sb -> (Y1 (M, N1), Y2 (M, N - N1) or None)"""
+    M, K1 = X1.shape
+    N1 = N if N1 is None else N1
+    Y1 = ops.new(X1, M, N1)
+    Y2 = ops.new(X1, M, N - N1) if N1 < N else None
+    ops.call("tatt_tokgemm_sb", ops.P(X1), ops.P(X2), K1, ops.P(Wpk), ops.P(bias), ops.P(Y1), ops.P(Y2), N1, M, N, K, ops.stream())
+    return Y1, Y2
 
 
 class GruBlockFn(Function):
@@ -504,17 +526,27 @@ class GruBlockFn(Function):
         x2 = x.reshape(-1, K1)
         xb2 = xb.reshape(-1, K - K1) if xb is not None else None
         pre = _PRE.table.pop(conv_w.data_ptr(), None)           # composed at the start of this forward (gru_precompose)?
+        Wfk = Wbk = None
         if pre is not None and pre[2] == conv_w._version and pre[0].device == x.device:
-            Wp, bp = pre[0], pre[1]
+            Wp, bp, Wfk, Wbk = pre[0], pre[1], pre[3], pre[4]
         else:
             Wp = ops.new(x, 192, K)                              # composed projection  [W_ih_f; W_ih_r] @ W_c
             bp = ops.new(x, 192)
             ops.call("tatt_gru_compose", ops.P(wih_f), ops.P(wih_r), ops.P(bih_f), ops.P(bih_r), ops.P(Wc), ops.P(conv_b),
                      ops.P(Wp), ops.P(bp), K, ops.stream())
-        gi = ops.linear_fwd(x2, Wp, bp, x2b=xb2)
+        use_tg = TOKGEMM_SB and x2.shape[0] % 64 == 0 and K in (64, 128) and K1 % 4 == 0
+        if use_tg and Wfk is None:
+            Wfk, Wbk = ops.new(x, 192 * K), ops.new(x, 192 * K)
+            ops.call("tatt_tokgemm_pack", ops.P(Wp), ops.P(Wfk), 192, K, K, 0, ops.stream())
+            ops.call("tatt_tokgemm_pack", ops.P(Wp), ops.P(Wbk), K, 192, K, 1, ops.stream())
+        if use_tg:
+            gi, _ = _tokgemm(x2, xb2, Wfk, bp, 192, K)
+        else:
+            gi = ops.linear_fwd(x2, Wp, bp, x2b=xb2)
+            Wbk = None
         geom = ops.seq_geom(B, H, W, vertical)
         out, gates = ops.gru32_fwd(gi, whh_f, bhh_f, whh_r, bhh_r, geom, save=any(ctx.needs_input_grad))
-        ctx.save_for_backward(x, xb, Wc, Wp, gates, out, wih_f, whh_f, wih_r, whh_r, conv_b)
+        ctx.save_for_backward(x, xb, Wc, Wp, gates, out, wih_f, whh_f, wih_r, whh_r, conv_b, Wbk)
         ctx.geom = geom
         ctx.wshape = conv_w.shape
         ctx.leaves = (conv_w, conv_b, wih_f, whh_f, bih_f, bhh_f, wih_r, whh_r, bih_r, bhh_r)
@@ -522,13 +554,17 @@ class GruBlockFn(Function):
 
     @staticmethod
     def backward(ctx, dout):
-        x, xb, Wc, Wp, gates, out, wih_f, whh_f, wih_r, whh_r, conv_b = ctx.saved_tensors
+        x, xb, Wc, Wp, gates, out, wih_f, whh_f, wih_r, whh_r, conv_b, Wbk = ctx.saved_tensors
         K1 = x.shape[-1]
         K = Wc.shape[1]
         x2 = x.reshape(-1, K1)
         dgi, dgh, hprev = ops.gru32_bwd(gates, out, _c(dout).reshape(-1, 64), whh_f, whh_r, ctx.geom)
         dxb = None
-        if xb is not None and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and K == 2 * K1:
+        if Wbk is not None and ctx.needs_input_grad[0] and (xb is None or ctx.needs_input_grad[1]):
+            dx, dxb = _tokgemm(dgi, None, Wbk, None, K, 192, K1)      # dx | dxb = dgi Wp on the bf16 matrix cores (split operands)
+            dx = dx.reshape(x.shape)
+            dxb = dxb.reshape(xb.shape) if xb is not None else None
+        elif xb is not None and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and K == 2 * K1:
             dx, dxb = ops.linear_bwd_input_halves(dgi, Wp)          # both halves of the concatenated input: one launch
             dx, dxb = dx.reshape(x.shape), dxb.reshape(xb.shape)
         else:

@@ -806,3 +806,27 @@ def test_flash_self_attention_equals_materialised_path_with_dropout(dev, B, Pn):
         assert err < 2e-5, (name, err)
     out0 = Fh.SelfAttnFlashFn.apply(*(t.to(dev) for t in base), 4, 0.0, 77)
     assert float((res[0][0] - out0.cpu()).abs().max()) > 1e-3          # masks were applied
+
+
+# ------------------------------------------------------------------------------------------- split-bf16 token projections
+@pytest.mark.parametrize("N,K,K1,N1", [(192, 128, 64, 192), (192, 64, 64, 192), (128, 192, 192, 64), (64, 192, 192, 64), (64, 64, 64, 64),
+                                        (64, 128, 128, 64)])
+def test_tokgemm_split_bf16_vs_fp64(dev, N, K, K1, N1):
+    """tatt_tokgemm_sb (Y = [X1 | X2] W^T + b on the bf16 matrix cores, hi/lo operand split) against fp64 for every instantiated
+    (N, K): two sources / two destinations included; both packings (W (N, K) and the transposed view of a (K, N) matrix)."""
+    from tatt_amd import ops
+    from tatt_amd import functional as Fh
+    M = 64 * 37
+    X, W, b = R(M, K, seed=1), R(N, K, seed=2) / math.sqrt(K), R(N, seed=3)
+    ref = X.double() @ W.double().t() + b.double()
+    Xd = X.to(dev)
+    for trans in (0, 1):
+        src = (W if trans == 0 else W.t().contiguous()).to(dev)           # trans = 1: the operand is stored (K, N)
+        Wpk = torch.empty(N * K, device=dev)
+        ops.call("tatt_tokgemm_pack", ops.P(src), ops.P(Wpk), N, K, K if trans == 0 else N, trans, ops.stream())
+        X1 = Xd[:, :K1].contiguous()
+        X2 = Xd[:, K1:].contiguous() if K1 < K else None
+        Y1, Y2 = Fh._tokgemm(X1, X2, Wpk, b.to(dev), N, K, N1)
+        Y = Y1 if Y2 is None else torch.cat([Y1, Y2], 1)
+        err = float((Y.cpu().double() - ref).abs().max() / ref.abs().max())
+        assert err < 1e-5, (trans, err)
