@@ -55,8 +55,8 @@ int tatt_conv2d_wgrad(const float* x, long xsn, long xsh, long xsw, long xsc, co
 
 /* OIHW nn.Conv2d weight -> GEMM operand; mode 0: [KH][KW][Cin][Cout]; mode 1: [KH][KW][Cout][Cin], taps flipped (data gradient);
  * mode 2: [KH][KW][Cout][Cin]; mode 3: [KH][KW][Cin][Cout], taps flipped -- forward / data-gradient filters with the
- * contraction axis contiguous, for tatt_conv3_c64_fwd_t; modes 4 / 5: the same two 3x3 filters (64 contraction channels) in the
- * per-lane register order of tatt_conv3_c64_fwd_ws; modes 6 / 7: in the register order of tatt_conv3_c64_fwd_ws16;
+ * contraction axis contiguous, for tatt_conv3_c64_fwd_t; modes 6 / 7: the same two 3x3 filters (64 contraction channels) in the
+ * per-lane register order of tatt_conv3_c64_fwd_ws16 (4 / 5: retired);
  * modes 8 / 9: the Toeplitz-expanded 9x9 filter [9][64][16][20] of tatt_conv9_c64_to_c4_mfma (out needs 184,320 floats);
  * modes 10 / 11: the split-bf16 (hi / lo) forward / data-gradient operand of tatt_conv3_c64_fwd_sb (3x3, channel counts multiples
  * of 64; Cout*Cin*9 32-bit words of two bf16, one chunk per 64 contraction channels) */
@@ -87,13 +87,10 @@ int tatt_reduce_flush(hipStream_t st);
  * read with 16-byte LDS loads along the contraction axis.  Used when Cin != 64. */
 int tatt_conv3_c64_fwd_t(const float* x, const float* wt, const float* bias, float* y, int B, int H, int W, int Cin,
                          int Cout, int act, float beta, hipStream_t st);
-/* weight-stationary 3x3 convolution for 64 input channels (reference nn.Conv2d(64, Cout, 3, padding=1): model/tsrn.py:877,885,
- * 612,1043 and their data gradients): every wave keeps its 32 output channels' whole filter in registers; wl = filter from
- * tatt_repack_conv_weight mode 4 (forward) / mode 5 (data gradient of a 64-output-channel convolution) */
-int tatt_conv3_c64_fwd_ws(const float* x, const float* wl, const float* bias, float* y, int B, int H, int W,
-                          int Cout, int act, float beta, hipStream_t st);
-/* the same convolution with the 64 px x 64 co tile cut along the output channels: every wave owns 32 pixels x 16 channels and the
- * whole 9 x 64 contraction (v_mfma_f32_16x16x4_f32), no partial sums to exchange; wl = tatt_repack_conv_weight mode 6 / mode 7 */
+/* weight-stationary 3x3 convolution for 64 input channels in exact fp32 (reference nn.Conv2d(64, Cout, 3, padding=1):
+ * model/tsrn.py:877,885,612,1043 and their data gradients): a persistent work-group keeps the filter in registers, wave = 32 pixels
+ * x 16 output channels and the whole 9 x 64 contraction on v_mfma_f32_16x16x4_f32; wl = tatt_repack_conv_weight mode 6 (forward)
+ * / mode 7 (data gradient of a 64-output-channel convolution) */
 int tatt_conv3_c64_fwd_ws16(const float* x, const float* wl, const float* bias, float* y, int B, int H, int W,
                             int Cout, int act, float beta, hipStream_t st);
 /* tatt_conv3_c64_fwd_ws16 with BatchNorm folded in on either side (reference model/tsrn.py:877-886: conv -> bn -> mish -> conv -> bn):

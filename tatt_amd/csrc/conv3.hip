@@ -2,16 +2,18 @@
 // forward, reference model/tsrn.py:877,885,612,1043) -- on v_mfma_f32_32x32x2_f32 (exact fp32).
 //
 // Forward / data-gradient, one work-group tile = one 64-pixel row segment x 64 output channels, persistent work-groups:
-//   * 64 input channels (tatt_conv3_c64_fwd_ws): WEIGHT-STATIONARY -- the filter lives in registers for the lifetime of the
-//     work-group, the loop streams only activations through a double-buffered LDS halo (conv3_c64_ws_kernel);
-//   * more input channels (tatt_conv3_c64_fwd_t): the filter slice of each tap is re-staged through LDS
+//   * 64-channel contractions on the bf16 matrix cores by operand splitting (tatt_conv3_c64_fwd_sb, the default: three bf16 products
+//     per fp32 product, fp32 accumulation; wider inputs are chunked) or in exact fp32 (tatt_conv3_c64_fwd_ws16): WEIGHT-STATIONARY,
+//     the filter lives in registers for the lifetime of the work-group, the loop streams only activations through a double-buffered
+//     LDS halo; both fold the producer's BatchNorm + activation into the halo staging and emit BatchNorm statistics of their output;
+//   * more input channels in exact fp32 (tatt_conv3_c64_fwd_t): the filter slice of each tap is re-staged through LDS
 //     (conv3_c64_fwd_v5_kernel), both MFMA operands read with 16-byte LDS loads.
 // Weight-gradient (tatt_conv3_c64_wgrad_partial): persistent work-groups walk row segments; each wave keeps the 9 taps x
 //   (32 ci x 32 co) quadrant in 9 accumulators (144 VGPRs); A = x halo read channel-contiguous, B = dy tile; per-block
 //   partials are summed deterministically and scattered to the OIHW parameter layout by the split-K reducer of gemm.hip.
 // History (measured on MI355X, B=48, 64->64 channels, 3.62 GFLOP/launch): one tile per work-group 59.6 us; persistent +
-// prefetch 54 us; 8 waves / loader-wave variants 55-61 us; 16-byte LDS operand reads (v5) 52 us; weight-stationary 4 waves
-// 45 us; weight-stationary 8 waves (two waves per SIMD) 39 us.  Only the last two designs are kept.
+// prefetch 54 us; 16-byte LDS operand reads (v5) 52 us; weight-stationary 39 us (round 1), 38 us (ws16, round 2); split-bf16 18.6 us
+// (round 3).
 #include "common.h"
 #include <mutex>
 #include <stdlib.h>
@@ -200,189 +202,31 @@ TATT_API int tatt_conv3_c64_fwd_t(const float* x, const float* wt, const float* 
                                   int Cout, int act, float beta, hipStream_t st) {
     if (Cin % 64 || Cout % 64 || W % C3_PX) return 1;
     Conv3P p = {x, wt, bias, y, B, H, W, Cin, Cout, act, beta};
-    static int ck = 32;
     static std::once_flag attr_once;                 // C++11 call_once: safe if several host threads launch
     std::call_once(attr_once, [&] {
-#define C5_ATTR(CKV) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_fwd_v5_kernel<CKV>), \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, C5<CKV>::LDS);
-        C5_ATTR(64) C5_ATTR(32) C5_ATTR(16)
-        const char* e = getenv("TATT_CONV3_CK");   // 64: one work-group per CU; 32 (default): two per CU; 16: three per CU
-        if (e) ck = atoi(e);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_fwd_v5_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  C5<32>::LDS);
     });
+    // 32 input channels per work item: 75.5 KB of LDS, two work-groups per CU (64: one per CU and 16: three per CU measured slower)
     const int ntiles = B * H * (W / C3_PX) * (Cout / 64);
-    const int per_cu = ck == 64 ? 1 : (ck == 16 ? 3 : 2);
-    const int G = ntiles < 256 * per_cu ? ntiles : 256 * per_cu;
-#define C5_LAUNCH(CKV) hipLaunchKernelGGL((conv3_c64_fwd_v5_kernel<CKV>), dim3(G), dim3(256), C5<CKV>::LDS, st, p);
-    if (ck == 64) { C5_LAUNCH(64) } else if (ck == 16) { C5_LAUNCH(16) } else { C5_LAUNCH(32) }
-    return LAUNCH_CHECK();
-}
-
-// ---- weight-stationary forward (Cin == 64) ---------------------------------------------------------------------------
-// The filter of a work-group's 64 output channels (9 taps x 64 ci x 64 co = 147 KB) lives in REGISTERS for the lifetime of the
-// persistent work-group, so the main loop streams only activations: the next tile's halo is prefetched global -> registers ->
-// LDS underneath the MFMAs and there is one halo hand-off per tile instead of one filter hand-off per tap; the filter is read
-// from L2 once per work-group instead of once per tile (113 MB per launch in the kernel above).
-#define WS_XP 68                              // halo pitch (floats): 64 ci + 4 pad -> conflict-free ds_read_b128
-#define WS_HALO (3 * C3_HW * WS_XP)           // floats per halo buffer (53.9 KB)
-#define WS_TP 36                              // transpose-tile pitch (floats)
-#define WS_TT (32 * WS_TP)                    // floats per per-wave epilogue tile
-// 512 threads: waves w and w+4 share one 32 px x 32 co output block and each contracts HALF of the input channels
-// (ci [0,32) / [32,64)) for all 9 taps -> 144 filter registers per lane, so TWO waves fit per SIMD and the hardware interleaves
-// them: while one wave is in its epilogue / halo addressing / LDS latency the other keeps the MFMA pipe busy (a single
-// 288-register wave per SIMD measured 45 us per launch, this arrangement 39 us).  The two partial accumulators are summed
-// through LDS in [px][co] order, so each wave finishes half of the block's pixels with 16-byte stores.
-#define WS_LDS ((2 * WS_HALO + 8 * WS_TT) * 4)               // two halos + one [32 px][36] exchange tile per wave
-__global__ __launch_bounds__(512, 1) void conv3_c64_ws_kernel(Conv3P p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wm = wave & 1, wn = (wave >> 1) & 1, kh2 = wave >> 2;
-    const int segs = p.W / C3_PX, cob = p.Cout / 64;
-    const int npt = p.B * p.H * segs;
-    // XCD-aware tile order: work-groups are dealt round-robin to the 8 XCDs (private L2 each), so XCD x = blockIdx % 8 takes
-    // a CONTIGUOUS run of row tiles (the 3-row halos of neighbouring rows then hit the same L2 instead of being fetched
-    // through the fabric once per XCD) and a single cout block (one filter per L2).
-    const int stride = gridDim.x / cob;
-    int cb = blockIdx.x % cob, pt = blockIdx.x / cob;
-    if (gridDim.x % 8 == 0 && 8 % cob == 0 && stride % (8 / cob) == 0) {
-        const int x = blockIdx.x & 7, m = blockIdx.x >> 3, xg = 8 / cob;
-        cb = x % cob;
-        pt = (x / cob) * (stride / xg) + m;
-    }
-    if (pt >= npt) return;
-    const int co0 = cb * 64;
-    f32x4 wq[36];                                             // [tap][c]: input channels 32 kh2 + 8c + 4 (lane >> 5) + u
-    {
-        const f32x4* wsrc = reinterpret_cast<const f32x4*>(p.w) + ((long)(cb * 2 + wn) * 72 + 4 * kh2) * 64 + lane;
-#pragma unroll
-        for (int q = 0; q < 36; ++q) wq[q] = wsrc[((q >> 2) * 8 + (q & 3)) * 64];
-    }
-    auto decode = [&](int tile, int& n, int& h, int& w0) {
-        const int seg = tile % segs; tile /= segs;
-        h = tile % p.H; n = tile / p.H; w0 = seg * C3_PX;
-    };
-    // halo float4 #idx of 3168: c4 = idx & 15, pixel = (idx >> 4) % 66, row = (idx >> 4) / 66
-    auto halo_load = [&](int n, int h, int w0, int idx) -> f32x4 {
-        const int pix = idx >> 4, r = pix / C3_HW, px = pix - r * C3_HW;
-        const int hh = h + r - 1, ww = w0 + px - 1;
-        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (idx < 3 * C3_HW * 16 && hh >= 0 && hh < p.H && ww >= 0 && ww < p.W)
-            v = *reinterpret_cast<const f32x4*>(p.x + (((long)n * p.H + hh) * p.W + ww) * 64 + 4 * (idx & 15));
-        return v;
-    };
-    auto halo_store = [&](float* Xs, int idx, f32x4 v) {
-        if (idx < 3 * C3_HW * 16) *reinterpret_cast<f32x4*>(Xs + (idx >> 4) * WS_XP + 4 * (idx & 15)) = v;
-    };
-    int n, h, w0;
-    decode(pt, n, h, w0);
-    {
-        f32x4 hp[7];
-#pragma unroll
-        for (int q = 0; q < 7; ++q) hp[q] = halo_load(n, h, w0, t + 512 * q);
-#pragma unroll
-        for (int q = 0; q < 7; ++q) halo_store(smem, t + 512 * q, hp[q]);
-    }
-    __syncthreads();
-    const int abase = (wm * 32 + (lane & 31)) * WS_XP + 4 * (lane >> 5) + 32 * kh2;
-    f32x4 bj4 = (f32x4){0.f, 0.f, 0.f, 0.f};                 // bias of the 4 output channels this lane stores
-    if (p.bias) bj4 = *reinterpret_cast<const f32x4*>(p.bias + co0 + wn * 32 + 4 * (lane & 7));
-    float* red = smem + 2 * WS_HALO;
-    int xbuf = 0;
-    while (true) {
-        const int npt_next = pt + stride;
-        const bool has_next = npt_next < npt;
-        int nn = n, nh = h, nw0 = w0;
-        if (has_next) decode(npt_next, nn, nh, nw0);
-        const float* Xs = smem + xbuf * WS_HALO + abase;
-        float* XsN = smem + (xbuf ^ 1) * WS_HALO;
-        f32x16 acc;                     // one chain: the partner wave on the same SIMD fills the dependent-issue bubbles
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-        f32x4 va[5];                                         // ring: reads run 4 groups ahead of the MFMAs
-        f32x4 hq = (f32x4){0.f, 0.f, 0.f, 0.f};
-        // local group l = tap * 4 + c: one 16-byte A read, four MFMAs
-#define WS_AOFF(l) ((((l) >> 2) / 3 * C3_HW + ((l) >> 2) % 3) * WS_XP + 8 * ((l) & 3))
-#define WS_LD(l) va[(l) % 5] = *reinterpret_cast<const f32x4*>(Xs + WS_AOFF(l));
-        WS_LD(0) WS_LD(1) WS_LD(2) WS_LD(3)
-#pragma unroll
-        for (int l = 0; l < 36; ++l) {
-            if (l % 5 == 0 && has_next) hq = halo_load(nn, nh, nw0, t + 512 * (l / 5));       // 7 rounds: l = 0,5,...,30
-            if (l + 4 < 36) { WS_LD(l + 4) }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(va[l % 5][u], wq[l][u], acc, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (l % 5 == 4 && has_next) halo_store(XsN, t + 512 * (l / 5), hq);
-        }
-        // ---- epilogue: every wave writes its partial 32 px x 32 co block to its own LDS tile in [px][co] order; after the
-        // barrier (which also publishes the next halo) each wave of a pair sums both tiles for HALF of the pixels and stores
-        // 16 bytes per lane (2 dwordx4 stores per lane: the store tail is issue-bound) ----
-        {
-            float* T = red + wave * WS_TT;
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int px = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-                T[px * WS_TP + (lane & 31)] = acc[reg];
-            }
-            __syncthreads();
-            const float* T0 = red + (wave & 3) * WS_TT;
-            const float* T1 = T0 + 4 * WS_TT;
-            const int c4 = lane & 7;
-            const long rowbase = ((long)n * p.H + h) * p.W + w0 + wm * 32;
-            f32x4 v[2];
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int px = 16 * kh2 + (lane >> 3) + 8 * q;
-                const f32x4 a0 = *reinterpret_cast<const f32x4*>(T0 + px * WS_TP + 4 * c4);
-                const f32x4 a1 = *reinterpret_cast<const f32x4*>(T1 + px * WS_TP + 4 * c4);
-                v[q] = a0 + a1;
-            }
-            __syncthreads();                                 // all tiles consumed: the next tile's partials may overwrite them
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int px = 16 * kh2 + (lane >> 3) + 8 * q;
-                float* dst = p.y + (rowbase + px) * p.Cout + co0 + wn * 32 + 4 * c4;
-                f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (p.beta != 0.f) o = *reinterpret_cast<const f32x4*>(dst);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[q][e] = apply_act(v[q][e] + bj4[e], p.act) + p.beta * o[e];
-                *reinterpret_cast<f32x4*>(dst) = v[q];
-            }
-        }
-        if (!has_next) break;
-        pt = npt_next; n = nn; h = nh; w0 = nw0;
-        xbuf ^= 1;
-    }
-}
-
-// x (B,H,W,64) NHWC contiguous; wl = filter in the per-lane register order (tatt_repack_conv_weight mode 4; mode 5 for the
-// data gradient of a 64-output-channel convolution); y (B,H,W,Cout)
-TATT_API int tatt_conv3_c64_fwd_ws(const float* x, const float* wl, const float* bias, float* y, int B, int H, int W,
-                                   int Cout, int act, float beta, hipStream_t st) {
-    if (Cout % 64 || W % C3_PX) return 1;
-    Conv3P p = {x, wl, bias, y, B, H, W, 64, Cout, act, beta};
-    static std::once_flag attr_once;                 // C++11 call_once: safe if several host threads launch
-    std::call_once(attr_once, [&] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS);
-    });
-    const int cob = Cout / 64, npt = B * H * (W / C3_PX);
-    int per = 256 / cob;
-    if (per > npt) per = npt;
-    hipLaunchKernelGGL(conv3_c64_ws_kernel, dim3(per * cob), dim3(512), WS_LDS, st, p);
+    const int G = ntiles < 512 ? ntiles : 512;
+    hipLaunchKernelGGL((conv3_c64_fwd_v5_kernel<32>), dim3(G), dim3(256), C5<32>::LDS, st, p);
     return LAUNCH_CHECK();
 }
 
 // ---- weight-stationary forward, 16 output channels per wave (Cin == 64) ----------------------------------------------------------
-// Same idea as conv3_c64_ws_kernel -- the filter lives in registers, the loop streams activations through a double-buffered LDS
-// halo -- but the 64 px x 64 co tile is cut along the OUTPUT CHANNELS: wave (pxh, cq) owns 32 pixels x 16 channels and contracts
-// all 9 x 64 input channels itself on v_mfma_f32_16x16x4_f32 (144 filter registers per lane again, two waves per SIMD).  There is
-// no partial sum to exchange, so the epilogue is nothing but stores (they retire under the next tile's MFMAs) and ONE barrier
-// per tile is left (the halo hand-off).  In the kernel above the two barriers + LDS exchange of the epilogue stall all eight waves
-// at once: 24 k of a launch's 79 k resident cycles (profiles/r01_step10_pmc_sq_counters.txt).
+// WEIGHT-STATIONARY: the filter lives in registers for the lifetime of a persistent work-group (one per CU, 8 waves), the loop
+// streams activations through a double-buffered LDS halo.  The 64 px x 64 co tile is cut along the OUTPUT CHANNELS: wave (pxh, cq)
+// owns 32 pixels x 16 channels and contracts all 9 x 64 input channels itself on v_mfma_f32_16x16x4_f32 (144 filter registers per
+// lane, two waves per SIMD).  There is no partial sum to exchange, so the epilogue is nothing but stores (they retire under the next
+// tile's MFMAs) and ONE barrier per tile is left (the halo hand-off).  (Rounds 1-2 also carried a variant with 32 x 32 blocks and
+// the contraction split over a wave pair: its two barriers + LDS exchange per tile stalled all eight waves at once, 24 k of a
+// launch's 79 k resident cycles, profiles/r01_step10_pmc_sq_counters.txt; removed in round 3.)
 //   A operand (activations): lane (i = lane & 15, kq = lane >> 4) reads 4 consecutive input channels 16 g + 4 kq + u of pixel i
 //     with one ds_read_b128 and feeds MFMA u of group (tap, g) with element u -- the k-slot kq of that MFMA then stands for input
 //     channel 16 g + 4 kq + u on BOTH operands (any bijection slot -> channel is a valid contraction order).
 //   halo pitch 72 floats: pixel i -> 16-byte slot 2 i (mod 16), k-slot kq -> +kq: the lane groups ds_read_b128 is served in
-//     ({0-3,12-15,20-27}, ...) touch 16 distinct slots -- conflict-free (pitch 68 of the kernel above is 2-way on two of four groups).
+//     ({0-3,12-15,20-27}, ...) touch 16 distinct slots -- conflict-free (a pitch of 68 is 2-way on two of four groups).
 #define W16_XP 72
 #define W16_HALO (3 * C3_HW * W16_XP)                        // floats per halo buffer (57.0 KB)
 #define W16_LDS (2 * W16_HALO * 4)
@@ -396,6 +240,8 @@ __global__ __launch_bounds__(512, 1) void conv3_c64_ws16_kernel(Conv3P p) {
     const int stride = gridDim.x / cob;
     int cb = blockIdx.x % cob, pt = blockIdx.x / cob;
     if (gridDim.x % 8 == 0 && 8 % cob == 0 && stride % (8 / cob) == 0) {
+        // XCD-aware tile order: work-groups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8); give each XCD a contiguous
+        // run of rows so that a row's halo is fetched by one L2 only (round 1: 37.8 MB fetched for a 12.6 MB input otherwise)
         const int x = blockIdx.x & 7, m = blockIdx.x >> 3, xg = 8 / cob;
         cb = x % cob;
         pt = (x / cob) * (stride / xg) + m;
@@ -798,6 +644,8 @@ __device__ __forceinline__ void wgrad_segment(f32x16 (&acc)[5], const float* __r
 #undef C3W_LOAD
 }
 
+#define WS_TP 36                              // transpose-tile pitch (floats) of the weight-gradient epilogue
+#define WS_TT (32 * WS_TP)                    // floats per per-wave epilogue tile
 __global__ __launch_bounds__(512, 1) void conv3_c64_wgrad_kernel(Conv3WP p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;

@@ -567,7 +567,6 @@ __global__ __launch_bounds__(256) void gemm_fast32_kernel(GemmP p, int cvec) {
     }
 }
 
-static const bool g_gemm_fast = [] { const char* e = getenv("TATT_GEMM_FAST"); return !(e && e[0] == '0'); }();   // A/B switch
 static inline bool al16(const void* q) { return ((uintptr_t)q & 15) == 0; }
 // 0 = launched, -1 = shape/alignment not eligible (caller uses the general kernel)
 static int try_gemm_fast(const GemmP& p, int Z, hipStream_t st) {
@@ -820,7 +819,7 @@ TATT_API int tatt_gemm(const float* A, long sam, long sak, const float* A2, long
     // (64-deep K chunks were measured slower than 16-deep on the token GEMMs: 2 work-groups/CU instead of 8.)
     set_split(p, splitk, ws, KC);
     bool ak = (sak == 1), bk = (sbk == 1 && sbn != 1);
-    int rc = g_gemm_fast ? try_gemm_fast(p, Z, st) : -1;
+    int rc = try_gemm_fast(p, Z, st);
     if (rc == 0) return p.splitk > 1 ? finish_splitk(p, Z, 0, 0, st) : 0;
     if (rc > 0) return rc;
     rc = A2 ? launch_gemm<2, 16>(p, Z, ak, bk, st) : launch_gemm<0, 16>(p, Z, ak, bk, st);
@@ -849,7 +848,7 @@ TATT_API int tatt_conv2d_fwd(const float* x, long xsn, long xsh, long xsw, long 
     p.alpha = 1.f; p.beta = beta; p.act = act;
     fill_conv(p, H, W, Cin, KH, KW, xsn, xsh, xsw, xsc);
     set_split(p, splitk, ws);        // split-K (ws >= splitk*Bn*H*W*Cout floats) spreads small-M / deep-K convs (STN tail) over the CUs
-    int rc = g_gemm_fast ? try_conv_fast(p, st) : -1;
+    int rc = try_conv_fast(p, st);
     if (rc == 0) return p.splitk > 1 ? finish_splitk(p, 1, 0, 0, st) : 0;
     if (rc > 0) return rc;
     rc = launch_gemm<3, 16>(p, 1, true, false, st);
@@ -872,7 +871,7 @@ TATT_API int tatt_conv2d_wgrad(const float* x, long xsn, long xsh, long xsw, lon
     fill_conv(p, H, W, Cin, KH, KW, xsn, xsh, xsw, xsc);
     set_split(p, splitk < 2 ? 2 : splitk, ws);
     if (p.splitk < 2) { p.splitk = 2; p.chunks_per_split = cdiv(cdiv(p.K, KC), 2); }
-    int rc = g_gemm_fast ? try_wgrad_fast(p, st) : -1;
+    int rc = try_wgrad_fast(p, st);
     if (rc < 0) rc = launch_gemm<4, 16>(p, 1, false, false, st);
     if (rc) return rc;
     return finish_splitk(p, 1, Cin, KH * KW, st);
@@ -881,7 +880,7 @@ TATT_API int tatt_conv2d_wgrad(const float* x, long xsn, long xsh, long xsw, lon
 // OIHW filter -> implicit-GEMM operand.  mode 0: [KH][KW][Cin][Cout] (forward);
 // mode 1: [KH][KW][Cout][Cin] spatially flipped (data-gradient: dX = conv(dY, flip(W)^T)).
 // modes 2 / 3: the same two filters with the contraction axis contiguous ([tap][out][in]) for tatt_conv3_c64_fwd_t.
-// modes 4 / 5: the same two filters in the register order of the weight-stationary kernel tatt_conv3_c64_fwd_ws;
+// (modes 4 / 5 belonged to the retired 32x32 weight-stationary kernel;)
 // modes 6 / 7: in the register order of tatt_conv3_c64_fwd_ws16.
 // modes 8 / 9: Toeplitz-expanded 9x9 filter of tatt_conv9_c64_to_c4_mfma, out[ky][ci 64][n = 4 j + o][20]:
 //   value(dx < 12) = f[o][ci][ky][dx - j] if 0 <= dx - j < 9 else 0, 0 for dx >= 12;  mode 8: f = w (OIHW, Cout = 4, Cin = 64);
@@ -945,28 +944,22 @@ __global__ void repack_weight_kernel(const float* __restrict__ w, float* __restr
         int co = idx % Cout; int r = idx / Cout; int ci = r % Cin; int tap = r / Cin;
         out[idx] = w[((long)co * Cin + ci) * T + (T - 1 - tap)];
     } else {
-        // modes 4 / 5 (3x3, 64 contraction channels): the per-lane MFMA B-operand register order of tatt_conv3_c64_fwd_ws:
-        // out[((ob * 72 + tap * 8 + c) * 64 + lane) * 4 + u] = filter[out ch ob*32 + (lane & 31)][in ch 8c + 4 (lane >> 5) + u][tap]
-        const int u = idx & 3, lane = (idx >> 2) & 63, q = (idx >> 8) % 72, ob = idx / (72 * 256);
-        const int tap = q >> 3, c = q & 7;
-        const int o = ob * 32 + (lane & 31), i = 8 * c + 4 * (lane >> 5) + u;
-        if (mode == 4) out[idx] = w[((long)o * Cin + i) * T + tap];                 // forward: o = co, i = ci (Cin == 64)
-        else if (mode == 5) out[idx] = w[((long)i * Cin + o) * T + (T - 1 - tap)];  // data gradient: o = ci, i = co (Cout == 64)
-        else {
-            // modes 6 / 7: register order of tatt_conv3_c64_fwd_ws16 (16 output channels per wave, v_mfma_f32_16x16x4_f32):
-            // out[((blk * 36 + tap * 4 + g) * 64 + lane) * 4 + u] = filter[out ch 16 blk + (lane & 15)][in ch 16 g + 4 (lane >> 4) + u][tap]
-            const int q6 = (idx >> 8) % 36, blk = idx / (36 * 256);
-            const int tap6 = q6 >> 2, g6 = q6 & 3;
-            const int o6 = blk * 16 + (lane & 15), i6 = 16 * g6 + 4 * (lane >> 4) + u;
-            if (mode == 6) out[idx] = w[((long)o6 * Cin + i6) * T + tap6];
-            else out[idx] = w[((long)i6 * Cin + o6) * T + (T - 1 - tap6)];
-        }
+        // modes 6 / 7 (3x3, 64 contraction channels): the per-lane MFMA B-operand register order of tatt_conv3_c64_fwd_ws16
+        // (16 output channels per wave, v_mfma_f32_16x16x4_f32):
+        // out[((blk * 36 + tap * 4 + g) * 64 + lane) * 4 + u] = filter[out ch 16 blk + (lane & 15)][in ch 16 g + 4 (lane >> 4) + u][tap]
+        const int u = idx & 3, lane = (idx >> 2) & 63;
+        const int q6 = (idx >> 8) % 36, blk = idx / (36 * 256);
+        const int tap6 = q6 >> 2, g6 = q6 & 3;
+        const int o6 = blk * 16 + (lane & 15), i6 = 16 * g6 + 4 * (lane >> 4) + u;
+        if (mode == 6) out[idx] = w[((long)o6 * Cin + i6) * T + tap6];
+        else out[idx] = w[((long)i6 * Cin + o6) * T + (T - 1 - tap6)];
     }
 }
 TATT_API int tatt_repack_conv_weight(const float* w_oihw, float* out, int Cout, int Cin, int KH, int KW,
                                      int mode, hipStream_t st) {
     if ((mode == 8 || mode == 9) && !(KH == 9 && KW == 9 && ((mode == 8 && Cout == 4 && Cin == 64) || (mode == 9 && Cout == 64 && Cin == 4)))) return 1;
     if (mode >= 10 && !(mode <= 11 && KH == 3 && KW == 3 && Cout % 64 == 0 && Cin % 64 == 0)) return 1;
+    if (mode == 4 || mode == 5 || mode < 0 || mode > 11) return 1;     // (4 / 5: the retired 32x32 weight-stationary kernel)
     long total = repack_total(Cout, Cin, KH, KW, mode);
     hipLaunchKernelGGL(repack_weight_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w_oihw, out, Cout, Cin,
                        KH, KW, mode);
@@ -1001,17 +994,11 @@ __global__ void repack_batch_kernel(RepackTable t) {
     else if (e.mode == 2) { int ci = idx % Cin; int r = idx / Cin; int co = r % Cout; int tap = r / Cout; v = w[((long)co * Cin + ci) * T + tap]; }
     else if (e.mode == 3) { int co = idx % Cout; int r = idx / Cout; int ci = r % Cin; int tap = r / Cin; v = w[((long)co * Cin + ci) * T + (T - 1 - tap)]; }
     else {
-        const int u = idx & 3, lane = (idx >> 2) & 63, q = (idx >> 8) % 72, ob = idx / (72 * 256);
-        const int tap = q >> 3, c = q & 7;
-        const int o = ob * 32 + (lane & 31), i = 8 * c + 4 * (lane >> 5) + u;
-        if (e.mode == 4) v = w[((long)o * Cin + i) * T + tap];
-        else if (e.mode == 5) v = w[((long)i * Cin + o) * T + (T - 1 - tap)];
-        else {
-            const int q6 = (idx >> 8) % 36, blk = idx / (36 * 256);
-            const int tap6 = q6 >> 2, g6 = q6 & 3;
-            const int o6 = blk * 16 + (lane & 15), i6 = 16 * g6 + 4 * (lane >> 4) + u;
-            v = e.mode == 6 ? w[((long)o6 * Cin + i6) * T + tap6] : w[((long)i6 * Cin + o6) * T + (T - 1 - tap6)];
-        }
+        const int u = idx & 3, lane = (idx >> 2) & 63;
+        const int q6 = (idx >> 8) % 36, blk = idx / (36 * 256);
+        const int tap6 = q6 >> 2, g6 = q6 & 3;
+        const int o6 = blk * 16 + (lane & 15), i6 = 16 * g6 + 4 * (lane >> 4) + u;
+        v = e.mode == 6 ? w[((long)o6 * Cin + i6) * T + tap6] : w[((long)i6 * Cin + o6) * T + (T - 1 - tap6)];
     }
     e.out[idx] = v;
 }

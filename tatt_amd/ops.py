@@ -307,14 +307,10 @@ def _conv3_fast_ok(x_bhwc, Cin, Cout, KH, KW):
             and x_bhwc.shape[2] % 64 == 0)
 
 
-# A/B switch for measurements: "16" (default): weight-stationary kernel, 16 output channels per wave (no partial-sum exchange);
-# "1": weight-stationary, 32 x 32 blocks with the contraction split over a wave pair; "0": LDS-staged filter (v5 kernel)
-CONV3_WS = os.environ.get("TATT_CONV3_WS", "16")
-_CONV3_WS = CONV3_WS != "0"
-_WS_ENTRY, _WS_FWD_MODE, _WS_DGRAD_MODE = (("tatt_conv3_c64_fwd_ws16", 6, 7) if CONV3_WS == "16" else ("tatt_conv3_c64_fwd_ws", 4, 5))
+# exact-fp32 3x3 kernels (used when CONV3_SB is off): weight-stationary ws16 kernel for 64 input channels, filter packings 6 / 7
+_WS_ENTRY, _WS_FWD_MODE, _WS_DGRAD_MODE = "tatt_conv3_c64_fwd_ws16", 6, 7
 
 
-CONV9_MFMA = os.environ.get("TATT_CONV9_MFMA", "1") != "0"       # A/B switch: 0 -> vector-ALU 9x9 kernel
 # The 3x3 convolutions between multiples of 64 channels on the bf16 matrix cores by operand splitting (tatt_conv3_c64_fwd_sb: three
 # bf16 products per fp32 product, fp32 accumulation; measured effect on SR 1e-6, profiles/r03_split_bf16_probe.txt).  Test / A-B hook:
 # False -> the exact-fp32 MFMA kernels.
@@ -338,7 +334,7 @@ def _conv3_sb(x_bhwc, w_oihw, mode, bias, act=ACT_NONE, in_scale=None, in_shift=
 
 
 def _conv9_mfma_ok(x_bhwc):
-    return CONV9_MFMA and x_bhwc.is_contiguous() and x_bhwc.shape[1] % 8 == 0 and x_bhwc.shape[2] % 64 == 0 and x_bhwc.shape[3] == 64
+    return x_bhwc.is_contiguous() and x_bhwc.shape[1] % 8 == 0 and x_bhwc.shape[2] % 64 == 0 and x_bhwc.shape[3] == 64
 
 
 def conv2d_forward(x_bhwc, weight_oihw, bias, act=ACT_NONE):
@@ -354,7 +350,7 @@ def conv2d_forward(x_bhwc, weight_oihw, bias, act=ACT_NONE):
         if CONV3_SB and (Cin == 64 or act == ACT_NONE):
             return _conv3_sb(x_bhwc, weight_oihw, 10, bias, act)
         y = new(x_bhwc, B, H, W, Cout)
-        if Cin == 64 and _CONV3_WS:                              # weight-stationary kernel: the filter lives in registers
+        if Cin == 64:                                            # weight-stationary kernel: the filter lives in registers
             wl = repack_weight(weight_oihw, _WS_FWD_MODE)
             call(_WS_ENTRY, P(x_bhwc), P(wl), P(bias), P(y), B, H, W, Cout, act, 0.0, stream())
             return y
@@ -367,7 +363,7 @@ def conv2d_forward(x_bhwc, weight_oihw, bias, act=ACT_NONE):
 def conv3_bn_fusable(x_bhwc, weight_oihw):
     """The 3x3 64 -> 64 convolutions of the residual blocks / block7 on a contiguous NHWC map whose width is a multiple of 64: the
     weight-stationary kernel can fold the producer's BatchNorm into its input staging and emit this layer's batch statistics."""
-    return (_CONV3_WS and CONV3_WS == "16" and tuple(weight_oihw.shape) == (64, 64, 3, 3) and x_bhwc.is_contiguous()
+    return (tuple(weight_oihw.shape) == (64, 64, 3, 3) and x_bhwc.is_contiguous()
             and x_bhwc.shape[3] == 64 and x_bhwc.shape[2] % 64 == 0)
 
 
@@ -408,7 +404,7 @@ def conv2d_dgrad(dy_bhwc, weight_oihw):
         if CONV3_SB:
             return _conv3_sb(dy_bhwc, weight_oihw, 11, None)
         dx = new(dy_bhwc, B, H, W, Cin)
-        if Cout == 64 and _CONV3_WS:
+        if Cout == 64:
             wl = repack_weight(weight_oihw, _WS_DGRAD_MODE)
             call(_WS_ENTRY, P(dy_bhwc), P(wl), None, P(dx), B, H, W, Cin, ACT_NONE, 0.0, stream())
             return dx

@@ -564,7 +564,7 @@ def test_cat_positional_table(dev):
 @pytest.mark.parametrize("B,H,W,Cout,act,beta", [(2, 16, 64, 64, 0, 0.0), (3, 5, 128, 256, 2, 0.0), (1, 1, 64, 64, 0, 0.5),
                                                  (48, 16, 64, 64, 0, 0.0), (7, 16, 64, 128, 1, 0.0)])
 def test_conv3_weight_stationary_kernel(dev, B, H, W, Cout, act, beta):
-    """tatt_conv3_c64_fwd_ws / _ws16 (filter in registers) against F.conv2d, forward filters (repack modes 4 / 6)."""
+    """tatt_conv3_c64_fwd_ws16 (exact-fp32 weight-stationary kernel) against F.conv2d, forward filter (repack mode 6)."""
     from tatt_amd import ops
     g = torch.Generator().manual_seed(21)
     x = torch.randn(B, H, W, 64, generator=g)
@@ -574,7 +574,7 @@ def test_conv3_weight_stationary_kernel(dev, B, H, W, Cout, act, beta):
     ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), padding=1).permute(0, 2, 3, 1)
     ref = {0: lambda t: t, 1: torch.relu, 2: lambda t: O.mish(t.float()).double()}[act](ref) + beta * y0.double()
     xd, wd, bd, yd = x.to(dev), w.to(dev), b.to(dev), y0.to(dev).clone()
-    for entry, mode in (("tatt_conv3_c64_fwd_ws", 4), ("tatt_conv3_c64_fwd_ws16", 6)):
+    for entry, mode in (("tatt_conv3_c64_fwd_ws16", 6),):
         yd = y0.to(dev).clone()
         wl = ops.repack_weight(wd, mode)
         ops.call(entry, ops.P(xd), ops.P(wl), ops.P(bd), ops.P(yd), B, H, W, Cout, act, beta, ops.stream())
@@ -582,7 +582,7 @@ def test_conv3_weight_stationary_kernel(dev, B, H, W, Cout, act, beta):
 
 
 def test_conv3_weight_stationary_dgrad(dev):
-    """repack mode 5: the data gradient of a 64-output-channel 3x3 convolution (Cin = 64 and 256)."""
+    """repack mode 7: the data gradient of a 64-output-channel 3x3 convolution (Cin = 64 and 256), exact fp32."""
     from tatt_amd import ops
     g = torch.Generator().manual_seed(22)
     for Cin in (64, 256):
@@ -593,7 +593,7 @@ def test_conv3_weight_stationary_dgrad(dev):
         dx = ops.conv2d_dgrad(dy.to(dev), w.to(dev))
         check_close("conv3_ws_dgrad_%d" % Cin, dx, x.grad.permute(0, 2, 3, 1), 2e-4, 2e-4)
         dyd, wd = dy.to(dev), w.to(dev)                # keep the operands alive while the kernels run
-        for entry, mode in (("tatt_conv3_c64_fwd_ws", 5), ("tatt_conv3_c64_fwd_ws16", 7)):
+        for entry, mode in (("tatt_conv3_c64_fwd_ws16", 7),):
             dxe = torch.empty(2, 16, 64, Cin, device=dev)
             wl = ops.repack_weight(wd, mode)
             ops.call(entry, ops.P(dyd), ops.P(wl), None, ops.P(dxe), 2, 16, 64, Cin, 0, 0.0, ops.stream())

@@ -60,9 +60,6 @@ f33 = 2.0 * M * 576 * 64
 wt = ops.repack_weight(w33, 2)
 timeit("conv3_fwd_t_64_64", lambda: ops.call("tatt_conv3_c64_fwd_t", ops.P(x64), ops.P(wt), ops.P(b64), ops.P(y64), B, 16, 64, 64, 64,
                                               0, 0.0, ops.stream()), f33)
-wl = ops.repack_weight(w33, 4)
-timeit("conv3_fwd_ws_64_64", lambda: ops.call("tatt_conv3_c64_fwd_ws", ops.P(x64), ops.P(wl), ops.P(b64), ops.P(y64), B, 16, 64, 64,
-                                               0, 0.0, ops.stream()), f33)
 wl16 = ops.repack_weight(w33, 6)
 timeit("conv3_fwd_ws16_64_64", lambda: ops.call("tatt_conv3_c64_fwd_ws16", ops.P(x64), ops.P(wl16), ops.P(b64), ops.P(y64), B, 16, 64, 64,
                                                  0, 0.0, ops.stream()), f33)
@@ -80,9 +77,6 @@ y256 = torch.empty(B, 16, 64, 256, device=dev)
 wt256 = ops.repack_weight(w256, 2)
 timeit("conv3_fwd_t_64_256", lambda: ops.call("tatt_conv3_c64_fwd_t", ops.P(x64), ops.P(wt256), None, ops.P(y256), B, 16, 64, 64, 256,
                                                0, 0.0, ops.stream()), 4 * f33)
-wl256 = ops.repack_weight(w256, 4)
-timeit("conv3_fwd_ws_64_256", lambda: ops.call("tatt_conv3_c64_fwd_ws", ops.P(x64), ops.P(wl256), None, ops.P(y256), B, 16, 64, 256,
-                                                0, 0.0, ops.stream()), 4 * f33)
 wl16_256 = ops.repack_weight(w256, 6)
 timeit("conv3_fwd_ws16_64_256", lambda: ops.call("tatt_conv3_c64_fwd_ws16", ops.P(x64), ops.P(wl16_256), None, ops.P(y256), B, 16, 64, 256,
                                                   0, 0.0, ops.stream()), 4 * f33)
@@ -160,3 +154,12 @@ timeit("tplayer_fwd", lambda: ops.tplayer_fwd(tx, tq, tK, tV, lp, lnF, 0.5, 1, 0
        B * L * 4 * 2 * 64 * 64, B * L * (64 * 4 * 3 + 26 * 4))
 timeit("tplayer_bwd", lambda: ops.tplayer_bwd(tx, tq, tK, tV, lp, lnF, 0.5, 1, 0.1, 0.1, 0.1, sd, 10, 1e-5, None, tup, None, None, True),
        B * L * (12 * 2 * 64 * 64 + 2 * 2 * 26 * 64), B * L * 64 * 4 * 5)
+
+# ---- split-bf16 token projections (csrc/tokgemm.hip) ----
+for (N_, K_, K1_, N1_) in ((192, 128, 64, 192), (192, 64, 64, 192), (128, 192, 192, 64), (64, 192, 192, 64)):
+    Xa = R(M, K1_)
+    Xb = R(M, K_ - K1_) if K1_ < K_ else None
+    Wt = R(N_, K_) * 0.1
+    Wk = torch.empty(N_ * K_, device=dev)
+    ops.call("tatt_tokgemm_pack", ops.P(Wt), ops.P(Wk), N_, K_, K_, 0, ops.stream())
+    timeit("tokgemm_sb_%dx%d" % (N_, K_), lambda: Fh._tokgemm(Xa, Xb, Wk, None, N_, K_, N1_), 2.0 * M * N_ * K_, M * (N_ + K_) * 4)

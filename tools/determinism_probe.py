@@ -45,7 +45,8 @@ for name, setup, kw in [
         ("forward fork off", lambda: setattr(Fh.FWD_FORK, "run", lambda ref, fn: fn()), {}),
         ("one stream", lambda: setattr(Fh.FWD_FORK, "run", orig_fork), dict(side_stream=False)),
         ("no deferral", lambda: None, dict(defer_param_grads=False)),
-        ("conv9 vector-ALU kernel, one stream", lambda: setattr(ops, "CONV9_MFMA", False), dict(side_stream=False))]:
+        ("exact-fp32 3x3 convolutions and GRU projections, one stream",
+         lambda: (setattr(ops, "CONV3_SB", False), setattr(Fh, "TOKGEMM_SB", False)), dict(side_stream=False))]:
     setup()
     rs = [run(**kw) for _ in range(4)]
     same = all(r == rs[0] for r in rs)
