@@ -125,7 +125,9 @@ int tatt_conv9_c64_to_c4(const float* x, const float* wpacked, const float* bias
  * block1's 4->64 convolution, :597); x (B,H,W,64) NHWC contiguous, H % 8 == 0, W % 64 == 0; y (B,H,W,4) */
 int tatt_conv9_c64_to_c4_mfma(const float* x, const float* wt, const float* bias, float* y, int B, int H, int W,
                               hipStream_t st);
-/* dw (4,64,9,9) = sum_px x[px+tap][ci] * dy[px][co]; part >= min(B*H*W/256, 256)*81*64*4 floats */
+/* dw (4,64,9,9) = sum_px x[px+tap][ci] * dy[px][co] on v_mfma_f32_16x16x4_f32 (rows = input channels, columns = (tap, output
+ * channel) read Toeplitz-fashion from the dy tile; weight gradient of reference model/tsrn.py:623); H % 4 == 0, W % 64 == 0;
+ * part >= min(B*(H/4)*(W/64), 256) * 64 * 336 floats */
 int tatt_conv9_c64_c4_wgrad(const float* x, const float* dy, float* dw, float* part, int B, int H, int W,
                             hipStream_t st);
 

@@ -198,95 +198,135 @@ TATT_API int tatt_conv9_c64_to_c4_mfma(const float* x, const float* wt, const fl
     return LAUNCH_CHECK();
 }
 
-// ---- weight gradient ---------------------------------------------------------------------------------------------
-// thread (ci = t & 15, tap lane tl = t >> 4): taps tl, tl+16, ..., 4 output channels each -> 6 x 4 accumulators per 16-channel
-// chunk, kept in registers over all the tiles a (persistent) block walks.  Halo tile channel-contiguous: Xc[row][col][16].
-#define W9_TAPS 6
-__global__ __launch_bounds__(256) void conv9_c64_c4_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                                 float* __restrict__ part, int B, int H, int W) {
-    __shared__ float Xc[T9_HH][T9_WW][T9_CK];
-    __shared__ f32x4 Dy[T9_H][T9_W];
-    const int tiles_w = W / T9_W, tiles_h = H / T9_H;
-    const int ntiles = B * tiles_h * tiles_w;
-    const int ci = threadIdx.x & 15, tl = threadIdx.x >> 4;
-    float acc[4][W9_TAPS][4];
+// ---- weight gradient on the matrix cores -------------------------------------------------------------------------
+// dW[ky][kx][ci][co] = sum_{b,r,p} X[b][r][p][ci] * dY[b][r-ky+4][p-kx+4][co]  (r, p = position of the INPUT pixel).
+// As a GEMM per input row: A[m = ci][k = p] = X[r][p][ci] (64 rows), B[k = p][n = tap*4 + co] = dY[r-ky+4][p-kx+4][co]: the
+// Toeplitz expansion sits on the small operand (4 channels) and is never materialised -- an MFMA B fragment is one LDS dword per
+// lane and every lane may take it from its own (row, pixel, channel) address.  n = 81 taps x 4 channels = 324 -> 21 column
+// tiles of 16 (96 % useful), 4 row tiles of 16 input channels: 84 accumulator tiles (v_mfma_f32_16x16x4_f32).
+// Work-group = 12 waves: wave (mt = w & 3, ng = w >> 2) owns row tile mt and column tiles 7*ng .. 7*ng+6 -> 28 accumulator
+// registers that stay live over every tile the (persistent) group walks; per k-step of 4 pixels a wave reads 1 A and 7 B dwords
+// and issues 7 MFMAs.  Tile = 4 input rows x 64 pixels of one image: the dY window (12 rows x 72 pixels x 4 channels, zeros
+// outside the image) is staged once per tile, the X rows (64 pixels x 64 channels, LDS pitch 80 dwords so that the two pixels
+// of an A read's lane group fall in different bank halves) are double-buffered through registers one row ahead.
+#define W9_R 4
+#define W9_P 64
+#define W9_XP 80
+#define W9_DW (W9_P + 8)
+#define W9_DROWS (W9_R + 8)
+#define W9_NT 21
+#define W9_N (W9_NT * 16)        // 336 columns per partial row (324 used)
+struct W9P { const float* x; const float* dy; float* part; int B, H, W, ntiles; };
+__global__ __launch_bounds__(768) void conv9_c64_c4_wgrad_mfma_kernel(W9P p) {
+    __shared__ __attribute__((aligned(16))) float Xs[2][W9_P * W9_XP];
+    __shared__ __attribute__((aligned(16))) float Ds[(W9_DROWS + 1) * W9_DW * 4];     // + one row of zeros for the 12 unused columns
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int mt = wave & 3, ng = wave >> 2, li = lane & 15, lk = lane >> 4;
+    const int tiles_w = p.W / W9_P, tiles_h = p.H / W9_R;
+    int bbase[7], bstep[7];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < W9_TAPS; ++b)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[a][b][c] = 0.f;
-    int kh[W9_TAPS], kw[W9_TAPS];
-#pragma unroll
-    for (int j = 0; j < W9_TAPS; ++j) {
-        int tap = tl + 16 * j;
-        if (tap > 80) tap = 80;          // clamped lanes recompute tap 80; their result is discarded at the end
-        kh[j] = tap / 9; kw[j] = tap - 9 * (tap / 9);
+    for (int j = 0; j < 7; ++j) {
+        const int n = 16 * (7 * ng + j) + li, tap = n >> 2, co = n & 3;
+        if (tap < 81) {
+            const int ky = tap / 9, kx = tap - 9 * ky;
+            bbase[j] = ((8 - ky) * W9_DW + lk + 8 - kx) * 4 + co;
+            bstep[j] = W9_DW * 4;
+        } else { bbase[j] = W9_DROWS * W9_DW * 4; bstep[j] = 0; }
     }
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        int bid = tile;
-        const int tw = bid % tiles_w; bid /= tiles_w;
-        const int th = bid % tiles_h; const int n = bid / tiles_h;
-        const int h0 = th * T9_H, w0 = tw * T9_W;
+    for (int e = t; e < W9_DW * 4; e += 768) Ds[W9_DROWS * W9_DW * 4 + e] = 0.f;
+    f32x4 acc[7];
 #pragma unroll
-        for (int ch = 0; ch < 4; ++ch) {
-            __syncthreads();
-            for (int i = threadIdx.x; i < T9_HH * T9_WW * 4; i += 256) {
-                const int c4 = i & 3, p = i >> 2;
-                const int r = p / T9_WW, cc = p - r * T9_WW;
-                const int hh = h0 + r - 4, ww = w0 + cc - 4;
-                f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (hh >= 0 && hh < H && ww >= 0 && ww < W)
-                    v = *reinterpret_cast<const f32x4*>(x + (((long)n * H + hh) * W + ww) * 64 + ch * T9_CK + 4 * c4);
-                *reinterpret_cast<f32x4*>(&Xc[r][cc][4 * c4]) = v;
-            }
-            if (ch == 0) {
-                const int r = threadIdx.x >> 5, cc = threadIdx.x & 31;
-                Dy[r][cc] = *reinterpret_cast<const f32x4*>(dy + (((long)n * H + h0 + r) * W + w0 + cc) * 4);
-            }
-            __syncthreads();
-            for (int r = 0; r < T9_H; ++r)
-                for (int cc = 0; cc < T9_W; ++cc) {
-                    const f32x4 g = Dy[r][cc];
+    for (int j = 0; j < 7; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int my_tiles = p.ntiles > (int)blockIdx.x ? (p.ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int nsteps = my_tiles * W9_R;
+    // staging registers: X row of step s+1 (1024 float4 over 768 threads), dY window of the next tile (864 float4)
+    f32x4 xr0, xr1 = (f32x4){0.f, 0.f, 0.f, 0.f}, dr0, dr1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto tile_of = [&](int s, int& b, int& r0, int& p0) {
+        int tile = blockIdx.x + (s / W9_R) * gridDim.x;
+        const int tw = tile % tiles_w; tile /= tiles_w;
+        r0 = (tile % tiles_h) * W9_R; b = tile / tiles_h; p0 = tw * W9_P;
+    };
+    auto load_x = [&](int s) {
+        int b, r0, p0; tile_of(s, b, r0, p0);
+        const float* src = p.x + (((long)b * p.H + r0 + s % W9_R) * p.W + p0) * 64;
+        xr0 = *reinterpret_cast<const f32x4*>(src + 4 * t);
+        if (t < 256) xr1 = *reinterpret_cast<const f32x4*>(src + 4 * (t + 768));
+    };
+    auto store_x = [&](int buf) {
+        *reinterpret_cast<f32x4*>(&Xs[buf][(t >> 4) * W9_XP + 4 * (t & 15)]) = xr0;
+        if (t < 256) *reinterpret_cast<f32x4*>(&Xs[buf][((t + 768) >> 4) * W9_XP + 4 * (t & 15)]) = xr1;
+    };
+    auto load_d1 = [&](int e, int b, int r0, int p0) -> f32x4 {
+        const int d = e / W9_DW, q = e - d * W9_DW, row = r0 - 4 + d, px = p0 - 4 + q;
+        if (row < 0 || row >= p.H || px < 0 || px >= p.W) return (f32x4){0.f, 0.f, 0.f, 0.f};
+        return *reinterpret_cast<const f32x4*>(p.dy + (((long)b * p.H + row) * p.W + px) * 4);
+    };
+    auto load_d = [&](int s) {
+        int b, r0, p0; tile_of(s, b, r0, p0);
+        dr0 = load_d1(t, b, r0, p0);
+        if (t < W9_DROWS * W9_DW - 768) dr1 = load_d1(t + 768, b, r0, p0);
+    };
+    auto store_d = [&]() {
+        *reinterpret_cast<f32x4*>(&Ds[4 * t]) = dr0;
+        if (t < W9_DROWS * W9_DW - 768) *reinterpret_cast<f32x4*>(&Ds[4 * (t + 768)]) = dr1;
+    };
+    if (nsteps > 0) { load_x(0); load_d(0); }
+    for (int s = 0; s < nsteps; ++s) {
+        const int rr = s % W9_R, buf = s & 1;
+        if (rr == 0) __syncthreads();            // the previous tile's last row has been consumed: Ds may change
+        store_x(buf);
+        if (rr == 0) store_d();
+        if (s + 1 < nsteps) { load_x(s + 1); if (rr == W9_R - 1) load_d(s + 1); }
+        __syncthreads();
+        const float* xa = &Xs[buf][lk * W9_XP + 16 * mt + li];
+        const float* db[7];
 #pragma unroll
-                    for (int j = 0; j < W9_TAPS; ++j) {
-                        const float xv = Xc[r + kh[j]][cc + kw[j]][ci];
-                        acc[ch][j][0] = fmaf(xv, g[0], acc[ch][j][0]); acc[ch][j][1] = fmaf(xv, g[1], acc[ch][j][1]);
-                        acc[ch][j][2] = fmaf(xv, g[2], acc[ch][j][2]); acc[ch][j][3] = fmaf(xv, g[3], acc[ch][j][3]);
-                    }
-                }
+        for (int j = 0; j < 7; ++j) db[j] = &Ds[bbase[j] + rr * bstep[j]];
+#pragma unroll 4
+        for (int ks = 0; ks < W9_P / 4; ++ks) {
+            const float a = xa[ks * 4 * W9_XP];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, db[j][ks * 16], acc[j], 0, 0, 0);
         }
     }
-    // partial[block][(tap*64 + c)][4]
-    float* P = part + (long)blockIdx.x * 81 * 64 * 4;
+    // partial[block][ci][n]: C row = 4*(lane>>4)+e -> ci = 16*mt + 4*lk + e, column = lane&15 -> n = 16*(7*ng+j) + li
+    float* P = p.part + (long)blockIdx.x * 64 * W9_N;
 #pragma unroll
-    for (int ch = 0; ch < 4; ++ch)
+    for (int j = 0; j < 7; ++j)
 #pragma unroll
-        for (int j = 0; j < W9_TAPS; ++j) {
-            const int tap = tl + 16 * j;
-            if (tap <= 80)
-                *reinterpret_cast<f32x4*>(P + ((long)tap * 64 + ch * T9_CK + ci) * 4) =
-                    (f32x4){acc[ch][j][0], acc[ch][j][1], acc[ch][j][2], acc[ch][j][3]};
-        }
+        for (int e = 0; e < 4; ++e) P[(long)(16 * mt + 4 * lk + e) * W9_N + 16 * (7 * ng + j) + li] = acc[j][e];
 }
-__global__ void conv9_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int G) {
-    // dw[co][ci][tap] (OIHW, Cout=4, Cin=64) = sum_g part[g][tap*64+ci][co]
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // enumerates (tap*64+ci)*4 + co
-    if (idx >= 81 * 64 * 4) return;
-    float s0 = 0.f, s1 = 0.f;
-    int g = 0;
-    for (; g + 2 <= G; g += 2) { s0 += part[(long)g * 20736 + idx]; s1 += part[(long)(g + 1) * 20736 + idx]; }
-    if (g < G) s0 += part[(long)g * 20736 + idx];
-    const int co = idx & 3, r = idx >> 2, ci = r & 63, tap = r >> 6;
-    dw[((long)co * 64 + ci) * 81 + tap] = s0 + s1;
+// dw[co][ci][tap] (OIHW, Cout = 4, Cin = 64) = sum_g part[g][ci][tap*4 + co]; block = 64 outputs x 16 lanes over g
+__global__ __launch_bounds__(1024) void conv9_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int G) {
+    __shared__ float sh[16][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + tx;                      // enumerates ci*324 + n
+    const int ci = idx / 324, n = idx - ci * 324;
+    const float* src = part + (long)ci * W9_N + n;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int g = ty;
+    for (; g + 48 < G; g += 64) {
+        s0 += src[(long)g * 64 * W9_N]; s1 += src[(long)(g + 16) * 64 * W9_N];
+        s2 += src[(long)(g + 32) * 64 * W9_N]; s3 += src[(long)(g + 48) * 64 * W9_N];
+    }
+    for (; g < G; g += 16) s0 += src[(long)g * 64 * W9_N];
+    sh[ty][tx] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (ty == 0) {
+        float s = 0.f;
+#pragma unroll
+        for (int l = 0; l < 16; ++l) s += sh[l][tx];
+        dw[((long)(n & 3) * 64 + ci) * 81 + (n >> 2)] = s;
+    }
 }
-// x (B,H,W,64), dy (B,H,W,4) -> dw (4,64,9,9); part >= nblocks*81*64*4 floats, nblocks = min(#tiles, 256)
+// x (B,H,W,64), dy (B,H,W,4) -> dw (4,64,9,9); H % 4 == 0, W % 64 == 0; part >= min(#tiles, 256) * 64 * 336 floats,
+// #tiles = B * (H/4) * (W/64)
 TATT_API int tatt_conv9_c64_c4_wgrad(const float* x, const float* dy, float* dw, float* part, int B, int H, int W,
                                      hipStream_t st) {
-    if (H % T9_H || W % T9_W) return 1;
-    int ntiles = B * (H / T9_H) * (W / T9_W);
-    int G = ntiles < 256 ? ntiles : 256;
-    hipLaunchKernelGGL(conv9_c64_c4_wgrad_kernel, dim3(G), dim3(256), 0, st, x, dy, part, B, H, W);
-    hipLaunchKernelGGL(conv9_wgrad_reduce_kernel, dim3(cdiv(81 * 64 * 4, 256)), dim3(256), 0, st, part, dw, G);
+    if (H % W9_R || W % W9_P) return 1;
+    W9P p = {x, dy, part, B, H, W, B * (H / W9_R) * (W / W9_P)};
+    const int G = p.ntiles < 256 ? p.ntiles : 256;
+    hipLaunchKernelGGL(conv9_c64_c4_wgrad_mfma_kernel, dim3(G), dim3(768), 0, st, p);
+    hipLaunchKernelGGL(conv9_wgrad_reduce_kernel, dim3(64 * 324 / 64), dim3(1024), 0, st, part, dw, G);
     return LAUNCH_CHECK();
 }

@@ -558,12 +558,25 @@ __global__ void gru_tail_kernel(const float* __restrict__ dWp, const float* __re
                                 float* __restrict__ dbc, int K, const float* __restrict__ dWhh,
                                 float* __restrict__ dwhh_f, float* __restrict__ dwhh_r) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < 2 * 96 * 64) {
+    if (idx < 2 * 96 * 64) {   // 48 whole blocks; a wave = one row (d, r), lane = c.  W_c goes through LDS transposed, 64 k at a time:
+        // read straight from memory each lane would walk its own row of W_c (64 cache lines per load instruction)
+        __shared__ float WcT[64 * 65];
         const int d = idx / 6144, r = (idx % 6144) / 64, c = idx & 63;
         const float* a = dWp + (long)(96 * d + r) * K;
-        const float* b = Wc + (long)c * K;
         float s0 = dbp[96 * d + r] * bc[c], s1 = 0.f;
-        for (int k = 0; k < K; k += 2) { s0 = fmaf(a[k], b[k], s0); s1 = fmaf(a[k + 1], b[k + 1], s1); }
+        for (int kc = 0; kc < K; kc += 64) {
+            const int kn = K - kc < 64 ? K - kc : 64;
+            __syncthreads();
+            for (int e = threadIdx.x; e < 4096; e += 256) {
+                const int cc = e >> 6, k = e & 63;
+                if (k < kn) WcT[k * 65 + cc] = Wc[(long)cc * K + kc + k];
+            }
+            __syncthreads();
+            for (int k = 0; k < kn; k += 2) {
+                s0 = fmaf(a[kc + k], WcT[k * 65 + c], s0);
+                s1 = fmaf(a[kc + k + 1], WcT[(k + 1) * 65 + c], s1);
+            }
+        }
         (d ? dwih_r : dwih_f)[r * 64 + c] = s0 + s1;
         return;
     }

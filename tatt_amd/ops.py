@@ -439,9 +439,9 @@ def conv_wgrad(x_bhwc, dy_bhwc, Cout, KH, KW, want_db=False):
 def _conv_wgrad_general(x_bhwc, dy_bhwc, dw, Cout, KH, KW, contig):
     B, H, W, Cin = x_bhwc.shape
     sn, sh, sw, sc = x_bhwc.stride()
-    if contig and KH == 9 and KW == 9 and Cout == 4 and Cin == 64 and H % 8 == 0 and W % 32 == 0:
-        G = min(B * (H // 8) * (W // 32), 256)
-        part = new(x_bhwc, G * 81 * 64 * 4)
+    if contig and KH == 9 and KW == 9 and Cout == 4 and Cin == 64 and H % 4 == 0 and W % 64 == 0:
+        G = min(B * (H // 4) * (W // 64), 256)
+        part = new(x_bhwc, G * 64 * 336)
         call("tatt_conv9_c64_c4_wgrad", P(x_bhwc), P(dy_bhwc), P(dw), P(part), B, H, W, stream())
         return dw
     Mo, Kred = KH * KW * Cin, B * H * W

@@ -676,6 +676,24 @@ def test_conv9_mfma_toeplitz(dev, B, H, W):
     check_close("conv9_mfma_fwd_after_update", ops.conv2d_forward(xd, wd, bd), (2 * (ref - b.double()) + b.double()).float(), 4e-4, 4e-4)
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 32, 128), (3, 4, 64), (1, 8, 192), (67, 8, 64), (2, 64, 256)])
+def test_conv9_wgrad_mfma(dev, B, H, W):
+    """tatt_conv9_c64_c4_wgrad: weight gradient of the 64->4 reconstruction convolution (reference model/tsrn.py:623) with the
+    Toeplitz expansion on the dy operand, against autograd in fp64.  Shapes cover one tile, a ragged tile count over the persistent
+    groups (67 x 2 tiles), three pixel chunks per row and the large-tile geometry."""
+    from tatt_amd import ops
+    g = torch.Generator().manual_seed(47)
+    x = torch.randn(B, H, W, 64, generator=g)
+    dy = torch.randn(B, H, W, 4, generator=g)
+    w = torch.zeros(4, 64, 9, 9, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w, None, padding=4).backward(dy.permute(0, 3, 1, 2).double())
+    dw = ops.conv_wgrad(x.to(dev), dy.to(dev), 4, 9, 9)
+    scale = float(w.grad.abs().max())
+    err = float((dw.double().cpu() - w.grad).abs().max())
+    assert err <= 2e-6 * scale * max(1.0, (B * H * W / 8192) ** 0.5), (err, scale)
+    assert torch.equal(dw, ops.conv_wgrad(x.to(dev), dy.to(dev), 4, 9, 9))          # deterministic
+
+
 # ------------------------------------------------------------------------------------------- conv + BatchNorm folding
 @pytest.mark.parametrize("B,H,W", [(2, 16, 64), (5, 3, 128)])
 def test_conv_bn_folded_equals_operator_chain(dev, B, H, W):
