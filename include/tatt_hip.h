@@ -57,7 +57,7 @@ int tatt_conv2d_wgrad(const float* x, long xsn, long xsh, long xsw, long xsc, co
  * mode 2: [KH][KW][Cout][Cin]; mode 3: [KH][KW][Cin][Cout], taps flipped -- forward / data-gradient filters with the
  * contraction axis contiguous, for tatt_conv3_c64_fwd_t; modes 6 / 7: the same two 3x3 filters (64 contraction channels) in the
  * per-lane register order of tatt_conv3_c64_fwd_ws16 (4 / 5: retired);
- * modes 8 / 9: the Toeplitz-expanded 9x9 filter [9][64][16][20] of tatt_conv9_c64_to_c4_mfma (out needs 184,320 floats);
+ * modes 8 / 9: the Toeplitz-expanded 9x9 filter of tatt_conv9_c64_to_c4_mfma in its MFMA fragment order (out needs 110,592 floats);
  * modes 10 / 11: the split-bf16 (hi / lo) forward / data-gradient operand of tatt_conv3_c64_fwd_sb (3x3, channel counts multiples
  * of 64; Cout*Cin*9 32-bit words of two bf16, one chunk per 64 contraction channels) */
 int tatt_repack_conv_weight(const float* w_oihw, float* out, int Cout, int Cin, int KH, int KW,
@@ -121,14 +121,23 @@ int tatt_conv3_c64_wgrad_partial(const float* x, const float* dy, float* part, f
 int tatt_conv9_c64_to_c4(const float* x, const float* wpacked, const float* bias, float* y, int B, int H, int W,
                          int C, hipStream_t st);
 /* the same convolution on v_mfma_f32_16x16x4_f32: tile columns = (4 neighbouring pixels x 4 output channels), Toeplitz-expanded
- * filter wt [9][64][16][20] from tatt_repack_conv_weight mode 8 (forward, reference model/tsrn.py:623) / mode 9 (data gradient of
- * block1's 4->64 convolution, :597); x (B,H,W,64) NHWC contiguous, H % 8 == 0, W % 64 == 0; y (B,H,W,4) */
+ * filter wt (110,592 floats) from tatt_repack_conv_weight mode 8 (forward, reference model/tsrn.py:623) / mode 9 (data gradient of
+ * block1's 4->64 convolution, :597); x (B,H,W,64) NHWC contiguous, H % 4 == 0, W % 64 == 0; y (B,H,W,4) */
 int tatt_conv9_c64_to_c4_mfma(const float* x, const float* wt, const float* bias, float* y, int B, int H, int W,
                               hipStream_t st);
+/* 9x9 convolution from 4 channels to 64 (weight-stationary MFMA kernel, k = the 4 input channels): y = act(conv(in, wp) + bias),
+ * wp [81][4][64] = tatt_repack_conv_weight mode 0 of block1's filter (reference model/tsrn.py:597) or mode 1 of the 64->4
+ * reconstruction filter (its data gradient, :623); in (B,H,W,4), out (B,H,W,64) NHWC contiguous, H % 4 == 0, W % 64 == 0 */
+int tatt_conv9_c4_to_c64(const float* in, const float* wp, const float* bias, float* out, int B, int H, int W, int act,
+                         hipStream_t st);
 /* dw (4,64,9,9) = sum_px x[px+tap][ci] * dy[px][co] on v_mfma_f32_16x16x4_f32 (rows = input channels, columns = (tap, output
  * channel) read Toeplitz-fashion from the dy tile; weight gradient of reference model/tsrn.py:623); H % 4 == 0, W % 64 == 0;
  * part >= min(B*(H/4)*(W/64), 256) * 64 * 336 floats */
 int tatt_conv9_c64_c4_wgrad(const float* x, const float* dy, float* dw, float* part, int B, int H, int W,
+                            hipStream_t st);
+/* x (B,H,W,4), dy (B,H,W,64) -> dw (64,4,9,9): the same kernel with the two tensors' roles exchanged (weight gradient of block1's
+ * 4->64 convolution, reference model/tsrn.py:597); same constraints and workspace */
+int tatt_conv9_c4_c64_wgrad(const float* x, const float* dy, float* dw, float* part, int B, int H, int W,
                             hipStream_t st);
 
 /* ---- reductions / normalisation ------------------------------------------------------------------- */

@@ -83,118 +83,228 @@ TATT_API int tatt_conv9_c64_to_c4(const float* x, const float* wpacked, const fl
 // (64 pixels of one image row), and the contraction runs over (ky, dx, ci) with dx = kx + j in [0, 12): the filter becomes a
 // Toeplitz-expanded matrix Wt[ky][ci][n][dx] = w[o][ci][ky][dx - j] (zero outside the 9 taps) -- 12/9 of the useful FLOPs instead
 // of 4x, i.e. 75 % of the fp32 matrix peak is the ceiling (the vector-ALU kernel above reaches 24 %).
-//   work-group = 8 rows x 64 pixels, 4 waves x 2 rows; input channels in chunks of 16:
-//   Xs[16 halo rows][16 ci][96]  (pixel-contiguous): lane (i, kq) reads pixels 4 g(i) + 4 d .. + 3 of channel 4 cq + kq with one
+//   (persistent) work-group = 4 rows x 64 pixels per tile, 8 waves = 2 per SIMD: wave (row = w & 3, kh = w >> 2) computes one output row over half of
+//   the input channels (channel quads kh and kh + 2 of every chunk of 16); the two halves meet through LDS at the end.
+//   Xs[12 halo rows][16 ci][96]  (pixel-contiguous): lane (i, kq) reads pixels 4 g(i) + 4 d .. + 3 of channel 4 cq + kq with one
 //       ds_read_b128 and feeds MFMA u (dx = 4 d + u) with element u.  Channel rows are 96 floats = 24 slots of 16 bytes apart
 //       (= 8 mod 16) and matrix row i stands for pixel group g(i) = i ^ 4 for i < 8, i otherwise: with that the four lane groups a
 //       ds_read_b128 is served in hit 16 distinct slots each.
-//   Ws[16 ci][16 n][20]  (dx-contiguous, one (ky, chunk) slab of the expanded filter, 20 KB, re-staged per ky): pitch 20 floats =
-//       5 slots per n, channel rows 80 slots (= 0 mod 16) apart -- conflict-free as well.
-#define M9_TH 8
+//   The expanded filter never touches LDS: a lane's B fragments come straight from global memory (packed in fragment order: a
+//   wave's load reads 1 KB of consecutive memory; the whole filter is 442 KB, L2-resident) into registers THREE PHASES AHEAD of their
+//   use (four register sets; a phase = one filter row of one chunk = 24 MFMAs per wave, shorter than a trip to L2 -- and loads
+//   retire in order, so a filter fragment also waits for the halo prefetches issued before it, which come from HBM).  Without filter
+//   slabs in LDS there is no barrier per phase: the waves only meet at the 3 chunk boundaries, where the next chunk's halo
+//   (prefetched to registers under the MFMAs: a thread holds the 16 channels of up to 2 halo pixels) replaces the current one.  The
+//   halo stores walk pixels along the lanes (bank = pixel mod 32; channel rows are 0 mod 32 apart, so channel-along-lanes would be
+//   a 4-way conflict).
+#define M9_TH 4
 #define M9_TW 64
 #define M9_PW 96
 #define M9_ROWS (M9_TH + 8)
-#define M9_XS (M9_ROWS * 16 * M9_PW)          // floats: 24,576
-#define M9_WS (16 * 16 * 20)                  // floats: 5,120
-#define M9_LDS ((M9_XS + 2 * M9_WS) * 4)      // 139,264 B
-__global__ __launch_bounds__(256) void conv9_c64_to_c4_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wt,
+#define M9_HPX (M9_ROWS * 72)                 // halo pixels per chunk: 864
+#define M9_HQ 2                               // halo pixels per thread (512 threads)
+#define M9_D 3                                // filter fragments are fetched M9_D phases ahead (M9_D + 1 divides 36)
+#define M9_XS (M9_ROWS * 16 * M9_PW)          // floats: 18,432 = 73,728 B
+__global__ __launch_bounds__(512) void conv9_c64_to_c4_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wt,
                                                                    const float* __restrict__ bias, float* __restrict__ y,
-                                                                   int B, int H, int W) {
-    extern __shared__ __attribute__((aligned(16))) float smem9[];
-    float* Xs = smem9;
-    float* Ws = smem9 + M9_XS;
+                                                                   int B, int H, int W, int ntiles) {
+    __shared__ __attribute__((aligned(16))) float Xs[M9_XS];
+    __shared__ __attribute__((aligned(16))) float Red[4 * 64 * 4];    // the kh = 1 accumulators of the four rows
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int row = wave & 3, kh = wave >> 2;
     const int tiles_w = W / M9_TW, tiles_h = H / M9_TH;
-    int bid = blockIdx.x;
-    const int tw = bid % tiles_w; bid /= tiles_w;
-    const int th = bid % tiles_h; const int n = bid / tiles_h;
-    const int h0 = th * M9_TH, w0 = tw * M9_TW;
     const int i = lane & 15, kq = lane >> 4;
     const int g = (i & 8) ? i : (i ^ 4);                      // pixel group of matrix row i
-    f32x4 acc[2];
-    acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const float* xa = Xs + (2 * wave * 16 + kq) * M9_PW + 4 * g;      // + ((ky + r2) * 16 + 4 cq) * PW + 4 d
-    const float* wb = Ws + (kq * 16 + i) * 20;                         // + (4 cq * 16) * 20 + 4 d
-    // 36 phases (4 channel chunks x 9 filter rows): the NEXT phase's filter slab travels global -> registers under the MFMAs of the
-    // current one and is stored to the other Ws buffer afterwards (one barrier per phase); the halo is re-staged per chunk.
-    f32x4 wpre[5];
-    auto slab_load = [&](int p) {
-        const f32x4* src = reinterpret_cast<const f32x4*>(wt + ((long)(p % 9) * 64 + 16 * (p / 9)) * 320);
+    const float* xa = Xs + (row * 16 + 4 * kh + kq) * M9_PW + 4 * g;  // + (ky * 16 + 8 cqi) * PW + 4 d
+    // filter fragments: buffer loads with the lane part of the address in voffset and the (phase, fragment) part in soffset -- with
+    // plain pointers the compiler hoists a 64-bit address per fragment out of the tile loop (200+ registers, spills)
+    const int wl = (kh * 6 * 64 + lane) * 16;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wt), 0, 9 * 4 * 2 * 6 * 64 * 4 * 4, 0x00020000);
+    f32x4 wpre[M9_D + 1][6];                                           // filter fragments of phase p sit in set p % (M9_D + 1)
+    f32x4 hpre[M9_HQ][4];
+    auto filt_load = [&](int p) {
 #pragma unroll
-        for (int q = 0; q < 5; ++q) wpre[q] = src[t + 256 * q];
+        for (int f = 0; f < 6; ++f)
+            wpre[p % (M9_D + 1)][f] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                wrs, wl, (((p % 9) * 4 + p / 9) * 12 + f) * 1024, 0));
     };
-    auto slab_store = [&](int buf) {
-        f32x4* dst = reinterpret_cast<f32x4*>(Ws + buf * M9_WS);
+    // halo rows h0-4 .. h0+7, pixels w0-4 .. w0+67, channels c0 .. c0+15 of tile `tile`: thread t owns halo pixels t and t+512 (< 864)
+    auto halo_load = [&](int tile, int c0, int q) {
+        const int tw = tile % tiles_w, th = (tile / tiles_w) % tiles_h, n = tile / (tiles_w * tiles_h);
+        const int pp = t + 512 * q;
+        const int r = pp / 72, px = pp - r * 72;
+        const int hh = th * M9_TH + r - 4, ww = tw * M9_TW + px - 4;
+        const bool ok = tile < ntiles && pp < M9_HPX && hh >= 0 && hh < H && ww >= 0 && ww < W;
+        const f32x4* src = reinterpret_cast<const f32x4*>(x + (((long)n * H + hh) * W + ww) * 64 + c0);
 #pragma unroll
-        for (int q = 0; q < 5; ++q) dst[t + 256 * q] = wpre[q];
+        for (int c4 = 0; c4 < 4; ++c4) hpre[q][c4] = ok ? src[c4] : (f32x4){0.f, 0.f, 0.f, 0.f};
     };
-    auto halo_stage = [&](int c0) {
-        // halo rows h0-4 .. h0+11, pixels w0-4 .. w0+67, channels c0 .. c0+15 (quads of lanes read 64 contiguous bytes)
-        for (int idx = t; idx < M9_ROWS * 72 * 4; idx += 256) {
-            const int c4 = idx & 3, pp = idx >> 2;
+    auto halo_store = [&](int q) {
+        const int pp = t + 512 * q;
+        if (pp < M9_HPX) {
             const int r = pp / 72, px = pp - r * 72;
-            const int hh = h0 + r - 4, ww = w0 + px - 4;
-            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (hh >= 0 && hh < H && ww >= 0 && ww < W)
-                v = *reinterpret_cast<const f32x4*>(x + (((long)n * H + hh) * W + ww) * 64 + c0 + 4 * c4);
-            float* d = Xs + (r * 16 + 4 * c4) * M9_PW + px;
-            d[0] = v[0]; d[M9_PW] = v[1]; d[2 * M9_PW] = v[2]; d[3 * M9_PW] = v[3];
+            float* d = Xs + r * 16 * M9_PW + px;
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[(4 * c4 + e) * M9_PW] = hpre[q][c4][e];
         }
     };
-    slab_load(0);
-    halo_stage(0);
-    slab_store(0);
+#pragma unroll
+    for (int q = 0; q < M9_D; ++q) filt_load(q);
+#pragma unroll
+    for (int q = 0; q < M9_HQ; ++q) halo_load(blockIdx.x, 0, q);
+#pragma unroll
+    for (int q = 0; q < M9_HQ; ++q) halo_store(q);
     __syncthreads();
+    const float bo = bias ? bias[i & 3] : 0.f;
+    // persistent over tiles; per tile 36 phases = 4 channel chunks x 9 filter rows, unrolled so that the register-set indices are
+    // static (36 is a multiple of the M9_D + 1 sets, so the rotation continues seamlessly into the next tile)
 #pragma unroll 1
-    for (int p = 0; p < 36; ++p) {
-        const int ky = p % 9;
-        if (p + 1 < 36) slab_load(p + 1);
-        const float* wbp = wb + (p & 1) * M9_WS;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        f32x4 acc4[4];
 #pragma unroll
-        for (int d = 0; d < 3; ++d)
+        for (int q = 0; q < 4; ++q) acc4[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int cq = 0; cq < 4; ++cq) {
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(wbp + cq * 4 * 320 + 4 * d);
-                const f32x4 a0 = *reinterpret_cast<const f32x4*>(xa + ((ky + 0) * 16 + 4 * cq) * M9_PW + 4 * d);
-                const f32x4 a1 = *reinterpret_cast<const f32x4*>(xa + ((ky + 1) * 16 + 4 * cq) * M9_PW + 4 * d);
+        for (int c = 0; c < 4; ++c) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u], bv[u], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u], bv[u], acc[1], 0, 0, 0);
+            for (int ky = 0; ky < 9; ++ky) {
+                const int p = 9 * c + ky;
+                filt_load((p + M9_D) % 36);                   // beyond phase 35: the next tile's first phases (same filter)
+                if (ky < M9_HQ) {                             // the next chunk's halo: of this tile, or chunk 0 of the next one
+                    if (c < 3) halo_load(tile, 16 * (c + 1), ky);
+                    else halo_load(tile + gridDim.x, 0, ky);
+                }
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(xa + (ky * 16 + 0) * M9_PW + 4 * d);
+                    const f32x4 a1 = *reinterpret_cast<const f32x4*>(xa + (ky * 16 + 8) * M9_PW + 4 * d);
+                    const f32x4 b0 = wpre[p % (M9_D + 1)][d], b1 = wpre[p % (M9_D + 1)][3 + d];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {             // four accumulator chains, consecutive MFMAs never depend on each other
+                        acc4[u & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u], b0[u], acc4[u & 1], 0, 0, 0);
+                        acc4[2 + (u & 1)] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u], b1[u], acc4[2 + (u & 1)], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);            // keep the scheduler from hoisting a whole chunk's LDS reads (it spills)
+                if (ky == 8) {                                // chunk boundary: every wave must have left the halo first
+                    f32x4 acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+                    __syncthreads();
+#pragma unroll
+                    for (int q = 0; q < M9_HQ; ++q) halo_store(q);
+                    if (c == 3 && kh == 1) *reinterpret_cast<f32x4*>(&Red[(row * 64 + lane) * 4]) = acc;
+                    __syncthreads();
+                    if (c == 3 && kh == 0) {                  // the two channel halves of a row meet
+                        acc += *reinterpret_cast<const f32x4*>(&Red[(row * 64 + lane) * 4]);
+                        // C layout: column n = lane & 15 = (j, o); row 4 (lane >> 4) + reg -> pixel group g(row).  The 16 columns
+                        // of a row are 16 consecutive floats of y: pixel 4 g + j, channel o.
+                        const int tw = tile % tiles_w, th = (tile / tiles_w) % tiles_h, n = tile / (tiles_w * tiles_h);
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) {
+                            const int mrow = 4 * kq + reg;
+                            const int gg = (mrow & 8) ? mrow : (mrow ^ 4);
+                            y[(((long)n * H + th * M9_TH + row) * W + tw * M9_TW + 4 * gg) * 4 + i] = acc[reg] + bo;
+                        }
+                    }
                 }
             }
-        if (p + 1 < 36) {
-            slab_store((p + 1) & 1);                          // the other buffer: last read in phase p - 1, before the previous barrier
-            if (ky == 8) {                                    // chunk boundary: every wave must have left the halo first
-                __syncthreads();
-                halo_stage(16 * ((p + 1) / 9));
-            }
-            __syncthreads();
         }
     }
-    // C layout: column n = lane & 15 = (j, o); row 4 (lane >> 4) + reg -> pixel group g(row).  The 16 columns of a row are 16
-    // consecutive floats of y: pixel 4 g + j, channel o.
-    const float bo = bias ? bias[i & 3] : 0.f;
-#pragma unroll
-    for (int r2 = 0; r2 < 2; ++r2)
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int row = 4 * kq + reg;
-            const int gg = (row & 8) ? row : (row ^ 4);
-            y[(((long)n * H + h0 + 2 * wave + r2) * W + w0 + 4 * gg) * 4 + i] = acc[r2][reg] + bo;
-        }
 }
-// x (B,H,W,64) NHWC contiguous, H % 8 == 0, W % 64 == 0; wt = Toeplitz-expanded filter [9][64][16][20] from
+// x (B,H,W,64) NHWC contiguous, H % 4 == 0, W % 64 == 0; wt = Toeplitz-expanded filter (110,592 floats in MFMA fragment order) from
 // tatt_repack_conv_weight mode 8 (forward filter of a 64->4 convolution) / mode 9 (data gradient of a 4->64 one); y (B,H,W,4)
 TATT_API int tatt_conv9_c64_to_c4_mfma(const float* x, const float* wt, const float* bias, float* y, int B, int H, int W,
                                        hipStream_t st) {
     if (H % M9_TH || W % M9_TW) return 1;
-    static std::once_flag attr_once;                 // C++11 call_once: safe if several host threads launch
-    std::call_once(attr_once, [&] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv9_c64_to_c4_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, M9_LDS);
-    });
-    hipLaunchKernelGGL(conv9_c64_to_c4_mfma_kernel, dim3(B * (H / M9_TH) * (W / M9_TW)), dim3(256), M9_LDS, st, x, wt, bias, y, B, H, W);
+    const int ntiles = B * (H / M9_TH) * (W / M9_TW);
+    hipLaunchKernelGGL(conv9_c64_to_c4_mfma_kernel, dim3(ntiles < 256 ? ntiles : 256), dim3(512), 0, st, x, wt, bias, y, B, H, W,
+                       ntiles);
+    return LAUNCH_CHECK();
+}
+
+// ---- 9x9 convolution FROM 4 channels TO 64 on the matrix cores -----------------------------------------------------------------
+// y[px][n] = act(sum_{tap, k} in[px + tap - 4][k] * wp[tap][k][n] + bias[n]),  wp = [81][4][64] (repack mode 0: block1's forward
+// convolution, reference model/tsrn.py:597; mode 1: the data gradient of the 64->4 reconstruction convolution, :623).
+// The 4 input channels are exactly the k = 4 of v_mfma_f32_16x16x4_f32 -- one MFMA per (tap, 16 outputs x 16 pixels), no padding
+// anywhere.  A[i = output channel][k] = wp[tap][k][16 nt + i] is WEIGHT-STATIONARY: 81 registers per lane hold a wave's whole
+// filter slice for every tile the (persistent) group walks.  B[k][j = pixel] = one LDS dword per lane from the 4-channel halo tile
+// (12 rows x 72 pixels x 4 channels = 13.8 KB; the 64 lanes of a read cover 64 consecutive dwords).  C rows = output channels:
+// a lane ends up with 4 consecutive channels of one pixel = one 16-byte store.
+// Work-group = 8 waves on a 4-row x 64-pixel tile: wave (nt = w & 3, half = w >> 2) computes output channels 16 nt .. +15 of rows
+// 2 half, 2 half + 1; the four 16-pixel groups of a row are four independent accumulator chains.  The next tile's halo travels
+// global -> registers under the MFMAs.
+#define F9_TH 4
+#define F9_TW 64
+#define F9_DW (F9_TW + 8)
+#define F9_ROWS (F9_TH + 8)
+struct F9P { const float* in; const float* wp; const float* bias; float* out; int B, H, W, ntiles, act; };
+__global__ __launch_bounds__(512) void conv9_c4_to_c64_kernel(F9P p) {
+    __shared__ __attribute__((aligned(16))) float Ds[F9_ROWS * F9_DW * 4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int nt = wave & 3, half = wave >> 2, li = lane & 15, lk = lane >> 4;
+    const int tiles_w = p.W / F9_TW, tiles_h = p.H / F9_TH;
+    float wreg[81];
+#pragma unroll
+    for (int tap = 0; tap < 81; ++tap) wreg[tap] = p.wp[(tap * 4 + lk) * 64 + 16 * nt + li];
+    f32x4 bo = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bo = *reinterpret_cast<const f32x4*>(p.bias + 16 * nt + 4 * lk);
+    f32x4 dr0, dr1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto decode = [&](int tile, int& b, int& h0, int& w0) {
+        const int tw = tile % tiles_w; tile /= tiles_w;
+        h0 = (tile % tiles_h) * F9_TH; b = tile / tiles_h; w0 = tw * F9_TW;
+    };
+    auto load1 = [&](int e, int b, int h0, int w0) -> f32x4 {
+        const int d = e / F9_DW, q = e - d * F9_DW, row = h0 - 4 + d, px = w0 - 4 + q;
+        if (row < 0 || row >= p.H || px < 0 || px >= p.W) return (f32x4){0.f, 0.f, 0.f, 0.f};
+        return *reinterpret_cast<const f32x4*>(p.in + (((long)b * p.H + row) * p.W + px) * 4);
+    };
+    auto load_halo = [&](int tile) {
+        int b, h0, w0; decode(tile, b, h0, w0);
+        dr0 = load1(t, b, h0, w0);
+        if (t < F9_ROWS * F9_DW - 512) dr1 = load1(t + 512, b, h0, w0);
+    };
+    if ((int)blockIdx.x < p.ntiles) load_halo(blockIdx.x);
+    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        __syncthreads();                                   // the previous tile has been consumed
+        *reinterpret_cast<f32x4*>(&Ds[4 * t]) = dr0;
+        if (t < F9_ROWS * F9_DW - 512) *reinterpret_cast<f32x4*>(&Ds[4 * (t + 512)]) = dr1;
+        if (tile + (int)gridDim.x < p.ntiles) load_halo(tile + gridDim.x);
+        __syncthreads();
+        int b, h0, w0; decode(tile, b, h0, w0);
+#pragma unroll 1
+        for (int r = 0; r < 2; ++r) {
+            const int row = 2 * half + r;
+            const float* db = &Ds[(row * F9_DW + li) * 4 + lk];
+            f32x4 acc[4];
+#pragma unroll
+            for (int mg = 0; mg < 4; ++mg) acc[mg] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ky = 0; ky < 9; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 9; ++kx)
+#pragma unroll
+                    for (int mg = 0; mg < 4; ++mg)
+                        acc[mg] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[ky * 9 + kx], db[(ky * F9_DW + kx + 16 * mg) * 4], acc[mg], 0, 0, 0);
+            float* o = p.out + (((long)b * p.H + h0 + row) * p.W + w0 + li) * 64 + 16 * nt + 4 * lk;
+#pragma unroll
+            for (int mg = 0; mg < 4; ++mg) {
+                f32x4 v = acc[mg] + bo;
+                if (p.act != ACT_NONE) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+                }
+                *reinterpret_cast<f32x4*>(o + (long)16 * mg * 64) = v;
+            }
+        }
+    }
+}
+// in (B,H,W,4) NHWC contiguous, H % 4 == 0, W % 64 == 0; wp [81][4][64]; out (B,H,W,64)
+TATT_API int tatt_conv9_c4_to_c64(const float* in, const float* wp, const float* bias, float* out, int B, int H, int W, int act,
+                                  hipStream_t st) {
+    if (H % F9_TH || W % F9_TW) return 1;
+    F9P p = {in, wp, bias, out, B, H, W, B * (H / F9_TH) * (W / F9_TW), act};
+    const int G = p.ntiles < 256 ? p.ntiles : 256;
+    hipLaunchKernelGGL(conv9_c4_to_c64_kernel, dim3(G), dim3(512), 0, st, p);
     return LAUNCH_CHECK();
 }
 
@@ -216,7 +326,7 @@ TATT_API int tatt_conv9_c64_to_c4_mfma(const float* x, const float* wt, const fl
 #define W9_DROWS (W9_R + 8)
 #define W9_NT 21
 #define W9_N (W9_NT * 16)        // 336 columns per partial row (324 used)
-struct W9P { const float* x; const float* dy; float* part; int B, H, W, ntiles; };
+struct W9P { const float* x; const float* dy; float* part; int B, H, W, ntiles, flip; };
 __global__ __launch_bounds__(768) void conv9_c64_c4_wgrad_mfma_kernel(W9P p) {
     __shared__ __attribute__((aligned(16))) float Xs[2][W9_P * W9_XP];
     __shared__ __attribute__((aligned(16))) float Ds[(W9_DROWS + 1) * W9_DW * 4];     // + one row of zeros for the 12 unused columns
@@ -229,7 +339,8 @@ __global__ __launch_bounds__(768) void conv9_c64_c4_wgrad_mfma_kernel(W9P p) {
         const int n = 16 * (7 * ng + j) + li, tap = n >> 2, co = n & 3;
         if (tap < 81) {
             const int ky = tap / 9, kx = tap - 9 * ky;
-            bbase[j] = ((8 - ky) * W9_DW + lk + 8 - kx) * 4 + co;
+            // flip: the 4-channel tensor is the convolution's INPUT (weight gradient of a 4->64 convolution): rows r+ky-4, pixels p+kx-4
+            bbase[j] = p.flip ? (ky * W9_DW + lk + kx) * 4 + co : ((8 - ky) * W9_DW + lk + 8 - kx) * 4 + co;
             bstep[j] = W9_DW * 4;
         } else { bbase[j] = W9_DROWS * W9_DW * 4; bstep[j] = 0; }
     }
@@ -297,7 +408,9 @@ __global__ __launch_bounds__(768) void conv9_c64_c4_wgrad_mfma_kernel(W9P p) {
         for (int e = 0; e < 4; ++e) P[(long)(16 * mt + 4 * lk + e) * W9_N + 16 * (7 * ng + j) + li] = acc[j][e];
 }
 // dw[co][ci][tap] (OIHW, Cout = 4, Cin = 64) = sum_g part[g][ci][tap*4 + co]; block = 64 outputs x 16 lanes over g
-__global__ __launch_bounds__(1024) void conv9_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int G) {
+// (swap: dw[ci][co][tap], the OIHW gradient of the 4->64 convolution whose 64 OUTPUT channels are the matrix rows)
+__global__ __launch_bounds__(1024) void conv9_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int G,
+                                                                  int swap) {
     __shared__ float sh[16][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int idx = blockIdx.x * 64 + tx;                      // enumerates ci*324 + n
@@ -316,17 +429,27 @@ __global__ __launch_bounds__(1024) void conv9_wgrad_reduce_kernel(const float* _
         float s = 0.f;
 #pragma unroll
         for (int l = 0; l < 16; ++l) s += sh[l][tx];
-        dw[((long)(n & 3) * 64 + ci) * 81 + (n >> 2)] = s;
+        dw[(swap ? (long)ci * 4 + (n & 3) : (long)(n & 3) * 64 + ci) * 81 + (n >> 2)] = s;
     }
 }
 // x (B,H,W,64), dy (B,H,W,4) -> dw (4,64,9,9); H % 4 == 0, W % 64 == 0; part >= min(#tiles, 256) * 64 * 336 floats,
 // #tiles = B * (H/4) * (W/64)
-TATT_API int tatt_conv9_c64_c4_wgrad(const float* x, const float* dy, float* dw, float* part, int B, int H, int W,
-                                     hipStream_t st) {
+static int conv9_wgrad_launch(const float* x64, const float* t4, float* dw, float* part, int B, int H, int W, int flip,
+                              hipStream_t st) {
     if (H % W9_R || W % W9_P) return 1;
-    W9P p = {x, dy, part, B, H, W, B * (H / W9_R) * (W / W9_P)};
+    W9P p = {x64, t4, part, B, H, W, B * (H / W9_R) * (W / W9_P), flip};
     const int G = p.ntiles < 256 ? p.ntiles : 256;
     hipLaunchKernelGGL(conv9_c64_c4_wgrad_mfma_kernel, dim3(G), dim3(768), 0, st, p);
-    hipLaunchKernelGGL(conv9_wgrad_reduce_kernel, dim3(64 * 324 / 64), dim3(1024), 0, st, part, dw, G);
+    hipLaunchKernelGGL(conv9_wgrad_reduce_kernel, dim3(64 * 324 / 64), dim3(1024), 0, st, part, dw, G, flip);
     return LAUNCH_CHECK();
+}
+TATT_API int tatt_conv9_c64_c4_wgrad(const float* x, const float* dy, float* dw, float* part, int B, int H, int W,
+                                     hipStream_t st) {
+    return conv9_wgrad_launch(x, dy, dw, part, B, H, W, 0, st);
+}
+// x (B,H,W,4), dy (B,H,W,64) -> dw (64,4,9,9): the same GEMM with the roles of the two tensors exchanged (rows = the 64 OUTPUT
+// channels from dy, Toeplitz columns = (tap, input channel) from x); weight gradient of block1 (reference model/tsrn.py:597)
+TATT_API int tatt_conv9_c4_c64_wgrad(const float* x, const float* dy, float* dw, float* part, int B, int H, int W,
+                                     hipStream_t st) {
+    return conv9_wgrad_launch(dy, x, dw, part, B, H, W, 1, st);
 }

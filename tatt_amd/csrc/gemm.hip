@@ -882,17 +882,27 @@ TATT_API int tatt_conv2d_wgrad(const float* x, long xsn, long xsh, long xsw, lon
 // modes 2 / 3: the same two filters with the contraction axis contiguous ([tap][out][in]) for tatt_conv3_c64_fwd_t.
 // (modes 4 / 5 belonged to the retired 32x32 weight-stationary kernel;)
 // modes 6 / 7: in the register order of tatt_conv3_c64_fwd_ws16.
-// modes 8 / 9: Toeplitz-expanded 9x9 filter of tatt_conv9_c64_to_c4_mfma, out[ky][ci 64][n = 4 j + o][20]:
-//   value(dx < 12) = f[o][ci][ky][dx - j] if 0 <= dx - j < 9 else 0, 0 for dx >= 12;  mode 8: f = w (OIHW, Cout = 4, Cin = 64);
+// modes 8 / 9: Toeplitz-expanded 9x9 filter of tatt_conv9_c64_to_c4_mfma in the per-lane MFMA B-fragment order of that kernel
+// (a wave's 16-byte fragment load reads 1 KB of consecutive memory):
+//   out[((((ky * 4 + c) * 2 + kh) * 6 + cqi * 3 + d) * 64 + lane) * 4 + u] = Wt[ky][ci][n][dx],
+//   ci = 16 c + 4 (kh + 2 cqi) + (lane >> 4), n = lane & 15 = 4 j + o, dx = 4 d + u (< 12),
+//   Wt = f[o][ci][ky][dx - j] if 0 <= dx - j < 9 else 0;  mode 8: f = w (OIHW, Cout = 4, Cin = 64);
 //   mode 9 (data gradient of a 4 -> 64 convolution, w OIHW with Cout = 64, Cin = 4): f[o][ci][ky][kx] = w[ci][o][8 - ky][8 - kx].
+#define TOEPLITZ9_WORDS (9 * 4 * 2 * 6 * 64 * 4)
 __device__ __forceinline__ float toeplitz9(const float* __restrict__ w, int idx, int mode) {
-    const int dx = idx % 20, nn = (idx / 20) & 15, ci = (idx / 320) & 63, ky = idx / (320 * 64);
-    const int j = nn >> 2, o = nn & 3, kx = dx - j;
-    if (dx >= 12 || kx < 0 || kx >= 9) return 0.f;
+    const int u = idx & 3, lane = (idx >> 2) & 63;
+    int r = idx >> 8;
+    const int f = r % 6; r /= 6;
+    const int kh = r & 1; r >>= 1;
+    const int c = r & 3, ky = r >> 2;
+    const int cqi = f / 3, d = f - 3 * cqi;
+    const int ci = 16 * c + 4 * (kh + 2 * cqi) + (lane >> 4), nn = lane & 15;
+    const int j = nn >> 2, o = nn & 3, kx = 4 * d + u - j;
+    if (kx < 0 || kx >= 9) return 0.f;
     return mode == 8 ? w[(((long)o * 64 + ci) * 9 + ky) * 9 + kx] : w[(((long)ci * 4 + o) * 9 + (8 - ky)) * 9 + (8 - kx)];
 }
 static inline long repack_total(int Cout, int Cin, int KH, int KW, int mode) {
-    return (mode == 8 || mode == 9) ? 9L * 64 * 16 * 20 : (long)Cout * Cin * KH * KW;
+    return (mode == 8 || mode == 9) ? (long)TOEPLITZ9_WORDS : (long)Cout * Cin * KH * KW;
 }
 // modes 10 / 11: the split-bf16 B operand of tatt_conv3_c64_fwd_sb (3x3; conv input channels a multiple of 64, output channels of 16):
 // 32-bit words of two bf16 with consecutive input channels,
@@ -924,7 +934,7 @@ __global__ void repack_weight_kernel(const float* __restrict__ w, float* __restr
         return;
     }
     if (mode >= 8) {
-        if (idx < 9 * 64 * 16 * 20) out[idx] = toeplitz9(w, idx, mode);
+        if (idx < TOEPLITZ9_WORDS) out[idx] = toeplitz9(w, idx, mode);
         return;
     }
     int total = Cout * Cin * KH * KW;
@@ -981,7 +991,7 @@ __global__ void repack_batch_kernel(RepackTable t) {
         return;
     }
     if (e.mode >= 8) {
-        if (idx < 9 * 64 * 16 * 20) e.out[idx] = toeplitz9(e.w, idx, e.mode);
+        if (idx < TOEPLITZ9_WORDS) e.out[idx] = toeplitz9(e.w, idx, e.mode);
         return;
     }
     const int total = e.Cout * e.Cin * e.KH * e.KW;

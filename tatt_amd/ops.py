@@ -177,7 +177,7 @@ def colsum(x2, *, out=None, scale=1.0, beta=0.0):
 # --------------------------------------------------------------------------------------------------
 def _packed_numel(shape, mode):
     Cout, Cin, KH, KW = shape
-    return 9 * 64 * 16 * 20 if mode >= 8 else KH * KW * Cin * Cout
+    return 9 * 4 * 2 * 6 * 64 * 4 if mode >= 8 else KH * KW * Cin * Cout
 
 
 class _PackedHolder:
@@ -290,6 +290,10 @@ def conv_fwd(x_bhwc, wpacked, bias, Cout, KH, KW, *, act=ACT_NONE, out=None, bet
             and act == ACT_NONE and beta == 0.0:
         call("tatt_conv9_c64_to_c4", P(x_bhwc), P(wpacked), P(bias), P(y), B, H, W, Cin, stream())
         return y
+    if contig and KH == 9 and KW == 9 and Cout == 64 and Cin == 4 and H % 4 == 0 and W % 64 == 0 and beta == 0.0 \
+            and y.is_contiguous():
+        call("tatt_conv9_c4_to_c64", P(x_bhwc), P(wpacked), P(bias), P(y), B, H, W, act, stream())
+        return y
     M, K = B * H * W, KH * KW * Cin
     tiles, nchunks = cdiv(M, 64) * cdiv(Cout, 64), cdiv(K, 16)
     splitk, ws = 1, None
@@ -334,7 +338,7 @@ def _conv3_sb(x_bhwc, w_oihw, mode, bias, act=ACT_NONE, in_scale=None, in_shift=
 
 
 def _conv9_mfma_ok(x_bhwc):
-    return x_bhwc.is_contiguous() and x_bhwc.shape[1] % 8 == 0 and x_bhwc.shape[2] % 64 == 0 and x_bhwc.shape[3] == 64
+    return x_bhwc.is_contiguous() and x_bhwc.shape[1] % 4 == 0 and x_bhwc.shape[2] % 64 == 0 and x_bhwc.shape[3] == 64
 
 
 def conv2d_forward(x_bhwc, weight_oihw, bias, act=ACT_NONE):
@@ -443,6 +447,11 @@ def _conv_wgrad_general(x_bhwc, dy_bhwc, dw, Cout, KH, KW, contig):
         G = min(B * (H // 4) * (W // 64), 256)
         part = new(x_bhwc, G * 64 * 336)
         call("tatt_conv9_c64_c4_wgrad", P(x_bhwc), P(dy_bhwc), P(dw), P(part), B, H, W, stream())
+        return dw
+    if contig and KH == 9 and KW == 9 and Cout == 64 and Cin == 4 and H % 4 == 0 and W % 64 == 0:
+        G = min(B * (H // 4) * (W // 64), 256)
+        part = new(x_bhwc, G * 64 * 336)
+        call("tatt_conv9_c4_c64_wgrad", P(x_bhwc), P(dy_bhwc), P(dw), P(part), B, H, W, stream())
         return dw
     Mo, Kred = KH * KW * Cin, B * H * W
     splitk = max(2, _auto_split(Mo, Cout, Kred))

@@ -650,7 +650,7 @@ def test_semantic_loss_and_psnr_kernels(dev):
     assert float(calculate_psnr(a, a)) == float("inf")
 
 
-@pytest.mark.parametrize("B,H,W", [(2, 32, 128), (3, 16, 64), (1, 8, 64), (5, 64, 256)])
+@pytest.mark.parametrize("B,H,W", [(2, 32, 128), (3, 16, 64), (1, 8, 64), (1, 4, 64), (5, 64, 256)])
 def test_conv9_mfma_toeplitz(dev, B, H, W):
     """tatt_conv9_c64_to_c4_mfma (4 pixels x 4 channels per MFMA column block, Toeplitz-expanded filter): the 64->4 reconstruction
     convolution (repack mode 8) and the data gradient of a 4->64 convolution (mode 9) against F.conv2d in fp64."""
@@ -676,6 +676,29 @@ def test_conv9_mfma_toeplitz(dev, B, H, W):
     check_close("conv9_mfma_fwd_after_update", ops.conv2d_forward(xd, wd, bd), (2 * (ref - b.double()) + b.double()).float(), 4e-4, 4e-4)
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 16, 64), (3, 4, 64), (1, 8, 192), (67, 8, 64), (2, 32, 128)])
+def test_conv9_c4_to_c64_weight_stationary(dev, B, H, W):
+    """tatt_conv9_c4_to_c64 (k = the 4 input channels, 81 filter registers per lane): block1's 4->64 convolution with bias
+    (reference model/tsrn.py:597) and the data gradient of the 64->4 reconstruction convolution (:623) against F.conv2d in fp64.
+    (67, 8, 64): more tiles than persistent groups' first round can take evenly."""
+    from tatt_amd import ops
+    g = torch.Generator().manual_seed(53)
+    x = torch.randn(B, H, W, 4, generator=g)
+    w = torch.randn(64, 4, 9, 9, generator=g) * 0.05
+    b = torch.randn(64, generator=g)
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), padding=4).permute(0, 2, 3, 1)
+    y = ops.conv2d_forward(x.to(dev), w.to(dev), b.to(dev))
+    check_close("conv9_4_64_fwd", y, ref.float(), 1e-4, 1e-4)
+    y = ops.conv2d_forward(x.to(dev), w.to(dev), b.to(dev), act=ops.ACT_RELU)
+    check_close("conv9_4_64_fwd_relu", y, ref.clamp_min(0).float(), 1e-4, 1e-4)
+    w2 = torch.randn(4, 64, 9, 9, generator=g) * 0.02
+    xin = torch.randn(B, 64, H, W, generator=g, dtype=torch.float64).requires_grad_(True)
+    dy = torch.randn(B, H, W, 4, generator=g)
+    torch.nn.functional.conv2d(xin, w2.double(), None, padding=4).backward(dy.permute(0, 3, 1, 2).double())
+    dx = ops.conv2d_dgrad(dy.to(dev), w2.to(dev))
+    check_close("conv9_64_4_dgrad", dx, xin.grad.permute(0, 2, 3, 1).float(), 1e-4, 1e-4)
+
+
 @pytest.mark.parametrize("B,H,W", [(2, 32, 128), (3, 4, 64), (1, 8, 192), (67, 8, 64), (2, 64, 256)])
 def test_conv9_wgrad_mfma(dev, B, H, W):
     """tatt_conv9_c64_c4_wgrad: weight gradient of the 64->4 reconstruction convolution (reference model/tsrn.py:623) with the
@@ -692,6 +715,15 @@ def test_conv9_wgrad_mfma(dev, B, H, W):
     err = float((dw.double().cpu() - w.grad).abs().max())
     assert err <= 2e-6 * scale * max(1.0, (B * H * W / 8192) ** 0.5), (err, scale)
     assert torch.equal(dw, ops.conv_wgrad(x.to(dev), dy.to(dev), 4, 9, 9))          # deterministic
+    # the same kernel with the tensors' roles exchanged: weight gradient of block1's 4 -> 64 convolution (model/tsrn.py:597)
+    x4 = torch.randn(B, H, W, 4, generator=g)
+    dy64 = torch.randn(B, H, W, 64, generator=g)
+    w1 = torch.zeros(64, 4, 9, 9, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv2d(x4.permute(0, 3, 1, 2).double(), w1, None, padding=4).backward(dy64.permute(0, 3, 1, 2).double())
+    dw1 = ops.conv_wgrad(x4.to(dev), dy64.to(dev), 64, 9, 9)
+    scale = float(w1.grad.abs().max())
+    err = float((dw1.double().cpu() - w1.grad).abs().max())
+    assert err <= 2e-6 * scale * max(1.0, (B * H * W / 8192) ** 0.5), (err, scale)
 
 
 # ------------------------------------------------------------------------------------------- conv + BatchNorm folding
