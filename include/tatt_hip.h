@@ -62,6 +62,9 @@ int tatt_conv2d_wgrad(const float* x, long xsn, long xsh, long xsw, long xsc, co
  * of 64; Cout*Cin*9 32-bit words of two bf16, one chunk per 64 contraction channels) */
 int tatt_repack_conv_weight(const float* w_oihw, float* out, int Cout, int Cin, int KH, int KW,
                             int mode, hipStream_t st);
+/* number of 32-bit words the packed layout `mode` of a (Cout, Cin, KH, KW) filter occupies = the size of `out` above; -1 for an
+ * unknown mode.  Host-only (no launch): the one place the layout sizes are defined. */
+int tatt_repack_words(int Cout, int Cin, int KH, int KW, int mode);
 /* the same for n filters in one launch (all packed layouts of a model, refreshed once per optimiser step): ws / outs are HOST arrays
  * of n device pointers, dims a host array of n x 5 ints (Cout, Cin, KH, KW, mode) */
 int tatt_repack_conv_weight_batch(const float* const* ws, float* const* outs, const int* dims, int n, hipStream_t st);

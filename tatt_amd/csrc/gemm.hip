@@ -965,6 +965,11 @@ __global__ void repack_weight_kernel(const float* __restrict__ w, float* __restr
         else out[idx] = w[((long)i6 * Cin + o6) * T + (T - 1 - tap6)];
     }
 }
+// 32-bit words a packed layout occupies (what `out` of tatt_repack_conv_weight must hold); -1 for an unknown mode.  Host-only.
+TATT_API int tatt_repack_words(int Cout, int Cin, int KH, int KW, int mode) {
+    if (mode == 4 || mode == 5 || mode < 0 || mode > 11) return -1;
+    return (int)repack_total(Cout, Cin, KH, KW, mode);
+}
 TATT_API int tatt_repack_conv_weight(const float* w_oihw, float* out, int Cout, int Cin, int KH, int KW,
                                      int mode, hipStream_t st) {
     if ((mode == 8 || mode == 9) && !(KH == 9 && KW == 9 && ((mode == 8 && Cout == 4 && Cin == 64) || (mode == 9 && Cout == 64 && Cin == 4)))) return 1;

@@ -176,8 +176,12 @@ def colsum(x2, *, out=None, scale=1.0, beta=0.0):
 # convolution (x given as a (B,H,W,C)-indexed tensor with arbitrary strides)
 # --------------------------------------------------------------------------------------------------
 def _packed_numel(shape, mode):
+    """Words of the packed layout -- asked from the library (tatt_repack_words), the one place the sizes are defined."""
     Cout, Cin, KH, KW = shape
-    return 9 * 4 * 2 * 6 * 64 * 4 if mode >= 8 else KH * KW * Cin * Cout
+    n = LIB.tatt_repack_words(int(Cout), int(Cin), int(KH), int(KW), int(mode))
+    if n <= 0:
+        raise RuntimeError("tatt_repack_words: unknown filter packing mode %d" % mode)
+    return n
 
 
 class _PackedHolder:

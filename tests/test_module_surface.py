@@ -100,6 +100,23 @@ def test_c_abi_exports_every_declared_symbol():
     assert defined == set(protos), defined ^ set(protos)
 
 
+def test_packed_filter_sizes_come_from_the_library():
+    """tatt_repack_words (host-only) is the one definition of the packed-layout sizes: the Python allocation asks it, so a layout
+    change in csrc/gemm.hip cannot leave a buffer short (the split-bf16 3x3 operands once shared the 9x9 Toeplitz size by accident)."""
+    from tatt_amd._lib import LIB
+    from tatt_amd.ops import _packed_numel
+    for mode in (0, 1, 2, 3, 6, 7):
+        assert LIB.tatt_repack_words(64, 64, 3, 3, mode) == 64 * 64 * 9
+    assert LIB.tatt_repack_words(4, 64, 9, 9, 8) == LIB.tatt_repack_words(64, 4, 9, 9, 9) == 9 * 4 * 2 * 6 * 64 * 4
+    assert LIB.tatt_repack_words(256, 64, 3, 3, 10) == LIB.tatt_repack_words(256, 64, 3, 3, 11) == 256 * 64 * 9
+    assert LIB.tatt_repack_words(64, 4, 9, 9, 0) == 64 * 4 * 81
+    for mode in (-1, 4, 5, 12):
+        assert LIB.tatt_repack_words(64, 64, 3, 3, mode) == -1
+        with pytest.raises(RuntimeError):
+            _packed_numel((64, 64, 3, 3), mode)
+    assert _packed_numel((256, 64, 3, 3), 10) == 256 * 64 * 9
+
+
 def test_bench_cpu_baseline_leg_runs_without_a_gpu():
     """`bench.py --cpu-baseline-only` (the child process of the cpu_baseline leg): bounded thread count, JSON contract."""
     import json

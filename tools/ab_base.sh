@@ -8,7 +8,7 @@ mkdir -p gpurun_out
 for i in $(seq 1 $rounds); do
   for side in base new; do
     if [ $side == base ]; then dir=$root/_base; else dir=$root; fi
-    ( cd $dir && python bench.py --steps 30 --warmup 5 --no-cpu-baseline "$@" 2>$root/gpurun_out/ab_$side.err | tail -1 > $root/gpurun_out/ab_$side.json )
+    ( cd $dir && timeout 240 python bench.py --steps 30 --warmup 5 --no-cpu-baseline "$@" 2>$root/gpurun_out/ab_$side.err | tail -1 > $root/gpurun_out/ab_$side.json )
     echo "$side $i [$*] $(python -c 'import json,sys; d=json.load(open(sys.argv[1])); print(d["ms_per_step"], d["value"], "kernel_ms", d["roofline"]["kernel_ms"])' gpurun_out/ab_$side.json 2>&1 | tail -1)"
   done
 done

@@ -10,7 +10,7 @@ for cfg in "$@"; do
   name=${cfg%%:*}; flags=${cfg#*:}
   if [ "$name" == "prof" ]; then
     cd /tmp
-    timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/${tag}_prof -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 5 --no-cpu-baseline $flags > $GRAFT_REPO_ROOT/gpurun_out/${tag}_prof.log 2>&1
+    timeout 240 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/${tag}_prof -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 5 --no-cpu-baseline $flags > $GRAFT_REPO_ROOT/gpurun_out/${tag}_prof.log 2>&1
     cd $GRAFT_REPO_ROOT
     db=$(find gpurun_out/${tag}_prof -name "*.db" | head -1)
     python tools/prof_summary.py $db 15 > gpurun_out/${tag}_kernel_stats.txt 2>&1
@@ -20,6 +20,6 @@ for cfg in "$@"; do
     head -40 gpurun_out/${tag}_timeline.txt
     continue
   fi
-  timeout 600 python bench.py --steps 30 --warmup 10 $flags > gpurun_out/${tag}_bench_${name}.json 2> gpurun_out/${tag}_bench_${name}.err
+  timeout 300 python bench.py --steps 30 --warmup 10 $flags > gpurun_out/${tag}_bench_${name}.json 2> gpurun_out/${tag}_bench_${name}.err
   echo "bench $name rc=$? $(cut -c1-400 gpurun_out/${tag}_bench_${name}.json)"
 done
