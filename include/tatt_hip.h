@@ -69,6 +69,15 @@ int tatt_repack_words(int Cout, int Cin, int KH, int KW, int mode);
  * of n device pointers, dims a host array of n x 5 ints (Cout, Cin, KH, KW, mode) */
 int tatt_repack_conv_weight_batch(const float* const* ws, float* const* outs, const int* dims, int n, hipStream_t st);
 
+/* Weight gradients of one GruBlock in one pass over the tokens (split-bf16 MFMA, hi hi + hi lo + lo hi): per-group partials of
+ * dW' (192 x K) = dgi^T [x | xb] with the row sums of dgi (= db') and dW_hh (192 x 64) = dgh^T hprev with the row sums of dgh
+ * (= db_hh); reference model/tsrn.py:1075-1084 (GruBlock: 1x1 conv composed with nn.GRU's input projection).  dgi, dgh (M, 192),
+ * x, xb, hprev (M, 64) contiguous, xb may be null (K = 64, else 128), M % 32 == 0.  G = persistent work-groups = partial slabs,
+ * 1 <= G <= min(M / 32, 256): ws1 >= G*192*K + G*192 floats, ws2 >= G*192*64 + G*192; sum them with tatt_splitk_reduce(ws1, dWp, 192, K, G, 0, 0, 0, dbp, 192) and
+ * tatt_splitk_reduce(ws2, dWhh, 192, 64, G, 0, 0, 0, dbhh, 192). */
+int tatt_gru_wgrad_sb(const float* dgi, const float* dgh, const float* x, const float* xb, const float* hprev,
+                      float* ws1, float* ws2, int M, int G, hipStream_t st);
+
 /* C = sum over S partial (M x N) slabs (+ beta*C); remap_cin > 0: row i = tap*remap_cin + ci, col j = co is scattered to
  * the OIHW filter layout dW[co][ci][tap].  vec (may be NULL): additionally vec[i] = sum over S partial vectors of vec_len
  * floats stored behind the S slabs (the bias-gradient partials of tatt_conv3_c64_wgrad_partial) */

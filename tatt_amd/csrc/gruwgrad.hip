@@ -1,0 +1,193 @@
+// Weight gradients of one GruBlock in ONE pass over the tokens, on the bf16 matrix cores by operand splitting.
+//   dW' (192 x K)  = dgi^T [x | xb]      (composed input projection: 1x1 conv x W_ih, reference model/tsrn.py:1075-1084)
+//   dW_hh (192 x 64) = dgh^T hprev         (both directions: the two diagonal 96 x 32 blocks are the nn.GRU gradients)
+//   db' (192) = column sums of dgi,  db_hh (192) = column sums of dgh
+// M = 49,152 tokens at B = 48.  The three fp32-MFMA GEMMs this replaces (gemm_fast, 3 launches per block, 30 per TATT step) were
+// matrix-core-bound (3.6 GFLOP per block on the fp32 pipe) and read dgi twice.  Here every token row (dgi 192 | dgh 192 | x 64 |
+// xb 64 | hprev 64 = 576 floats) is read once, and the products run as hi hi + hi lo + lo hi on v_mfma_f32_16x16x32_bf16 (a = hi +
+// lo, hi = bf16(a), lo = bf16(a - hi): 2^-16 relative, fp32 accumulation -- the arithmetic of tatt_conv3_c64_fwd_sb / tatt_tokgemm_sb;
+// profiles/r03_split_bf16_probe.txt).  The contraction runs over TOKENS, so an MFMA operand needs 8 consecutive tokens of one
+// channel per lane: a chunk (32 tokens x 576 floats) is staged token-major in LDS exactly as it lies in memory (coalesced 16-byte
+// loads, one chunk ahead in registers, two LDS buffers) and a fragment is gathered with 8 ds_read_b32 down a column and split in registers.  Row pitch
+// 578 dwords: the two token octets of a 32-lane read group are 8 x 578 = 16 (mod 32) banks apart -- conflict-free.  One MFMA
+// contracts the 32 tokens of a chunk.
+// Work-group = 8 waves, persistent over chunks g, g + G, ..: waves 0-5 own dW' rows 32 w .. 32 w + 31 (2 row tiles x 8 column tiles
+// + the ones column = 18 accumulator tiles), waves 6-7 own dW_hh rows 96 (w - 6) .. + 95 (6 x (4 + 1) = 30 tiles); either kind
+// gathers and splits 20 fragments per chunk, which is what the waves spend their time on.  The bias gradients ride along as a
+// constant all-ones B fragment.  Per-group partial results go to the split-K workspace layout of
+// tatt_splitk_reduce ([G][192][N] slabs, then [G][192] row sums), which sums them deterministically.
+#include "common.h"
+#include <mutex>
+
+typedef __bf16 gw_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 gw_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float gw_f32x2 __attribute__((ext_vector_type(2)));
+
+#define GW_TOK 32
+#define GW_PITCH 578
+#define GW_BUF (GW_TOK * GW_PITCH)               // floats of one chunk image
+#define GW_LDS (2 * GW_BUF * 4)                  // two buffers: 147,968 bytes
+#define GW_THREADS 512
+
+struct GruWgP {
+    const float* dgi; const float* dgh;           // (M, 192) each
+    const float* x; const float* xb;              // (M, 64); xb may be null (K = 64)
+    const float* hprev;                           // (M, 64)
+    float* p1; float* p2;                         // workspaces: G*192*K + G*192 and G*192*64 + G*192 floats
+    int nchunks, K;
+};
+
+// 8 consecutive tokens (rows 8 kq .. 8 kq + 7 of the chunk) of one column -> the hi and lo bf16 fragments of an MFMA operand
+__device__ __forceinline__ void gw_frag(const float* __restrict__ col, gw_bf16x8& hi, gw_bf16x8& lo) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = col[e * GW_PITCH];
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+        const gw_f32x2 a = (gw_f32x2){v[e], v[e + 1]};
+        const gw_bf16x2 h = __builtin_convertvector(a, gw_bf16x2);
+        const gw_bf16x2 l = __builtin_convertvector(a - __builtin_convertvector(h, gw_f32x2), gw_bf16x2);
+        hi[e] = h[0]; hi[e + 1] = h[1];
+        lo[e] = l[0]; lo[e + 1] = l[1];
+    }
+}
+__device__ __forceinline__ f32x4 gw_mma3(const gw_bf16x8& ah, const gw_bf16x8& al, const gw_bf16x8& bh, const gw_bf16x8& bl, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
+}
+__device__ __forceinline__ gw_bf16x8 gw_ones() {
+    gw_bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (__bf16)1.0f;
+    return o;
+}
+// dW' waves: 2 row tiles (kept) x NT column tiles (streamed) + the ones column.  acc[m * (NT + 1) + n]
+template <int NT>
+__device__ __forceinline__ void gw_compute_gi(const float* __restrict__ base, int acol, f32x4* __restrict__ acc) {
+    const gw_bf16x8 ones = gw_ones();
+    gw_bf16x8 ah[2], al[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        gw_frag(base + acol + 16 * m, ah[m], al[m]);
+        acc[m * (NT + 1) + NT] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], ones, acc[m * (NT + 1) + NT], 0, 0, 0);
+        acc[m * (NT + 1) + NT] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[m], ones, acc[m * (NT + 1) + NT], 0, 0, 0);
+    }
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        gw_bf16x8 bh, bl;
+        gw_frag(base + 384 + 16 * n, bh, bl);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) acc[m * (NT + 1) + n] = gw_mma3(ah[m], al[m], bh, bl, acc[m * (NT + 1) + n]);
+    }
+}
+// dW_hh waves: 4 column tiles of hprev (kept) x 6 row tiles (streamed) + the ones column.  acc[m * 5 + n]
+__device__ __forceinline__ void gw_compute_gh(const float* __restrict__ base, int acol, f32x4* __restrict__ acc) {
+    const gw_bf16x8 ones = gw_ones();
+    gw_bf16x8 bh[4], bl[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) gw_frag(base + 512 + 16 * n, bh[n], bl[n]);
+#pragma unroll
+    for (int m = 0; m < 6; ++m) {
+        gw_bf16x8 ah, al;
+        gw_frag(base + acol + 16 * m, ah, al);
+        acc[m * 5 + 4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, ones, acc[m * 5 + 4], 0, 0, 0);
+        acc[m * 5 + 4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, ones, acc[m * 5 + 4], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m * 5 + n] = gw_mma3(ah, al, bh[n], bl[n], acc[m * 5 + n]);
+    }
+}
+// C layout: row = 4 (lane >> 4) + r, column = lane & 15.  slab: (192 x N) partial of this group, sums: its 192 row sums
+template <int MT, int NT>
+__device__ __forceinline__ void gw_store(const f32x4* __restrict__ acc, float* __restrict__ slab, float* __restrict__ sums, int N,
+                                         int row0, int li, int kq) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = row0 + 16 * m + 4 * kq + r;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) slab[(long)row * N + 16 * n + li] = acc[m * (NT + 1) + n][r];
+            if (li == 0) sums[row] = acc[m * (NT + 1) + NT][r];
+        }
+    }
+}
+
+template <bool HAS_XB>
+__global__ __launch_bounds__(GW_THREADS) void gru_wgrad_sb_kernel(GruWgP p) {
+    extern __shared__ __attribute__((aligned(16))) float gw_T[];
+    constexpr int NX = HAS_XB ? 8 : 4;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, kq = lane >> 4;
+    const int G = gridDim.x, g = blockIdx.x;
+    f32x4 pre[9];
+    // chunk staging: three sets of 32 rows x 48 16-byte vectors (dgi | dgh | x, xb, hprev), 3 vectors of each per thread
+    auto fetch = [&](int chunk) {
+        const long tok0 = (long)chunk * GW_TOK;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int f = t + GW_THREADS * i, row = f / 48, c4 = f - row * 48;
+            const long tok = tok0 + row;
+            pre[i] = *reinterpret_cast<const f32x4*>(p.dgi + tok * 192 + 4 * c4);
+            pre[3 + i] = *reinterpret_cast<const f32x4*>(p.dgh + tok * 192 + 4 * c4);
+            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (c4 < 16) v = *reinterpret_cast<const f32x4*>(p.x + tok * 64 + 4 * c4);
+            else if (c4 < 32) { if (HAS_XB) v = *reinterpret_cast<const f32x4*>(p.xb + tok * 64 + 4 * (c4 - 16)); }
+            else v = *reinterpret_cast<const f32x4*>(p.hprev + tok * 64 + 4 * (c4 - 32));
+            pre[6 + i] = v;
+        }
+    };
+    auto stash = [&](float* T) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int f = t + GW_THREADS * i, row = f / 48, c4 = f - row * 48;
+            float* d = T + row * GW_PITCH + 4 * c4;               // rows are 8-byte aligned (578 dwords): two 8-byte stores
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const f32x4 v = pre[3 * s + i];
+                *reinterpret_cast<float2*>(d + 192 * s) = make_float2(v[0], v[1]);
+                *reinterpret_cast<float2*>(d + 192 * s + 2) = make_float2(v[2], v[3]);
+            }
+        }
+    };
+    f32x4 acc[30];                                                // waves 0-5: [2][NX + 1], waves 6-7: [6][5]
+#pragma unroll
+    for (int q = 0; q < 30; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (g < p.nchunks) { fetch(g); stash(gw_T); }
+    __syncthreads();
+    int buf = 0;
+    for (int chunk = g; chunk < p.nchunks; chunk += G) {
+        const bool has_next = chunk + G < p.nchunks;
+        if (has_next) fetch(chunk + G);
+        const float* base = gw_T + buf * GW_BUF + 8 * kq * GW_PITCH + li;
+        if (wave < 6) gw_compute_gi<NX>(base, 32 * wave, acc);
+        else gw_compute_gh(base, 192 + 96 * (wave - 6), acc);
+        if (has_next) stash(gw_T + (buf ^ 1) * GW_BUF);           // the other buffer: last read before the previous barrier
+        __syncthreads();
+        buf ^= 1;
+    }
+    if (wave < 6)
+        gw_store<2, NX>(acc, p.p1 + (long)g * 192 * p.K, p.p1 + (long)G * 192 * p.K + g * 192, p.K, 32 * wave, li, kq);
+    else
+        gw_store<6, 4>(acc, p.p2 + (long)g * 192 * 64, p.p2 + (long)G * 192 * 64 + g * 192, 64, 96 * (wave - 6), li, kq);
+}
+
+// dgi, dgh (M, 192); x (M, 64); xb (M, 64) or null; hprev (M, 64) -- all contiguous; M % 32 == 0.
+// G = number of persistent work-groups = partial slabs (1 .. min(M / 32, 256); fewer groups = less reduction traffic and fewer
+// CUs taken from the kernels running beside it); ws1 >= G*192*K + G*192 floats (K = 128 with xb, 64 without), ws2 >= G*192*64 + G*192.
+// Leaves the per-group partials; the caller sums them with tatt_splitk_reduce(ws1, dWp, 192, K, G, 0, 0, 0, dbp, 192) and
+// tatt_splitk_reduce(ws2, dWhh, 192, 64, G, 0, 0, 0, dbhh, 192) (batched with the stage's other reductions).
+TATT_API int tatt_gru_wgrad_sb(const float* dgi, const float* dgh, const float* x, const float* xb, const float* hprev,
+                               float* ws1, float* ws2, int M, int G, hipStream_t st) {
+    if (M <= 0 || M % GW_TOK) return 1;
+    const int nchunks = M / GW_TOK;
+    if (G < 1 || G > nchunks || G > 256) return 2;
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [&] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gru_wgrad_sb_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, GW_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gru_wgrad_sb_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, GW_LDS);
+    });
+    GruWgP p = {dgi, dgh, x, xb, hprev, ws1, ws2, nchunks, xb ? 128 : 64};
+    if (xb) hipLaunchKernelGGL(gru_wgrad_sb_kernel<true>, dim3(G), dim3(GW_THREADS), GW_LDS, st, p);
+    else hipLaunchKernelGGL(gru_wgrad_sb_kernel<false>, dim3(G), dim3(GW_THREADS), GW_LDS, st, p);
+    return LAUNCH_CHECK();
+}

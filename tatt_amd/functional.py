@@ -495,7 +495,8 @@ def gru_precompose(blocks):
     _PRE.table = outs
 
 
-TOKGEMM_SB = True          # test / A-B hook: False -> the exact-fp32 MFMA GEMMs for the GRU input projections
+TOKGEMM_SB = True           # test / A-B hook: False -> the exact-fp32 MFMA GEMMs for the GRU input projections
+GRU_WGRAD_SB = True         # test / A-B hook: False -> three fp32-MFMA weight-gradient GEMMs per GruBlock instead of the fused pass
 
 
 def _tokgemm(X1, X2, Wpk, bias, N, K, N1=None):
@@ -576,10 +577,15 @@ class GruBlockFn(Function):
             # weight-gradient GEMMs over the tokens; the bias gradients (column sums of dgi / dgh) ride along as a virtual ones column
             dbp, dbhh = ops.new(dgi, 192), ops.new(dgi, 192)
             dWp = ops.new(dgi, 192, K)
-            ops.linear_bwd_weight(dgi, x2, out=dWp, out_ld=K, rowsum=dbp)
-            if xb is not None:
-                ops.linear_bwd_weight(dgi, xb.reshape(-1, K - K1), out=dWp.reshape(-1)[K1:], out_ld=K)
-            dWhh = ops.linear_bwd_weight(dgh, hprev, rowsum=dbhh)     # (192, 64): diagonal blocks are the two directions
+            xb2 = xb.reshape(-1, K - K1) if xb is not None else None
+            if GRU_WGRAD_SB and K in (64, 128) and K1 == 64 and ops.gru_wgrad_fusable(dgi, dgh, x2, xb2, hprev):
+                dWhh = ops.new(dgi, 192, 64)                          # one pass over the tokens for all four results (split-bf16 MFMA)
+                ops.gru_wgrad_sb(dgi, dgh, x2, xb2, hprev, dWp, dWhh, dbp, dbhh)
+            else:
+                ops.linear_bwd_weight(dgi, x2, out=dWp, out_ld=K, rowsum=dbp)
+                if xb is not None:
+                    ops.linear_bwd_weight(dgi, xb2, out=dWp.reshape(-1)[K1:], out_ld=K)
+                dWhh = ops.linear_bwd_weight(dgh, hprev, rowsum=dbhh)     # (192, 64): diagonal blocks are the two directions
             yield                                                     # (batched split-K reduction of the three GEMMs above)
             dwih_f, dwih_r = ops.new(dgi, 96, 64), ops.new(dgi, 96, 64)
             dwhh_f, dwhh_r = ops.new(dgi, 96, 32), ops.new(dgi, 96, 32)

@@ -162,6 +162,32 @@ def linear_bwd_weight(dy, x2, *, alpha=1.0, out=None, out_ld=None, beta=0.0, row
     return dW
 
 
+GRU_WGRAD_GROUPS = 128        # persistent work-groups (= partial slabs) of tatt_gru_wgrad_sb
+CONV3_WGRAD_GROUPS = 256      # persistent work-groups of tatt_conv3_c64_wgrad_partial (all 64x64 channel blocks together)
+
+
+def gru_wgrad_fusable(dgi, dgh, x2, xb2, hprev):
+    """The fused split-bf16 weight-gradient pass of a GruBlock takes contiguous (M, 192) gate gradients and (M, 64) inputs."""
+    M = dgi.shape[0]
+    ok = lambda t, n: t.dim() == 2 and t.shape[0] == M and t.shape[1] == n and t.is_contiguous()
+    return (M % 32 == 0 and M >= 32 and ok(dgi, 192) and ok(dgh, 192) and ok(x2, 64) and ok(hprev, 64)
+            and (xb2 is None or ok(xb2, 64)))
+
+
+def gru_wgrad_sb(dgi, dgh, x2, xb2, hprev, dWp, dWhh, dbp, dbhh):
+    """dWp (192, K) = dgi^T [x2 | xb2], dbp = dgi.sum(0), dWhh (192, 64) = dgh^T hprev, dbhh = dgh.sum(0): one pass over the tokens
+    (tatt_gru_wgrad_sb) + two (deferrable) split-K reductions."""
+    _check_dev(dgi)
+    M = dgi.shape[0]
+    K = 128 if xb2 is not None else 64
+    G = max(1, min(M // 32, GRU_WGRAD_GROUPS, 256))
+    ws1 = _split_ws(new(dgi, G * 192 * K + G * 192))
+    ws2 = _split_ws(new(dgi, G * 192 * 64 + G * 192))
+    call("tatt_gru_wgrad_sb", P(dgi), P(dgh), P(x2), P(xb2), P(hprev), P(ws1), P(ws2), M, G, stream())
+    call("tatt_splitk_reduce", P(ws1), P(dWp), 192, K, G, 0, 0, 0.0, P(dbp), 192, stream())
+    call("tatt_splitk_reduce", P(ws2), P(dWhh), 192, 64, G, 0, 0, 0.0, P(dbhh), 192, stream())
+
+
 def colsum(x2, *, out=None, scale=1.0, beta=0.0):
     """out[c] = scale * sum_m x2[m, c]  (+ beta*out)."""
     _check_dev(x2)
@@ -431,7 +457,7 @@ def conv_wgrad(x_bhwc, dy_bhwc, Cout, KH, KW, want_db=False):
     contig = x_bhwc.is_contiguous() and dy_bhwc.is_contiguous()
     if contig and KH == 3 and KW == 3 and Cin % 64 == 0 and Cout % 64 == 0 and W % 64 == 0:
         nseg = B * H * (W // 64)
-        G = min(nseg, max(1, 256 // ((Cin // 64) * (Cout // 64))))
+        G = min(nseg, max(1, CONV3_WGRAD_GROUPS // ((Cin // 64) * (Cout // 64))))
         n = G * 9 * Cin * Cout
         part = _split_ws(new(x_bhwc, n + (G * Cout if want_db else 0)))
         db = new(x_bhwc, Cout) if want_db else None

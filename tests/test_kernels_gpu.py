@@ -880,3 +880,36 @@ def test_tokgemm_split_bf16_vs_fp64(dev, N, K, K1, N1):
         Y = Y1 if Y2 is None else torch.cat([Y1, Y2], 1)
         err = float((Y.cpu().double() - ref).abs().max() / ref.abs().max())
         assert err < 1e-5, (trans, err)
+
+
+# ------------------------------------------------------------------------------------------- fused GruBlock weight gradients
+@pytest.mark.parametrize("M,with_xb,groups", [(32 * 200, True, 128), (32 * 200, False, 128), (32, True, 128), (32 * 7, True, 3),
+                                               (49152, True, 128), (49152, True, 256)])
+def test_gru_wgrad_split_bf16_vs_fp64(dev, M, with_xb, groups):
+    """tatt_gru_wgrad_sb + tatt_splitk_reduce: dW' = dgi^T [x | xb], db' = sum dgi, dW_hh = dgh^T hprev, db_hh = sum dgh of one
+    GruBlock (reference model/tsrn.py:1075-1084) in one pass over the tokens on the bf16 matrix cores (hi/lo operand split), against
+    fp64.  Ragged chunk counts over the persistent groups, a single chunk, no second input, and the full-size token count."""
+    from tatt_amd import ops
+    dgi, dgh = R(M, 192, seed=11), R(M, 192, seed=12)
+    x, xb, hp = R(M, 64, seed=13), (R(M, 64, seed=14) if with_xb else None), R(M, 64, seed=15)
+    K = 128 if with_xb else 64
+    xx = torch.cat([x, xb], 1) if with_xb else x
+    ref = (dgi.double().t() @ xx.double(), dgi.double().sum(0), dgh.double().t() @ hp.double(), dgh.double().sum(0))
+    old = ops.GRU_WGRAD_GROUPS
+    ops.GRU_WGRAD_GROUPS = groups
+    try:
+        outs = []
+        for _ in range(2):
+            dWp, dWhh = torch.empty(192, K, device=dev), torch.empty(192, 64, device=dev)
+            dbp, dbhh = torch.empty(192, device=dev), torch.empty(192, device=dev)
+            args = [t.to(dev) if t is not None else None for t in (dgi, dgh, x, xb, hp)]
+            assert ops.gru_wgrad_fusable(*args)
+            ops.gru_wgrad_sb(*args, dWp, dWhh, dbp, dbhh)
+            outs.append((dWp, dbp, dWhh, dbhh))
+    finally:
+        ops.GRU_WGRAD_GROUPS = old
+    for name, got, want in zip(("dWp", "dbp", "dWhh", "dbhh"), outs[0], ref):
+        err = float((got.cpu().double() - want).abs().max() / want.abs().max())
+        assert err < 2e-5, (name, err)
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)                                  # deterministic

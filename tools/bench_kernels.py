@@ -155,6 +155,25 @@ timeit("tplayer_fwd", lambda: ops.tplayer_fwd(tx, tq, tK, tV, lp, lnF, 0.5, 1, 0
 timeit("tplayer_bwd", lambda: ops.tplayer_bwd(tx, tq, tK, tV, lp, lnF, 0.5, 1, 0.1, 0.1, 0.1, sd, 10, 1e-5, None, tup, None, None, True),
        B * L * (12 * 2 * 64 * 64 + 2 * 2 * 26 * 64), B * L * 64 * 4 * 5)
 
+# ---- GruBlock weight gradients: three fp32-MFMA GEMMs vs the fused split-bf16 pass (csrc/gruwgrad.hip) ----
+gdgi, gdgh, gx, gxb, ghp = R(M, 192), R(M, 192), R(M, 64), R(M, 64), R(M, 64)
+gWp, gWhh, gbp, gbhh = (torch.empty(192, 128, device=dev), torch.empty(192, 64, device=dev), torch.empty(192, device=dev),
+                        torch.empty(192, device=dev))
+
+
+def _gru_wgrad_gemms():
+    ops.linear_bwd_weight(gdgi, gx, out=gWp, out_ld=128, rowsum=gbp)
+    ops.linear_bwd_weight(gdgi, gxb, out=gWp.reshape(-1)[64:], out_ld=128)
+    ops.linear_bwd_weight(gdgh, ghp, out=gWhh, rowsum=gbhh)
+
+
+timeit("gru_wgrad_3gemm", _gru_wgrad_gemms, 2.0 * M * 192 * 192, M * 576 * 4)
+for G_ in (64, 128, 256):
+    ops.GRU_WGRAD_GROUPS = G_
+    timeit("gru_wgrad_sb_G%d" % G_, lambda: ops.gru_wgrad_sb(gdgi, gdgh, gx, gxb, ghp, gWp, gWhh, gbp, gbhh), 2.0 * M * 192 * 192,
+           M * 576 * 4)
+ops.GRU_WGRAD_GROUPS = 128
+
 # ---- split-bf16 token projections (csrc/tokgemm.hip) ----
 for (N_, K_, K1_, N1_) in ((192, 128, 64, 192), (192, 64, 64, 192), (128, 192, 192, 64), (64, 192, 192, 64)):
     Xa = R(M, K1_)
