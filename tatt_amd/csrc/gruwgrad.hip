@@ -8,9 +8,11 @@
 // lo, hi = bf16(a), lo = bf16(a - hi): 2^-16 relative, fp32 accumulation -- the arithmetic of tatt_conv3_c64_fwd_sb / tatt_tokgemm_sb;
 // profiles/r03_split_bf16_probe.txt).  The contraction runs over TOKENS, so an MFMA operand needs 8 consecutive tokens of one
 // channel per lane: a chunk (32 tokens x 576 floats) is staged token-major in LDS exactly as it lies in memory (coalesced 16-byte
-// loads, one chunk ahead in registers, two LDS buffers) and a fragment is gathered with 8 ds_read_b32 down a column and split in registers.  Row pitch
-// 578 dwords: the two token octets of a 32-lane read group are 8 x 578 = 16 (mod 32) banks apart -- conflict-free.  One MFMA
-// contracts the 32 tokens of a chunk.
+// loads, one chunk ahead in registers); then the 8 waves share the transposition: each gathers 4-5 of the 36 column tiles with 8
+// ds_read_b32 down a column, splits them in registers and leaves the hi / lo fragments in LDS in MFMA order (every element is
+// converted ONCE; a fragment is then one conflict-free ds_read_b128 for whichever wave needs it).  Row pitch of the fp32 image 578
+// dwords: the two token octets of a 32-lane read group are 8 x 578 = 16 (mod 32) banks apart -- conflict-free.  One MFMA contracts
+// the 32 tokens of a chunk; two barriers per chunk.
 // Work-group = 8 waves, persistent over chunks g, g + G, ..: waves 0-5 own dW' rows 32 w .. 32 w + 31 (2 row tiles x 8 column tiles
 // + the ones column = 18 accumulator tiles), waves 6-7 own dW_hh rows 96 (w - 6) .. + 95 (6 x (4 + 1) = 30 tiles); either kind
 // gathers and splits 20 fragments per chunk, which is what the waves spend their time on.  The bias gradients ride along as a
@@ -25,8 +27,9 @@ typedef float gw_f32x2 __attribute__((ext_vector_type(2)));
 
 #define GW_TOK 32
 #define GW_PITCH 578
-#define GW_BUF (GW_TOK * GW_PITCH)               // floats of one chunk image
-#define GW_LDS (2 * GW_BUF * 4)                  // two buffers: 147,968 bytes
+#define GW_IMG (GW_TOK * GW_PITCH)               // floats of the fp32 chunk image (73,984 B)
+#define GW_FRAGS (36 * 2 * 64 * 4)               // floats of the fragment buffer: 36 column tiles x {hi, lo} x 64 lanes x 16 B (73,728 B)
+#define GW_LDS ((GW_IMG + GW_FRAGS) * 4)         // 147,712 bytes
 #define GW_THREADS 512
 
 struct GruWgP {
@@ -62,35 +65,38 @@ __device__ __forceinline__ gw_bf16x8 gw_ones() {
     for (int e = 0; e < 8; ++e) o[e] = (__bf16)1.0f;
     return o;
 }
-// dW' waves: 2 row tiles (kept) x NT column tiles (streamed) + the ones column.  acc[m * (NT + 1) + n]
+// fragment of column tile `tile` (hl = 0: hi, 1: lo) for this lane
+__device__ __forceinline__ gw_bf16x8 gw_ld(const float* __restrict__ F, int tile, int hl, int lane) {
+    return __builtin_bit_cast(gw_bf16x8, *reinterpret_cast<const f32x4*>(F + ((tile * 2 + hl) * 64 + lane) * 4));
+}
+// dW' waves: row tiles a0, a0 + 1 (kept) x NT column tiles from tile 24 on (streamed) + the ones column.  acc[m * (NT + 1) + n]
 template <int NT>
-__device__ __forceinline__ void gw_compute_gi(const float* __restrict__ base, int acol, f32x4* __restrict__ acc) {
+__device__ __forceinline__ void gw_compute_gi(const float* __restrict__ F, int a0, int lane, f32x4* __restrict__ acc) {
     const gw_bf16x8 ones = gw_ones();
     gw_bf16x8 ah[2], al[2];
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-        gw_frag(base + acol + 16 * m, ah[m], al[m]);
+        ah[m] = gw_ld(F, a0 + m, 0, lane);
+        al[m] = gw_ld(F, a0 + m, 1, lane);
         acc[m * (NT + 1) + NT] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], ones, acc[m * (NT + 1) + NT], 0, 0, 0);
         acc[m * (NT + 1) + NT] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[m], ones, acc[m * (NT + 1) + NT], 0, 0, 0);
     }
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
-        gw_bf16x8 bh, bl;
-        gw_frag(base + 384 + 16 * n, bh, bl);
+        const gw_bf16x8 bh = gw_ld(F, 24 + n, 0, lane), bl = gw_ld(F, 24 + n, 1, lane);
 #pragma unroll
         for (int m = 0; m < 2; ++m) acc[m * (NT + 1) + n] = gw_mma3(ah[m], al[m], bh, bl, acc[m * (NT + 1) + n]);
     }
 }
-// dW_hh waves: 4 column tiles of hprev (kept) x 6 row tiles (streamed) + the ones column.  acc[m * 5 + n]
-__device__ __forceinline__ void gw_compute_gh(const float* __restrict__ base, int acol, f32x4* __restrict__ acc) {
+// dW_hh waves: the 4 column tiles of hprev (tiles 32..35, kept) x row tiles a0 .. a0 + 5 (streamed) + the ones column.  acc[m * 5 + n]
+__device__ __forceinline__ void gw_compute_gh(const float* __restrict__ F, int a0, int lane, f32x4* __restrict__ acc) {
     const gw_bf16x8 ones = gw_ones();
     gw_bf16x8 bh[4], bl[4];
 #pragma unroll
-    for (int n = 0; n < 4; ++n) gw_frag(base + 512 + 16 * n, bh[n], bl[n]);
+    for (int n = 0; n < 4; ++n) { bh[n] = gw_ld(F, 32 + n, 0, lane); bl[n] = gw_ld(F, 32 + n, 1, lane); }
 #pragma unroll
     for (int m = 0; m < 6; ++m) {
-        gw_bf16x8 ah, al;
-        gw_frag(base + acol + 16 * m, ah, al);
+        const gw_bf16x8 ah = gw_ld(F, a0 + m, 0, lane), al = gw_ld(F, a0 + m, 1, lane);
         acc[m * 5 + 4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, ones, acc[m * 5 + 4], 0, 0, 0);
         acc[m * 5 + 4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, ones, acc[m * 5 + 4], 0, 0, 0);
 #pragma unroll
@@ -152,18 +158,23 @@ __global__ __launch_bounds__(GW_THREADS) void gru_wgrad_sb_kernel(GruWgP p) {
     f32x4 acc[30];                                                // waves 0-5: [2][NX + 1], waves 6-7: [6][5]
 #pragma unroll
     for (int q = 0; q < 30; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (g < p.nchunks) { fetch(g); stash(gw_T); }
-    __syncthreads();
-    int buf = 0;
+    float* const T = gw_T;
+    float* const F = gw_T + GW_IMG;
+    if (g < p.nchunks) fetch(g);
     for (int chunk = g; chunk < p.nchunks; chunk += G) {
-        const bool has_next = chunk + G < p.nchunks;
-        if (has_next) fetch(chunk + G);
-        const float* base = gw_T + buf * GW_BUF + 8 * kq * GW_PITCH + li;
-        if (wave < 6) gw_compute_gi<NX>(base, 32 * wave, acc);
-        else gw_compute_gh(base, 192 + 96 * (wave - 6), acc);
-        if (has_next) stash(gw_T + (buf ^ 1) * GW_BUF);           // the other buffer: last read before the previous barrier
-        __syncthreads();
-        buf ^= 1;
+        stash(T);                                                 // T: last read by the conversions of the previous chunk (before barrier 2)
+        __syncthreads();                                          // 1: image complete; every wave has left the previous chunk's MFMAs (F is free)
+        if (chunk + G < p.nchunks) fetch(chunk + G);
+        for (int tile = wave; tile < 36; tile += 8) {             // column tiles 0-11 dgi, 12-23 dgh, 24-27 x, 28-31 xb, 32-35 hprev
+            if (!HAS_XB && tile >= 28 && tile < 32) continue;
+            gw_bf16x8 hi, lo;
+            gw_frag(T + 8 * kq * GW_PITCH + 16 * tile + li, hi, lo);
+            *reinterpret_cast<f32x4*>(F + ((tile * 2 + 0) * 64 + lane) * 4) = __builtin_bit_cast(f32x4, hi);
+            *reinterpret_cast<f32x4*>(F + ((tile * 2 + 1) * 64 + lane) * 4) = __builtin_bit_cast(f32x4, lo);
+        }
+        __syncthreads();                                          // 2: fragments complete; T may be overwritten
+        if (wave < 6) gw_compute_gi<NX>(F, 2 * wave, lane, acc);
+        else gw_compute_gh(F, 12 + 6 * (wave - 6), lane, acc);
     }
     if (wave < 6)
         gw_store<2, NX>(acc, p.p1 + (long)g * 192 * p.K, p.p1 + (long)G * 192 * p.K + g * 192, p.K, 32 * wave, li, kq);
