@@ -374,8 +374,9 @@ def main():
                        "launch": ("hipGraph replay" if graph_ok else "eager") + ("" if a.no_defer else ", staged backward" + ("" if a.no_side_stream else " on 2 streams")), "final_loss": round(loss_v, 5),
                        "host_issue_ms_per_step": round(t_issue / a.steps * 1e3, 3), "known_answer": kat,
                        "arithmetic": "fp32 storage, accumulation and results throughout (the reference's arithmetic)"
-                                     + ("; the 3x3 convolutions evaluate every fp32 product as three bf16 matrix-core products of hi/lo operand "
-                                        "halves (2^-16 relative, measured 1e-6 on SR: profiles/r03_split_bf16_probe.txt)" if _ops.CONV3_SB else ""),
+                                     + ("; the 3x3 convolutions, the GruBlock input projections and the GruBlock weight gradients evaluate "
+                                        "every fp32 product as three bf16 matrix-core products of hi/lo operand halves (2^-16 relative, "
+                                        "measured 1e-6 on SR: profiles/r03_split_bf16_probe.txt)" if _ops.CONV3_SB else ""),
                        # algorithmic = the reference graph's FLOP count; executed = minus the query-GRU input projection
                        # the build hoists out of the recurrence
                        "whole_step_tflops": ({"algorithmic": round(ips * tile["flop_per_image"] / 1e12, 2),
