@@ -14,7 +14,7 @@ b dp_selftest --dp-selftest --no-cpu-baseline
 tools/gpu_quick.sh ${tag}_final none "prof:" > /dev/null 2>&1
 head -3 gpurun_out/${tag}_final_timeline.txt
 timeout 200 python tools/bench_kernels.py > gpurun_out/${tag}_kernel_microbench.txt 2>&1; tail -3 gpurun_out/${tag}_kernel_microbench.txt
-for k in conv9_fwd_mfma_64_4_hr conv9_dgrad_4_64_hr conv9_wgrad_64_4_hr gru_wgrad_sb_G128; do
+for k in conv9_fwd_mfma_64_4_hr gru_wgrad_sb_G128; do
   tools/pmc_collect.sh ${tag} $k > /dev/null 2>&1; echo "pmc $k: $(wc -l < gpurun_out/${tag}_pmc_${k}.txt) lines"
 done
 timeout 560 python -m pytest tests -m gpu -q --timeout=500 2>&1 | tail -15 > gpurun_out/${tag}_tests.log; tail -4 gpurun_out/${tag}_tests.log
