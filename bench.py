@@ -331,7 +331,8 @@ def main():
             kms, kflops = tf + tb, ff + fb
             ach = kflops / (kms * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None, "algorithmic_bytes": kbytes,
+                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": dominant_kernel_traffic(shape_key, "sattn_fwd_bwd"),
+                    "algorithmic_bytes": kbytes,
                     "hbm_gbps": round(kbytes / (kms * 1e-3) / 1e9, 1),
                     "kernel": "sattn_fwd_kernel + sattn_bwd_kv_kernel + sattn_bwd_q_kernel: score-free self-attention of one FeatureEnhancer "
                               "(B = %d, P = %d, 4 heads x 32; fp32 MFMA 16x16x4, online softmax, dropout on); 5 per step" % (

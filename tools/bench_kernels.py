@@ -155,6 +155,21 @@ timeit("tplayer_fwd", lambda: ops.tplayer_fwd(tx, tq, tK, tV, lp, lnF, 0.5, 1, 0
 timeit("tplayer_bwd", lambda: ops.tplayer_bwd(tx, tq, tK, tV, lp, lnF, 0.5, 1, 0.1, 0.1, 0.1, sd, 10, 1e-5, None, tup, None, None, True),
        B * L * (12 * 2 * 64 * 64 + 2 * 2 * 26 * 64), B * L * 64 * 4 * 5)
 
+# ---- TBSRN score-free self-attention (csrc/sattn.hip): P = 1024 tokens, 4 heads x 32 ----
+sQ, sK, sV, sdO = (R(B, 1024, 128) for _ in range(4))
+sO, slse, sws = torch.empty_like(sQ), torch.empty(B, 4, 1024, device=dev), torch.empty(B, 4, 1024, device=dev)
+sdQ, sdK, sdV = torch.empty_like(sQ), torch.empty_like(sQ), torch.empty_like(sQ)
+ssc = 32 ** -0.5
+
+
+def _sattn():
+    ops.call("tatt_sattn_fwd", ops.P(sQ), ops.P(sK), ops.P(sV), ops.P(sO), ops.P(slse), B, 1024, 4, ssc, 0.1, ops.P(sd), 100, ops.stream())
+    ops.call("tatt_sattn_bwd", ops.P(sQ), ops.P(sK), ops.P(sV), ops.P(sO), ops.P(slse), ops.P(sdO), ops.P(sdQ), ops.P(sdK), ops.P(sdV),
+             ops.P(sws), B, 1024, 4, ssc, 0.1, ops.P(sd), 100, ops.stream())
+
+
+timeit("sattn_fwd_bwd", _sattn, 18.0 * B * 4 * 1024 * 1024 * 32, B * 1024 * 128 * 4 * 11)
+
 # ---- GruBlock weight gradients: three fp32-MFMA GEMMs vs the fused split-bf16 pass (csrc/gruwgrad.hip) ----
 gdgi, gdgh, gx, gxb, ghp = R(M, 192), R(M, 192), R(M, 64), R(M, 64), R(M, 64)
 gWp, gWhh, gbp, gbhh = (torch.empty(192, 128, device=dev), torch.empty(192, 64, device=dev), torch.empty(192, device=dev),
