@@ -421,41 +421,53 @@ struct QBwdFusedP {
     float* dhcarry[2]; float* dgi_acc[2]; float* dgh_next[2];
     int Wb, HID;
 };
-__global__ __launch_bounds__(256) void qgru_bwd_fused_kernel(QBwdFusedP p) {
-    __shared__ float red[4][16][17];
+// 8 waves split the 3*HID contraction and walk it in trips of 96 with 6 + 6 sixteen-byte loads per lane in flight (HID = 512: two
+// trips to L2 instead of the six of a 4-wave / 64-wide walk -- the step is latency, not work: 47 of these follow each other)
+#define QB_WAVES 8
+__global__ __launch_bounds__(64 * QB_WAVES) void qgru_bwd_fused_kernel(QBwdFusedP p) {
+    __shared__ float red[QB_WAVES][16][17];
     const int d = blockIdx.z;
     const int m0 = blockIdx.x * 16, j0 = blockIdx.y * 16;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int HID = p.HID, K = 3 * p.HID;
     const float* dgh = p.dgh_cur[d];
     const float* whh = p.whhT[d];
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
     const int i = lane & 15, q = lane >> 4;
-    const int kspan = K / 4, kbeg = wave * kspan;
+    const int kspan = K / QB_WAVES, kbeg = wave * kspan;               // HID % 256 == 0: kspan is a multiple of 96
     const int arow = min(m0 + i, p.Wb - 1);
-    for (int kb = kbeg; kb < kbeg + kspan; kb += 64) {
-        f32x4 a[4], b[4];
+    const float* ap = dgh + (long)arow * K + kbeg + 4 * q;
+    const float* bp = whh + (long)(j0 + i) * K + kbeg + 4 * q;
+    for (int kb = 0; kb < kspan; kb += 96) {
+        f32x4 a[6], b[6];
 #pragma unroll
-        for (int sstep = 0; sstep < 4; ++sstep) {
-            a[sstep] = *reinterpret_cast<const f32x4*>(dgh + (long)arow * K + kb + 16 * sstep + 4 * q);
-            b[sstep] = *reinterpret_cast<const f32x4*>(whh + (long)(j0 + i) * K + kb + 16 * sstep + 4 * q);
+        for (int sstep = 0; sstep < 6; ++sstep) {
+            a[sstep] = *reinterpret_cast<const f32x4*>(ap + kb + 16 * sstep);
+            b[sstep] = *reinterpret_cast<const f32x4*>(bp + kb + 16 * sstep);
         }
 #pragma unroll
-        for (int sstep = 0; sstep < 4; ++sstep)
+        for (int sstep = 0; sstep < 6; ++sstep)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[sstep][u], b[sstep][u], acc, 0, 0, 0);
+            for (int u = 0; u < 4; ++u) {
+                if (u & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[sstep][u], b[sstep][u], acc1, 0, 0, 0);
+                else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[sstep][u], b[sstep][u], acc0, 0, 0, 0);
+            }
     }
     {
         const int col = lane & 15, rb = (lane >> 4) * 4;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[wave][rb + r][col] = acc[r];
+        for (int r = 0; r < 4; ++r) red[wave][rb + r][col] = acc0[r] + acc1[r];
     }
     __syncthreads();
+    if (t >= 256) return;
     const int m = t >> 4, j = t & 15;
     if (m0 + m >= p.Wb) return;
     const long row = m0 + m, e = row * HID + j0 + j;
     const long n_el = (long)p.Wb * HID;
-    const float dh = p.dhseq_next[d][e] + p.dhcarry[d][e] + ((red[0][m][j] + red[1][m][j]) + (red[2][m][j] + red[3][m][j]));
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < QB_WAVES; ++w) sum += red[w][m][j];
+    const float dh = p.dhseq_next[d][e] + p.dhcarry[d][e] + sum;
     const float* gs = p.gsave_next[d];
     const float r = gs[e], z = gs[n_el + e], n = gs[2 * n_el + e], hn = gs[3 * n_el + e];
     const float hp = p.hprev_next[d] ? p.hprev_next[d][e] : 0.f;
@@ -478,7 +490,7 @@ TATT_API int tatt_qgru_bwd_fused(const float* dgh_cur0, const float* dgh_cur1, c
     if (HID % 256) return 1;
     QBwdFusedP p = {{dgh_cur0, dgh_cur1}, {whhT0, whhT1}, {dhseq_next0, dhseq_next1}, {gsave_next0, gsave_next1},
                     {hprev_next0, hprev_next1}, {dhcarry0, dhcarry1}, {dgi_acc0, dgi_acc1}, {dgh_next0, dgh_next1}, Wb, HID};
-    hipLaunchKernelGGL(qgru_bwd_fused_kernel, dim3(cdiv(Wb, 16), HID / 16, 2), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(qgru_bwd_fused_kernel, dim3(cdiv(Wb, 16), HID / 16, 2), dim3(64 * QB_WAVES), 0, st, p);
     return LAUNCH_CHECK();
 }
 

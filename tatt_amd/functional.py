@@ -1065,8 +1065,8 @@ class QueryGruFn(Function):
             else:
                 dwhh = torch.zeros_like(whh)
             dbhh = ops.colsum(g2)
-            dwih = ops.linear_bwd_weight(dgi_acc[d], x)
-            dbih = ops.colsum(dgi_acc[d])
+            dbih = ops.new(dev, 3 * HID)
+            dwih = ops.linear_bwd_weight(dgi_acc[d], x, rowsum=dbih)     # the bias gradient rides along (row sums of dgi_acc^T)
             ops.linear_bwd_input(dgi_acc[d], wih, out=dx, beta=0.0 if d == 0 else 1.0)
             grads.append((dwih, dwhh, dbih, dbhh))
         demb = torch.empty_like(emb)

@@ -134,7 +134,11 @@ def linear_bwd_input(dy, W, *, col0=0, ncols=None, alpha=1.0, out=None, beta=0.0
     ncols = K if ncols is None else ncols
     dx = out if out is not None else new(dy, M, ncols)
     Wv = W.reshape(-1)[col0:] if col0 else W
-    gemm(dy, dy.stride(0), dy.stride(1), Wv, K, 1, dx, dx.stride(0), 1, M, ncols, N, alpha=alpha, beta=beta)
+    # few output tiles over a deep contraction (the query GRU's input gradient: 64 x 1024 outputs over 1536 gate columns = 16
+    # work-groups walking 96 K-chunks, 61 us): split the contraction over the idle CUs
+    tiles = cdiv(M, 64) * cdiv(ncols, 64)
+    splitk = max(1, min(256 // tiles, N // 96)) if (tiles <= 32 and N >= 768) else 1
+    gemm(dy, dy.stride(0), dy.stride(1), Wv, K, 1, dx, dx.stride(0), 1, M, ncols, N, alpha=alpha, beta=beta, splitk=splitk)
     return dx
 
 
