@@ -1069,6 +1069,9 @@ class QueryGruFn(Function):
             dwih = ops.linear_bwd_weight(dgi_acc[d], x, rowsum=dbih)     # the bias gradient rides along (row sums of dgi_acc^T)
             ops.linear_bwd_input(dgi_acc[d], wih, out=dx, beta=0.0 if d == 0 else 1.0)
             grads.append((dwih, dwhh, dbih, dbhh))
+        # dx is consumed right here, but its GEMMs split the contraction and, inside SIDE.flush, their reductions are only registered:
+        # the accumulating second one (beta = 1) already forces everything pending through -- say so explicitly (a no-op then)
+        ops.reduce_flush()
         demb = torch.empty_like(emb)
         ops.copy4d(dx, demb, (1, W, H, C), (0, IN, C, 1), (0, C, W * C, 1))
         (a0, b0, c0, d0), (a1, b1, c1, d1) = grads
