@@ -2,6 +2,8 @@
 # Same-box A/B against the baseline checkout in _base/ (git worktree of an earlier commit, built in place): box-to-box and
 # thermal variation between gpurun calls is ~5-15 %, larger than most single optimisations, so only interleaved runs inside one
 # call are comparable.   usage: tools/ab_base.sh [rounds] [bench flags...]
+# setup (once, in the build container): git worktree add _base <baseline commit> && (cd _base && python -m tatt_amd.build)
+# (_base/ is git-ignored but travels to the GPU box with the snapshot; `git worktree remove --force _base` when done)
 rounds=${1:-2}; shift
 root=$(pwd)
 mkdir -p gpurun_out
