@@ -126,6 +126,10 @@ int tatt_conv3_c64_fwd_sb(const float* x, int cin_total, int ci0, const float* w
  * tatt_splitk_reduce(part, dw_oihw, 9*Cin, Cout, G, Cin, 9, beta, db, Cout) where pdb = part + G*9*Cin*Cout */
 int tatt_conv3_c64_wgrad_partial(const float* x, const float* dy, float* part, float* pdb, int B, int H, int W,
                                  int Cin, int Cout, int G, hipStream_t st);
+/* the same partials on the bf16 matrix cores by operand splitting (hi hi + hi lo + lo hi, fp32 accumulation; csrc/conv3w.hip): same
+ * arguments, same outputs up to 2^-16 relative per product */
+int tatt_conv3_c64_wgrad_partial_sb(const float* x, const float* dy, float* part, float* pdb, int B, int H, int W,
+                                    int Cin, int Cout, int G, hipStream_t st);
 
 /* 9x9 convolution 64 -> 4 channels (fp32 vector ALU; filter through the scalar cache): the final reconstruction conv
  * (model/tsrn.py:623) and, with the mode-1 packed filter, the data gradient of block1 (model/tsrn.py:597).

@@ -993,21 +993,27 @@ class QueryGruFn(Function):
         x = ops.new(dev, W, IN)
         ops.copy4d(emb, x, (1, W, H, C), (0, C, W * C, 1), (0, IN, C, 1))
         gi = [ops.linear_fwd(x, wih0, bih0), ops.linear_fwd(x, wih1, bih1)]       # (W, 3*HID) each
-        hseq = ops.new(dev, 2, B, W, HID)
+        # h of both directions with ONE zero time slot: in front of the forward direction's sequence, behind the reverse one's -- so
+        # that "h_prev of every step" is one contiguous (B*W, HID) matrix per direction (the W_hh gradient GEMM then covers all rows
+        # and its row sums are the hidden-bias gradient: no separate column-sum pass)
+        hbuf = ops.new(dev, 2, B + 1, W, HID)
+        hbuf[0, 0].zero_()
+        hbuf[1, B].zero_()
+        hseq = (hbuf[0, 1:], hbuf[1, :B])
         gsave = ops.new(dev, 2, B, 4, W, HID)
         for s in range(B):
             t0, t1 = s, B - 1 - s
-            hp0 = hseq[0, t0 - 1] if s > 0 else None
-            hp1 = hseq[1, t1 + 1] if s > 0 else None
+            hp0 = hseq[0][t0 - 1] if s > 0 else None
+            hp1 = hseq[1][t1 + 1] if s > 0 else None
             ops.call("tatt_qgru_fwd_step", ops.P(gi[0]), ops.P(gi[1]), ops.P(whh0), ops.P(whh1), ops.P(bhh0),
-                     ops.P(bhh1), ops.P(hp0), ops.P(hp1), ops.P(hseq[0, t0]), ops.P(hseq[1, t1]),
+                     ops.P(bhh1), ops.P(hp0), ops.P(hp1), ops.P(hseq[0][t0]), ops.P(hseq[1][t1]),
                      ops.P(gsave[0, t0]), ops.P(gsave[1, t1]), W, HID, ops.stream())
         # q[n, h, w, c] = hseq[d][n][w][(h % (H/2))*C + c], d = h // (H/2)
         q = ops.new(dev, B, H, W, C)
         Hh = H // 2
         for d in range(2):
             ops.copy4d(hseq[d], q[:, d * Hh:], (B, W, Hh, C), (W * HID, HID, C, 1), (H * W * C, C, W * C, 1))
-        ctx.save_for_backward(emb, x, wih0, whh0, wih1, whh1, hseq, gsave)
+        ctx.save_for_backward(emb, x, wih0, whh0, wih1, whh1, hbuf, gsave)
         ctx.dims = (B, H, W, C, HID, IN)
         return q
 
@@ -1020,8 +1026,9 @@ class QueryGruFn(Function):
 
     @staticmethod
     def _backward(ctx, saved, dq):
-        emb, x, wih0, whh0, wih1, whh1, hseq, gsave = saved
+        emb, x, wih0, whh0, wih1, whh1, hbuf, gsave = saved
         B, H, W, C, HID, IN = ctx.dims
+        hseq = (hbuf[0, 1:], hbuf[1, :B])
         dq = _c(dq)
         dev = emb
         Hh = H // 2
@@ -1037,7 +1044,7 @@ class QueryGruFn(Function):
             ops.copy4d(whh, tT, (1, 1, HID, 3 * HID), (0, 0, 1, HID), (0, 0, 3 * HID, 1))
             whhT.append(tT)
         def prev_h(t0, t1):
-            return (hseq[0, t0 - 1] if t0 > 0 else None), (hseq[1, t1 + 1] if t1 < B - 1 else None)
+            return (hseq[0][t0 - 1] if t0 > 0 else None), (hseq[1][t1 + 1] if t1 < B - 1 else None)
 
         # backward sweep: step s visits time B-1-s in the forward direction and time s in the reverse direction
         hp0, hp1 = prev_h(B - 1, 0)
@@ -1056,15 +1063,10 @@ class QueryGruFn(Function):
         dx = ops.new(dev, W, IN)
         for d, (wih, whh) in enumerate(((wih0, whh0), (wih1, whh1))):
             g2 = dgh[d].reshape(B * W, 3 * HID)
-            # dW_hh = sum_t dgh_t^T h_{t-1}: skip the step whose h_prev is the zero initial state
-            if B > 1:
-                if d == 0:
-                    dwhh = ops.linear_bwd_weight(g2[W:], hseq[0].reshape(B * W, HID)[:-W])
-                else:
-                    dwhh = ops.linear_bwd_weight(g2[:-W], hseq[1].reshape(B * W, HID)[W:])
-            else:
-                dwhh = torch.zeros_like(whh)
-            dbhh = ops.colsum(g2)
+            # dW_hh = sum_t dgh_t^T h_{t-1} over ALL steps (h_prev of the first step is the zero slot); db_hh = its row sums
+            hprev_all = (hbuf[0, :B] if d == 0 else hbuf[1, 1:]).reshape(B * W, HID)
+            dbhh = ops.new(dev, 3 * HID)
+            dwhh = ops.linear_bwd_weight(g2, hprev_all, rowsum=dbhh)
             dbih = ops.new(dev, 3 * HID)
             dwih = ops.linear_bwd_weight(dgi_acc[d], x, rowsum=dbih)     # the bias gradient rides along (row sums of dgi_acc^T)
             ops.linear_bwd_input(dgi_acc[d], wih, out=dx, beta=0.0 if d == 0 else 1.0)

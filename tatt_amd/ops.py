@@ -167,6 +167,7 @@ def linear_bwd_weight(dy, x2, *, alpha=1.0, out=None, out_ld=None, beta=0.0, row
 
 
 GRU_WGRAD_GROUPS = 128        # persistent work-groups (= partial slabs) of tatt_gru_wgrad_sb
+CONV3_WGRAD_SB = True          # test / A-B hook: False -> the fp32-MFMA weight-gradient kernel (conv3.hip)
 CONV3_WGRAD_GROUPS = 256      # persistent work-groups of tatt_conv3_c64_wgrad_partial (all 64x64 channel blocks together)
 
 
@@ -465,8 +466,8 @@ def conv_wgrad(x_bhwc, dy_bhwc, Cout, KH, KW, want_db=False):
         n = G * 9 * Cin * Cout
         part = _split_ws(new(x_bhwc, n + (G * Cout if want_db else 0)))
         db = new(x_bhwc, Cout) if want_db else None
-        call("tatt_conv3_c64_wgrad_partial", P(x_bhwc), P(dy_bhwc), P(part), P(part[n:]) if want_db else None, B, H, W, Cin,
-             Cout, G, stream())
+        call("tatt_conv3_c64_wgrad_partial_sb" if CONV3_WGRAD_SB else "tatt_conv3_c64_wgrad_partial", P(x_bhwc), P(dy_bhwc), P(part),
+             P(part[n:]) if want_db else None, B, H, W, Cin, Cout, G, stream())
         call("tatt_splitk_reduce", P(part), P(dw), 9 * Cin, Cout, G, Cin, 9, 0.0, P(db), Cout, stream())
         return (dw, db) if want_db else dw
     if want_db:

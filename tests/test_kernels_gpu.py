@@ -913,3 +913,32 @@ def test_gru_wgrad_split_bf16_vs_fp64(dev, M, with_xb, groups):
         assert err < 2e-5, (name, err)
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a, b)                                  # deterministic
+
+
+# ------------------------------------------------------------------------------------------- split-bf16 3x3 weight gradient
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(3, 16, 64, 64, 64), (2, 8, 128, 64, 256), (1, 4, 64, 256, 64), (5, 3, 192, 64, 64)])
+def test_conv3_wgrad_split_bf16_vs_fp64(dev, B, H, W, Cin, Cout):
+    """tatt_conv3_c64_wgrad_partial_sb (pixels as the contraction axis, operands transposed through an LDS fragment buffer) against
+    autograd in fp64 and against the fp32-MFMA kernel; bias gradient from the all-ones A fragment.  Channel blocks on both sides, a
+    height that leaves halo rows outside the image, three segments per row."""
+    from tatt_amd import ops
+    g = torch.Generator().manual_seed(61)
+    x = torch.randn(B, H, W, Cin, generator=g)
+    dy = torch.randn(B, H, W, Cout, generator=g)
+    w = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    b = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w, b, padding=1).backward(dy.permute(0, 3, 1, 2).double())
+    xd, dyd = x.to(dev), dy.to(dev)
+    assert ops.CONV3_WGRAD_SB
+    dw, db = ops.conv_wgrad(xd, dyd, Cout, 3, 3, want_db=True)
+    err = float((dw.double().cpu() - w.grad).abs().max() / w.grad.abs().max())
+    assert err < 2e-5, err
+    errb = float((db.double().cpu() - b.grad).abs().max() / b.grad.abs().max())
+    assert errb < 2e-5, errb
+    assert torch.equal(dw, ops.conv_wgrad(xd, dyd, Cout, 3, 3))                      # deterministic, with or without the bias part
+    ops.CONV3_WGRAD_SB = False
+    try:
+        dw32 = ops.conv_wgrad(xd, dyd, Cout, 3, 3)
+    finally:
+        ops.CONV3_WGRAD_SB = True
+    assert float((dw - dw32).abs().max() / dw32.abs().max()) < 3e-5
