@@ -265,6 +265,26 @@ int tatt_gru32_bwd(const float* gates, const float* out, const float* dout, cons
                    const float* whh_r, float* dgi, float* dgh, float* hprev, int nseq, int T, int s_in,
                    long stride_hi, long stride_lo, long stride_t, hipStream_t st);
 
+/* Second generation of the two recurrences above (round 4; same reference lines, same arguments, same results up to the order of
+ * fp32 summation): one WAVE per (sequence, direction), two lanes per hidden unit, halves joined by v_permlane32_swap. */
+int tatt_gru32_fwd2(const float* gi, const float* whh_f, const float* bhh_f, const float* whh_r,
+                    const float* bhh_r, float* out, float* gates, int nseq, int T, int s_in, long stride_hi,
+                    long stride_lo, long stride_t, hipStream_t st);
+/* frag == NULL: dgi, dgh, hprev as tatt_gru32_bwd.  frag != NULL (T % 8 == 0 and nseq * T / 8 % 4 == 0, else returns 1): dgi as
+ * before; instead of dgh / hprev (unused, may be NULL) the operands of the weight-gradient pass in bf16 hi / lo MFMA fragment
+ * order, nseq * T / 32 K-steps of 10240 floats: [K-step][slot 0..19][hi, lo][lane][4 dwords], slots d*8 + {r0 r1 z0 z1 n0 n1 gn0
+ * gn1}, 16 + d*2 + {0, 1} = h_{t-1}; consumed by tatt_gru_wgrad_frag */
+int tatt_gru32_bwd2(const float* gates, const float* out, const float* dout, const float* whh_f,
+                    const float* whh_r, float* dgi, float* dgh, float* hprev, float* frag, int nseq, int T, int s_in,
+                    long stride_hi, long stride_lo, long stride_t, hipStream_t st);
+/* Weight gradients of one GruBlock (as tatt_gru_wgrad_sb; reference model/tsrn.py:1075-1084) from that fragment stream and the
+ * token-major inputs x (M, 64) | xb (M, 64 or NULL) under the same sequence geometry.  1 <= G <= min(nseq * T / 32, 256);
+ * ws1 >= G*192*K + G*192 floats (K = 128 with xb, else 64), ws2 >= G*192*32 + G*192; finish with
+ * tatt_splitk_reduce(ws1, dWp, 192, K, G, 0, 0, 0, dbp, 192) and tatt_splitk_reduce(ws2, dWhh_c, 192, 32, G, 0, 0, 0, dbhh, 192)
+ * where dWhh_c (192, 32) = [dW_hh forward; dW_hh reverse] */
+int tatt_gru_wgrad_frag(const float* frag, const float* x, const float* xb, float* ws1, float* ws2, int nseq, int T,
+                        int s_in, long stride_hi, long stride_lo, long stride_t, int G, hipStream_t st);
+
 /* backward step, fused form: dh = dhseq_next + dhcarry + dgh_cur @ whh, then the gate part of the NEXT step on the same tile:
  * dgi_acc += input-side gate grads, dgh_next = recurrent-side gate grads, dhcarry = dh*z  (whhT = whh transposed) */
 int tatt_qgru_bwd_fused(const float* dgh_cur0, const float* dgh_cur1, const float* whhT0, const float* whhT1,
@@ -285,6 +305,11 @@ int tatt_gru_compose_batch(const float* const* ptrs, const int* Ks, int n, hipSt
 int tatt_gru_tail(const float* dWp, const float* dbp, const float* Wc, const float* bc, const float* wih_f,
                   const float* wih_r, float* dwih_f, float* dwih_r, float* dWc, float* dbc, int K,
                   const float* dWhh, float* dwhh_f, float* dwhh_r, hipStream_t st);
+
+/* tatt_gru_tail with dWhh given compact: dWhh_c (192, 32) = [dW_hh forward; dW_hh reverse] (tatt_gru_wgrad_frag) */
+int tatt_gru_tail_c(const float* dWp, const float* dbp, const float* Wc, const float* bc, const float* wih_f,
+                    const float* wih_r, float* dwih_f, float* dwih_r, float* dWc, float* dbc, int K,
+                    const float* dWhh_c, float* dwhh_f, float* dwhh_r, hipStream_t st);
 
 /* One time step of the query-embedding GRU (nn.GRU(64*H, 32*H, bidirectional), model/transformer_v2.py:177,218;
  * time axis = sample axis), both directions: gi* (Wb,3*HID) incl. b_ih, whh* (3*HID,HID),

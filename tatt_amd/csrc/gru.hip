@@ -237,6 +237,287 @@ TATT_API int tatt_gru32_bwd(const float* gates, const float* out, const float* d
 }
 
 // ------------------------------------------------------------------------------------------------
+// Second generation of the small BiGRU recurrences (round 4): ONE WAVE per (sequence, direction), two lanes per hidden unit.
+// ------------------------------------------------------------------------------------------------
+// The first generation (above: a 32-lane group per (sequence, direction), 96 recurrent weights per lane) spends a step waiting
+// for LDS: the 96 (backward) / 32 (forward) broadcast values are read two ds_read_b128 at a time because the 235 VGPRs leave no
+// room to have more in flight -- 12 dependent LDS round trips per backward step (disassembly: `s_waitcnt lgkmcnt(1)`,
+// `lgkmcnt(0)` alternating through the dot product), ~0.9 us per step at T = 64 against ~0.2 us of arithmetic.  Here lane
+// (j, half) of a wave owns hidden unit j and HALF of every dot product (48 weights per lane): all 12 (4) LDS reads of a step are
+// in flight at once, the two halves meet through v_permlane32_swap (VALU, no LDS), and the loads of a step are split between the
+// halves the same way (one 256-byte row per instruction, exchanged by the same swap).  Twice the waves for the same work, which
+// is what a latency-bound recurrence wants.
+//
+// FRAGS (backward): instead of dgh [tok][192] and hprev [tok][64] (1 KB per token written here and read back by the weight-
+// gradient pass, which then transposes 36 column tiles through LDS), the kernel leaves the operands of that pass in the order
+// the bf16 matrix cores take them.  The contraction there runs over TOKENS, and a lane of the recurrence owns ONE channel over
+// CONSECUTIVE time steps -- which is exactly an MFMA operand's "8 consecutive k per lane": 8 steps of one (sequence, direction)
+// are one k-octet, 4 octets one K-step of v_mfma_f32_16x16x32_bf16.  Layout (dwords): frag[K-step c][slot 0..19][hi, lo][lane'
+// = 16 kq + li][4], octet o = seq * T/8 + (t >> 3) = 4 c + kq, element e = t & 7 (token order, both directions); slots d*8 + {r0 r1
+// z0 z1 n0 n1 gn0 gn1} (16 channels each; n = dgi's n gate, gn = dgh's: scaled by r), 16 + d*2 + {0, 1} = h_{t-1}.  1.25 KB
+// per token, written as whole 16-byte lane operands (staged per wave in LDS for the 8 steps of a window).
+#define GRU2_PF 8
+// v_permlane32_swap_b32 a, b: lanes 32-63 of a <-> lanes 0-31 of b, i.e. a <- [a.lo | b.lo], b <- [a.hi | b.hi].  Inline asm on purpose:
+// ROCm 7.2's __builtin_amdgcn_permlane32_swap returns its FIRST result for both elements of the pair (checked in the disassembly),
+// so the exchange would silently be lost.  s_nop 1 covers the two wait states between a VALU write of an operand and the swap.
+__device__ __forceinline__ void lane32_swap(float& a, float& b) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float half_sum(float v) {          // v[l] + v[l ^ 32] in every lane
+    float a = v, b = v;
+    lane32_swap(a, b);
+    return a + b;
+}
+__device__ __forceinline__ void half_both(float v, float& lo, float& hi) {   // lo = v of lane l & 31, hi = v of lane (l & 31) + 32
+    lo = v; hi = v;
+    lane32_swap(lo, hi);
+}
+
+template <bool SAVE>
+__global__ __launch_bounds__(256) void gru32_fwd2_kernel(const float* __restrict__ gi,
+                                                         const float* __restrict__ whh_f, const float* __restrict__ bhh_f,
+                                                         const float* __restrict__ whh_r, const float* __restrict__ bhh_r,
+                                                         float* __restrict__ out, float* __restrict__ gates, SeqGeom g) {
+    __shared__ __attribute__((aligned(16))) float hs[4][32];
+    __shared__ float pf[2 * GRU2_PF][256];
+    const int t = threadIdx.x, lane = t & 63, j = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);       // wave-uniform: sequence, direction and every token address live in SGPRs
+    const int sd = (int)blockIdx.x * 4 + wave;
+    const int seq = min(sd >> 1, g.nseq - 1), dir = sd & 1;
+    const float* whh = dir ? whh_r : whh_f;
+    const float* bhh = dir ? bhh_r : bhh_f;
+    float wr[16], wz[16], wn[16];                                   // this half's 16 columns of the three gate rows of unit j
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        wr[k] = whh[(0 * 32 + j) * 32 + 16 * half + k];
+        wz[k] = whh[(1 * 32 + j) * 32 + 16 * half + k];
+        wn[k] = whh[(2 * 32 + j) * 32 + 16 * half + k];
+    }
+    const float br = half ? 0.f : bhh[j], bz = half ? 0.f : bhh[32 + j], bn = half ? 0.f : bhh[64 + j];   // biases enter once
+    const int T = g.T;
+    const long st_t = dir ? -g.stride_t : g.stride_t;
+    const long tok0 = seq_base(g, seq) + (dir ? (long)(T - 1) * g.stride_t : 0);
+    const float* gq = gi + dir * 96;
+    auto fetch = [&](int step, float& a, float& b) {
+        const float* q = gq + (tok0 + (long)min(step, T - 1) * st_t) * 192;
+        a = q[lane];                                                // half 0: r gate of unit j, half 1: z gate
+        b = q[64 + j];                                              // n gate (both halves)
+    };
+    float h = 0.f;
+    auto one_step = [&](int step, float grz, float gn) {
+        hs[wave][j] = h;                                            // both halves hold the same h: same value, same address
+        wave_lds_sync();
+        float ar0 = br, ar1 = 0.f, az0 = bz, az1 = 0.f, an0 = bn, an1 = 0.f;
+        const f32x4* hv = reinterpret_cast<const f32x4*>(hs[wave] + 16 * half);
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+            const f32x4 hh = hv[k4];
+            ar0 = fmaf(wr[k4 * 4 + 0], hh[0], ar0); ar1 = fmaf(wr[k4 * 4 + 1], hh[1], ar1);
+            az0 = fmaf(wz[k4 * 4 + 0], hh[0], az0); az1 = fmaf(wz[k4 * 4 + 1], hh[1], az1);
+            an0 = fmaf(wn[k4 * 4 + 0], hh[0], an0); an1 = fmaf(wn[k4 * 4 + 1], hh[1], an1);
+            ar0 = fmaf(wr[k4 * 4 + 2], hh[2], ar0); ar1 = fmaf(wr[k4 * 4 + 3], hh[3], ar1);
+            az0 = fmaf(wz[k4 * 4 + 2], hh[2], az0); az1 = fmaf(wz[k4 * 4 + 3], hh[3], az1);
+            an0 = fmaf(wn[k4 * 4 + 2], hh[2], an0); an1 = fmaf(wn[k4 * 4 + 3], hh[3], an1);
+        }
+        wave_lds_sync();
+        const float ar = half_sum(ar0 + ar1), az = half_sum(az0 + az1), an = half_sum(an0 + an1);
+        float gr, gz;
+        half_both(grz, gr, gz);
+        const float r = sigmoid_fast(gr + ar);
+        const float z = sigmoid_fast(gz + az);
+        const float n = tanh_fast(gn + r * an);
+        h = (1.f - z) * n + z * h;
+        const long tok = tok0 + (long)step * st_t;
+        if (half == 0) out[tok * 64 + dir * 32 + j] = h;
+        if (SAVE) {
+            float* q = gates + tok * 256 + dir * 128;               // [r | z | n | W_hn h + b_hn], 32 each: two 256-byte rows
+            q[lane] = half ? z : r;
+            q[64 + lane] = half ? an : n;
+        }
+    };
+    {
+        float a[GRU2_PF], b[GRU2_PF];                               // all loads of the first group in flight before any is parked
+#pragma unroll
+        for (int u = 0; u < GRU2_PF; ++u) fetch(u, a[u], b[u]);
+#pragma unroll
+        for (int u = 0; u < GRU2_PF; ++u) { pf[u * 2 + 0][t] = a[u]; pf[u * 2 + 1][t] = b[u]; }
+    }
+    int s0 = 0;
+    for (; s0 + GRU2_PF <= T; s0 += GRU2_PF) {
+        float na[GRU2_PF], nb[GRU2_PF];
+#pragma unroll
+        for (int u = 0; u < GRU2_PF; ++u) fetch(s0 + GRU2_PF + u, na[u], nb[u]);
+#pragma unroll
+        for (int u = 0; u < GRU2_PF; ++u) one_step(s0 + u, pf[u * 2 + 0][t], pf[u * 2 + 1][t]);
+#pragma unroll
+        for (int u = 0; u < GRU2_PF; ++u) { pf[u * 2 + 0][t] = na[u]; pf[u * 2 + 1][t] = nb[u]; }
+    }
+    for (; s0 < T; ++s0) {                                          // T % GRU2_PF leftover steps: plain loads
+        float a, b;
+        fetch(s0, a, b);
+        one_step(s0, a, b);
+    }
+}
+TATT_API int tatt_gru32_fwd2(const float* gi, const float* whh_f, const float* bhh_f, const float* whh_r,
+                             const float* bhh_r, float* out, float* gates, int nseq, int T, int s_in, long stride_hi,
+                             long stride_lo, long stride_t, hipStream_t st) {
+    if (nseq <= 0 || T <= 0) return 0;
+    SeqGeom g = {nseq, T, s_in, stride_hi, stride_lo, stride_t};
+    const dim3 grid(cdiv(2L * nseq, 4)), block(256);
+    if (gates) hipLaunchKernelGGL(gru32_fwd2_kernel<true>, grid, block, 0, st, gi, whh_f, bhh_f, whh_r, bhh_r, out, gates, g);
+    else hipLaunchKernelGGL(gru32_fwd2_kernel<false>, grid, block, 0, st, gi, whh_f, bhh_f, whh_r, bhh_r, out, gates, g);
+    return LAUNCH_CHECK();
+}
+
+typedef __bf16 gr_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float gr_f32x2 __attribute__((ext_vector_type(2)));
+// 8 fp32 values -> the hi (bf16(a)) or lo (bf16(a - hi)) halves, packed two per dword in element order
+__device__ __forceinline__ f32x4 gr_split8(const float* v, bool want_lo) {
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+        const gr_f32x2 a = (gr_f32x2){v[e], v[e + 1]};
+        const gr_bf16x2 hi = __builtin_convertvector(a, gr_bf16x2);
+        const gr_bf16x2 lo = __builtin_convertvector(a - __builtin_convertvector(hi, gr_f32x2), gr_bf16x2);
+        o[e >> 1] = want_lo ? __builtin_bit_cast(float, lo) : __builtin_bit_cast(float, hi);
+    }
+    return o;
+}
+
+template <bool FRAGS>
+__global__ __launch_bounds__(256) void gru32_bwd2_kernel(const float* __restrict__ gates, const float* __restrict__ out,
+                                                         const float* __restrict__ dout,
+                                                         const float* __restrict__ whh_f, const float* __restrict__ whh_r,
+                                                         float* __restrict__ dgi, float* __restrict__ dgh,
+                                                         float* __restrict__ hprev, float* __restrict__ frag, SeqGeom g) {
+    __shared__ __attribute__((aligned(16))) float ds[4][96];
+    __shared__ float pf[3 * GRU2_PF][256];
+    __shared__ float stg[FRAGS ? 4 : 1][5][8][32];                 // per wave: [drp, dzp, dnp, dghn, h_prev][e = t & 7][j]
+    const int t = threadIdx.x, lane = t & 63, j = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);       // wave-uniform: sequence, direction and every token address live in SGPRs
+    const int sd = (int)blockIdx.x * 4 + wave;
+    const int seq = min(sd >> 1, g.nseq - 1), dir = sd & 1;
+    const float* whh = dir ? whh_r : whh_f;
+    float wt[48];                                                   // this half's 48 rows of column j of W_hh
+#pragma unroll
+    for (int k = 0; k < 48; ++k) wt[k] = whh[(48 * half + k) * 32 + j];
+    const int T = g.T;
+    const long st_t = dir ? -g.stride_t : g.stride_t;
+    const long tok0 = seq_base(g, seq) + (dir ? (long)(T - 1) * g.stride_t : 0);          // token of (forward) step 0
+    const float* sq = gates + dir * 128;
+    const float* oq = out + dir * 32;
+    const float* dq = dout + dir * 32;
+    float dhc = 0.f;                                                // gradient carried to h_{t-1} (both halves)
+    auto fetch = [&](int step, float& a, float& b, float& c) {
+        const int sc = max(step, 0);
+        const long tok = tok0 + (long)sc * st_t;
+        const float* q = sq + tok * 256;
+        a = q[lane];                                                // half 0: r, half 1: z
+        b = q[64 + lane];                                           // half 0: n, half 1: W_hn h + b_hn
+        const float* pa = dq + tok * 64;                             // (both wave-uniform)
+        const float* pb = oq + (tok0 + (long)max(sc - 1, 0) * st_t) * 64;
+        c = (half ? pa : pb)[j];                                    // half 0: h_{t-1} (raw: 0 selected at step 0), half 1: dout
+    };
+    auto one_step = [&](int step, float a, float b, float c) {
+        float r, z, n, an, hp_raw, go;
+        half_both(a, r, z);
+        half_both(b, n, an);
+        half_both(c, hp_raw, go);
+        const long tok = tok0 + (long)step * st_t;
+        const float hp = step > 0 ? hp_raw : 0.f;
+        const float dh = dhc + go;
+        const float dn = dh * (1.f - z);
+        const float dz = dh * (hp - n);
+        const float dnp = dn * (1.f - n * n);
+        const float drp = dnp * an * r * (1.f - r);
+        const float dzp = dz * z * (1.f - z);
+        const float dghn = dnp * r;
+        const float rz = half ? dzp : drp;
+        ds[wave][lane] = rz;                                        // [drp | dzp | dghn]
+        if (half == 0) ds[wave][64 + j] = dghn;
+        wave_lds_sync();
+        {
+            float* q = dgi + tok * 192 + dir * 96;
+            q[lane] = rz;
+            if (half == 0) q[64 + j] = dnp;
+        }
+        if (FRAGS) {
+            const int e = (dir ? T - 1 - step : step) & 7;
+            stg[wave][half][e][j] = rz;
+            stg[wave][2 + half][e][j] = half ? dghn : dnp;
+            if (half == 0) stg[wave][4][e][j] = hp;
+        } else {
+            float* q = dgh + tok * 192 + dir * 96;
+            q[lane] = rz;
+            if (half == 0) { q[64 + j] = dghn; hprev[tok * 64 + dir * 32 + j] = hp; }
+        }
+        float c0 = half ? 0.f : dh * z, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+        const f32x4* dv = reinterpret_cast<const f32x4*>(ds[wave] + 48 * half);
+#pragma unroll
+        for (int k4 = 0; k4 < 12; ++k4) {
+            const f32x4 dd = dv[k4];
+            c0 = fmaf(wt[k4 * 4 + 0], dd[0], c0); c1 = fmaf(wt[k4 * 4 + 1], dd[1], c1);
+            c2 = fmaf(wt[k4 * 4 + 2], dd[2], c2); c3 = fmaf(wt[k4 * 4 + 3], dd[3], c3);
+        }
+        dhc = half_sum((c0 + c1) + (c2 + c3));
+        wave_lds_sync();
+    };
+    // the 8 steps s_hi .. s_hi - 7 just processed are one window of the sequence: leave its operand fragments
+    auto flush = [&](int s_hi) {
+        const int tt0 = dir ? T - 1 - s_hi : s_hi - 7;              // first token-time of the window (a multiple of 8)
+        const int o = seq * (T >> 3) + (tt0 >> 3), c = o >> 2, kq = o & 3;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = stg[wave][q][e][j];
+            const int slot = q < 4 ? dir * 8 + q * 2 + (j >> 4) : 16 + dir * 2 + (j >> 4);
+            float* dst = frag + (((long)c * 20 + slot) * 2 + half) * 256 + (kq * 16 + (j & 15)) * 4;
+            *reinterpret_cast<f32x4*>(dst) = gr_split8(v, half != 0);
+        }
+        wave_lds_sync();
+    };
+    {
+        float a[GRU2_PF][3];
+#pragma unroll
+        for (int u = 0; u < GRU2_PF; ++u) fetch(T - 1 - u, a[u][0], a[u][1], a[u][2]);
+#pragma unroll
+        for (int u = 0; u < GRU2_PF; ++u) { pf[u * 3 + 0][t] = a[u][0]; pf[u * 3 + 1][t] = a[u][1]; pf[u * 3 + 2][t] = a[u][2]; }
+    }
+    int s0 = T - 1;
+    for (; s0 >= GRU2_PF - 1; s0 -= GRU2_PF) {
+        float nx[GRU2_PF][3];
+#pragma unroll
+        for (int u = 0; u < GRU2_PF; ++u) fetch(s0 - GRU2_PF - u, nx[u][0], nx[u][1], nx[u][2]);
+#pragma unroll
+        for (int u = 0; u < GRU2_PF; ++u) one_step(s0 - u, pf[u * 3 + 0][t], pf[u * 3 + 1][t], pf[u * 3 + 2][t]);
+        if (FRAGS) flush(s0);
+#pragma unroll
+        for (int u = 0; u < GRU2_PF; ++u)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) pf[u * 3 + k][t] = nx[u][k];
+    }
+    for (; s0 >= 0; --s0) {                                         // T % GRU2_PF leftover steps (never with FRAGS): plain loads
+        float a, b, c;
+        fetch(s0, a, b, c);
+        one_step(s0, a, b, c);
+    }
+}
+// frag == NULL: dgh (M, 192) and hprev (M, 64) are written as by tatt_gru32_bwd.  frag != NULL (needs T % 8 == 0 and
+// nseq * T / 8 % 4 == 0; dgh / hprev unused): nseq * T / 32 * 10240 floats of operand fragments for tatt_gru_wgrad_frag.
+TATT_API int tatt_gru32_bwd2(const float* gates, const float* out, const float* dout, const float* whh_f,
+                             const float* whh_r, float* dgi, float* dgh, float* hprev, float* frag, int nseq, int T, int s_in,
+                             long stride_hi, long stride_lo, long stride_t, hipStream_t st) {
+    if (nseq <= 0 || T <= 0) return 0;
+    if (frag && (T % 8 || ((long)nseq * (T / 8)) % 4)) return 1;
+    SeqGeom g = {nseq, T, s_in, stride_hi, stride_lo, stride_t};
+    const dim3 grid(cdiv(2L * nseq, 4)), block(256);
+    if (frag) hipLaunchKernelGGL(gru32_bwd2_kernel<true>, grid, block, 0, st, gates, out, dout, whh_f, whh_r, dgi, dgh, hprev, frag, g);
+    else hipLaunchKernelGGL(gru32_bwd2_kernel<false>, grid, block, 0, st, gates, out, dout, whh_f, whh_r, dgi, dgh, hprev, frag, g);
+    return LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------------------------
 // query GRU, one time step, both directions (blockIdx.z).
 //   gi   [dir][Wb][3*HID]   time-invariant input projection (incl. b_ih)
 //   whh  [dir] -> (3*HID, HID) row-major,  bhh [dir] -> (3*HID)
@@ -568,7 +849,7 @@ __global__ void gru_tail_kernel(const float* __restrict__ dWp, const float* __re
                                 const float* __restrict__ wih_f, const float* __restrict__ wih_r,
                                 float* __restrict__ dwih_f, float* __restrict__ dwih_r, float* __restrict__ dWc,
                                 float* __restrict__ dbc, int K, const float* __restrict__ dWhh,
-                                float* __restrict__ dwhh_f, float* __restrict__ dwhh_r) {
+                                float* __restrict__ dwhh_f, float* __restrict__ dwhh_r, int whh_ld) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < 2 * 96 * 64) {   // 48 whole blocks; a wave = one row (d, r), lane = c.  W_c goes through LDS transposed, 64 k at a time:
         // read straight from memory each lane would walk its own row of W_c (64 cache lines per load instruction)
@@ -616,7 +897,8 @@ __global__ void gru_tail_kernel(const float* __restrict__ dWp, const float* __re
     idx -= 64;
     if (idx < 2 * 96 * 32) {
         const int d = idx / 3072, r = (idx % 3072) / 32, c = idx & 31;
-        (d ? dwhh_r : dwhh_f)[r * 32 + c] = dWhh[(long)(96 * d + r) * 64 + 32 * d + c];
+        // whh_ld 64: dWhh (192 x 64) = dgh^T hprev over both directions, the diagonal blocks are wanted; 32: compact [fwd; rev]
+        (d ? dwhh_r : dwhh_f)[r * 32 + c] = dWhh[(long)(96 * d + r) * whh_ld + (whh_ld == 64 ? 32 * d : 0) + c];
     }
 }
 TATT_API int tatt_gru_tail(const float* dWp, const float* dbp, const float* Wc, const float* bc, const float* wih_f,
@@ -625,6 +907,16 @@ TATT_API int tatt_gru_tail(const float* dWp, const float* dbp, const float* Wc, 
     if (K % 2) return 1;
     const int total = 2 * 96 * 64 + 64 * K + 64 + 2 * 96 * 32;
     hipLaunchKernelGGL(gru_tail_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, dWp, dbp, Wc, bc, wih_f, wih_r, dwih_f,
-                       dwih_r, dWc, dbc, K, dWhh, dwhh_f, dwhh_r);
+                       dwih_r, dWc, dbc, K, dWhh, dwhh_f, dwhh_r, 64);
+    return LAUNCH_CHECK();
+}
+// the same with dWhh compact: (192, 32) = [dW_hh forward; dW_hh reverse], as tatt_gru_wgrad_frag's reduction leaves it
+TATT_API int tatt_gru_tail_c(const float* dWp, const float* dbp, const float* Wc, const float* bc, const float* wih_f,
+                             const float* wih_r, float* dwih_f, float* dwih_r, float* dWc, float* dbc, int K,
+                             const float* dWhh_c, float* dwhh_f, float* dwhh_r, hipStream_t st) {
+    if (K % 2) return 1;
+    const int total = 2 * 96 * 64 + 64 * K + 64 + 2 * 96 * 32;
+    hipLaunchKernelGGL(gru_tail_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, dWp, dbp, Wc, bc, wih_f, wih_r, dwih_f,
+                       dwih_r, dWc, dbc, K, dWhh_c, dwhh_f, dwhh_r, 32);
     return LAUNCH_CHECK();
 }

@@ -202,3 +202,143 @@ TATT_API int tatt_gru_wgrad_sb(const float* dgi, const float* dgh, const float* 
     else hipLaunchKernelGGL(gru_wgrad_sb_kernel<false>, dim3(G), dim3(GW_THREADS), GW_LDS, st, p);
     return LAUNCH_CHECK();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Round 4: the same weight gradients from the OPERAND FRAGMENTS tatt_gru32_bwd2 leaves behind (gru.hip).
+// ------------------------------------------------------------------------------------------------
+// The recurrence's lanes own one channel over consecutive time steps, which is the "8 consecutive k per lane" of an MFMA operand
+// when the contraction runs over tokens -- so the gate-gradient side (dgi, dgh's n rows, h_{t-1}: 1.25 KB per token, already split
+// into bf16 hi / lo) arrives from HBM as ready operands: one 16-byte load per lane per (tile, half), no LDS, no conversion.  Only
+// the token-major activations x | xb (4 or 8 column tiles instead of 36) still pass through LDS to be transposed and split.
+// K-step c = 4 octets = 32 tokens: octet o = 4 c + kq = seq * T/8 + window, tokens seq_base(seq) + (8 window + e) * stride_t.
+// Work-group = 6 waves: wave w = (direction d = w / 3, gate = w % 3) owns rows 32 w .. 32 w + 31 of dW' (2 row tiles x K/16 column
+// tiles + the bias column) and of dW_hh (2 x 2 tiles against the h_{t-1} fragments of direction d; its A operand is dgi's r / z
+// fragment again, or the gn fragment for the n gate).  LDS: 32-token image of x | xb + its fragments = 17 / 33 KB (was 148 KB), so
+// the kernel shares a CU with the main lane's kernels.  Partials: ws1 [G][192][K] + [G][192] (as tatt_gru_wgrad_sb), ws2
+// [G][192][32] + [G][192]: dW_hh COMPACT -- rows 96 d .. 96 d + 95 are direction d's 96 x 32 matrix.
+#define GF_THREADS 384
+struct GruWfP {
+    const float* frag; const float* x; const float* xb;
+    float* p1; float* p2;
+    int nK, T8, s_in;
+    long stride_hi, stride_lo, stride_t;
+};
+template <int PITCH>
+__device__ __forceinline__ void gf_frag(const float* __restrict__ col, gw_bf16x8& hi, gw_bf16x8& lo) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = col[e * PITCH];
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+        const gw_f32x2 a = (gw_f32x2){v[e], v[e + 1]};
+        const gw_bf16x2 h = __builtin_convertvector(a, gw_bf16x2);
+        const gw_bf16x2 l = __builtin_convertvector(a - __builtin_convertvector(h, gw_f32x2), gw_bf16x2);
+        hi[e] = h[0]; hi[e + 1] = h[1];
+        lo[e] = l[0]; lo[e + 1] = l[1];
+    }
+}
+template <bool HAS_XB>
+__global__ __launch_bounds__(GF_THREADS) void gru_wgrad_frag_kernel(GruWfP p) {
+    constexpr int K = HAS_XB ? 128 : 64, NT = K / 16, PITCH = K + 2, NV = 32 * K / 4, VPT = (NV + GF_THREADS - 1) / GF_THREADS;
+    __shared__ __attribute__((aligned(16))) float gf_T[32 * PITCH];            // token-major image of the chunk's x | xb rows
+    __shared__ __attribute__((aligned(16))) float gf_F[NT * 2 * 64 * 4];       // their fragments: [tile][hi, lo][lane][4]
+    const int t = threadIdx.x, lane = t & 63, li = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int G = gridDim.x, g = blockIdx.x;
+    const int d = wave / 3, gate = wave - 3 * d;
+    const int a_slot = d * 8 + gate * 2;                           // dgi rows of (d, gate): the A operand of dW'
+    const int ah_slot = gate == 2 ? d * 8 + 6 : a_slot;            // dgh rows of (d, gate): dgi's for r / z, the gn fragments for n
+    const int bh_slot = 16 + d * 2;                                // h_{t-1} of direction d
+    f32x4 xpre[VPT], apre[12];
+    auto fetch = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int f = t + GF_THREADS * i;
+            if (NV % GF_THREADS == 0 || f < NV) {
+                const int row = f / (K / 4), c4 = f - row * (K / 4);
+                const int o = 4 * c + (row >> 3), s = o / p.T8, w = o - s * p.T8;
+                const long tok = (long)(s / p.s_in) * p.stride_hi + (long)(s % p.s_in) * p.stride_lo + (long)(8 * w + (row & 7)) * p.stride_t;
+                xpre[i] = (!HAS_XB || c4 < 16) ? *reinterpret_cast<const f32x4*>(p.x + tok * 64 + 4 * c4)
+                                               : *reinterpret_cast<const f32x4*>(p.xb + tok * 64 + 4 * (c4 - 16));
+            }
+        }
+        const float* base = p.frag + (long)c * (20 * 2 * 256) + lane * 4;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int hl = 0; hl < 2; ++hl) {
+                apre[m * 2 + hl] = *reinterpret_cast<const f32x4*>(base + ((a_slot + m) * 2 + hl) * 256);
+                apre[4 + m * 2 + hl] = *reinterpret_cast<const f32x4*>(base + ((ah_slot + m) * 2 + hl) * 256);
+                apre[8 + m * 2 + hl] = *reinterpret_cast<const f32x4*>(base + ((bh_slot + m) * 2 + hl) * 256);
+            }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int f = t + GF_THREADS * i;
+            if (NV % GF_THREADS == 0 || f < NV) {
+                const int row = f / (K / 4), c4 = f - row * (K / 4);
+                float* dst = gf_T + row * PITCH + 4 * c4;          // rows are 8-byte aligned (PITCH = 2 mod 4): two 8-byte stores
+                *reinterpret_cast<float2*>(dst) = make_float2(xpre[i][0], xpre[i][1]);
+                *reinterpret_cast<float2*>(dst + 2) = make_float2(xpre[i][2], xpre[i][3]);
+            }
+        }
+    };
+    f32x4 acc1[2 * (NT + 1)], acc2[2 * 3];                         // dW' [m][n | bias], dW_hh [m][n | bias]
+#pragma unroll
+    for (int q = 0; q < 2 * (NT + 1); ++q) acc1[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 6; ++q) acc2[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const gw_bf16x8 ones = gw_ones();
+    if (g < p.nK) fetch(g);
+    for (int c = g; c < p.nK; c += G) {
+        stash();                                                   // gf_T: last read by the conversions of the previous chunk (before barrier 2)
+        __syncthreads();                                           // 1: image complete; every wave has left the previous chunk's MFMAs (gf_F is free)
+        gw_bf16x8 a[12];
+#pragma unroll
+        for (int q = 0; q < 12; ++q) a[q] = __builtin_bit_cast(gw_bf16x8, apre[q]);
+        if (c + G < p.nK) fetch(c + G);
+        for (int tile = wave; tile < NT; tile += GF_THREADS / 64) {
+            gw_bf16x8 hi, lo;
+            gf_frag<PITCH>(gf_T + 8 * kq * PITCH + 16 * tile + li, hi, lo);
+            *reinterpret_cast<f32x4*>(gf_F + ((tile * 2 + 0) * 64 + lane) * 4) = __builtin_bit_cast(f32x4, hi);
+            *reinterpret_cast<f32x4*>(gf_F + ((tile * 2 + 1) * 64 + lane) * 4) = __builtin_bit_cast(f32x4, lo);
+        }
+        __syncthreads();                                           // 2: fragments complete; gf_T may be overwritten
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {                              // bias columns: row sums through an all-ones B operand
+            acc1[m * (NT + 1) + NT] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m * 2], ones, acc1[m * (NT + 1) + NT], 0, 0, 0);
+            acc1[m * (NT + 1) + NT] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m * 2 + 1], ones, acc1[m * (NT + 1) + NT], 0, 0, 0);
+            acc2[m * 3 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[4 + m * 2], ones, acc2[m * 3 + 2], 0, 0, 0);
+            acc2[m * 3 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[4 + m * 2 + 1], ones, acc2[m * 3 + 2], 0, 0, 0);
+        }
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+                acc2[m * 3 + n] = gw_mma3(a[4 + m * 2], a[4 + m * 2 + 1], a[8 + n * 2], a[8 + n * 2 + 1], acc2[m * 3 + n]);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const gw_bf16x8 bh = gw_ld(gf_F, n, 0, lane), bl = gw_ld(gf_F, n, 1, lane);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) acc1[m * (NT + 1) + n] = gw_mma3(a[m * 2], a[m * 2 + 1], bh, bl, acc1[m * (NT + 1) + n]);
+        }
+    }
+    gw_store<2, NT>(acc1, p.p1 + (long)g * 192 * K, p.p1 + (long)G * 192 * K + g * 192, K, 32 * wave, li, kq);
+    gw_store<2, 2>(acc2, p.p2 + (long)g * 192 * 32, p.p2 + (long)G * 192 * 32 + g * 192, 32, 32 * wave, li, kq);
+}
+
+// frag: the fragment stream of tatt_gru32_bwd2 (nK = nseq * T / 32 K-steps of 10240 floats) for the sequence geometry given;
+// x (M, 64), xb (M, 64) or null, contiguous.  1 <= G <= min(nK, 256).  ws1 >= G*192*K + G*192 floats (K = 128 with xb, 64 without),
+// ws2 >= G*192*32 + G*192.  Finish with tatt_splitk_reduce(ws1, dWp, 192, K, G, 0, 0, 0, dbp, 192) and
+// tatt_splitk_reduce(ws2, dWhh_c, 192, 32, G, 0, 0, 0, dbhh, 192): dWhh_c (192, 32) = [dW_hh forward; dW_hh reverse].
+TATT_API int tatt_gru_wgrad_frag(const float* frag, const float* x, const float* xb, float* ws1, float* ws2, int nseq, int T,
+                                 int s_in, long stride_hi, long stride_lo, long stride_t, int G, hipStream_t st) {
+    if (nseq <= 0 || T <= 0 || T % 8 || ((long)nseq * (T / 8)) % 4 || s_in <= 0) return 1;
+    const int nK = (int)((long)nseq * (T / 8) / 4);
+    if (G < 1 || G > nK || G > 256) return 2;
+    GruWfP p = {frag, x, xb, ws1, ws2, nK, T / 8, s_in, stride_hi, stride_lo, stride_t};
+    if (xb) hipLaunchKernelGGL(gru_wgrad_frag_kernel<true>, dim3(G), dim3(GF_THREADS), 0, st, p);
+    else hipLaunchKernelGGL(gru_wgrad_frag_kernel<false>, dim3(G), dim3(GF_THREADS), 0, st, p);
+    return LAUNCH_CHECK();
+}

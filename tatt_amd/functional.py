@@ -497,6 +497,7 @@ def gru_precompose(blocks):
 
 TOKGEMM_SB = True           # test / A-B hook: False -> the exact-fp32 MFMA GEMMs for the GRU input projections
 GRU_WGRAD_SB = True         # test / A-B hook: False -> three fp32-MFMA weight-gradient GEMMs per GruBlock instead of the fused pass
+GRU_WGRAD_FRAG = True       # test / A-B hook: False -> tatt_gru_wgrad_sb from dgi / dgh / hprev (round 3) instead of the fragment stream
 
 
 def _tokgemm(X1, X2, Wpk, bias, N, K, N1=None):
@@ -559,7 +560,15 @@ class GruBlockFn(Function):
         K1 = x.shape[-1]
         K = Wc.shape[1]
         x2 = x.reshape(-1, K1)
-        dgi, dgh, hprev = ops.gru32_bwd(gates, out, _c(dout).reshape(-1, 64), whh_f, whh_r, ctx.geom)
+        xb2 = xb.reshape(-1, K - K1) if xb is not None else None
+        # round 4: the recurrence leaves the weight-gradient pass's operands in MFMA fragment order (no dgh / hprev round trip)
+        use_frag = (GRU_WGRAD_FRAG and GRU_WGRAD_SB and K in (64, 128) and K1 == 64 and ops.gru_frag_ok(ctx.geom)
+                    and x2.is_contiguous() and (xb2 is None or xb2.is_contiguous()))
+        dgh = hprev = frag = None
+        if use_frag:
+            dgi, frag = ops.gru32_bwd_frag(gates, out, _c(dout).reshape(-1, 64), whh_f, whh_r, ctx.geom)
+        else:
+            dgi, dgh, hprev = ops.gru32_bwd(gates, out, _c(dout).reshape(-1, 64), whh_f, whh_r, ctx.geom)
         dxb = None
         if Wbk is not None and ctx.needs_input_grad[0] and (xb is None or ctx.needs_input_grad[1]):
             dx, dxb = _tokgemm(dgi, None, Wbk, None, K, 192, K1)      # dx | dxb = dgi Wp on the bf16 matrix cores (split operands)
@@ -572,13 +581,16 @@ class GruBlockFn(Function):
             dx = ops.linear_bwd_input(dgi, Wp, col0=0, ncols=K1).reshape(x.shape) if ctx.needs_input_grad[0] else None
             if xb is not None and ctx.needs_input_grad[1]:
                 dxb = ops.linear_bwd_input(dgi, Wp, col0=K1, ncols=K - K1).reshape(xb.shape)
+        geom = ctx.geom
 
         def param_grads():
             # weight-gradient GEMMs over the tokens; the bias gradients (column sums of dgi / dgh) ride along as a virtual ones column
             dbp, dbhh = ops.new(dgi, 192), ops.new(dgi, 192)
             dWp = ops.new(dgi, 192, K)
-            xb2 = xb.reshape(-1, K - K1) if xb is not None else None
-            if GRU_WGRAD_SB and K in (64, 128) and K1 == 64 and ops.gru_wgrad_fusable(dgi, dgh, x2, xb2, hprev):
+            if use_frag:
+                dWhh = ops.new(dgi, 192, 32)                          # compact: [forward; reverse]
+                ops.gru_wgrad_frag(frag, x2, xb2, geom, dWp, dWhh, dbp, dbhh)
+            elif GRU_WGRAD_SB and K in (64, 128) and K1 == 64 and ops.gru_wgrad_fusable(dgi, dgh, x2, xb2, hprev):
                 dWhh = ops.new(dgi, 192, 64)                          # one pass over the tokens for all four results (split-bf16 MFMA)
                 ops.gru_wgrad_sb(dgi, dgh, x2, xb2, hprev, dWp, dWhh, dbp, dbhh)
             else:
@@ -590,10 +602,11 @@ class GruBlockFn(Function):
             dwih_f, dwih_r = ops.new(dgi, 96, 64), ops.new(dgi, 96, 64)
             dwhh_f, dwhh_r = ops.new(dgi, 96, 32), ops.new(dgi, 96, 32)
             dWc, dbc = ops.new(dgi, 64, K), ops.new(dgi, 64)
-            ops.call("tatt_gru_tail", ops.P(dWp), ops.P(dbp), ops.P(Wc), ops.P(conv_b), ops.P(wih_f), ops.P(wih_r),
-                     ops.P(dwih_f), ops.P(dwih_r), ops.P(dWc), ops.P(dbc), K, ops.P(dWhh), ops.P(dwhh_f), ops.P(dwhh_r), ops.stream())
+            ops.call("tatt_gru_tail_c" if use_frag else "tatt_gru_tail", ops.P(dWp), ops.P(dbp), ops.P(Wc), ops.P(conv_b),
+                     ops.P(wih_f), ops.P(wih_r), ops.P(dwih_f), ops.P(dwih_r), ops.P(dWc), ops.P(dbc), K, ops.P(dWhh),
+                     ops.P(dwhh_f), ops.P(dwhh_r), ops.stream())
             return (dWc.reshape(ctx.wshape), dbc, dwih_f, dwhh_f, dbp[:96], dbhh[:96], dwih_r, dwhh_r, dbp[96:], dbhh[96:])
-        return (dx, dxb) + tuple(SIDE.submit(ctx.leaves, param_grads, dgi, dgh, hprev, x, xb, Wp, Wc)) + (None,)
+        return (dx, dxb) + tuple(SIDE.submit(ctx.leaves, param_grads, dgi, dgh, hprev, frag, x, xb, Wp, Wc)) + (None,)
 
 
 def gru_block(x, blk, vertical, xb=None):

@@ -674,18 +674,57 @@ def seq_geom(B, H, W, vertical):
     return B * H, W, 1, W, 0, 1
 
 
+GRU32_V2 = True             # test / A-B hook: False -> the first-generation recurrences (a 32-lane group per (sequence, direction))
+
+
 def gru32_fwd(gi, whh_f, bhh_f, whh_r, bhh_r, geom, save=False):
     """-> (out [tok][64], gates [tok][256] or None).  save: keep r, z, n and W_hn h + b_hn of every step for gru32_bwd."""
     out = new(gi, gi.shape[0], 64)
     gates = new(gi, gi.shape[0], 256) if save else None
-    call("tatt_gru32_fwd", P(gi), P(whh_f), P(bhh_f), P(whh_r), P(bhh_r), P(out), P(gates), *geom, stream())
+    call("tatt_gru32_fwd2" if GRU32_V2 else "tatt_gru32_fwd", P(gi), P(whh_f), P(bhh_f), P(whh_r), P(bhh_r), P(out), P(gates),
+         *geom, stream())
     return out, gates
 
 
 def gru32_bwd(gates, out, dout, whh_f, whh_r, geom):
     dgi, dgh, hprev = new(out, out.shape[0], 192), new(out, out.shape[0], 192), torch.empty_like(out)
-    call("tatt_gru32_bwd", P(gates), P(out), P(dout), P(whh_f), P(whh_r), P(dgi), P(dgh), P(hprev), *geom, stream())
+    if GRU32_V2:
+        call("tatt_gru32_bwd2", P(gates), P(out), P(dout), P(whh_f), P(whh_r), P(dgi), P(dgh), P(hprev), None, *geom, stream())
+    else:
+        call("tatt_gru32_bwd", P(gates), P(out), P(dout), P(whh_f), P(whh_r), P(dgi), P(dgh), P(hprev), *geom, stream())
     return dgi, dgh, hprev
+
+
+def gru_frag_ok(geom):
+    """Can tatt_gru32_bwd2 leave MFMA operand fragments for this sequence geometry?  (windows of 8 steps, K-steps of 4 windows)"""
+    nseq, T = geom[0], geom[1]
+    return GRU32_V2 and T % 8 == 0 and (nseq * (T // 8)) % 4 == 0
+
+
+def gru32_bwd_frag(gates, out, dout, whh_f, whh_r, geom):
+    """BPTT that leaves dgi (M, 192) and, instead of dgh / hprev, the weight-gradient pass's operands in fragment order."""
+    nseq, T = geom[0], geom[1]
+    dgi = new(out, out.shape[0], 192)
+    frag = new(out, nseq * T // 32 * 10240)
+    call("tatt_gru32_bwd2", P(gates), P(out), P(dout), P(whh_f), P(whh_r), P(dgi), None, None, P(frag), *geom, stream())
+    return dgi, frag
+
+
+GRU_WGRAD_FRAG_GROUPS = 128   # persistent work-groups (= partial slabs) of tatt_gru_wgrad_frag
+
+
+def gru_wgrad_frag(frag, x2, xb2, geom, dWp, dWhh_c, dbp, dbhh):
+    """dWp (192, K) = dgi^T [x2 | xb2], dbp = dgi.sum(0), dWhh_c (192, 32) = [dW_hh fwd; dW_hh rev], dbhh = dgh.sum(0) from the
+    fragment stream of gru32_bwd_frag: one streaming pass (tatt_gru_wgrad_frag) + two (deferrable) split-K reductions."""
+    _check_dev(frag)
+    nseq, T = geom[0], geom[1]
+    K = 128 if xb2 is not None else 64
+    G = max(1, min(nseq * T // 32, GRU_WGRAD_FRAG_GROUPS, 256))
+    ws1 = _split_ws(new(frag, G * 192 * K + G * 192))
+    ws2 = _split_ws(new(frag, G * 192 * 32 + G * 192))
+    call("tatt_gru_wgrad_frag", P(frag), P(x2), P(xb2), P(ws1), P(ws2), *geom, G, stream())
+    call("tatt_splitk_reduce", P(ws1), P(dWp), 192, K, G, 0, 0, 0.0, P(dbp), 192, stream())
+    call("tatt_splitk_reduce", P(ws2), P(dWhh_c), 192, 32, G, 0, 0, 0.0, P(dbhh), 192, stream())
 
 
 def attn_fwd(Q, K, V, pdrop, seed, site, need_weights=True):

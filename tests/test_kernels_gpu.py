@@ -942,3 +942,80 @@ def test_conv3_wgrad_split_bf16_vs_fp64(dev, B, H, W, Cin, Cout):
     finally:
         ops.CONV3_WGRAD_SB = True
     assert float((dw - dw32).abs().max() / dw32.abs().max()) < 3e-5
+
+
+# ------------------------------------------------------------------------------------------- second-generation BiGRU recurrences
+def _gru32_inputs(B, H, W, seed):
+    M = B * H * W
+    whh = [R(96, 32, seed=seed + k, scale=0.3) for k in range(2)]
+    bhh = [R(96, seed=seed + 2 + k, scale=0.3) for k in range(2)]
+    return R(M, 192, seed=seed + 4), whh, bhh, R(M, 64, seed=seed + 5)
+
+
+@pytest.mark.parametrize("vertical", [True, False])
+@pytest.mark.parametrize("B,H,W", [(2, 16, 64), (3, 5, 7), (1, 8, 12), (1, 1, 3)])
+def test_gru32_v2_matches_v1(dev, vertical, B, H, W):
+    """tatt_gru32_fwd2 / tatt_gru32_bwd2 (one wave per (sequence, direction), halves joined by v_permlane32_swap; model/tsrn.py:1072)
+    against the first-generation kernels on the same inputs: same outputs up to the order of fp32 summation.  Odd sequence counts
+    (padding waves), T not a multiple of the prefetch depth, T = 1."""
+    from tatt_amd import ops
+    gi, whh, bhh, dout = _gru32_inputs(B, H, W, 40)
+    geom = ops.seq_geom(B, H, W, vertical)
+    d = lambda t: t.to(dev)
+
+    def run(v2, saved=None):
+        ops.GRU32_V2 = v2
+        try:
+            out, gates = ops.gru32_fwd(d(gi), d(whh[0]), d(bhh[0]), d(whh[1]), d(bhh[1]), geom, save=True)
+            out_ns, none = ops.gru32_fwd(d(gi), d(whh[0]), d(bhh[0]), d(whh[1]), d(bhh[1]), geom, save=False)
+            assert none is None and torch.equal(out, out_ns)
+            o, g = saved if saved is not None else (out, gates)      # both backward generations start from the SAME saved forward
+            return (out, gates) + tuple(ops.gru32_bwd(g, o, d(dout), d(whh[0]), d(whh[1]), geom))
+        finally:
+            ops.GRU32_V2 = True
+
+    r1 = run(False)
+    r2 = run(True, saved=r1[:2])
+    for name, a, b in zip(("out", "gates", "dgi", "dgh", "hprev"), r1, r2):
+        err = float((a - b).abs().max() / (a.abs().max() + 1e-12))
+        assert err < 5e-6, (name, err)
+
+
+@pytest.mark.parametrize("vertical,B,H,W,cat,groups", [(True, 2, 16, 64, True, 128), (False, 2, 16, 64, False, 128), (False, 1, 8, 32, True, 3),
+                                                       (True, 3, 8, 16, True, 1), (True, 48, 16, 64, True, 128), (False, 48, 16, 64, False, 256)])
+def test_gru_wgrad_frag_vs_fp64(dev, vertical, B, H, W, cat, groups):
+    """tatt_gru32_bwd2 with fragment emission + tatt_gru_wgrad_frag + reductions: dW' = dgi^T [x | xb], db' = sum dgi, dW_hh (compact:
+    [forward; reverse]) = the diagonal blocks of dgh^T hprev, db_hh = sum dgh of one GruBlock (reference model/tsrn.py:1075-1084)
+    against fp64 products of the dgi / dgh / hprev the same recurrence writes without fragments; dgi itself must not change."""
+    from tatt_amd import ops
+    gi, whh, bhh, dout = _gru32_inputs(B, H, W, 50)
+    geom = ops.seq_geom(B, H, W, vertical)
+    assert ops.gru_frag_ok(geom)
+    M = B * H * W
+    x, xb = R(M, 64, seed=61), (R(M, 64, seed=62) if cat else None)
+    K = 128 if cat else 64
+    d = lambda t: None if t is None else t.to(dev)
+    out, gates = ops.gru32_fwd(d(gi), d(whh[0]), d(bhh[0]), d(whh[1]), d(bhh[1]), geom, save=True)
+    dgi, dgh, hprev = ops.gru32_bwd(gates, out, d(dout), d(whh[0]), d(whh[1]), geom)
+    dgi64, dgh64, hp64 = dgi.cpu().double(), dgh.cpu().double(), hprev.cpu().double()
+    xx = (torch.cat([x, xb], 1) if cat else x).double()
+    full = dgh64.t() @ hp64
+    ref = (dgi64.t() @ xx, dgi64.sum(0), torch.cat([full[:96, :32], full[96:, 32:]], 0), dgh64.sum(0))
+    old = ops.GRU_WGRAD_FRAG_GROUPS
+    ops.GRU_WGRAD_FRAG_GROUPS = groups
+    try:
+        outs = []
+        for _ in range(2):
+            dgi2, frag = ops.gru32_bwd_frag(gates, out, d(dout), d(whh[0]), d(whh[1]), geom)
+            assert torch.equal(dgi2, dgi)
+            dWp, dWhh = torch.empty(192, K, device=dev), torch.empty(192, 32, device=dev)
+            dbp, dbhh = torch.empty(192, device=dev), torch.empty(192, device=dev)
+            ops.gru_wgrad_frag(frag, d(x), d(xb), geom, dWp, dWhh, dbp, dbhh)
+            outs.append((dWp, dbp, dWhh, dbhh))
+    finally:
+        ops.GRU_WGRAD_FRAG_GROUPS = old
+    for name, got, want in zip(("dWp", "dbp", "dWhh", "dbhh"), outs[0], ref):
+        err = float((got.cpu().double() - want).abs().max() / want.abs().max())
+        assert err < 2e-5, (name, err)
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)                                  # deterministic
