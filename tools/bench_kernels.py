@@ -69,6 +69,9 @@ ys_ = torch.empty_like(xs_)
 timeit("conv3_fwd_sb_64_64", lambda: ops.call("tatt_conv3_c64_fwd_sb", ops.P(xs_), 64, 0, ops.P(wsb), ops.P(b64), ops.P(ys_), B, a.H, a.W, 64, 0, 0.0,
                                                None, None, 0, None, ops.stream()), 2.0 * B * a.H * a.W * 576 * 64, 2.0 * B * a.H * a.W * 64 * 4)
 timeit("conv3_wgrad_64_64", lambda: ops.conv_wgrad(x64, y64, 64, 3, 3), f33)
+ops.CONV3_WGRAD_SB = False
+timeit("conv3_wgrad_64_64_fp32", lambda: ops.conv_wgrad(x64, y64, 64, 3, 3), f33)
+ops.CONV3_WGRAD_SB = True
 xs = x64.permute(0, 3, 1, 2).contiguous().permute(0, 2, 3, 1)       # strided view -> generic implicit-GEMM kernel
 timeit("conv3_generic_64_64", lambda: ops.conv_fwd(xs, wp, b64, 64, 3, 3, out=y64), f33)
 w256 = R(256, 64, 3, 3) * 0.05
@@ -84,6 +87,9 @@ wt256d = ops.repack_weight(w256, 3)
 timeit("conv3_dgrad_t_256_64", lambda: ops.call("tatt_conv3_c64_fwd_t", ops.P(y256), ops.P(wt256d), None, ops.P(y64), B, 16, 64, 256, 64,
                                                  0, 0.0, ops.stream()), 4 * f33)
 timeit("conv3_wgrad_64_256", lambda: ops.conv_wgrad(x64, y256, 256, 3, 3), 4 * f33)
+ops.CONV3_WGRAD_SB = False
+timeit("conv3_wgrad_64_256_fp32", lambda: ops.conv_wgrad(x64, y256, 256, 3, 3), 4 * f33)
+ops.CONV3_WGRAD_SB = True
 xhr = R(B, 32, 128, 64)
 w99 = R(4, 64, 9, 9) * 0.02
 wp99 = ops.repack_weight(w99, 0)
@@ -127,15 +133,19 @@ timeit("ln_fwd", lambda: ops.ln_fwd(t64, t128, g64, b64), 0, M * 64 * 4 * 3)
 _, st = ops.ln_fwd(t64, t128, g64, b64)
 timeit("ln_bwd", lambda: ops.ln_bwd(t64, t128, o64, st, g64), 0, M * 64 * 4 * 4)
 
-# ---- GRU recurrences ----
+# ---- GRU recurrences: first generation (32-lane group per (sequence, direction)) vs second (one wave each), with / without fragments ----
 gi = R(M, 192)
 whh, bhh = R(96, 32) * 0.2, R(96) * 0.1
 for vert in (True, False):
     geom = ops.seq_geom(B, 16, 64, vert)
     nm = "v" if vert else "h"
-    timeit("gru32_fwd_" + nm, lambda: ops.gru32_fwd(gi, whh, bhh, whh, bhh, geom, save=True), 0, M * (192 + 64 + 256) * 4)
-    out, gates = ops.gru32_fwd(gi, whh, bhh, whh, bhh, geom, save=True)
-    timeit("gru32_bwd_" + nm, lambda: ops.gru32_bwd(gates, out, t64, whh, whh, geom), 0, M * (256 + 64 * 2 + 192 * 2 + 64) * 4)
+    for v2 in (False, True):
+        ops.GRU32_V2 = v2
+        sfx = nm + ("_v2" if v2 else "")
+        timeit("gru32_fwd_" + sfx, lambda: ops.gru32_fwd(gi, whh, bhh, whh, bhh, geom, save=True), 0, M * (192 + 64 + 256) * 4)
+        out, gates = ops.gru32_fwd(gi, whh, bhh, whh, bhh, geom, save=True)
+        timeit("gru32_bwd_" + sfx, lambda: ops.gru32_bwd(gates, out, t64, whh, whh, geom), 0, M * (256 + 64 * 2 + 192 * 2 + 64) * 4)
+    timeit("gru32_bwd_%s_v2_frag" % nm, lambda: ops.gru32_bwd_frag(gates, out, t64, whh, whh, geom), 0, M * (256 + 64 * 2 + 192 + 320) * 4)
 
 # ---- attention core ----
 seed = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -188,6 +198,19 @@ for G_ in (64, 128, 256):
     timeit("gru_wgrad_sb_G%d" % G_, lambda: ops.gru_wgrad_sb(gdgi, gdgh, gx, gxb, ghp, gWp, gWhh, gbp, gbhh), 2.0 * M * 192 * 192,
            M * 576 * 4)
 ops.GRU_WGRAD_GROUPS = 128
+# the same gradients from the recurrence's fragment stream (round 4): dgi | gn | hprev fragments 1.25 KB + x | xb 0.25 / 0.5 KB per token
+gWhc, gWp64 = torch.empty(192, 32, device=dev), torch.empty(192, 64, device=dev)
+for vert in (True, False):
+    geom = ops.seq_geom(B, 16, 64, vert)
+    out_, gates_ = ops.gru32_fwd(gi, whh, bhh, whh, bhh, geom, save=True)
+    _, gfrag = ops.gru32_bwd_frag(gates_, out_, t64, whh, whh, geom)
+    for G_ in (64, 128, 256):
+        ops.GRU_WGRAD_FRAG_GROUPS = G_
+        timeit("gru_wgrad_frag_%s_G%d" % ("v" if vert else "h", G_), lambda: ops.gru_wgrad_frag(gfrag, gx, gxb, geom, gWp, gWhc, gbp, gbhh),
+               2.0 * M * 192 * 160, M * (320 + 128) * 4)
+    ops.GRU_WGRAD_FRAG_GROUPS = 128
+    timeit("gru_wgrad_frag_%s_k64" % ("v" if vert else "h"), lambda: ops.gru_wgrad_frag(gfrag, gx, None, geom, gWp64, gWhc, gbp, gbhh),
+           2.0 * M * 192 * 96, M * (320 + 64) * 4)
 
 # ---- split-bf16 token projections (csrc/tokgemm.hip) ----
 for (N_, K_, K1_, N1_) in ((192, 128, 64, 192), (192, 64, 64, 192), (128, 192, 192, 64), (64, 192, 192, 64)):
