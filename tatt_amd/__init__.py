@@ -12,4 +12,29 @@ from .tsrn import TSRN, TSRN_TL_TRANS  # noqa: F401
 from .tbsrn import TBSRN  # noqa: F401
 from .crnn import CRNN  # noqa: F401
 
-__all__ = ["TSRN", "TSRN_TL_TRANS", "TBSRN", "CRNN"]
+__all__ = ["TSRN", "TSRN_TL_TRANS", "TBSRN", "CRNN", "set_arithmetic", "get_arithmetic"]
+
+
+def set_arithmetic(mode: str) -> None:
+    """Process-wide choice of the arithmetic inside the GEMM-shaped kernels of the path (storage, accumulation and results are fp32
+    either way; INTEGRATION.md "Arithmetic"):
+
+      "split_bf16" (default) -- the 64-channel 3x3 convolutions (forward, data and weight gradients), the GruBlock projections and
+          the GruBlock weight gradients run on the bf16 matrix cores with every fp32 operand split a = hi + lo and
+          a b ~ hi hi + hi lo + lo hi: 2^-16 relative per product, ~16-17 mantissa bits instead of 24
+          (profiles/r03_split_bf16_probe.txt: eval SR moves 1.1e-6, gradients ~1e-5 relative);
+      "fp32" -- the same operators on v_mfma_f32_* (exact fp32 products), about 0.7 ms per training step slower at B = 48.
+
+    Call it before building a Trainer / capturing a hipGraph: captured graphs keep the kernels they were captured with."""
+    from . import functional as _F, ops as _ops
+    if mode not in ("split_bf16", "fp32"):
+        raise ValueError("arithmetic must be 'split_bf16' or 'fp32', got %r" % (mode,))
+    on = mode == "split_bf16"
+    _ops.CONV3_SB = _ops.CONV3_WGRAD_SB = on
+    _F.TOKGEMM_SB = _F.GRU_WGRAD_SB = on
+
+
+def get_arithmetic() -> str:
+    from . import functional as _F, ops as _ops
+    flags = (_ops.CONV3_SB, _ops.CONV3_WGRAD_SB, _F.TOKGEMM_SB, _F.GRU_WGRAD_SB)
+    return "split_bf16" if all(flags) else ("fp32" if not any(flags) else "mixed")

@@ -495,6 +495,12 @@ def gru_precompose(blocks):
     _PRE.table = outs
 
 
+def gru_precompose_done():
+    """End of the generator's forward: drop whatever `gru_precompose` composed and no block popped (the table must not keep
+    composed / packed weights of one forward alive until the next)."""
+    _PRE.table = {}
+
+
 TOKGEMM_SB = True           # test / A-B hook: False -> the exact-fp32 MFMA GEMMs for the GRU input projections
 GRU_WGRAD_SB = True         # test / A-B hook: False -> three fp32-MFMA weight-gradient GEMMs per GruBlock instead of the fused pass
 GRU_WGRAD_FRAG = True       # test / A-B hook: False -> tatt_gru_wgrad_sb from dgi / dgh / hprev (round 3) instead of the fragment stream

@@ -171,6 +171,7 @@ def evaluate(model: torch.nn.Module, batches: Iterable, prior_fn=None, recognize
     n = 0
     correct = {"sr": 0, "lr": 0, "hr": 0}
     n_img = 0
+    rec_was_training = recognizer.training if recognizer is not None else False
     if recognizer is not None:
         recognizer.eval()
     for batch in batches:
@@ -188,6 +189,8 @@ def evaluate(model: torch.nn.Module, batches: Iterable, prior_fn=None, recognize
                 correct[name] += sum(str_filt(p, voc_type) == str_filt(t, voc_type) for p, t in zip(pred, labels))
             n_img += len(labels)
     model.train(was_training)
+    if recognizer is not None:
+        recognizer.train(rec_was_training)               # e.g. TextPriorSR.tpg under training: BatchNorm must not stay in eval mode
     res = {"psnr": float(psnr_sum) / max(n, 1), "ssim": float(ssim_sum) / max(n, 1), "n_batches": n}
     if n_img:
         res.update(accuracy=round(correct["sr"] / n_img, 4), accuracy_lr=round(correct["lr"] / n_img, 4),

@@ -217,10 +217,10 @@ def _packed_numel(shape, mode):
 
 class _PackedHolder:
     """Packed layouts of ONE filter: {mode: (buffer, torch version counter at packing time)}.  Owned by the parameter object."""
-    __slots__ = ("bufs", "key", "__weakref__")
+    __slots__ = ("bufs", "key", "owner", "__weakref__")
 
     def __init__(self):
-        self.bufs, self.key = {}, None
+        self.bufs, self.key, self.owner = {}, None, None      # owner: weak reference to the parameter object
 
 
 class _PackedFilters:
@@ -252,6 +252,7 @@ class _PackedFilters:
                 self.reg.pop(h.key, None)                # the old address is no longer this filter's
                 h.bufs = {}
             h.key = key
+            h.owner = weakref.ref(w)
             if len(self.reg) >= 4096:
                 self.reg = {k: v for k, v in self.reg.items() if v() is not None}
             self.reg[key] = weakref.ref(h)
@@ -269,10 +270,17 @@ class _PackedFilters:
         return out
 
     def _live(self, device=None):
+        """Entries whose filter still lives where the key says.  The weights are read through the raw address in the key (one batched
+        launch), so an entry whose owner is gone or has been re-homed since (FlatParams moved `.data`, `.to()`, a `.data =`
+        assignment) must NOT be refreshed from that address -- the block may have been freed.  Such entries are dropped: the next
+        `get()` re-registers the filter under its new address and packs it afresh."""
         for key, r in list(self.reg.items()):
             h = r()
-            if h is None:
+            w = h.owner() if (h is not None and h.owner is not None) else None
+            if h is None or w is None or (w.data_ptr(), tuple(w.shape), str(w.device)) != key:
                 del self.reg[key]
+                if h is not None and h.key == key:
+                    h.bufs, h.key = {}, None
             elif device is None or key[2] == str(device):
                 for mode, (out, _) in h.bufs.items():
                     yield key, mode, out
@@ -399,9 +407,14 @@ def conv2d_forward(x_bhwc, weight_oihw, bias, act=ACT_NONE):
     return conv_fwd(x_bhwc, repack_weight(weight_oihw, 0), bias, Cout, KH, KW, act=act)
 
 
-def conv3_bn_fusable(x_bhwc, weight_oihw):
+def conv3_bn_fusable(x_bhwc, weight_oihw, bn=None):
     """The 3x3 64 -> 64 convolutions of the residual blocks / block7 on a contiguous NHWC map whose width is a multiple of 64: the
-    weight-stationary kernel can fold the producer's BatchNorm into its input staging and emit this layer's batch statistics."""
+    weight-stationary kernel can fold the producer's BatchNorm into its input staging and emit this layer's batch statistics.
+    `bn`: the nn.BatchNorm2d holder that follows -- the folded path implements the reference's configuration (affine, running
+    statistics with a fixed momentum, model/tsrn.py:878,886); cumulative averaging (momentum=None), affine=False or
+    track_running_stats=False take the unfused operator chain."""
+    if bn is not None and (bn.momentum is None or not bn.affine or not bn.track_running_stats or bn.running_mean is None):
+        return False
     return (tuple(weight_oihw.shape) == (64, 64, 3, 3) and x_bhwc.is_contiguous()
             and x_bhwc.shape[3] == 64 and x_bhwc.shape[2] % 64 == 0)
 

@@ -52,20 +52,28 @@ def calculate_psnr(img1, img2):
 
 
 class TextPriorSR(torch.nn.Module):
-    """The generator together with its trainable text-prior generator, as the reference's loop composes them
-    (interfaces/super_resolution.py:786-815): lr image -> parse_crnn_data -> CRNN student -> softmax prior -> SR(x, prior).
-    Gradients of the SR loss reach the recogniser through the prior.  With a frozen `teacher` recogniser the step also carries
-    the prior-distillation term of the reference, `sem_loss(student prior on LR, teacher prior on HR) * 100`
-    (super_resolution.py:767,879): `Trainer` adds `extra_loss(hr)` to the image loss."""
+    """The generator together with its trainable text-prior generator, as the reference's loop composes them: lr image ->
+    parse_crnn_data -> CRNN student -> softmax prior -> SR(x, prior).  With a frozen `teacher` recogniser the step also carries the
+    prior-distillation term of the reference, `sem_loss(student prior on LR, teacher prior on HR) * 100`
+    (super_resolution.py:767,879): `Trainer` adds `extra_loss(hr)` to the image loss.
 
-    def __init__(self, sr, tpg, teacher=None, in_width=100):
+    `detach_prior` selects which of the reference's two compositions is built:
+      * True (default) -- `--arch tatt` and the rest of ABLATION_SET (interfaces/super_resolution.py:59-61, 770-914): the SR generator
+        receives `label_vecs_final.detach()` (:873); the student learns from the distillation term alone; the second forward of the
+        TSSIM recipe (:911) gets the SAME detached prior (`forward(x, reuse_prior=True)`: the student is not run again);
+      * False -- `--arch tsrn_tl` / `tsrn_tl_wmask` (:729-768): `model(images_lr, label_vecs_final)`, gradients of the SR loss reach the
+        recogniser through the prior."""
+
+    def __init__(self, sr, tpg, teacher=None, in_width=100, detach_prior=True):
         super().__init__()
         self.sr, self.tpg, self.in_width = sr, tpg, in_width
+        self.detach_prior = bool(detach_prior)
         if teacher is not None:                              # the reference calls aster.eval() and never optimises it
             teacher.eval()
             teacher.requires_grad_(False)
         object.__setattr__(self, "_teacher", teacher)        # frozen: deliberately NOT a registered sub-module / parameter owner
         self._student_probs = None
+        self._prior_cache = None                             # detached prior of the last full forward (recipe's second forward)
 
     def _apply(self, fn, *args, **kwargs):                 # .to(device) moves the (unregistered) teacher too
         super()._apply(fn, *args, **kwargs)
@@ -83,8 +91,8 @@ class TextPriorSR(torch.nn.Module):
 
     # -- Trainer protocol: the SR generator's stages, then one more for the recogniser --------------------------------------
     def grad_buckets(self, dp=False):
-        """The student receives gradient from two places -- the distillation loss (first backward stage) and the SR generator's
-        text encoder (stage "tp") -- so its own backward is a last stage, "tpg", fed by the sum of both (forward() cuts there)."""
+        """The student receives gradient from the distillation loss (first backward stage) and -- with detach_prior=False -- from the
+        SR generator's text encoder (stage "tp"), so its own backward is a last stage, "tpg", fed by their sum (forward() cuts there)."""
         b = [(n, list(ps)) for n, ps in self.sr.grad_buckets(dp)]
         b.append(("tpg", list(self.tpg.parameters())))
         return b
@@ -108,13 +116,20 @@ class TextPriorSR(torch.nn.Module):
         T, B, C = logits.shape
         return Fh.SoftmaxRowsFn.apply(logits.reshape(T * B, C)).reshape(T, B, C)
 
-    def forward(self, x):
+    def forward(self, x, reuse_prior=False):
+        if reuse_prior:                  # interfaces/super_resolution.py:911: the first forward's prior, detached; no second student pass
+            assert self._prior_cache is not None, "reuse_prior needs a full forward first"
+            return self.sr(x, self._prior_cache)
         probs = self._probs(self.tpg, x)
         cuts = getattr(self.sr, "_grad_cuts", None) if self.training else None
-        # staged backward: both consumers of the prior continue on their own detached copy; stage "tpg" adds their gradients up
+        # staged backward: every consumer of the prior continues on its own detached copy; stage "tpg" adds their gradients up
         self._student_probs = cuts.cut("tpg", probs) if cuts else probs
-        p_sr = cuts.cut("tpg", probs) if cuts else probs
+        if self.detach_prior:
+            p_sr = probs.detach()
+        else:
+            p_sr = cuts.cut("tpg", probs) if cuts else probs
         prior = p_sr.permute(1, 0, 2).unsqueeze(1).permute(0, 3, 1, 2)            # (B, 37, 1, T)
+        self._prior_cache = prior.detach()
         return self.sr(x, prior)
 
     def extra_loss(self, hr):
@@ -176,12 +191,14 @@ class TssimRecipe:
         # generators that take no external prior (TSRN, TBSRN, TextPriorSR: its student recogniser reads the rotated LR image, as the
         # reference's loop does, interfaces/super_resolution.py:786-815) are called with the image alone
         fwd = (lambda im: model(im, tp)) if tp is not None else model
+        # a generator with its own student recogniser: ONE student pass per step, its prior detached and shared by both forwards (:873,911)
+        fwd_ret = (lambda im: model(im, reuse_prior=True)) if (tp is None and hasattr(model, "tpg")) else fwd
         out = fwd(x_rot)
         sr = out[0] if isinstance(out, tuple) else out
         # the distillation term belongs to the FIRST forward (student prior on x_rot vs teacher prior on hr_rot, :767,879); it has to be
         # taken before the second forward overwrites the model's cached student prior
         extra = model.extra_loss(hr_rot) if hasattr(model, "extra_loss") else None
-        out = fwd(x_ret)
+        out = fwd_ret(x_ret)
         sr_ret = out[0] if isinstance(out, tuple) else out
         l_img = image_loss_mean(sr, hr_rot, scale=100.0)
         l_tssim = (1.0 - TRI_SSIM()(rot(sr_ret, self.theta_pos), sr, hr_rot)) * 10.0

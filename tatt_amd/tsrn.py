@@ -279,7 +279,7 @@ def _gru_block(x, blk: GruBlock, vertical, x_cat=None):
 
 def _srb(x, tp_map, blk: RecurrentResidualBlock):
     """RecurrentResidualBlock[TL].forward (model/tsrn.py:862-871, 892-910).  (num_batches_tracked: bumped by the generator.)"""
-    if blk.bn1.training and blk.bn2.training and ops.conv3_bn_fusable(x, blk.conv1.weight) and ops.conv3_bn_fusable(x, blk.conv2.weight):
+    if blk.bn1.training and blk.bn2.training and ops.conv3_bn_fusable(x, blk.conv1.weight, blk.bn1) and ops.conv3_bn_fusable(x, blk.conv2.weight, blk.bn2):
         # conv(+stats) | finish | conv(+bn1, mish on the way in, +stats) | finish | apply bn2: 5 launches instead of 8, and the
         # normalised + activated map between the two convolutions never exists in HBM
         y1, st1 = Fh.conv_bn(x, blk.conv1, blk.bn1)
@@ -563,7 +563,7 @@ class _GeneratorBase(_TrainPathMixin, nn.Module):
         if cuts and k > 0:
             h = cuts.cut("srb%d" % (k - 1), h)
         b7 = getattr(self, "block%d" % (k + 2))
-        if b7[1].training and ops.conv3_bn_fusable(h, b7[0].weight):
+        if b7[1].training and ops.conv3_bn_fusable(h, b7[0].weight, b7[1]):
             y7, st7 = Fh.conv_bn(_cc(h), b7[0], b7[1])
             h = Fh.bn_apply_stats(y7, st7, b7[1], ACT_NONE)
         else:
@@ -579,6 +579,7 @@ class _GeneratorBase(_TrainPathMixin, nn.Module):
         u = Fh.conv2d(u, last.weight, last.bias)
         feats[str(k + 3)] = u
         sr = Fh.ActFn.apply(u, ACT_TANH)                         # reference :675
+        Fh.gru_precompose_done()                                 # composed projections no block consumed do not outlive the forward
         self.block = {kk: _nchw(v) for kk, v in feats.items()}
         return _nchw(sr), tp_ret, pr_weights, b1
 

@@ -163,8 +163,9 @@ def test_general_maxpool_and_valid_conv(dev):
 
 @pytest.mark.gpu
 def test_sr_loss_trains_the_prior_generator(dev):
-    """TextPriorSR: lr image -> CRNN student -> softmax prior -> TSRN_TL_TRANS -> ImageLoss; the SR output and the gradients that
-    reach the recogniser through the prior against the oracle composition (dropout off, STN off for conditioning)."""
+    """TextPriorSR(detach_prior=False) = the reference's `tsrn_tl` composition (interfaces/super_resolution.py:729-768): lr image -> CRNN
+    student -> softmax prior -> TSRN_TL_TRANS -> ImageLoss; the SR output and the gradients that reach the recogniser through the prior
+    against the oracle composition (dropout off, STN off for conditioning)."""
     import tatt_amd
     from oracle import tatt_oracle as O
     from oracle.fixtures import make_inputs
@@ -180,7 +181,7 @@ def test_sr_loss_trains_the_prior_generator(dev):
     teacher.load_state_dict(sd_teacher)
     sd_sr = {k: v.detach().clone() for k, v in sr_m.state_dict().items()}
     sd_tpg = {k: v.detach().clone() for k, v in tpg.state_dict().items()}
-    m = TextPriorSR(sr_m, tpg, teacher=teacher).to(dev).train()
+    m = TextPriorSR(sr_m, tpg, teacher=teacher, detach_prior=False).to(dev).train()
     assert not teacher.training and len([k for k, _ in m.named_parameters() if "teacher" in k]) == 0
     sr_m.infoGen.dropout_on = False
     x, _, hr = make_inputs(3, seed=11)
@@ -223,7 +224,7 @@ def test_text_prior_sr_with_teacher_through_the_trainer(dev):
         tpg.load_state_dict(_sd())
         teacher = tatt_amd.CRNN(32, 1, 37, 256)
         teacher.load_state_dict(randomize_state_dict(teacher.state_dict(), seed=5))
-        m = TextPriorSR(sr_m, tpg, teacher=teacher).to(dev).train()
+        m = TextPriorSR(sr_m, tpg, teacher=teacher, detach_prior=False).to(dev).train()
         sr_m.infoGen.dropout_on = False
         return m
     x, _, hr = make_inputs(3, seed=11)
@@ -247,15 +248,16 @@ def test_text_prior_sr_with_teacher_through_the_trainer(dev):
 
 @pytest.mark.gpu
 def test_tssim_recipe_with_text_prior_generator_and_plain_tsrn(dev):
-    """The shipped configuration (train_TATT.sh: --use_distill --tssim_loss --rotate_train=5): the student recogniser reads the
-    ROTATED LR image and the distillation term (student prior on x_rot vs teacher prior on hr_rot, x100) is added to the recipe's
-    loss (reference interfaces/super_resolution.py:786-815,879,910-914).  Trainer step (staged) == the same composition written
-    out with plain forwards and a single-pass backward; the recipe also drives generators that take no prior (TSRN)."""
+    """The shipped configuration (train_TATT.sh: --arch tatt --use_distill --tssim_loss --rotate_train=5), reference
+    interfaces/super_resolution.py:770-914: the student recogniser reads the ROTATED LR image ONCE per step; the SR generator gets that
+    prior DETACHED in both of its forwards (:873 and :911 pass `label_vecs_final.detach()`), so the student learns from the
+    distillation term alone (student prior on x_rot vs teacher prior on hr_rot, x100, :879).  Trainer step (staged) == that composition
+    written out operator by operator with a single-pass backward; the recipe also drives generators that take no prior (TSRN)."""
     import tatt_amd
     from oracle.fixtures import make_inputs
     from tatt_amd import functional as Fh
     from tatt_amd.losses import TRI_SSIM
-    from tatt_amd.train import TextPriorSR, Trainer, TssimRecipe, image_loss_mean
+    from tatt_amd.train import TextPriorSR, Trainer, TssimRecipe, image_loss_mean, semantic_loss
     kw = dict(scale_factor=2, width=128, height=32, STN=False, mask=True, srb_nums=5, hidden_units=32)
 
     def build():
@@ -267,6 +269,7 @@ def test_tssim_recipe_with_text_prior_generator_and_plain_tsrn(dev):
         teacher = tatt_amd.CRNN(32, 1, 37, 256)
         teacher.load_state_dict(randomize_state_dict(teacher.state_dict(), seed=5))
         m = TextPriorSR(sr_m, tpg, teacher=teacher).to(dev).train()
+        assert m.detach_prior                                   # the default is the reference's `tatt` composition
         sr_m.infoGen.dropout_on = False
         return m
     x, _, hr = make_inputs(3, seed=11)
@@ -279,20 +282,34 @@ def test_tssim_recipe_with_text_prior_generator_and_plain_tsrn(dev):
     with torch.no_grad():
         x_rot, hr_rot = rot(x, rec.theta_pos), rot(hr, rec.theta_pos)
         x_ret = rot(x_rot, rec.theta_neg)
-    sr = m(x_rot)[0]
-    dist = m.extra_loss(hr_rot)
-    sr_ret = m(x_ret)[0]
+        gt = m._probs(m._teacher, hr_rot)
+    label_vecs = m._probs(m.tpg, x_rot)                                           # the ONE student pass of the step (T, B, 37)
+    label_vecs_final = label_vecs.permute(1, 0, 2).unsqueeze(1).permute(0, 3, 1, 2)
+    sr = m.sr(x_rot, label_vecs_final.detach())[0]                                # :873
+    sr_ret = m.sr(x_ret, label_vecs_final.detach())[0]                            # :911
+    dist = semantic_loss(label_vecs, gt) * 100.0                                  # :879
     loss = image_loss_mean(sr, hr_rot, scale=100.0) + (1.0 - TRI_SSIM()(rot(sr_ret, rec.theta_pos), sr, hr_rot)) * 10.0 + dist
     loss.backward()
     want, g_ref = float(loss), m.tpg.rnn[1].embedding.weight.grad.clone()
+    g_sr_ref = m.sr.block2.conv1.weight.grad.clone()
     assert float(dist) > 0.0
+    # the student's gradient is the distillation term's alone
+    m2 = build()
+    (semantic_loss(m2._probs(m2.tpg, x_rot), gt) * 100.0).backward()
+    assert rel_err(m2.tpg.rnn[1].embedding.weight.grad, g_ref) < 1e-6
+    calls = []
     for use_graph in (False, True):
         m = build()
+        hook = m.tpg.register_forward_hook(lambda *a: calls.append(1))
         tr = Trainer(m, use_graph=use_graph, warmup_eager=2, recipe=TssimRecipe(5.0, seed=4))
+        del calls[:]
         got = float(tr.step(x, None, hr))
+        assert len(calls) == 1, calls                            # one student pass per step (the second forward reuses the prior)
+        hook.remove()
         assert abs(got - want) < 2e-6 * abs(want), (use_graph, got, want)
         if not use_graph:
             assert rel_err(m.tpg.rnn[1].embedding.weight.grad, g_ref) < 1e-4
+            assert rel_err(m.sr.block2.conv1.weight.grad, g_sr_ref) < 1e-4
         ls = [float(tr.step(x, None, hr)) for _ in range(4)]
         assert all(l == l for l in ls)
     # a generator without a prior under the recipe

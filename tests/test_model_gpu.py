@@ -567,7 +567,7 @@ def test_gradients_vs_fp64(dev):
 
 
 def test_text_prior_sr_trainer_step_clips_per_model(dev):
-    """TextPriorSR through the Trainer: the SR generator is clipped by ITS OWN gradient norm, the recogniser is not clipped
+    """TextPriorSR (tsrn_tl composition: the SR loss reaches the student) through the Trainer: the SR generator is clipped by ITS OWN gradient norm, the recogniser is not clipped
     (reference: `for model in model_list: clip_grad_norm_(model.parameters(), 0.25)`, interfaces/super_resolution.py:1082-1083,
     model_list holds the SR models only); post-Adam weights of both against the oracle composition."""
     import tatt_amd
@@ -581,7 +581,7 @@ def test_text_prior_sr_trainer_step_clips_per_model(dev):
     tpg.load_state_dict(randomize_state_dict(tpg.state_dict()))
     sd_sr = {k: v.detach().clone() for k, v in sr_m.state_dict().items()}
     sd_tpg = {k: v.detach().clone() for k, v in tpg.state_dict().items()}
-    m = TextPriorSR(sr_m, tpg).to(dev).train()
+    m = TextPriorSR(sr_m, tpg, detach_prior=False).to(dev).train()
     sr_m.infoGen.dropout_on = False
     x, _, hr = make_inputs(3, seed=11)
     tr = Trainer(m, use_graph=False)
