@@ -273,6 +273,23 @@ __device__ __forceinline__ void half_both(float v, float& lo, float& hi) {   // 
     lane32_swap(lo, hi);
 }
 
+// The kernels are bound by INSTRUCTION ISSUE, not by latency (PMC, profiles/r04_c_pmc_gru32_*: a wave spends 57 % of its cycles
+// issuing, ~4 cycles per instruction, ~160 instructions per backward step), so the step is written for instruction count: token
+// addresses are scalar (wave-uniform sequence / direction) and enter the loads / stores as an SGPR base + one per-lane byte offset
+// that never changes; the dot products run as v_pk_fma_f32 on register pairs; nothing is predicated on the half (both halves hold
+// identical values wherever only one would need to store: same value, same address).  32-bit token arithmetic: the host checks
+// that every byte offset fits 32 bits.
+typedef float gr_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float ldg32(const float* base, unsigned byte_off) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ void stg32(float* base, unsigned byte_off, float v) {
+    *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+__device__ __forceinline__ int seq_base_i(const SeqGeom& g, int s) {
+    return (s / g.s_in) * (int)g.stride_hi + (s % g.s_in) * (int)g.stride_lo;
+}
+
 template <bool SAVE>
 __global__ __launch_bounds__(256) void gru32_fwd2_kernel(const float* __restrict__ gi,
                                                          const float* __restrict__ whh_f, const float* __restrict__ bhh_f,
@@ -286,53 +303,53 @@ __global__ __launch_bounds__(256) void gru32_fwd2_kernel(const float* __restrict
     const int seq = min(sd >> 1, g.nseq - 1), dir = sd & 1;
     const float* whh = dir ? whh_r : whh_f;
     const float* bhh = dir ? bhh_r : bhh_f;
-    float wr[16], wz[16], wn[16];                                   // this half's 16 columns of the three gate rows of unit j
+    gr_f32x2 wr[8], wz[8], wn[8];                                   // this half's 16 columns of the three gate rows of unit j, as pairs
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        wr[k] = whh[(0 * 32 + j) * 32 + 16 * half + k];
-        wz[k] = whh[(1 * 32 + j) * 32 + 16 * half + k];
-        wn[k] = whh[(2 * 32 + j) * 32 + 16 * half + k];
+    for (int k = 0; k < 8; ++k) {
+        wr[k] = (gr_f32x2){whh[(0 * 32 + j) * 32 + 16 * half + 2 * k], whh[(0 * 32 + j) * 32 + 16 * half + 2 * k + 1]};
+        wz[k] = (gr_f32x2){whh[(1 * 32 + j) * 32 + 16 * half + 2 * k], whh[(1 * 32 + j) * 32 + 16 * half + 2 * k + 1]};
+        wn[k] = (gr_f32x2){whh[(2 * 32 + j) * 32 + 16 * half + 2 * k], whh[(2 * 32 + j) * 32 + 16 * half + 2 * k + 1]};
     }
     const float br = half ? 0.f : bhh[j], bz = half ? 0.f : bhh[32 + j], bn = half ? 0.f : bhh[64 + j];   // biases enter once
     const int T = g.T;
-    const long st_t = dir ? -g.stride_t : g.stride_t;
-    const long tok0 = seq_base(g, seq) + (dir ? (long)(T - 1) * g.stride_t : 0);
+    const int st_t = dir ? -(int)g.stride_t : (int)g.stride_t;
+    const int tok0 = seq_base_i(g, seq) + (dir ? (T - 1) * (int)g.stride_t : 0);
+    const unsigned lane4 = lane * 4, j4 = j * 4;
     const float* gq = gi + dir * 96;
+    float* oq = out + dir * 32;
+    float* sq = gates + dir * 128;
     auto fetch = [&](int step, float& a, float& b) {
-        const float* q = gq + (tok0 + (long)min(step, T - 1) * st_t) * 192;
-        a = q[lane];                                                // half 0: r gate of unit j, half 1: z gate
-        b = q[64 + j];                                              // n gate (both halves)
+        const float* q = gq + (unsigned)(tok0 + min(step, T - 1) * st_t) * 192u;     // (scalar)
+        a = ldg32(q, lane4);                                        // half 0: r gate of unit j, half 1: z gate
+        b = ldg32(q + 64, j4);                                      // n gate (both halves)
     };
     float h = 0.f;
     auto one_step = [&](int step, float grz, float gn) {
         hs[wave][j] = h;                                            // both halves hold the same h: same value, same address
         wave_lds_sync();
-        float ar0 = br, ar1 = 0.f, az0 = bz, az1 = 0.f, an0 = bn, an1 = 0.f;
+        gr_f32x2 ar = (gr_f32x2){br, 0.f}, az = (gr_f32x2){bz, 0.f}, an2 = (gr_f32x2){bn, 0.f};
         const f32x4* hv = reinterpret_cast<const f32x4*>(hs[wave] + 16 * half);
 #pragma unroll
         for (int k4 = 0; k4 < 4; ++k4) {
             const f32x4 hh = hv[k4];
-            ar0 = fmaf(wr[k4 * 4 + 0], hh[0], ar0); ar1 = fmaf(wr[k4 * 4 + 1], hh[1], ar1);
-            az0 = fmaf(wz[k4 * 4 + 0], hh[0], az0); az1 = fmaf(wz[k4 * 4 + 1], hh[1], az1);
-            an0 = fmaf(wn[k4 * 4 + 0], hh[0], an0); an1 = fmaf(wn[k4 * 4 + 1], hh[1], an1);
-            ar0 = fmaf(wr[k4 * 4 + 2], hh[2], ar0); ar1 = fmaf(wr[k4 * 4 + 3], hh[3], ar1);
-            az0 = fmaf(wz[k4 * 4 + 2], hh[2], az0); az1 = fmaf(wz[k4 * 4 + 3], hh[3], az1);
-            an0 = fmaf(wn[k4 * 4 + 2], hh[2], an0); an1 = fmaf(wn[k4 * 4 + 3], hh[3], an1);
+            const gr_f32x2 h01 = (gr_f32x2){hh[0], hh[1]}, h23 = (gr_f32x2){hh[2], hh[3]};
+            ar = wr[2 * k4] * h01 + ar;  az = wz[2 * k4] * h01 + az;  an2 = wn[2 * k4] * h01 + an2;
+            ar = wr[2 * k4 + 1] * h23 + ar;  az = wz[2 * k4 + 1] * h23 + az;  an2 = wn[2 * k4 + 1] * h23 + an2;
         }
         wave_lds_sync();
-        const float ar = half_sum(ar0 + ar1), az = half_sum(az0 + az1), an = half_sum(an0 + an1);
+        const float sr = half_sum(ar[0] + ar[1]), sz = half_sum(az[0] + az[1]), an = half_sum(an2[0] + an2[1]);
         float gr, gz;
         half_both(grz, gr, gz);
-        const float r = sigmoid_fast(gr + ar);
-        const float z = sigmoid_fast(gz + az);
+        const float r = sigmoid_fast(gr + sr);
+        const float z = sigmoid_fast(gz + sz);
         const float n = tanh_fast(gn + r * an);
         h = (1.f - z) * n + z * h;
-        const long tok = tok0 + (long)step * st_t;
-        if (half == 0) out[tok * 64 + dir * 32 + j] = h;
+        const unsigned tok = (unsigned)(tok0 + step * st_t);        // (scalar)
+        stg32(oq + tok * 64u, j4, h);
         if (SAVE) {
-            float* q = gates + tok * 256 + dir * 128;               // [r | z | n | W_hn h + b_hn], 32 each: two 256-byte rows
-            q[lane] = half ? z : r;
-            q[64 + lane] = half ? an : n;
+            float* q = sq + tok * 256u;                             // [r | z | n | W_hn h + b_hn], 32 each: two 256-byte rows
+            stg32(q, lane4, half ? z : r);
+            stg32(q + 64, lane4, half ? an : n);
         }
     };
     {
@@ -358,10 +375,18 @@ __global__ __launch_bounds__(256) void gru32_fwd2_kernel(const float* __restrict
         one_step(s0, a, b);
     }
 }
+// every byte offset the second-generation kernels form must fit 32 bits: (largest token index + 1) * 1024 bytes (the gates rows)
+static bool gru2_fits(int nseq, int T, int s_in, long stride_hi, long stride_lo, long stride_t) {
+    if (s_in <= 0 || stride_hi < 0 || stride_lo < 0 || stride_t <= 0) return false;
+    const long last = (long)((nseq - 1) / s_in) * stride_hi + (long)(s_in - 1) * stride_lo + (long)(T - 1) * stride_t;
+    return last + 1 < (1L << 22);
+}
 TATT_API int tatt_gru32_fwd2(const float* gi, const float* whh_f, const float* bhh_f, const float* whh_r,
                              const float* bhh_r, float* out, float* gates, int nseq, int T, int s_in, long stride_hi,
                              long stride_lo, long stride_t, hipStream_t st) {
     if (nseq <= 0 || T <= 0) return 0;
+    if (!gru2_fits(nseq, T, s_in, stride_hi, stride_lo, stride_t))          // huge token grids: the first generation (64-bit addressing)
+        return tatt_gru32_fwd(gi, whh_f, bhh_f, whh_r, bhh_r, out, gates, nseq, T, s_in, stride_hi, stride_lo, stride_t, st);
     SeqGeom g = {nseq, T, s_in, stride_hi, stride_lo, stride_t};
     const dim3 grid(cdiv(2L * nseq, 4)), block(256);
     if (gates) hipLaunchKernelGGL(gru32_fwd2_kernel<true>, grid, block, 0, st, gi, whh_f, bhh_f, whh_r, bhh_r, out, gates, g);
@@ -370,7 +395,6 @@ TATT_API int tatt_gru32_fwd2(const float* gi, const float* whh_f, const float* b
 }
 
 typedef __bf16 gr_bf16x2 __attribute__((ext_vector_type(2)));
-typedef float gr_f32x2 __attribute__((ext_vector_type(2)));
 // 8 fp32 values -> the hi (bf16(a)) or lo (bf16(a - hi)) halves, packed two per dword in element order
 __device__ __forceinline__ f32x4 gr_split8(const float* v, bool want_lo) {
     f32x4 o;
@@ -391,116 +415,145 @@ __global__ __launch_bounds__(256) void gru32_bwd2_kernel(const float* __restrict
                                                          float* __restrict__ dgi, float* __restrict__ dgh,
                                                          float* __restrict__ hprev, float* __restrict__ frag, SeqGeom g) {
     __shared__ __attribute__((aligned(16))) float ds[4][96];
-    __shared__ float pf[3 * GRU2_PF][256];
-    __shared__ float stg[FRAGS ? 4 : 1][5][8][32];                 // per wave: [drp, dzp, dnp, dghn, h_prev][e = t & 7][j]
+    __shared__ float pf[4 * GRU2_PF][256];                         // parked loads of a group of steps: (r | z), (n | an), h_{t-1}, dout
+    __shared__ float stg[FRAGS ? 4 : 1][4][8][32];                 // per wave: [drp, dzp, dnp, dghn][e = t & 7][j]
     const int t = threadIdx.x, lane = t & 63, j = lane & 31, half = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);       // wave-uniform: sequence, direction and every token address live in SGPRs
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int sd = (int)blockIdx.x * 4 + wave;
     const int seq = min(sd >> 1, g.nseq - 1), dir = sd & 1;
     const float* whh = dir ? whh_r : whh_f;
-    float wt[48];                                                   // this half's 48 rows of column j of W_hh
+    gr_f32x2 wt[24];                                                // this half's 48 rows of column j of W_hh, as pairs
 #pragma unroll
-    for (int k = 0; k < 48; ++k) wt[k] = whh[(48 * half + k) * 32 + j];
+    for (int k = 0; k < 24; ++k) wt[k] = (gr_f32x2){whh[(48 * half + 2 * k) * 32 + j], whh[(48 * half + 2 * k + 1) * 32 + j]};
     const int T = g.T;
-    const long st_t = dir ? -g.stride_t : g.stride_t;
-    const long tok0 = seq_base(g, seq) + (dir ? (long)(T - 1) * g.stride_t : 0);          // token of (forward) step 0
+    const int st_t = dir ? -(int)g.stride_t : (int)g.stride_t;
+    const int tok0 = seq_base_i(g, seq) + (dir ? (T - 1) * (int)g.stride_t : 0);          // token of (forward) step 0
+    const unsigned lane4 = lane * 4, j4 = j * 4;
     const float* sq = gates + dir * 128;
     const float* oq = out + dir * 32;
     const float* dq = dout + dir * 32;
+    float* gq = dgi + dir * 96;
     float dhc = 0.f;                                                // gradient carried to h_{t-1} (both halves)
-    auto fetch = [&](int step, float& a, float& b, float& c) {
+    auto fetch = [&](int step, float& a, float& b, float& c, float& d) {
         const int sc = max(step, 0);
-        const long tok = tok0 + (long)sc * st_t;
-        const float* q = sq + tok * 256;
-        a = q[lane];                                                // half 0: r, half 1: z
-        b = q[64 + lane];                                           // half 0: n, half 1: W_hn h + b_hn
-        const float* pa = dq + tok * 64;                             // (both wave-uniform)
-        const float* pb = oq + (tok0 + (long)max(sc - 1, 0) * st_t) * 64;
-        c = (half ? pa : pb)[j];                                    // half 0: h_{t-1} (raw: 0 selected at step 0), half 1: dout
+        const unsigned tok = (unsigned)(tok0 + sc * st_t), tokp = (unsigned)(tok0 + max(sc - 1, 0) * st_t);    // (scalar)
+        const float* q = sq + tok * 256u;
+        a = ldg32(q, lane4);                                        // half 0: r, half 1: z
+        b = ldg32(q + 64, lane4);                                   // half 0: n, half 1: W_hn h + b_hn
+        c = ldg32(oq + tokp * 64u, j4);                             // h_{t-1} (raw: 0 is selected at step 0)
+        d = ldg32(dq + tok * 64u, j4);                              // dout
     };
-    auto one_step = [&](int step, float a, float b, float c) {
-        float r, z, n, an, hp_raw, go;
+    auto one_step = [&](int step, float a, float b, float hp_raw, float go) {
+        float r, z, n, an;
         half_both(a, r, z);
         half_both(b, n, an);
-        half_both(c, hp_raw, go);
-        const long tok = tok0 + (long)step * st_t;
+        const unsigned tok = (unsigned)(tok0 + step * st_t);        // (scalar)
         const float hp = step > 0 ? hp_raw : 0.f;
         const float dh = dhc + go;
-        const float dn = dh * (1.f - z);
+        const float omz = 1.f - z;
+        const float dn = dh * omz;
         const float dz = dh * (hp - n);
         const float dnp = dn * (1.f - n * n);
         const float drp = dnp * an * r * (1.f - r);
-        const float dzp = dz * z * (1.f - z);
+        const float dzp = dz * z * omz;
         const float dghn = dnp * r;
         const float rz = half ? dzp : drp;
         ds[wave][lane] = rz;                                        // [drp | dzp | dghn]
-        if (half == 0) ds[wave][64 + j] = dghn;
+        ds[wave][64 + j] = dghn;
         wave_lds_sync();
-        {
-            float* q = dgi + tok * 192 + dir * 96;
-            q[lane] = rz;
-            if (half == 0) q[64 + j] = dnp;
-        }
+        stg32(gq + tok * 192u, lane4, rz);
+        stg32(gq + tok * 192u + 64, j4, dnp);
         if (FRAGS) {
-            const int e = (dir ? T - 1 - step : step) & 7;
+            const int e = (dir ? T - 1 - step : step) & 7;          // (scalar)
             stg[wave][half][e][j] = rz;
             stg[wave][2 + half][e][j] = half ? dghn : dnp;
-            if (half == 0) stg[wave][4][e][j] = hp;
         } else {
-            float* q = dgh + tok * 192 + dir * 96;
-            q[lane] = rz;
-            if (half == 0) { q[64 + j] = dghn; hprev[tok * 64 + dir * 32 + j] = hp; }
+            float* q = dgh + tok * 192u + dir * 96;
+            stg32(q, lane4, rz);
+            stg32(q + 64, j4, dghn);
+            stg32(hprev + tok * 64u + dir * 32, j4, hp);
         }
-        float c0 = half ? 0.f : dh * z, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+        gr_f32x2 c01 = (gr_f32x2){half ? 0.f : dh * z, 0.f}, c23 = (gr_f32x2){0.f, 0.f};
         const f32x4* dv = reinterpret_cast<const f32x4*>(ds[wave] + 48 * half);
+        // broadcast reads in two batches (8, then 4 behind the first FMAs) -- left to itself the scheduler issues them one by one (9
+        // exposed LDS round trips per step); all 12 at once cost the third wave per SIMD (172 VGPRs)
+        f32x4 da[8], db[4];
 #pragma unroll
-        for (int k4 = 0; k4 < 12; ++k4) {
-            const f32x4 dd = dv[k4];
-            c0 = fmaf(wt[k4 * 4 + 0], dd[0], c0); c1 = fmaf(wt[k4 * 4 + 1], dd[1], c1);
-            c2 = fmaf(wt[k4 * 4 + 2], dd[2], c2); c3 = fmaf(wt[k4 * 4 + 3], dd[3], c3);
+        for (int k4 = 0; k4 < 8; ++k4) da[k4] = dv[k4];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+            c01 = wt[2 * k4] * (gr_f32x2){da[k4][0], da[k4][1]} + c01;
+            c23 = wt[2 * k4 + 1] * (gr_f32x2){da[k4][2], da[k4][3]} + c23;
         }
-        dhc = half_sum((c0 + c1) + (c2 + c3));
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) db[k4] = dv[8 + k4];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k4 = 4; k4 < 8; ++k4) {
+            c01 = wt[2 * k4] * (gr_f32x2){da[k4][0], da[k4][1]} + c01;
+            c23 = wt[2 * k4 + 1] * (gr_f32x2){da[k4][2], da[k4][3]} + c23;
+        }
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+            c01 = wt[16 + 2 * k4] * (gr_f32x2){db[k4][0], db[k4][1]} + c01;
+            c23 = wt[16 + 2 * k4 + 1] * (gr_f32x2){db[k4][2], db[k4][3]} + c23;
+        }
+        dhc = half_sum((c01[0] + c01[1]) + (c23[0] + c23[1]));
         wave_lds_sync();
     };
-    // the 8 steps s_hi .. s_hi - 7 just processed are one window of the sequence: leave its operand fragments
+    // the 8 steps s_hi .. s_hi - 7 just processed are one window of the sequence: leave its operand fragments.  Half 0 stores the hi
+    // halves, half 1 the lo halves.  h_{t-1} of the window is still parked in the prefetch ring (own column, slot u = step s_hi - u).
     auto flush = [&](int s_hi) {
         const int tt0 = dir ? T - 1 - s_hi : s_hi - 7;              // first token-time of the window (a multiple of 8)
         const int o = seq * (T >> 3) + (tt0 >> 3), c = o >> 2, kq = o & 3;
+        float* fb = frag + (long)c * (20 * 2 * 256) + half * 256 + (kq * 16 + (j & 15)) * 4;
+        const int jt = j >> 4;
 #pragma unroll
-        for (int q = 0; q < 5; ++q) {
+        for (int q = 0; q < 4; ++q) {
             float v[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = stg[wave][q][e][j];
-            const int slot = q < 4 ? dir * 8 + q * 2 + (j >> 4) : 16 + dir * 2 + (j >> 4);
-            float* dst = frag + (((long)c * 20 + slot) * 2 + half) * 256 + (kq * 16 + (j & 15)) * 4;
-            *reinterpret_cast<f32x4*>(dst) = gr_split8(v, half != 0);
+            *reinterpret_cast<f32x4*>(fb + (dir * 8 + q * 2 + jt) * 512) = gr_split8(v, half != 0);
+        }
+        {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {                           // token-time e of the window <-> ring slot u: step = s_hi - u
+                const int u = dir ? e : 7 - e;
+                const float raw = pf[u * 4 + 2][t];
+                v[e] = (s_hi - u) > 0 ? raw : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(fb + (16 + dir * 2 + jt) * 512) = gr_split8(v, half != 0);
         }
         wave_lds_sync();
     };
     {
-        float a[GRU2_PF][3];
+        float a[GRU2_PF][4];
 #pragma unroll
-        for (int u = 0; u < GRU2_PF; ++u) fetch(T - 1 - u, a[u][0], a[u][1], a[u][2]);
+        for (int u = 0; u < GRU2_PF; ++u) fetch(T - 1 - u, a[u][0], a[u][1], a[u][2], a[u][3]);
 #pragma unroll
-        for (int u = 0; u < GRU2_PF; ++u) { pf[u * 3 + 0][t] = a[u][0]; pf[u * 3 + 1][t] = a[u][1]; pf[u * 3 + 2][t] = a[u][2]; }
+        for (int u = 0; u < GRU2_PF; ++u)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pf[u * 4 + k][t] = a[u][k];
     }
     int s0 = T - 1;
     for (; s0 >= GRU2_PF - 1; s0 -= GRU2_PF) {
-        float nx[GRU2_PF][3];
+        float nx[GRU2_PF][4];
 #pragma unroll
-        for (int u = 0; u < GRU2_PF; ++u) fetch(s0 - GRU2_PF - u, nx[u][0], nx[u][1], nx[u][2]);
+        for (int u = 0; u < GRU2_PF; ++u) fetch(s0 - GRU2_PF - u, nx[u][0], nx[u][1], nx[u][2], nx[u][3]);
 #pragma unroll
-        for (int u = 0; u < GRU2_PF; ++u) one_step(s0 - u, pf[u * 3 + 0][t], pf[u * 3 + 1][t], pf[u * 3 + 2][t]);
+        for (int u = 0; u < GRU2_PF; ++u) one_step(s0 - u, pf[u * 4 + 0][t], pf[u * 4 + 1][t], pf[u * 4 + 2][t], pf[u * 4 + 3][t]);
         if (FRAGS) flush(s0);
 #pragma unroll
         for (int u = 0; u < GRU2_PF; ++u)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) pf[u * 3 + k][t] = nx[u][k];
+            for (int k = 0; k < 4; ++k) pf[u * 4 + k][t] = nx[u][k];
     }
     for (; s0 >= 0; --s0) {                                         // T % GRU2_PF leftover steps (never with FRAGS): plain loads
-        float a, b, c;
-        fetch(s0, a, b, c);
-        one_step(s0, a, b, c);
+        float a, b, c, d;
+        fetch(s0, a, b, c, d);
+        one_step(s0, a, b, c, d);
     }
 }
 // frag == NULL: dgh (M, 192) and hprev (M, 64) are written as by tatt_gru32_bwd.  frag != NULL (needs T % 8 == 0 and
@@ -510,6 +563,10 @@ TATT_API int tatt_gru32_bwd2(const float* gates, const float* out, const float* 
                              long stride_hi, long stride_lo, long stride_t, hipStream_t st) {
     if (nseq <= 0 || T <= 0) return 0;
     if (frag && (T % 8 || ((long)nseq * (T / 8)) % 4)) return 1;
+    if (!gru2_fits(nseq, T, s_in, stride_hi, stride_lo, stride_t)) {
+        if (frag) return 3;
+        return tatt_gru32_bwd(gates, out, dout, whh_f, whh_r, dgi, dgh, hprev, nseq, T, s_in, stride_hi, stride_lo, stride_t, st);
+    }
     SeqGeom g = {nseq, T, s_in, stride_hi, stride_lo, stride_t};
     const dim3 grid(cdiv(2L * nseq, 4)), block(256);
     if (frag) hipLaunchKernelGGL(gru32_bwd2_kernel<true>, grid, block, 0, st, gates, out, dout, whh_f, whh_r, dgi, dgh, hprev, frag, g);

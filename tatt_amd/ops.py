@@ -168,7 +168,7 @@ def linear_bwd_weight(dy, x2, *, alpha=1.0, out=None, out_ld=None, beta=0.0, row
 
 GRU_WGRAD_GROUPS = 128        # persistent work-groups (= partial slabs) of tatt_gru_wgrad_sb
 CONV3_WGRAD_SB = True          # test / A-B hook: False -> the fp32-MFMA weight-gradient kernel (conv3.hip)
-CONV3_WGRAD_GROUPS = 256      # persistent work-groups of tatt_conv3_c64_wgrad_partial (all 64x64 channel blocks together)
+CONV3_WGRAD_GROUPS = 128      # persistent work-groups of the 3x3 weight-gradient kernels (all 64x64 channel blocks together); round 4, split-bf16 kernel: 128 measured 0.15 ms per step better than 256 (half the partial slabs to write and reduce, half the CUs left to the main lane)
 
 
 def gru_wgrad_fusable(dgi, dgh, x2, xb2, hprev):
@@ -688,13 +688,17 @@ def seq_geom(B, H, W, vertical):
 
 
 GRU32_V2 = True             # test / A-B hook: False -> the first-generation recurrences (a 32-lane group per (sequence, direction))
+GRU32_FWD_V2_MIN_T = 32     # forward recurrences shorter than this stay on the first generation (test hook: 0 = always the second)
 
 
 def gru32_fwd(gi, whh_f, bhh_f, whh_r, bhh_r, geom, save=False):
     """-> (out [tok][64], gates [tok][256] or None).  save: keep r, z, n and W_hn h + b_hn of every step for gru32_bwd."""
     out = new(gi, gi.shape[0], 64)
     gates = new(gi, gi.shape[0], 256) if save else None
-    call("tatt_gru32_fwd2" if GRU32_V2 else "tatt_gru32_fwd", P(gi), P(whh_f), P(bhh_f), P(whh_r), P(bhh_r), P(out), P(gates),
+    # forward: the one-wave-per-(sequence, direction) kernel wins where the recurrence is long (T = 64: 30.7 vs 40.8 us); the 16-step
+    # vertical scans are HBM-bound and the first generation is a little ahead there (26.5 vs 29.1 us, profiles/r04_d_ubench_gru.txt)
+    v2 = GRU32_V2 and geom[1] >= GRU32_FWD_V2_MIN_T
+    call("tatt_gru32_fwd2" if v2 else "tatt_gru32_fwd", P(gi), P(whh_f), P(bhh_f), P(whh_r), P(bhh_r), P(out), P(gates),
          *geom, stream())
     return out, gates
 

@@ -964,7 +964,8 @@ def test_gru32_v2_matches_v1(dev, vertical, B, H, W):
     d = lambda t: t.to(dev)
 
     def run(v2, saved=None):
-        ops.GRU32_V2 = v2
+        ops.GRU32_V2, min_t = v2, ops.GRU32_FWD_V2_MIN_T
+        ops.GRU32_FWD_V2_MIN_T = 0                                  # the second-generation forward at every length
         try:
             out, gates = ops.gru32_fwd(d(gi), d(whh[0]), d(bhh[0]), d(whh[1]), d(bhh[1]), geom, save=True)
             out_ns, none = ops.gru32_fwd(d(gi), d(whh[0]), d(bhh[0]), d(whh[1]), d(bhh[1]), geom, save=False)
@@ -972,7 +973,7 @@ def test_gru32_v2_matches_v1(dev, vertical, B, H, W):
             o, g = saved if saved is not None else (out, gates)      # both backward generations start from the SAME saved forward
             return (out, gates) + tuple(ops.gru32_bwd(g, o, d(dout), d(whh[0]), d(whh[1]), geom))
         finally:
-            ops.GRU32_V2 = True
+            ops.GRU32_V2, ops.GRU32_FWD_V2_MIN_T = True, min_t
 
     r1 = run(False)
     r2 = run(True, saved=r1[:2])
