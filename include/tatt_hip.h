@@ -121,6 +121,17 @@ int tatt_conv3_c64_fwd_ws16_bn(const float* x, const float* wl, const float* bia
 int tatt_conv3_c64_fwd_sb(const float* x, int cin_total, int ci0, const float* wl, const float* bias, float* y, int B, int H,
                           int W, int Cout, int act, float beta, const float* in_scale, const float* in_shift, int in_act,
                           double* stats, hipStream_t st);
+/* The data-gradient convolution (64 -> 64 channels, wl = mode-11 packed filter) of a conv -> bn -> act -> conv -> bn chain (reference
+ * model/tsrn.py:877-886, backward) with the BatchNorm backward folded in on both sides:
+ *   input side (x2 != NULL): the gradient entering is x * in_scale + x2 * in_scale2 + in_shift per channel -- the BatchNorm backward
+ *     dy = a du + b y + c of the layer above with (a, b, c) from tatt_bn_bwd_finish, x = du, x2 = that BatchNorm's input y;
+ *   output side (ep_x != NULL): y = (convolution) * ep_act'(ep_gamma xhat + ep_beta), xhat = (ep_x - ep_mean) ep_rstd -- the gradient
+ *     through the activation that follows the layer below's BatchNorm -- and stats [min(256, B*H*W/64)][2][64] doubles = the
+ *     per-work-group sums of y and y * xhat, i.e. the stage-1 partials of THAT BatchNorm's backward (tatt_bn_bwd_finish sums them). */
+int tatt_conv3_c64_dgrad_bn_sb(const float* x, const float* x2, const float* in_scale, const float* in_scale2,
+                               const float* in_shift, const float* wl, float* y, int B, int H, int W, const float* ep_x,
+                               const float* ep_mean, const float* ep_rstd, const float* ep_gamma, const float* ep_beta,
+                               int ep_act, double* stats, hipStream_t st);
 /* weight-gradient partials part[G][9*Cin][Cout] (G persistent work-groups, G <= B*H*W/64) and, if pdb != NULL, bias-gradient
  * partials pdb[G][Cout] (the column sums of dy the kernel streams anyway; nn.Conv2d's bias gradient); finish with
  * tatt_splitk_reduce(part, dw_oihw, 9*Cin, Cout, G, Cin, 9, beta, db, Cout) where pdb = part + G*9*Cin*Cout */
@@ -182,6 +193,17 @@ int tatt_bn_apply(const float* X, long ldx, float* Y, long ldy, int M, int C, co
 int tatt_bn_bwd(const float* X, long ldx, const float* dY, long lddy, float* dX, long lddx, int M, int C,
                 const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
                 int training, float* dgamma, float* dbeta, float* sums, double* ws, hipStream_t st);
+/* The same backward in pieces (round 4): stage-1 partials alone (part: tatt_bn_bwd_groups(M) x 2 x C doubles: sums of
+ * du = dY act'(gamma xhat + beta) and du xhat) -- or produced by tatt_conv3_c64_dgrad_bn_sb's epilogue; */
+int tatt_bn_bwd_groups(int M);
+int tatt_bn_bwd_partials(const float* X, long ldx, const float* dY, long lddy, int M, int C, const float* mean,
+                         const float* rstd, const float* gamma, const float* beta, int act, double* part, hipStream_t st);
+/* ... their sum over G groups -> dgamma, dbeta and coef[3][C] = (a, b, c) of dX = a du + b X + c (= gamma rstd (du - mean(du) -
+ * xhat mean(du xhat))), which a consumer applies while staging (tatt_conv3_c64_dgrad_bn_sb) ... */
+int tatt_bn_bwd_finish(const double* part, int G, int C, int M, const float* mean, const float* rstd, const float* gamma,
+                       float* dgamma, float* dbeta, float* coef, hipStream_t st);
+/* ... or this kernel materialises: dX = a dU + b X + c (M, C contiguous, C % 4 == 0) */
+int tatt_bn_bwd_affine(const float* X, const float* dU, float* dX, int M, int C, const float* coef, hipStream_t st);
 
 /* Y = LayerNorm(A + Bres) * gamma + beta over the last axis (C <= 256), stats[M][2] = (mean, 1/denominator).
  * mode 0 = nn.LayerNorm (biased variance, eps inside the sqrt); mode 1 = the TBSRN variant's own LayerNorm

@@ -412,7 +412,18 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define SB_PW 40                                             // halo pitch in 32-bit words (two bf16 each)
 #define SB_IMG (3 * C3_HW * SB_PW)                           // words of one image (hi or lo) of one halo buffer: 7920
 #define SB_LDS (4 * SB_IMG * 4)                              // two buffers x (hi, lo): 126,720 B
-struct Conv3SB { Conv3P c; int cin_total, ci0; };
+// Round 4, backward of conv -> bn -> mish -> conv -> bn (model/tsrn.py:877-886) without the BatchNorm-backward passes over the maps:
+//   IN2:  the kernel's input is the BatchNorm backward of the NEXT layer applied on the fly: two maps are staged per pixel and
+//         combined per channel, v = x * in_scale + x2 * in_scale2 + in_shift  (x = upstream gradient du, x2 = that BatchNorm's input y;
+//         dy = gamma rstd (du - mean(du) - xhat mean(du xhat)) is affine in (du, y) once the two means are known: tatt_bn_bwd_finish);
+//   EPBN: the kernel's output is the gradient w.r.t. act(bn(ep_x)): the epilogue multiplies by act'(gamma xhat + beta) (xhat from ep_x
+//         and that BatchNorm's batch statistics), stores du, and leaves the per-work-group partial sums of du and du * xhat in `stats`
+//         (the stage-1 partials of THAT BatchNorm's backward) -- the mirror of the forward's epilogue statistics.
+struct Conv3SB {
+    Conv3P c; int cin_total, ci0;
+    const float* x2; const float* in_scale2;                                            // IN2
+    const float* ep_x; const float* ep_mean; const float* ep_rstd; const float* ep_gamma; const float* ep_beta; int ep_act;   // EPBN
+};
 __device__ __forceinline__ void sb_split(f32x4 v, uint2& hi, uint2& lo) {
     const bf16x2 h0 = __builtin_convertvector((f32x2){v[0], v[1]}, bf16x2), h1 = __builtin_convertvector((f32x2){v[2], v[3]}, bf16x2);
     const f32x2 r0 = (f32x2){v[0], v[1]} - __builtin_convertvector(h0, f32x2), r1 = (f32x2){v[2], v[3]} - __builtin_convertvector(h1, f32x2);
@@ -420,6 +431,7 @@ __device__ __forceinline__ void sb_split(f32x4 v, uint2& hi, uint2& lo) {
     hi = make_uint2(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1));
     lo = make_uint2(__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1));
 }
+template <bool IN2, bool EPBN>
 __global__ __launch_bounds__(512, 1) void conv3_c64_sb_kernel(Conv3SB q) {
     const Conv3P& p = q.c;
     extern __shared__ __attribute__((aligned(16))) unsigned smem_u[];
@@ -445,6 +457,13 @@ __global__ __launch_bounds__(512, 1) void conv3_c64_sb_kernel(Conv3SB q) {
         isc = *reinterpret_cast<const f32x4*>(p.in_scale + 4 * (t & 15));
         ish = *reinterpret_cast<const f32x4*>(p.in_shift + 4 * (t & 15));
     }
+    f32x4 isc2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (IN2) isc2 = *reinterpret_cast<const f32x4*>(q.in_scale2 + 4 * (t & 15));
+    float ep_mu = 0.f, ep_rs = 0.f, ep_g = 0.f, ep_b = 0.f;
+    if (EPBN) {
+        const int c = co0 + (lane & 15);
+        ep_mu = q.ep_mean[c]; ep_rs = q.ep_rstd[c]; ep_g = q.ep_gamma[c]; ep_b = q.ep_beta[c];
+    }
     float st_s = 0.f, st_q = 0.f;
     f32x4 wq[36];                                            // [kstep * 2 + {hi, lo}]: 8 bf16 = input channels 32 half + 8 (lane >> 4) .. of output channel co0 + (lane & 15)
     {
@@ -462,7 +481,11 @@ __global__ __launch_bounds__(512, 1) void conv3_c64_sb_kernel(Conv3SB q) {
         f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (idx < 3 * C3_HW * 16 && hh >= 0 && hh < p.H && ww >= 0 && ww < p.W) {
             v = *reinterpret_cast<const f32x4*>(p.x + (((long)n * p.H + hh) * p.W + ww) * q.cin_total + q.ci0 + 4 * (idx & 15));
-            if (p.in_scale) {
+            if (IN2) {                                       // (both maps hold exactly 64 channels per pixel)
+                const f32x4 v2 = *reinterpret_cast<const f32x4*>(q.x2 + (((long)n * p.H + hh) * p.W + ww) * 64 + 4 * (idx & 15));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], isc[e], fmaf(v2[e], isc2[e], ish[e]));
+            } else if (p.in_scale) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float u = fmaf(v[e], isc[e], ish[e]);
@@ -538,8 +561,15 @@ __global__ __launch_bounds__(512, 1) void conv3_c64_sb_kernel(Conv3SB q) {
                     float* dst = p.y + (rowbase + 16 * m + r) * p.Cout + co0 + (lane & 15);
                     float v = apply_act((accM[m][r] + accC[m][r]) + bj, p.act);
                     if (p.beta != 0.f) v += p.beta * *dst;
-                    *dst = v;
-                    st_s += v; st_q += v * v;
+                    if (EPBN) {                              // v = gradient w.r.t. act(bn(ep_x)); Cout == 64
+                        const float xh = (q.ep_x[(rowbase + 16 * m + r) * 64 + co0 + (lane & 15)] - ep_mu) * ep_rs;
+                        if (q.ep_act != ACT_NONE) v *= act_grad(fmaf(ep_g, xh, ep_b), q.ep_act);
+                        *dst = v;
+                        st_s += v; st_q += v * xh;
+                    } else {
+                        *dst = v;
+                        st_s += v; st_q += v * v;
+                    }
                 }
         }
         if (!has_next) break;
@@ -558,22 +588,53 @@ __global__ __launch_bounds__(512, 1) void conv3_c64_sb_kernel(Conv3SB q) {
 // Split-bf16 3x3 convolution (see the kernel): x holds cin_total >= 64 channels per pixel, the 64-channel slice starting at ci0 is
 // contracted; wl = the matching 64-input-channel chunk of the filter from tatt_repack_conv_weight mode 10 (forward) / mode 11 (data
 // gradient): chunk c of a mode-10/11 buffer starts c * Cout * 576 words in.  BatchNorm folding arguments as tatt_conv3_c64_fwd_ws16_bn.
+static int conv3_sb_launch(const Conv3SB& q, hipStream_t st) {
+    const Conv3P& p = q.c;
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [&] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_sb_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SB_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_sb_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SB_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_sb_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SB_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_sb_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SB_LDS);
+    });
+    const int cob = p.Cout / 64, npt = p.B * p.H * (p.W / C3_PX);
+    int per = 256 / cob;
+    if (per > npt) per = npt;
+    const dim3 grid(per * cob), block(512);
+    const bool in2 = q.x2 != nullptr, ep = q.ep_x != nullptr;
+    if (in2 && ep) hipLaunchKernelGGL((conv3_c64_sb_kernel<true, true>), grid, block, SB_LDS, st, q);
+    else if (in2) hipLaunchKernelGGL((conv3_c64_sb_kernel<true, false>), grid, block, SB_LDS, st, q);
+    else if (ep) hipLaunchKernelGGL((conv3_c64_sb_kernel<false, true>), grid, block, SB_LDS, st, q);
+    else hipLaunchKernelGGL((conv3_c64_sb_kernel<false, false>), grid, block, SB_LDS, st, q);
+    return LAUNCH_CHECK();
+}
 TATT_API int tatt_conv3_c64_fwd_sb(const float* x, int cin_total, int ci0, const float* wl, const float* bias, float* y, int B, int H,
                                    int W, int Cout, int act, float beta, const float* in_scale, const float* in_shift, int in_act,
                                    double* stats, hipStream_t st) {
     if (Cout % 64 || W % C3_PX || cin_total % 4 || ci0 % 4 || ci0 + 64 > cin_total) return 1;
     if (stats && (Cout != 64 || act != ACT_NONE || beta != 0.f)) return 2;
     if (in_scale && (!in_shift || in_act == ACT_TANH)) return 3;
-    Conv3SB q = {{x, wl, bias, y, B, H, W, 64, Cout, act, beta, in_scale, in_shift, in_act, stats}, cin_total, ci0};
-    static std::once_flag attr_once;
-    std::call_once(attr_once, [&] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_sb_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SB_LDS);
-    });
-    const int cob = Cout / 64, npt = B * H * (W / C3_PX);
-    int per = 256 / cob;
-    if (per > npt) per = npt;
-    hipLaunchKernelGGL(conv3_c64_sb_kernel, dim3(per * cob), dim3(512), SB_LDS, st, q);
-    return LAUNCH_CHECK();
+    Conv3SB q = {{x, wl, bias, y, B, H, W, 64, Cout, act, beta, in_scale, in_shift, in_act, stats}, cin_total, ci0,
+                 nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    return conv3_sb_launch(q, st);
+}
+// The data-gradient convolution of a conv -> bn -> act -> conv -> bn chain with the BatchNorm backward folded in on both sides (64 -> 64
+// channels, wl = mode-11 packed filter of the convolution whose data gradient this is):
+//   input side (x2 != NULL): the gradient entering is  x * in_scale + x2 * in_scale2 + in_shift  per channel (coefficients from
+//       tatt_bn_bwd_finish: x = upstream gradient du, x2 = the BatchNorm's input);  x2 == NULL: x is taken as it is;
+//   output side (ep_x != NULL): y = (conv result) * ep_act'(ep_gamma xhat + ep_beta), xhat = (ep_x - ep_mean) ep_rstd, and stats
+//       [min(256, B*H*W/64)][2][64] doubles = per-work-group sums of y and of y * xhat (stage-1 partials of that BatchNorm's backward).
+TATT_API int tatt_conv3_c64_dgrad_bn_sb(const float* x, const float* x2, const float* in_scale, const float* in_scale2,
+                                        const float* in_shift, const float* wl, float* y, int B, int H, int W, const float* ep_x,
+                                        const float* ep_mean, const float* ep_rstd, const float* ep_gamma, const float* ep_beta,
+                                        int ep_act, double* stats, hipStream_t st) {
+    if (W % C3_PX) return 1;
+    if (x2 && (!in_scale || !in_scale2 || !in_shift)) return 2;
+    if (ep_x && (!ep_mean || !ep_rstd || !ep_gamma || !ep_beta || !stats)) return 3;
+    if (!ep_x && stats) return 4;
+    Conv3SB q = {{x, wl, nullptr, y, B, H, W, 64, 64, ACT_NONE, 0.f, x2 ? in_scale : nullptr, x2 ? in_shift : nullptr, ACT_NONE, stats}, 64, 0,
+                 x2, in_scale2, ep_x, ep_mean, ep_rstd, ep_gamma, ep_beta, ep_act};
+    return conv3_sb_launch(q, st);
 }
 
 // ---- weight gradient -------------------------------------------------------------------------------------------------

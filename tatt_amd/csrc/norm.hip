@@ -485,6 +485,74 @@ TATT_API int tatt_bn_bwd(const float* X, long ldx, const float* dY, long lddy, f
     return LAUNCH_CHECK();
 }
 
+// ---- BatchNorm backward in pieces (round 4): the stage-1 partials may come from the PRODUCER of the upstream gradient (the data-gradient
+// convolution's epilogue, tatt_conv3_c64_dgrad_bn_sb) and the result may be applied by the CONSUMER while it stages its input:
+//   dx = gamma rstd (du - mean(du) - xhat mean(du xhat)),  xhat = (x - mean) rstd      is affine per channel in (du, x):
+//   dx = a du + b x + c,   a = gamma rstd,  b = -gamma rstd^2 mean(du xhat),  c = -gamma rstd mean(du) - b mean
+__global__ __launch_bounds__(64 * S2_L) void bn_bwd_finish_kernel(const double* __restrict__ part, int G, int C, int M,
+                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                  const float* __restrict__ gamma, float* __restrict__ dgamma,
+                                                                  float* __restrict__ dbeta, float* __restrict__ coef) {
+    __shared__ double sh[2][S2_L][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    double s = 0.0, q = 0.0;
+    if (c < C && ty < G) {
+        s = sum_strided<double, 8>(part + ((long)ty * 2 + 0) * C + c, (G - ty + S2_L - 1) / S2_L, (long)2 * S2_L * C);
+        q = sum_strided<double, 8>(part + ((long)ty * 2 + 1) * C + c, (G - ty + S2_L - 1) / S2_L, (long)2 * S2_L * C);
+    }
+    sh[0][ty][tx] = s; sh[1][ty][tx] = q;
+    __syncthreads();
+    if (ty != 0 || c >= C) return;
+    s = s2_combine(sh[0], tx);
+    q = s2_combine(sh[1], tx);
+    dbeta[c] = (float)s; dgamma[c] = (float)q;
+    const float inv = 1.f / (float)M, g = gamma[c], rs = rstd[c];
+    const float a = g * rs;
+    const float b = -a * rs * ((float)q * inv);
+    coef[c] = a;
+    coef[C + c] = b;
+    coef[2 * C + c] = -a * ((float)s * inv) - b * mean[c];
+}
+// stage 1 alone: part[G][2][C] doubles (G = tatt_bn_bwd_groups(M)) of du = dy act'(gamma xhat + beta) and du xhat
+TATT_API int tatt_bn_bwd_groups(int M) { return cs_groups(M); }
+TATT_API int tatt_bn_bwd_partials(const float* X, long ldx, const float* dY, long lddy, int M, int C, const float* mean,
+                                  const float* rstd, const float* gamma, const float* beta, int act, double* part, hipStream_t st) {
+    const int G = cs_groups(M), rpb = cdiv(M, G);
+    const bool v4 = v4_ok(X, ldx, C) && v4_ok(dY, lddy, C) &&
+                    !((((uintptr_t)mean) | ((uintptr_t)rstd) | ((uintptr_t)gamma) | ((uintptr_t)beta)) & 15);
+    if (v4) hipLaunchKernelGGL(bn_bwd_stage1_v4, dim3(G), dim3(256), 0, st, X, ldx, dY, lddy, M, C, rpb, mean, rstd, gamma, beta, act, part);
+    else hipLaunchKernelGGL(bn_bwd_stage1, dim3(G), dim3(256), 0, st, X, ldx, dY, lddy, M, C, rpb, mean, rstd, gamma, beta, act, part);
+    return LAUNCH_CHECK();
+}
+// partials of G groups -> dgamma, dbeta (C each) and coef[3][C] = (a, b, c) of  dx = a du + b x + c
+TATT_API int tatt_bn_bwd_finish(const double* part, int G, int C, int M, const float* mean, const float* rstd, const float* gamma,
+                                float* dgamma, float* dbeta, float* coef, hipStream_t st) {
+    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(cdiv(C, 64)), dim3(64 * S2_L), 0, st, part, G, C, M, mean, rstd, gamma, dgamma, dbeta, coef);
+    return LAUNCH_CHECK();
+}
+// dX = a dU + b X + c per channel (coef from tatt_bn_bwd_finish): the materialised BatchNorm backward, for consumers that cannot
+// apply it themselves (the weight-gradient pass).  X, dU, dX (M, C) contiguous, C % 4 == 0.
+__global__ __launch_bounds__(256) void bn_bwd_affine_kernel(const float* __restrict__ X, const float* __restrict__ dU, float* __restrict__ dX,
+                                                            long n4, int C, const float* __restrict__ coef) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int c4 = (int)(i % (C >> 2)) * 4;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(coef + c4), b = *reinterpret_cast<const f32x4*>(coef + C + c4);
+    const f32x4 c = *reinterpret_cast<const f32x4*>(coef + 2 * C + c4);
+    const f32x4 x = reinterpret_cast<const f32x4*>(X)[i], u = reinterpret_cast<const f32x4*>(dU)[i];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = fmaf(a[e], u[e], fmaf(b[e], x[e], c[e]));
+    reinterpret_cast<f32x4*>(dX)[i] = o;
+}
+TATT_API int tatt_bn_bwd_affine(const float* X, const float* dU, float* dX, int M, int C, const float* coef, hipStream_t st) {
+    if (C % 4) return 1;
+    const long n4 = (long)M * (C / 4);
+    hipLaunchKernelGGL(bn_bwd_affine_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, st, X, dU, dX, n4, C, coef);
+    return LAUNCH_CHECK();
+}
+
 // ---------------------------------------------------------------------------------------------
 // LayerNorm over the last axis with fused residual:  y = LN(a + b) * gamma + beta
 // (reference nn.LayerNorm: model/transformer_v2.py:459-460,793-795; residual adds :478-483,826-832)

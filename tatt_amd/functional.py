@@ -361,6 +361,76 @@ def bn_apply_stats(y, stats, bn, act=ACT_NONE):
     return BatchNormApplyFn.apply(y, stats[0], stats[1], bn.weight, bn.bias, act)
 
 
+SRB_BWD_FUSED = False       # True -> SrbTrunkFn (BatchNorm backward folded into the data-gradient convolutions).  Built, parity green, and SLOWER on the
+                            # GPU: 5.49 vs 5.34 ms per step (profiles/r04_e_ab_srb_fused.txt) -- the split-bf16 convolution is bound by instruction
+                            # issue, so the activation derivative + partial sums in its epilogue (~160 VALU per tile) and the second staged map cost
+                            # as much there as the 12 us bandwidth-bound stage-1 / apply launches they replace.  Off; kept as the measured alternative
+
+
+class SrbTrunkFn(Function):
+    """conv1 -> bn1 -> mish -> conv2 -> bn2 of a RecurrentResidualBlock (reference model/tsrn.py:877-886, 896-903) as ONE operator, so
+    that the BACKWARD can fold the two BatchNorm backwards into the data-gradient convolutions the way the forward folds the
+    BatchNorms into the convolutions:
+
+      forward   conv1(+stats) | finish | conv2(bn1 + mish on the way in, +stats) | finish | apply bn2             (as conv_bn / bn_apply_stats)
+      backward  partials(bn2) | finish | dgrad conv2 (bn2 backward on the way in; mish' and bn1's partials in the epilogue)
+                | finish | dgrad conv1 (bn1 backward on the way in)                                                 5 launches, was 8
+
+    dx = gamma rstd (du - mean(du) - xhat mean(du xhat)) is affine per channel in (du, x) once the two means are known, so the consumer
+    applies it while staging its halo (tatt_conv3_c64_dgrad_bn_sb).  The materialised dy maps are needed by the weight gradients
+    only: they are rebuilt on the side lane (tatt_bn_bwd_affine) with the rest of the parameter-gradient work."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, g1, be1, rm1, rv1, mom1, eps1, w2, b2, g2, be2, rm2, rv2, mom2, eps2):
+        B, H, W, C = x.shape
+        M = B * H * W
+        y1, part1, G1 = ops.conv3_bn_forward(x, w1, b1, None, None, ACT_NONE, True)
+        mean1, rstd1, sc1, sh1 = ops.bn_stats_finish(part1, G1, 64, M, eps1, mom1, g1, be1, rm1, rv1)
+        y2, part2, G2 = ops.conv3_bn_forward(y1, w2, b2, sc1, sh1, ACT_MISH, True)
+        mean2, rstd2, _, _ = ops.bn_stats_finish(part2, G2, 64, M, eps2, mom2, g2, be2, rm2, rv2)
+        r = ops.bn_apply(y2.reshape(-1, 64), mean2, rstd2, g2, be2, ACT_NONE).reshape(x.shape)
+        ctx.save_for_backward(x, y1, y2, w1, w2, g1, be1, g2, be2, mean1, rstd1, mean2, rstd2)
+        ctx.has_b = (b1 is not None, b2 is not None)
+        ctx.leaves = (w1, b1, w2, b2)
+        return r
+
+    @staticmethod
+    def backward(ctx, d):
+        x, y1, y2, w1, w2, g1, be1, g2, be2, mean1, rstd1, mean2, rstd2 = ctx.saved_tensors
+        B, H, W, C = x.shape
+        M = B * H * W
+        d = _c(d)
+        y1f, y2f = y1.reshape(M, 64), y2.reshape(M, 64)
+        part2, G2 = ops.bn_bwd_partials(y2f, d.reshape(M, 64), mean2, rstd2, g2, be2, ACT_NONE)
+        dg2, dbe2, coef2 = ops.bn_bwd_finish(part2, G2, 64, M, mean2, rstd2, g2)
+        du1, part1, G1 = ops.conv3_dgrad_bn(d, w2, y2, coef2, ep=(y1, mean1, rstd1, g1, be1, ACT_MISH))
+        dg1, dbe1, coef1 = ops.bn_bwd_finish(part1, G1, 64, M, mean1, rstd1, g1)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx, _, _ = ops.conv3_dgrad_bn(du1, w1, y1, coef1)
+        want_b1, want_b2 = ctx.has_b
+
+        def param_grads():
+            # the weight gradients want the materialised maps: dy2, dy1 (BatchNorm backward applied) and conv2's actual input
+            dy2 = ops.bn_bwd_affine(y2f, d.reshape(M, 64), coef2).reshape(x.shape)
+            a1 = ops.bn_apply(y1f, mean1, rstd1, g1, be1, ACT_MISH).reshape(x.shape)
+            r2 = ops.conv_wgrad(a1, dy2, 64, 3, 3, want_db=want_b2)
+            dy1 = ops.bn_bwd_affine(y1f, du1.reshape(M, 64), coef1).reshape(x.shape)
+            r1 = ops.conv_wgrad(x, dy1, 64, 3, 3, want_db=want_b1)
+            dw2, db2 = r2 if want_b2 else (r2, None)
+            dw1, db1 = r1 if want_b1 else (r1, None)
+            return dw1, db1, dw2, db2
+        dw1, db1, dw2, db2 = SIDE.submit(ctx.leaves, param_grads, x, y1, y2, d, du1, coef1, coef2, mean1, rstd1, g1, be1, w1, w2)
+        return (dx, dw1, db1, dg1, dbe1, None, None, None, None, dw2, db2, dg2, dbe2, None, None, None, None)
+
+
+def srb_trunk(x, blk):
+    """blk: a RecurrentResidualBlock parameter holder (conv1, bn1, conv2, bn2); train mode, 64-channel NHWC map (conv3_bn_fusable)."""
+    c1, n1, c2, n2 = blk.conv1, blk.bn1, blk.conv2, blk.bn2
+    return SrbTrunkFn.apply(x, c1.weight, c1.bias, n1.weight, n1.bias, n1.running_mean, n1.running_var, n1.momentum, n1.eps,
+                            c2.weight, c2.bias, n2.weight, n2.bias, n2.running_mean, n2.running_var, n2.momentum, n2.eps)
+
+
 # --------------------------------------------------------------------------------------------------
 class LinearFn(Function):
     """y = act(alpha*(x @ W^T + b)); optional second input concatenated along the feature axis."""

@@ -544,6 +544,50 @@ def bn_bwd(x2, dy2, mean, rstd, gamma, beta, act, training):
     return dx, dgamma, dbeta
 
 
+def bn_bwd_partials(x2, dy2, mean, rstd, gamma, beta, act):
+    """Stage 1 of the train-mode BatchNorm backward alone: (part [G][2][C] doubles, G) of du = dy act'(gamma xhat + beta), du xhat."""
+    M, C = x2.shape
+    G = LIB.tatt_bn_bwd_groups(int(M))
+    part = new(x2, G * 2 * C, dtype=torch.float64)
+    call("tatt_bn_bwd_partials", P(x2), x2.stride(0), P(dy2), dy2.stride(0), M, C, P(mean), P(rstd), P(gamma), P(beta), int(act),
+         P(part), stream())
+    return part, G
+
+
+def bn_bwd_finish(part, G, C, M, mean, rstd, gamma):
+    """partials -> (dgamma, dbeta, coef (3, C)): dx = coef[0] du + coef[1] x + coef[2] is the BatchNorm backward, to be applied by the
+    consumer while it stages its input (conv3_dgrad_bn) or materialised by bn_bwd_affine."""
+    dgamma, dbeta, coef = new(gamma, C), new(gamma, C), new(gamma, 3, C)
+    call("tatt_bn_bwd_finish", P(part), G, C, M, P(mean), P(rstd), P(gamma), P(dgamma), P(dbeta), P(coef), stream())
+    return dgamma, dbeta, coef
+
+
+def bn_bwd_affine(x2, du2, coef):
+    M, C = x2.shape
+    dx = new(x2, M, C)
+    call("tatt_bn_bwd_affine", P(x2), P(du2), P(dx), M, C, P(coef), stream())
+    return dx
+
+
+def conv3_dgrad_bn(du_bhwc, weight_oihw, x2_bhwc=None, coef=None, ep=None):
+    """Data gradient of a 64 -> 64 3x3 convolution (split-bf16 kernel) with the BatchNorm backward folded in: the gradient entering is
+    coef[0] du + coef[1] x2 + coef[2] (x2 / coef None: du as it is); ep = (y_below, mean, rstd, gamma, beta, act): the result is
+    multiplied by act'(bn(y_below)) and the stage-1 partials of that BatchNorm's backward come back -> (out, part or None, G)."""
+    _check_dev(du_bhwc)
+    B, H, W, _ = du_bhwc.shape
+    wl = repack_weight(weight_oihw, 11)
+    out = new(du_bhwc, B, H, W, 64)
+    G = min(256, B * H * (W // 64))
+    part = new(du_bhwc, G * 128, dtype=torch.float64) if ep is not None else None
+    a = b = c = None
+    if x2_bhwc is not None:
+        a, b, c = coef[0], coef[1], coef[2]
+    e = ep if ep is not None else (None,) * 5 + (ACT_NONE,)
+    call("tatt_conv3_c64_dgrad_bn_sb", P(du_bhwc), P(x2_bhwc), P(a), P(b), P(c), P(wl), P(out), B, H, W, P(e[0]), P(e[1]), P(e[2]),
+         P(e[3]), P(e[4]), int(e[5]), P(part), stream())
+    return out, part, G
+
+
 def ln_fwd(a2, b2, gamma, beta, eps=1e-5, mode=0, pdrop=0.0, seed=None, site=0):
     """LayerNorm(a2 + b2), or LayerNorm(a2 + Dropout_pdrop(b2)) with the mask of `dropout(b2, pdrop, seed, site)`."""
     M, C = a2.shape

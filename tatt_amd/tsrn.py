@@ -282,9 +282,12 @@ def _srb(x, tp_map, blk: RecurrentResidualBlock):
     if blk.bn1.training and blk.bn2.training and ops.conv3_bn_fusable(x, blk.conv1.weight, blk.bn1) and ops.conv3_bn_fusable(x, blk.conv2.weight, blk.bn2):
         # conv(+stats) | finish | conv(+bn1, mish on the way in, +stats) | finish | apply bn2: 5 launches instead of 8, and the
         # normalised + activated map between the two convolutions never exists in HBM
-        y1, st1 = Fh.conv_bn(x, blk.conv1, blk.bn1)
-        y2, st2 = Fh.conv_bn(y1, blk.conv2, blk.bn2, prev=(st1, blk.bn1, ACT_MISH))
-        r = Fh.bn_apply_stats(y2, st2, blk.bn2, ACT_NONE)
+        if Fh.SRB_BWD_FUSED and ops.CONV3_SB:
+            r = Fh.srb_trunk(_cc(x), blk)                        # the same forward; the backward folds both BatchNorm backwards too
+        else:
+            y1, st1 = Fh.conv_bn(x, blk.conv1, blk.bn1)
+            y2, st2 = Fh.conv_bn(y1, blk.conv2, blk.bn2, prev=(st1, blk.bn1, ACT_MISH))
+            r = Fh.bn_apply_stats(y2, st2, blk.bn2, ACT_NONE)
     else:
         r = Fh.conv2d(x, blk.conv1.weight, blk.conv1.bias)
         r = Fh.batch_norm_act(r, blk.bn1, ACT_MISH, False)

@@ -771,6 +771,91 @@ def test_conv_bn_folded_equals_operator_chain(dev, B, H, W):
     assert not bad, "\n".join(bad)
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 16, 64), (5, 3, 128), (48, 16, 64)])
+def test_srb_trunk_fused_backward_equals_operator_chain(dev, B, H, W):
+    """SrbTrunkFn -- conv -> bn -> mish -> conv -> bn (reference model/tsrn.py:877-886) as one operator whose backward folds both
+    BatchNorm backwards into the data-gradient convolutions (partials from the epilogue, the affine form dx = a du + b x + c applied
+    while the next convolution stages its input; tatt_conv3_c64_dgrad_bn_sb, tatt_bn_bwd_finish, tatt_bn_bwd_affine) == the operator
+    chain conv2d | batch_norm_act | conv2d | batch_norm_act: output, running statistics, every gradient; with and without the deferred
+    parameter-gradient lane (the Trainer's mode)."""
+    from tatt_amd import functional as Fh
+    from tatt_amd.tsrn import RecurrentResidualBlock
+    from tatt_amd.ops import ACT_MISH, ACT_NONE
+    res = []
+    for mode in ("fused", "fused_deferred", "chain"):
+        torch.manual_seed(5)
+        blk = RecurrentResidualBlock(64, 0).to(dev).train()
+        with torch.no_grad():
+            for bn in (blk.bn1, blk.bn2):
+                bn.weight.add_(0.3 * R(64).to(dev))
+                bn.bias.add_(0.3 * R(64, seed=1).to(dev))
+        x = (R(B, H, W, 64, seed=2) + 0.5).to(dev).requires_grad_(True)
+        if mode != "chain":
+            out = Fh.srb_trunk(x, blk)
+        else:
+            r = Fh.conv2d(x, blk.conv1.weight, blk.conv1.bias)
+            r = Fh.batch_norm_act(r, blk.bn1, ACT_MISH, False)
+            r = Fh.conv2d(r, blk.conv2.weight, blk.conv2.bias)
+            out = Fh.batch_norm_act(r, blk.bn2, ACT_NONE, False)
+        loss = (out * R(B, H, W, 64, seed=3).to(dev)).sum()
+        if mode == "fused_deferred":
+            Fh.SIDE.enabled, Fh.SIDE.stage = True, 0
+            try:
+                loss.backward()
+                assert blk.conv1.weight.grad is None               # registered, not computed, while the main lane runs
+                Fh.SIDE.flush()
+            finally:
+                Fh.SIDE.enabled = False
+                Fh.SIDE.release()
+        else:
+            loss.backward()
+        d = {"out": out, "dx": x.grad}
+        for n in ("conv1.weight", "conv1.bias", "conv2.weight", "conv2.bias", "bn1.weight", "bn1.bias", "bn2.weight", "bn2.bias"):
+            d["g." + n] = blk.get_parameter(n).grad
+        for n in ("bn1.running_mean", "bn1.running_var", "bn2.running_mean", "bn2.running_var"):
+            d[n] = blk.get_buffer(n)
+        res.append({k: v.detach().float().cpu().clone() for k, v in d.items()})
+    bad = []
+    for k in res[0]:
+        ref = float(res[2][k].abs().max()) + 1e-12
+        noise = k in ("g.conv1.bias", "g.conv2.bias")          # mathematically zero (a bias in front of a BatchNorm): round-off only
+        for name, got in (("fused", res[0]), ("deferred", res[1])):
+            err = float((got[k] - res[2][k]).abs().max()) / (1.0 if noise else ref)
+            if not err < (2e-7 * B * H * W if noise else 2e-4):    # (noise: a sum of B H W round-offs of unit-scale terms)
+                bad.append("%s %s: %.3e" % (name, k, err))
+    assert not bad, "\n".join(bad)
+    for k in res[0]:
+        assert torch.equal(res[0][k], res[1][k]), k                # the lanes change the schedule, not the arithmetic
+
+
+def test_bn_backward_pieces_vs_fp64(dev):
+    """tatt_bn_bwd_partials | tatt_bn_bwd_finish | tatt_bn_bwd_affine (the train-mode BatchNorm backward in pieces, with Mish) against
+    autograd in fp64: dgamma, dbeta and dx = a du + b x + c."""
+    from tatt_amd import ops
+    from tatt_amd.ops import ACT_MISH
+    M, C = 3000, 64
+    x, dy = R(M, C, seed=1) * 1.5 + 0.3, R(M, C, seed=2)
+    gamma, beta = R(C, seed=3) * 0.3 + 1.0, R(C, seed=4) * 0.3
+    xd = x.double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    mean, var = xd.mean(0), xd.var(0, unbiased=False)
+    xh = (xd - mean) / torch.sqrt(var + 1e-5)
+    u = gd * xh + bd
+    (u * torch.tanh(torch.nn.functional.softplus(u)) * dy.double()).sum().backward()
+    d = lambda t: t.to(dev)
+    mean_f, rstd_f = d(mean.detach().float()), d((1.0 / torch.sqrt(var + 1e-5)).detach().float())
+    part, G = ops.bn_bwd_partials(d(x), d(dy), mean_f, rstd_f, d(gamma), d(beta), ACT_MISH)
+    dg, db, coef = ops.bn_bwd_finish(part, G, C, M, mean_f, rstd_f, d(gamma))
+    # du = dy * mish'(u) in fp32 on the host (the affine kernel takes du)
+    uu = (gamma * ((x - mean.detach().float()) * (1.0 / torch.sqrt(var + 1e-5)).detach().float()) + beta).double().requires_grad_(True)
+    (uu * torch.tanh(torch.nn.functional.softplus(uu))).sum().backward()
+    du = (dy.double() * uu.grad).float()
+    dx = ops.bn_bwd_affine(d(x), d(du), coef)
+    for name, got, want in (("dgamma", dg, gd.grad), ("dbeta", db, bd.grad), ("dx", dx, xd.grad)):
+        err = float((got.cpu().double() - want).abs().max() / want.abs().max())
+        assert err < 2e-5, (name, err)
+
+
 # ------------------------------------------------------------------------------------------- split-bf16 3x3 convolution
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 16, 64, 64, 64), (3, 5, 128, 64, 256), (2, 16, 64, 256, 64), (1, 1, 64, 128, 128)])
 def test_conv3_split_bf16_vs_fp64(dev, B, H, W, Cin, Cout):
