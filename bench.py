@@ -7,9 +7,12 @@ dropout ON, STN ON) on synthetic 16x64 -> 32x128 batches, B = 48 per GPU, fp32 (
         bench.py --gpus N --steps K --warmup W
 
 Prints ONE JSON line on rank 0.  `value` is the whole-job aggregate (weak scaling: 48 images per GPU per step).
-Extra objects: `roofline` (the dominant kernel -- the fp32-MFMA 3x3 convolution -- timed live with HIP
-events on the launch stream after the timed region) and `cpu_baseline` (the CPU oracle timed on this host's cores,
-N=1 only, a bounded sample).
+Extra objects: `roofline` -- the step's DOMINANT kernel, chosen from the committed per-step kernel table of the last rocprofv3 trace
+(profiles/step_kernel_table.json) and timed live with HIP events on the launch stream after the timed region; `frac` = ALGORITHMIC
+FLOPs (or bytes) / time / the peak of the unit the kernel actually issues on (the bf16 matrix cores for the split-bf16 kernels: the two
+extra products per fp32 product are reported separately as `mfma_pipe_util`); `roofline_hbm` / `roofline_mfma` -- the same for the
+heaviest kernel on the other roof; `roofline_attn` -- the attention path; `cpu_baseline` -- the CPU oracle timed on this host's cores
+(N=1 only, a bounded sample).
 """
 import argparse
 import json
@@ -28,7 +31,8 @@ PEAK_HBM_GBPS = 8000.0               # same guide: HBM3E spec peak (6.3 TB/s mea
 # SURVEY.md 8d (FlopCounterMode on the reference graph): forward + backward FLOPs per LR image
 TILES = {"std": dict(H=16, W=64, batch=48, flop_per_image=7.613e9, stn=True, loss_key="tatt_b48_16x64"),           # configs[1]/[2]
          "large": dict(H=32, W=128, batch=16, flop_per_image=36.66e9, stn=False, loss_key="tatt_b16_32x128")}     # configs[4]
-PMC_FILE = os.path.join(ROOT, "profiles", "conv3_ws_pmc.json")      # HBM traffic of the dominant kernel (rocprofv3 --pmc passes)
+PMC_FILE = os.path.join(ROOT, "profiles", "conv3_ws_pmc.json")      # HBM traffic per kernel (separate rocprofv3 --pmc passes)
+TABLE_FILE = os.path.join(ROOT, "profiles", "step_kernel_table.json")   # per-kernel time of ONE replayed step (tools/prof_timeline.py --json)
 LOSS_FILE = os.path.join(ROOT, "tests", "golden", "bench_losses.json")
 
 
@@ -103,25 +107,130 @@ def _timed_ms(run, n=50, warm=5):
     return e0.elapsed_time(e1) / n
 
 
-def time_dominant_kernel(dev, B, H=16, W=64):
-    """Average duration of the dominant kernel of the TATT / TSRN step -- the 3x3 convolution 64->64 channels on B x H x W pixels
-    (22 forward / data-gradient launches of this exact shape per training step; conv3_c64_sb_kernel: split-bf16 on the bf16 matrix
-    cores, or conv3_c64_ws16_kernel with tatt_amd.ops.CONV3_SB = False) -- measured with HIP events on the stream it is launched on.
-    Algorithmic FLOPs per launch = 2 * pixels * (3*3*64) * 64 (the fp32 convolution); the split executes three bf16 products each."""
+def _k_conv3_sb(dev, B, H, W):
+    """3x3 convolution 64 -> 64 channels on B x H x W pixels, forward / data-gradient launches of the step (conv3_c64_sb_kernel:
+    split-bf16 operands on the bf16 matrix cores; conv3_c64_ws16_kernel with tatt_amd.ops.CONV3_SB = False: exact fp32 MFMA)."""
     from tatt_amd import ops
     x = torch.randn(B, H, W, 64, device=dev)
     w = torch.randn(64, 64, 3, 3, device=dev) * 0.05
     b = torch.zeros(64, device=dev)
+    y = torch.empty(B, H, W, 64, device=dev)
+    px = B * H * W
     if ops.CONV3_SB:
         wl = ops.repack_weight(w, 10)
-        y = torch.empty(B, H, W, 64, device=dev)
         run = lambda: ops.call("tatt_conv3_c64_fwd_sb", ops.P(x), 64, 0, ops.P(wl), ops.P(b), ops.P(y), B, H, W, 64, 0, 0.0, None, None, 0,
                                None, ops.stream())
     else:
         wl = ops.repack_weight(w, ops._WS_FWD_MODE)
-        y = torch.empty(B, H, W, 64, device=dev)
         run = lambda: ops.call(ops._WS_ENTRY, ops.P(x), ops.P(wl), ops.P(b), ops.P(y), B, H, W, 64, 0, 0.0, ops.stream())
-    return _timed_ms(run), 2.0 * B * H * W * 576 * 64
+    return dict(ms=_timed_ms(run), flops=2.0 * px * 576 * 64, bytes=2 * px * 64 * 4 + 9 * 64 * 64 * 4, split=bool(ops.CONV3_SB), bound="mfma",
+                what="3x3 conv, 64->64 ch, %d x%dx%d px; fp32 in/out" % (B, H, W))
+
+
+def _k_conv3_wgrad(dev, B, H, W):
+    """Weight gradient of that convolution: dW[tap][ci][co] = sum over pixels (tatt_conv3_c64_wgrad_partial[_sb]); the partial slabs of
+    the G persistent groups are part of its algorithmic output."""
+    from tatt_amd import ops
+    x, dy = torch.randn(B, H, W, 64, device=dev), torch.randn(B, H, W, 64, device=dev)
+    px = B * H * W
+    G = min(B * H * (W // 64), ops.CONV3_WGRAD_GROUPS)
+    part = torch.empty(G * 36864 + G * 64, device=dev)
+    name = "tatt_conv3_c64_wgrad_partial_sb" if ops.CONV3_WGRAD_SB else "tatt_conv3_c64_wgrad_partial"
+    run = lambda: ops.call(name, ops.P(x), ops.P(dy), ops.P(part), ops.P(part[G * 36864:]), B, H, W, 64, 64, G, ops.stream())
+    return dict(ms=_timed_ms(run), flops=2.0 * px * 576 * 64, bytes=2 * px * 64 * 4 + G * 36864 * 4, split=bool(ops.CONV3_WGRAD_SB), bound="mfma",
+                what="3x3 weight gradient, 64x64 ch, %d x%dx%d px, %d partial slabs" % (B, H, W, G))
+
+
+def _gru_setup(dev, B, H, W, vertical):
+    from tatt_amd import ops
+    M = B * H * W
+    gi, whh, bhh = torch.randn(M, 192, device=dev), torch.randn(96, 32, device=dev) * 0.2, torch.randn(96, device=dev) * 0.1
+    geom = ops.seq_geom(B, H, W, vertical)
+    out, gates = ops.gru32_fwd(gi, whh, bhh, whh, bhh, geom, save=True)
+    return M, whh, geom, out, gates, torch.randn(M, 64, device=dev)
+
+
+def _k_gru32_bwd(dev, B, H, W):
+    """BPTT of one bidirectional GRU (hidden 32) of a GruBlock, both scan directions of the image averaged (tatt_gru32_bwd2: reads the
+    saved gates, h, dout = 1.5 KB per token; writes dgi + the weight-gradient pass's operand fragments = 2 KB per token)."""
+    from tatt_amd import ops
+    ms = []
+    for vertical in (True, False):
+        M, whh, geom, out, gates, dout = _gru_setup(dev, B, H, W, vertical)
+        if ops.gru_frag_ok(geom):
+            ms.append(_timed_ms(lambda: ops.gru32_bwd_frag(gates, out, dout, whh, whh, geom), 30, 3))
+            per_tok = (256 + 64 + 64 + 192 + 320) * 4
+        else:
+            ms.append(_timed_ms(lambda: ops.gru32_bwd(gates, out, dout, whh, whh, geom), 30, 3))
+            per_tok = (256 + 64 + 64 + 192 + 192 + 64) * 4
+    return dict(ms=sum(ms) / 2, flops=2.0 * M * 2 * 96 * 32, bytes=M * per_tok, split=False, bound="hbm",
+                what="BiGRU(32) backward recurrence over %d tokens (vertical %.1f us, horizontal %.1f us)" % (M, ms[0] * 1e3, ms[1] * 1e3))
+
+
+def _k_gru_wgrad(dev, B, H, W):
+    """Weight gradients of one GruBlock from the recurrence's operand fragments (tatt_gru_wgrad_frag; K = 128: the concatenated input)."""
+    from tatt_amd import ops
+    M, whh, geom, out, gates, dout = _gru_setup(dev, B, H, W, True)
+    _, frag = ops.gru32_bwd_frag(gates, out, dout, whh, whh, geom)
+    x, xb = torch.randn(M, 64, device=dev), torch.randn(M, 64, device=dev)
+    G = max(1, min(M // 32, ops.GRU_WGRAD_FRAG_GROUPS, 256))
+    ws1, ws2 = torch.empty(G * 192 * 129, device=dev), torch.empty(G * 192 * 33, device=dev)
+    run = lambda: ops.call("tatt_gru_wgrad_frag", ops.P(frag), ops.P(x), ops.P(xb), ops.P(ws1), ops.P(ws2), *geom, G, ops.stream())
+    return dict(ms=_timed_ms(run, 30, 3), flops=2.0 * M * 192 * 160, bytes=M * (320 + 128) * 4 + G * 192 * 162 * 4, split=True, bound="hbm",
+                what="GruBlock weight gradients (192 x 128 + 2 x 96 x 32) over %d tokens, %d partial slabs" % (M, G))
+
+
+# kernels bench.py can time live, by the name they carry in the per-step table (prefix match)
+TIMEABLE = [("conv3_c64_sb_kernel", _k_conv3_sb), ("conv3_c64_ws16_kernel", _k_conv3_sb), ("conv3_c64_wgrad_sb_kernel", _k_conv3_wgrad),
+            ("conv3_c64_wgrad_kernel", _k_conv3_wgrad), ("gru32_bwd2_kernel", _k_gru32_bwd), ("gru32_bwd_kernel", _k_gru32_bwd),
+            ("gru_wgrad_frag_kernel", _k_gru_wgrad)]
+
+
+def step_table():
+    try:
+        return json.load(open(TABLE_FILE))
+    except (OSError, ValueError):
+        return None
+
+
+def pick_kernels(table):
+    """-> [(table name, timer, per-step us, launches)] of the timeable kernels, heaviest first.  Without a table: the 3x3 convolution."""
+    if not table:
+        return [("conv3_c64_sb_kernel", _k_conv3_sb, None, None)]
+    agg = {}
+    for name, e in table["kernels"].items():
+        for key, fn in TIMEABLE:
+            if name.startswith(key):
+                a = agg.setdefault(key, [key, fn, 0.0, 0])
+                a[2] += e["us"]
+                a[3] += e["launches"]
+                break
+    return sorted((tuple(v) for v in agg.values()), key=lambda v: -v[2]) or [("conv3_c64_sb_kernel", _k_conv3_sb, None, None)]
+
+
+def roofline_block(name, k, per_step_us, launches, shape_key):
+    """The bench line's roofline object for one timed kernel.  achieved = ALGORITHMIC flops (bytes) per launch / average launch time;
+    peak = the unit the kernel issues on: the bf16 matrix cores for the split-bf16 kernels (dense 2.5 PFLOP/s), fp32 MFMA otherwise."""
+    sec = k["ms"] * 1e-3
+    tflops, gbps = k["flops"] / sec / 1e12, k["bytes"] / sec / 1e9
+    peak_f = PEAK_BF16_MFMA_TFLOPS if k["split"] else PEAK_FP32_MFMA_TFLOPS
+    r = {"bound": k["bound"], "kernel": "%s (%s%s)" % (name, k["what"], "; split-bf16 hi+lo operands, 3 bf16 MFMA products per fp32 product, fp32 "
+                                                        "accumulation" if k["split"] else ""),
+         "kernel_ms": round(k["ms"], 4), "flops_per_launch": k["flops"], "algorithmic_bytes": k["bytes"],
+         "traffic": dominant_kernel_traffic(shape_key, name)}
+    if k["bound"] == "mfma":
+        r.update(achieved=round(tflops, 2), peak=peak_f, unit="TFLOP/s", frac=round(tflops / peak_f, 4),
+                 hbm_gbps=round(gbps, 1), hbm_frac=round(gbps / PEAK_HBM_GBPS, 4))
+    else:
+        r.update(achieved=round(gbps, 1), peak=PEAK_HBM_GBPS, unit="GB/s", frac=round(gbps / PEAK_HBM_GBPS, 4),
+                 tflops=round(tflops, 2), mfma_frac=round(tflops / peak_f, 4))
+    if k["split"]:
+        r["mfma_pipe_util"] = round(3.0 * tflops / PEAK_BF16_MFMA_TFLOPS, 4)     # issue slots of the bf16 pipe taken (three products per fp32 product)
+        r["fp32_equivalent_tflops"] = round(tflops, 2)
+    if per_step_us is not None:
+        r["in_step"] = {"us_per_step": round(per_step_us, 1), "launches_per_step": launches,
+                        "source": "profiles/step_kernel_table.json (one replayed step of the last rocprofv3 kernel trace)"}
+    return r
 
 
 def time_tp_layer(dev, B, L, S=26):
@@ -307,6 +416,8 @@ def main():
     graph_ok = use_graph                        # a failed hipGraph capture raises: the line below never reports eager as graph
     for _ in range(a.warmup):
         tr.step(x, tp, hr)
+    if pg is not None:
+        tr.profile_collectives = True               # event pairs around every wait for a collective: the time the step stream was blocked
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -326,6 +437,7 @@ def main():
         ips = a.batch * world * a.steps / dt
         from tatt_amd import ops as _ops
         shape_key = "B%d_%dx%d" % (a.batch, tile["H"], tile["W"])
+        roof_other = None
         if a.arch == "tbsrn":
             tf, tb, ff, fb, kbytes = time_tbsrn_attention(dev, a.batch, tile["H"] * tile["W"])
             kms, kflops = tf + tb, ff + fb
@@ -340,32 +452,22 @@ def main():
                     "kernel_ms": round(kms, 4), "fwd_ms": round(tf, 4), "bwd_ms": round(tb, 4), "flops_per_launch": kflops,
                     "fwd_tflops": round(ff / (tf * 1e-3) / 1e12, 2), "bwd_tflops": round(fb / (tb * 1e-3) / 1e12, 2)}
         else:
-            kms, kflops = time_dominant_kernel(dev, a.batch, tile["H"], tile["W"])
-            alg_bytes = 2 * a.batch * tile["H"] * tile["W"] * 64 * 4 + 9 * 64 * 64 * 4
-            if _ops.CONV3_SB:          # three bf16 products per fp32 product on the bf16 matrix cores
-                ach = 3.0 * kflops / (kms * 1e-3) / 1e12
-                roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4),
-                        "traffic": dominant_kernel_traffic(shape_key, "conv3_c64_sb_kernel"), "algorithmic_bytes": alg_bytes,
-                        "fp32_equivalent_tflops": round(kflops / (kms * 1e-3) / 1e12, 2),
-                        "hbm_gbps": round(alg_bytes / (kms * 1e-3) / 1e9, 1), "hbm_frac": round(alg_bytes / (kms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
-                        "kernel": "conv3_c64_sb_kernel (3x3 conv, 64->64 ch, %d x%dx%d px; fp32 in/out, split-bf16 hi+lo operands, 3 bf16 "
-                                  "MFMA products per fp32 product, fp32 accumulation)" % (a.batch, tile["H"], tile["W"]),
-                        "kernel_ms": round(kms, 4), "flops_per_launch": kflops, "executed_bf16_flops_per_launch": 3.0 * kflops}
-            else:
-                ach = kflops / (kms * 1e-3) / 1e12
-                roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
-                        "traffic": dominant_kernel_traffic(shape_key, "conv3_c64_ws16_kernel"), "algorithmic_bytes": alg_bytes,
-                        "hbm_gbps": round(alg_bytes / (kms * 1e-3) / 1e9, 1), "hbm_frac": round(alg_bytes / (kms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
-                        "kernel": "conv3_c64_ws16_kernel (3x3 conv, 64->64 ch, %d x%dx%d px, fp32 MFMA)" % (a.batch, tile["H"], tile["W"]),
-                        "kernel_ms": round(kms, 4), "flops_per_launch": kflops}
+            cands = pick_kernels(step_table() if (a.arch == "tatt" and a.tile == "std") else None)
+            name, fn, us, nl = cands[0]
+            k0 = fn(dev, a.batch, tile["H"], tile["W"])
+            roof = roofline_block(name, k0, us, nl, shape_key)
+            for name2, fn2, us2, nl2 in cands[1:]:           # the heaviest kernel on the OTHER roof
+                k2 = fn2(dev, a.batch, tile["H"], tile["W"])
+                if k2["bound"] != k0["bound"]:
+                    roof_other = ("roofline_" + k2["bound"], roofline_block(name2, k2, us2, nl2, shape_key))
+                    break
         attn = time_tp_layer(dev, a.batch, tile["H"] * tile["W"]) if a.arch in ("tatt", "tatt_tpg") else None
         out = {
             "metric": "LR images/s (train fwd+bwd+clip+Adam) at %dx%d->%dx%d" % (tile["H"], tile["W"], 2 * tile["H"], 2 * tile["W"]),
             "value": round(ips, 2), "unit": "LR images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "fp32", "data": "synthetic",
+            "dtype": "fp32" + (" (split-bf16 MFMA operands in conv3 / conv3-wgrad / tokgemm / gru-wgrad)" if _ops.CONV3_SB else ""),
+            "data": "synthetic",
             "config": {"workload": "TATT (TSRN_TL_TRANS, STN %s, dropout on) train step, batch %d/GPU, %dx%d LR -> %dx%d SR, "
                                    "ImageLoss + clip 0.25 + Adam(1e-3,(0.5,0.999))" % (
                                        "on" if tile["stn"] else "off", a.batch, tile["H"], tile["W"], 2 * tile["H"], 2 * tile["W"])
@@ -381,12 +483,18 @@ def main():
                        # algorithmic = the reference graph's FLOP count; executed = minus the query-GRU input projection
                        # the build hoists out of the recurrence
                        "whole_step_tflops": ({"algorithmic": round(ips * tile["flop_per_image"] / 1e12, 2),
-                                              "executed": round(ips * executed_flop_per_image(tile, a.batch) / 1e12, 2)}
+                                              "executed": round(ips * executed_flop_per_image(tile, a.batch) / 1e12, 2),
+                                              "note": "mixed pipes (about a third of the FLOPs run as split-bf16 on the bf16 matrix cores, "
+                                                      "the rest on fp32 MFMA / VALU): quoted against no single peak"}
                                              if a.arch == "tatt" else None)},
             "roofline": roof,
         }
+        if roof_other is not None:
+            out[roof_other[0]] = roof_other[1]
         if attn is not None:
             out["roofline_attn"] = attn
+        if pg is not None:
+            out["collectives"] = tr.collective_report()
         if world == 1 and not a.no_cpu_baseline and a.arch != "tatt_tpg":
             out["cpu_baseline"] = cpu_baseline(a.arch, a.cpu_batch if a.tile == "std" else min(a.cpu_batch, a.batch), a.tile)
         line = json.dumps(out)

@@ -265,6 +265,8 @@ class Trainer:
         self.kernels = kernels if kernels is not None else HipStepKernels()
         self.loss_fn = loss_fn if loss_fn is not None else _default_loss
         self.recipe = recipe                             # e.g. TssimRecipe: computes the step's loss itself (several forwards)
+        self.profile_collectives = False                 # True: time every wait for a collective (collective_report)
+        self._coll_events = []
         dev = next(model.parameters()).device
         self.dev = dev
         self.cuda = dev.type == "cuda"
@@ -418,10 +420,41 @@ class Trainer:
         return nst - 1 if (self._merge_last and k >= nst - 1) else min(k - 1, nst - 1)
 
     def _wait_reduces(self):
-        """The current stream waits for the collectives (device-side waits; the host does not block on a GPU)."""
-        for w in self._works:
-            w.wait()
+        """The current stream waits for the collectives (device-side waits; the host does not block on a GPU).  With
+        `profile_collectives` an event pair brackets every wait: their distance is the time the step's stream sat blocked behind that
+        collective -- its EXPOSED time (0 when it finished under the passes launched after it)."""
+        prof = self.profile_collectives and self.cuda
+        for i, w in enumerate(self._works):
+            if prof:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                w.wait()
+                e1.record()
+                self._coll_events.append((i, e0, e1))
+            else:
+                w.wait()
         self._works = []
+
+    def collective_report(self):
+        """What the data-parallel step sent and what it cost, for the bench line: the world size as the process group's backend reports it,
+        the all-reduces of one step (bytes, the pass they were issued after) and -- if profiled -- the average exposed time of each."""
+        if not self.dp:
+            return None
+        rep = {"backend": torch.distributed.get_backend(self.pg), "world_size": torch.distributed.get_world_size(self.pg),
+               "per_step": [{"after_pass": ap, "buckets": [self.flat.bucket_names[k] for k in range(lo, hi + 1)],
+                             "bytes": 4 * (self.flat.ranges[hi][1] - self.flat.ranges[lo][0])} for ap, lo, hi in self.reduce_log]}
+        if self._coll_events:
+            torch.cuda.synchronize(self.dev)
+            n = max(i for i, _, _ in self._coll_events) + 1
+            tot, cnt = [0.0] * n, [0] * n
+            for i, e0, e1 in self._coll_events:
+                tot[i] += e0.elapsed_time(e1)
+                cnt[i] += 1
+            for i in range(min(n, len(rep["per_step"]))):
+                rep["per_step"][i]["exposed_ms"] = round(tot[i] / max(cnt[i], 1), 4)
+            rep["exposed_ms_per_step"] = round(sum(t / max(c, 1) for t, c in zip(tot, cnt)), 4)
+            rep["steps_profiled"] = max(cnt)
+        return rep
 
     @property
     def last_grad_norm(self):

@@ -15,7 +15,7 @@ for cfg in "$@"; do
     db=$(find gpurun_out/${tag}_prof -name "*.db" | head -1)
     python tools/prof_summary.py $db 15 > gpurun_out/${tag}_kernel_stats.txt 2>&1
     python tools/prof_timeline.py $db > gpurun_out/${tag}_timeline.txt 2>&1
-    python tools/prof_timeline.py $db --dump > gpurun_out/${tag}_timeline_dump.txt 2>&1
+    python tools/prof_timeline.py $db --dump --json gpurun_out/${tag}_step_kernel_table.json > gpurun_out/${tag}_timeline_dump.txt 2>&1
     rm -rf gpurun_out/${tag}_prof
     head -40 gpurun_out/${tag}_timeline.txt
     continue

@@ -1,6 +1,8 @@
 """Per-queue view of ONE replayed training step from a rocprofv3 --kernel-trace database (the step before the last Adam launch):
 busy time per hardware queue, GPU idle time, the heaviest kernels per queue and, with --dump, the launch-by-launch timeline.
-usage: python tools/prof_timeline.py <results.db> [--dump [from_us [to_us]]]"""
+usage: python tools/prof_timeline.py <results.db> [--dump [from_us [to_us]]] [--json out.json]
+--json: the per-kernel table of that one step ({kernel: {"launches", "us"}} by demangled-name prefix) -- bench.py reads the committed copy
+(profiles/step_kernel_table.json) to decide which kernel is the step's dominant one."""
 import collections
 import sqlite3
 import sys
@@ -47,6 +49,29 @@ def main():
             cnt[r[3][:44]] += 1
         for k, t in agg.most_common(14):
             print("      %-46s %4d %8.0f us" % (k, cnt[k], t))
+    if "--json" in sys.argv:
+        import json
+        import re
+        import subprocess
+        agg, cnt = collections.Counter(), collections.Counter()
+        for r in seg:
+            agg[r[3]] += (r[1] - r[0]) / 1e3
+            cnt[r[3]] += 1
+        names = list(agg)
+        try:                                                     # demangle (c++filt ships with binutils / llvm)
+            dem = subprocess.run(["c++filt"], input="\n".join(n[:-3] if n.endswith(".kd") else n for n in names), capture_output=True,
+                                 text=True).stdout.splitlines()
+        except OSError:
+            dem = names
+        table = {}
+        for n, d in zip(names, dem):
+            key = re.sub(r"\(.*$", "", d).replace("void ", "").strip()
+            e = table.setdefault(key, {"launches": 0, "us": 0.0})
+            e["launches"] += cnt[n]
+            e["us"] = round(e["us"] + agg[n], 1)
+        out = {"step_us_profiled": round(T, 1), "launches": len(seg),
+               "kernels": dict(sorted(table.items(), key=lambda kv: -kv[1]["us"]))}
+        json.dump(out, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)
     if "--dump" in sys.argv:
         i = sys.argv.index("--dump")
         lo = float(sys.argv[i + 1]) if len(sys.argv) > i + 1 else 0.0

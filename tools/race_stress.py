@@ -67,3 +67,53 @@ def fwd():
 
 
 repeat("train-mode forward with the query-GRU fork", fwd, 150)
+
+# ---- round 4: the new kernels (second-generation BiGRU recurrences, fragment stream, split-bf16 3x3 weight gradient) -----------------
+M = B * 16 * 64
+gi = torch.randn(M, 192, generator=g).to(dev)
+whh, bhh = (torch.randn(96, 32, generator=g) * 0.2).to(dev), (torch.randn(96, generator=g) * 0.1).to(dev)
+dout = torch.randn(M, 64, generator=g).to(dev)
+xa, xb_ = torch.randn(M, 64, generator=g).to(dev), torch.randn(M, 64, generator=g).to(dev)
+for vert in (True, False):
+    geom = ops.seq_geom(B, 16, 64, vert)
+    nm = "vertical" if vert else "horizontal"
+    repeat("gru32 forward, " + nm, lambda: torch.cat([t.reshape(-1) for t in ops.gru32_fwd(gi, whh, bhh, whh, bhh, geom, save=True)]), 100)
+    out_, gates_ = ops.gru32_fwd(gi, whh, bhh, whh, bhh, geom, save=True)
+    repeat("gru32 backward + fragments, " + nm,
+           lambda: torch.cat([t.reshape(-1) for t in ops.gru32_bwd_frag(gates_, out_, dout, whh, whh, geom)]), 100)
+    _, frag_ = ops.gru32_bwd_frag(gates_, out_, dout, whh, whh, geom)
+
+    def wg():
+        dWp, dWh, dbp, dbh = (torch.empty(192, 128, device=dev), torch.empty(192, 32, device=dev), torch.empty(192, device=dev),
+                              torch.empty(192, device=dev))
+        ops.gru_wgrad_frag(frag_, xa, xb_, geom, dWp, dWh, dbp, dbh)
+        return torch.cat([dWp.reshape(-1), dWh.reshape(-1), dbp, dbh])
+    repeat("gru weight gradients from fragments, " + nm, wg, 100)
+repeat("conv3 wgrad split-bf16 (+ bias)", lambda: torch.cat([t.reshape(-1) for t in ops.conv_wgrad(xl, xl, 64, 3, 3, want_db=True)]), 100)
+
+# ---- the whole staged two-lane step, replayed from identical state: loss and every weight bit for bit --------------------------------
+from tatt_amd.train import Trainer  # noqa: E402
+
+
+def train_run(nsteps, use_graph):
+    torch.manual_seed(1234)
+    mm = tatt_amd.TSRN_TL_TRANS(scale_factor=2, width=128, height=32, STN=True, mask=True, srb_nums=5, hidden_units=32)
+    mm.load_state_dict(randomize_state_dict(mm.state_dict()))
+    mm = mm.to(dev).train()
+    Fh.set_seed(dev, 99)
+    tr = Trainer(mm, use_graph=use_graph, warmup_eager=2)
+    x8, tp8, hr8 = (t.to(dev) for t in make_inputs(48, seed=5))
+    ls = [float(tr.step(x8, tp8, hr8)) for _ in range(nsteps)]
+    torch.cuda.synchronize()
+    return ls, tr.flat_p.clone()
+
+
+ref_l, ref_p = train_run(6, True)
+bad = 0
+for rep in range(6):
+    l, pp = train_run(6, True)
+    bad += int(l != ref_l or not torch.equal(pp, ref_p))
+print("%-44s %4d repetitions, %d differ" % ("6 training steps (graph, 2 lanes, B = 48)", 6, bad), flush=True)
+l, pp = train_run(6, False)
+print("%-44s eager vs graph: losses %s, weights %s" % ("", "equal" if l == ref_l else "DIFFER", "equal" if torch.equal(pp, ref_p) else "DIFFER"),
+      flush=True)
