@@ -74,8 +74,12 @@ def main():
         json.dump(out, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)
     if "--dump" in sys.argv:
         i = sys.argv.index("--dump")
-        lo = float(sys.argv[i + 1]) if len(sys.argv) > i + 1 else 0.0
-        hi = float(sys.argv[i + 2]) if len(sys.argv) > i + 2 else 1e12
+        def num(j, dflt):
+            try:
+                return float(sys.argv[j])
+            except (IndexError, ValueError):
+                return dflt
+        lo, hi = num(i + 1, 0.0), num(i + 2, 1e12)
         for r in seg:
             ts = (r[0] - t0) / 1e3
             if lo <= ts <= hi:
