@@ -267,6 +267,7 @@ class Trainer:
         self.recipe = recipe                             # e.g. TssimRecipe: computes the step's loss itself (several forwards)
         self.profile_collectives = False                 # True: time every wait for a collective (collective_report)
         self._coll_events = []
+        self._group_events = []                          # (group of passes, start, end) when profiling: GPU time of each group
         dev = next(model.parameters()).device
         self.dev = dev
         self.cuda = dev.type == "cuda"
@@ -454,6 +455,15 @@ class Trainer:
                 rep["per_step"][i]["exposed_ms"] = round(tot[i] / max(cnt[i], 1), 4)
             rep["exposed_ms_per_step"] = round(sum(t / max(c, 1) for t, c in zip(tot, cnt)), 4)
             rep["steps_profiled"] = max(cnt)
+        if self._group_events:
+            torch.cuda.synchronize(self.dev)
+            n = max(i for i, _, _ in self._group_events) + 1
+            tot, cnt = [0.0] * n, [0] * n
+            for i, e0, e1 in self._group_events:
+                tot[i] += e0.elapsed_time(e1)
+                cnt[i] += 1
+            rep["pass_groups"] = [{"passes": [self.stages[k] if k < len(self.stages) else "side(%s)" % self.stages[-1] for k in g],
+                                   "gpu_ms": round(tot[i] / max(cnt[i], 1), 4)} for i, g in enumerate(self._groups)]
         return rep
 
     @property
@@ -484,12 +494,20 @@ class Trainer:
             return self.last_loss.clone()            # (the captured tensor is overwritten by the next replay)
         self.reduce_log = []
         sent = -1                                    # last bucket already on the wire
+        prof = self.profile_collectives and self.cuda
         for gi, group in enumerate(self._groups):
+            if prof:
+                g0 = torch.cuda.Event(enable_timing=True)
+                g0.record()
             if graphs is None:
                 for k in group:
                     self._pass(k, x, tp, hr)
             else:
                 graphs["pass"][gi].replay()
+            if prof:
+                g1 = torch.cuda.Event(enable_timing=True)
+                g1.record()
+                self._group_events.append((gi, g0, g1))
             done = self._buckets_done_by(group[-1])
             self._reduce(sent + 1, done, group[-1])  # what this group completed: on the wire while the next group computes
             sent = max(sent, done)

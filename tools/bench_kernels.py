@@ -220,3 +220,28 @@ for (N_, K_, K1_, N1_) in ((192, 128, 64, 192), (192, 64, 64, 192), (128, 192, 1
     Wk = torch.empty(N_ * K_, device=dev)
     ops.call("tatt_tokgemm_pack", ops.P(Wt), ops.P(Wk), N_, K_, K_, 0, ops.stream())
     timeit("tokgemm_sb_%dx%d" % (N_, K_), lambda: Fh._tokgemm(Xa, Xb, Wk, None, N_, K_, N1_), 2.0 * M * N_ * K_, M * (N_ + K_) * 4)
+
+# ---- query GRU (hidden 512, time axis = the 48 samples): the whole forward / backward chains as the model issues them -----------
+qg = torch.nn.GRU(1024, 512, bidirectional=True, batch_first=True).to(dev)
+qemb = R(16 * 64, 64) * 0.3                                      # init_factor: (H * W, C)
+qnames = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0", "weight_ih_l0_reverse", "weight_hh_l0_reverse", "bias_ih_l0_reverse",
+          "bias_hh_l0_reverse"]
+qparams = [getattr(qg, n).detach().requires_grad_(True) for n in qnames]
+qe = qemb.clone().requires_grad_(True)
+
+
+def _qgru_fwd():
+    with torch.no_grad():
+        return Fh.QueryGruFn.apply(qemb, *[p_.detach() for p_ in qparams], B, 16, 64)
+
+
+timeit("qgru_fwd_chain", _qgru_fwd, 2.0 * B * 64 * 1536 * 512 * 2, 0)
+qout = Fh.QueryGruFn.apply(qe, *qparams, B, 16, 64)
+qdq = torch.randn_like(qout)
+
+
+def _qgru_bwd():
+    torch.autograd.grad(qout, [qe] + qparams, qdq, retain_graph=True)
+
+
+timeit("qgru_bwd_chain", _qgru_bwd, 3 * 2.0 * B * 64 * 1536 * 512 * 2, 0)
