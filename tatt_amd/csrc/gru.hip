@@ -762,31 +762,12 @@ struct QBwdFusedP {
 // 8 waves split the 3*HID contraction and walk it in trips of 96 with 6 + 6 sixteen-byte loads per lane in flight (HID = 512: two
 // trips to L2 instead of the six of a 4-wave / 64-wide walk -- the step is latency, not work: 47 of these follow each other)
 #define QB_WAVES 8
-// Round 4: the step is a chain of dependent round trips (47 of these kernels follow each other at the end of the training step,
-// where nothing hides them), so every load is issued before the first wait: the gate values of the epilogue at the very top, then the
-// whole 192-wide contraction slice of this wave (12 + 12 sixteen-byte loads per lane: ONE trip to L2 instead of two).
 __global__ __launch_bounds__(64 * QB_WAVES) void qgru_bwd_fused_kernel(QBwdFusedP p) {
     __shared__ float red[QB_WAVES][16][17];
     const int d = blockIdx.z;
     const int m0 = blockIdx.x * 16, j0 = blockIdx.y * 16;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int HID = p.HID, K = 3 * p.HID;
-    // epilogue operands of thread t < 256 (element (m, j) of the tile): requested now, used after the reduction
-    const int em = (t >> 4) & 15, ej = t & 15;
-    const bool ep_on = t < 256 && m0 + em < p.Wb;
-    const long erow = min(m0 + em, p.Wb - 1), e = erow * HID + j0 + ej;
-    const long n_el = (long)p.Wb * HID;
-    // (every thread loads -- threads 256 .. 511 repeat the addresses of 0 .. 255 -- and no load sits behind a branch: a value that
-    // merges with a constant at a join is waited for AT the join, which would put this round trip in front of the big one)
-    const long g3 = erow * 3 * HID + j0 + ej;
-    const float* gs = p.gsave_next[d];
-    const float* ga_in = p.dgi_acc[d];
-    const float* hpp = p.hprev_next[d] ? p.hprev_next[d] : p.dhcarry[d];      // (any valid address; scaled to zero below)
-    const float hp_on = p.hprev_next[d] ? 1.f : 0.f;
-    const float g_dhs = p.dhseq_next[d][e], g_dhc = p.dhcarry[d][e];
-    const float g_r = gs[e], g_z = gs[n_el + e], g_n = gs[2 * n_el + e], g_hn = gs[3 * n_el + e];
-    const float g_hp = hpp[e] * hp_on;
-    const float g_a0 = ga_in[g3], g_a1 = ga_in[g3 + HID], g_a2 = ga_in[g3 + 2 * HID];
     const float* dgh = p.dgh_cur[d];
     const float* whh = p.whhT[d];
     f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
@@ -795,37 +776,20 @@ __global__ __launch_bounds__(64 * QB_WAVES) void qgru_bwd_fused_kernel(QBwdFused
     const int arow = min(m0 + i, p.Wb - 1);
     const float* ap = dgh + (long)arow * K + kbeg + 4 * q;
     const float* bp = whh + (long)(j0 + i) * K + kbeg + 4 * q;
-    if (kspan == 192) {                                                 // HID = 512 (the 16 x 64 tile): the whole slice in one trip
-        f32x4 a[12], b[12];
+    for (int kb = 0; kb < kspan; kb += 96) {
+        f32x4 a[6], b[6];
 #pragma unroll
-        for (int sstep = 0; sstep < 12; ++sstep) {
-            a[sstep] = *reinterpret_cast<const f32x4*>(ap + 16 * sstep);
-            b[sstep] = *reinterpret_cast<const f32x4*>(bp + 16 * sstep);
+        for (int sstep = 0; sstep < 6; ++sstep) {
+            a[sstep] = *reinterpret_cast<const f32x4*>(ap + kb + 16 * sstep);
+            b[sstep] = *reinterpret_cast<const f32x4*>(bp + kb + 16 * sstep);
         }
-        __builtin_amdgcn_sched_barrier(0);                              // (keep the 24 loads together: the scheduler would interleave them with the MFMAs)
 #pragma unroll
-        for (int sstep = 0; sstep < 12; ++sstep)
+        for (int sstep = 0; sstep < 6; ++sstep)
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (u & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[sstep][u], b[sstep][u], acc1, 0, 0, 0);
                 else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[sstep][u], b[sstep][u], acc0, 0, 0, 0);
             }
-    } else {
-        for (int kb = 0; kb < kspan; kb += 96) {
-            f32x4 a[6], b[6];
-#pragma unroll
-            for (int sstep = 0; sstep < 6; ++sstep) {
-                a[sstep] = *reinterpret_cast<const f32x4*>(ap + kb + 16 * sstep);
-                b[sstep] = *reinterpret_cast<const f32x4*>(bp + kb + 16 * sstep);
-            }
-#pragma unroll
-            for (int sstep = 0; sstep < 6; ++sstep)
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (u & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[sstep][u], b[sstep][u], acc1, 0, 0, 0);
-                    else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[sstep][u], b[sstep][u], acc0, 0, 0, 0);
-                }
-        }
     }
     {
         const int col = lane & 15, rb = (lane >> 4) * 4;
@@ -833,18 +797,25 @@ __global__ __launch_bounds__(64 * QB_WAVES) void qgru_bwd_fused_kernel(QBwdFused
         for (int r = 0; r < 4; ++r) red[wave][rb + r][col] = acc0[r] + acc1[r];
     }
     __syncthreads();
-    if (!ep_on) return;
+    if (t >= 256) return;
+    const int m = t >> 4, j = t & 15;
+    if (m0 + m >= p.Wb) return;
+    const long row = m0 + m, e = row * HID + j0 + j;
+    const long n_el = (long)p.Wb * HID;
     float sum = 0.f;
 #pragma unroll
-    for (int w = 0; w < QB_WAVES; ++w) sum += red[w][em][ej];
-    const float dh = g_dhs + g_dhc + sum;
-    const float r = g_r, z = g_z, n = g_n, hn = g_hn, hp = g_hp;
+    for (int w = 0; w < QB_WAVES; ++w) sum += red[w][m][j];
+    const float dh = p.dhseq_next[d][e] + p.dhcarry[d][e] + sum;
+    const float* gs = p.gsave_next[d];
+    const float r = gs[e], z = gs[n_el + e], n = gs[2 * n_el + e], hn = gs[3 * n_el + e];
+    const float hp = p.hprev_next[d] ? p.hprev_next[d][e] : 0.f;
     const float dn = dh * (1.f - z), dz = dh * (hp - n);
     const float dnp = dn * (1.f - n * n);
     const float drp = dnp * hn * r * (1.f - r);
     const float dzp = dz * z * (1.f - z);
+    const long g3 = row * 3 * HID + j0 + j;
     float* ga = p.dgi_acc[d];
-    ga[g3] = g_a0 + drp; ga[g3 + HID] = g_a1 + dzp; ga[g3 + 2 * HID] = g_a2 + dnp;
+    ga[g3] += drp; ga[g3 + HID] += dzp; ga[g3 + 2 * HID] += dnp;
     float* dg = p.dgh_next[d];
     dg[g3] = drp; dg[g3 + HID] = dzp; dg[g3 + 2 * HID] = dnp * r;
     p.dhcarry[d][e] = dh * z;

@@ -245,3 +245,31 @@ def _qgru_bwd():
 
 
 timeit("qgru_bwd_chain", _qgru_bwd, 3 * 2.0 * B * 64 * 1536 * 512 * 2, 0)
+
+
+def timeit_graph(name, fn, iters=20):
+    """the same work captured once and replayed as a hipGraph (what the training step does: no host launch cost between the kernels)"""
+    if (a.only and a.only != name) or (a.match and a.match not in name):
+        return
+    st_ = torch.cuda.Stream()
+    with torch.cuda.stream(st_):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        gph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gph):
+            fn()
+    torch.cuda.synchronize()
+    gph.replay()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        gph.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    print("%-28s %9.1f us  (hipGraph replay)" % (name, e0.elapsed_time(e1) / iters * 1e3), flush=True)
+
+
+timeit_graph("qgru_fwd_chain_graph", _qgru_fwd)
+# (the backward chain allocates its split-K workspaces through torch outside a Trainer: not capturable on its own)
