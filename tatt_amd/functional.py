@@ -93,46 +93,35 @@ class _DeferredParamGrads:
             if p is not None and g is not None:
                 p.grad = g if p.grad is None else p.grad + g
 
-    def submit(self, params, fn, *keep, lag=0, solo=False):
+    def submit(self, params, fn, *keep, lag=0):
         """params: tuple of leaf tensors (or None); fn() -> tuple of their gradients (or None), same order (or a generator that
         yields once between its split-K GEMMs and their consumer and returns the tuple).  The closure runs with the side lane of
         the current stage, or of a later one: `lag` stages later, and not before the stage whose gradient bucket holds its
         parameters (`due_of`, from the model's grad_buckets(): the query GRU's 47 dependent launches and the 9x9 output
-        convolution's 0.4 ms weight gradient are filed under later buckets, where the main lane beside them has room).
-        `solo`: a long dependent chain (the query GRU's backward) that the Trainer may give a lane of its own from the moment it is
-        submitted to the end of the step (`flush(solo=True)`), instead of a place in some stage's side lane."""
+        convolution's 0.4 ms weight gradient are filed under later buckets, where the main lane beside them has room)."""
         if not self.enabled or any(p is not None and not p.is_leaf for p in params):
             return self._run(fn)
         due = self.stage + lag
         for p in params:                 # a parameter filed under a LATER bucket: its kernels run with that stage's side lane
             if p is not None:
                 due = max(due, self.due_of.get(id(p), 0))
-        self._pending.append((due, params, fn, bool(solo)))
+        self._pending.append((due, params, fn))
         self._keep.append(keep)
         return (None,) * len(params)
 
-    def solo_params(self):
-        """ids of the parameters of the pending solo closures (the Trainer gathers their buckets after the solo lane has joined)"""
-        return {id(p) for e in self._pending if e[3] for p in e[1] if p is not None}
-
-    def flush(self, upto=None, solo=None):
+    def flush(self, upto=None):
         """Run the pending closures due at stage <= `upto` (all of them if None) in submission order on the CURRENT stream;
-        results become / are added to `.grad`.  `solo`: None = regardless, True = only the solo closures (whatever their due stage),
-        False = only the others.  While they run, the split-K reductions behind their weight-gradient GEMMs are only
+        results become / are added to `.grad`.  While they run, the split-K reductions behind their weight-gradient GEMMs are only
         registered and then summed by one launch per 36 (ops.reduce_defer); a closure that consumes such a result itself is a
         GENERATOR: it yields once after issuing its GEMMs and is resumed after the batched reduction."""
-        def take(e):
-            if solo is True:
-                return e[3]
-            return (upto is None or e[0] <= upto) and not (solo is False and e[3])
-        pending = [e for e in self._pending if take(e)]
+        pending = [e for e in self._pending if upto is None or e[0] <= upto]
         if not pending:
             return
-        self._pending = [e for e in self._pending if not take(e)]
+        self._pending = [e for e in self._pending if not (upto is None or e[0] <= upto)]
         results = []
         ops.reduce_defer(True)
         try:
-            for _, params, fn, _s in pending:
+            for _, params, fn in pending:
                 r = fn()
                 if hasattr(r, "send"):                # generator: run up to its yield
                     next(r)
@@ -1122,7 +1111,7 @@ class QueryGruFn(Function):
         # every output of this backward is a parameter gradient (the embedding depends on parameters only): all of it is deferrable
         dq = _c(dq)
         saved = ctx.saved_tensors
-        return tuple(SIDE.submit(ctx.leaves, lambda: QueryGruFn._backward(ctx, saved, dq), dq, saved, solo=True)) + (None, None, None)
+        return tuple(SIDE.submit(ctx.leaves, lambda: QueryGruFn._backward(ctx, saved, dq), dq, saved)) + (None, None, None)
 
     @staticmethod
     def _backward(ctx, saved, dq):

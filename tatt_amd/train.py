@@ -100,9 +100,6 @@ class TextPriorSR(torch.nn.Module):
     def set_grad_cuts(self, cuts):
         self.sr.set_grad_cuts(cuts)
 
-    def solo_after_stage(self):
-        return self.sr.solo_after_stage() if hasattr(self.sr, "solo_after_stage") else None
-
     def clip_groups(self, clip):
         """The reference clips each model of `model_list` by its own norm (`for model in model_list: clip_grad_norm_(...)`,
         interfaces/super_resolution.py:1082-1083) and leaves the recogniser's gradients unclipped."""
@@ -209,9 +206,6 @@ class TssimRecipe:
         return loss if extra is None else loss + extra
 
 
-SOLO_TAIL = True            # default of Trainer(solo_tail=...): the query GRU's backward chain gets the second stream to itself for the step's tail
-
-
 class HipStepKernels:
     """The optimiser side of a step on the GPU: global-norm clip + Adam on flat buffers (tatt_l2norm, tatt_adam_step)."""
 
@@ -260,7 +254,7 @@ class Trainer:
 
     def __init__(self, model, lr=1e-3, betas=(0.5, 0.999), eps=1e-8, clip=0.25, use_graph=False, warmup_eager=2,
                  process_group=None, broadcast_init=True, defer_param_grads=True, side_stream=True, kernels=None, loss_fn=None,
-                 dropout_seed=None, recipe=None, solo_tail=None):
+                 dropout_seed=None, recipe=None):
         self.model = model
         self.lr, self.betas, self.eps, self.clip = lr, betas, eps, clip
         self.pg = process_group
@@ -312,17 +306,6 @@ class Trainer:
                 Fh.set_seed(dev, rank_dropout_seed(base, self.rank) if self.dp else base)
         self.side = torch.cuda.Stream(device=dev) if self.two_lanes else None
         self._merge_last = len(self.stages) >= 2         # (also without a second stream: one pass structure everywhere)
-        # The tail of the step (round 4): a model may name the stage whose main lane submits a SOLO closure -- a long dependent chain, the
-        # query GRU's backward (47 launches + GEMMs, 0.75 ms).  From the pass after that stage to the end of the step that chain has the
-        # second stream to itself (forked once, joined once); the ordinary parameter-gradient work of those passes follows each main lane
-        # on the main stream.  Measured layout before: pass "first" 0.17 ms + pass "stn" 0.91 ms, the latter bound by the chain.
-        solo_tail = SOLO_TAIL if solo_tail is None else bool(solo_tail)
-        after = model.solo_after_stage() if (solo_tail and hasattr(model, "solo_after_stage")) else None
-        self._solo_from = (self.stages.index(after) + 1) if (after in self.stages and self.two_lanes and self.cuts is not None) else None
-        if self._solo_from is not None and self._solo_from >= len(self.stages):
-            self._solo_from = None
-        self._solo_active = False
-        self._solo_ids = set()
         self._npass = len(self.stages) + (0 if self._merge_last else 1)
         self.gnorms = [torch.zeros(1, device=dev) for _ in self.groups]
         self.gnorm = self.gnorms[0]
@@ -341,8 +324,6 @@ class Trainer:
         # launches and three collectives per step instead of ten and ten.
         n = self._npass
         groups = [list(range(0, n - 2)), [n - 2], [n - 1]] if n >= 3 else [[k] for k in range(n)]
-        if self._solo_from is not None:                  # the solo lane spans the passes from _solo_from on: they are one group
-            groups = [list(range(0, self._solo_from)), list(range(self._solo_from, n))]
         self._groups = [g for g in groups if g]
         self.reduce_log = []                         # [(last pass of the group, first bucket, last bucket)] of the latest step
 
@@ -393,10 +374,6 @@ class Trainer:
         parallel branch, which the hipGraph executor does overlap (tools/graph_sched_probe.py); otherwise it simply runs first."""
         nst = len(self.stages)
         main = torch.cuda.current_stream(self.dev) if self.cuda else None
-        if k == 0:
-            self._solo_active = False
-        if self._solo_from is not None and k >= self._solo_from and k < nst:
-            return self._pass_solo_tail(k, main, x, tp, hr)
         # The LAST stage's own parameter-gradient kernels follow its main lane on the main stream, beside the side lane of the
         # stage before it (the query GRU's 47-launch chain is still running there) -- there is no pass of its own for them.
         merge_last = self._merge_last
@@ -416,33 +393,6 @@ class Trainer:
         if k >= 1 and self.two_lanes:
             main.wait_stream(self.side)          # (without this per-pass join the side lanes form one long branch, which the
                                                  #  hipGraph executor does not overlap with the main lane: 8.98 ms instead of 7.86)
-
-    def _pass_solo_tail(self, k, main, x, tp, hr):
-        """Pass k of the step's tail: the solo closures (submitted by the main lane of stage _solo_from - 1) run on the second stream
-        from the first of these passes to the join at the end of the last one; everything else is one chain on the main stream --
-        main lane k, then the ordinary closures of stage k - 1 and its bucket.  Buckets that hold a solo closure's parameters are
-        gathered after the join."""
-        nst = len(self.stages)
-        if not self._solo_active:
-            self._solo_ids = Fh.SIDE.solo_params()
-            self.side.wait_stream(main)
-            with torch.cuda.stream(self.side):
-                Fh.SIDE.flush(None, solo=True)
-            self._solo_active = True
-        self._main_lane(k, x, tp, hr)
-        last = k == nst - 1
-
-        def has_solo(b):
-            return any(id(p) in self._solo_ids for p in self.flat.bucket_params[b])
-        Fh.SIDE.flush(k - 1, solo=False)
-        if not has_solo(k - 1):
-            self.flat.gather_grads(k - 1)
-        if last:
-            Fh.SIDE.flush(None, solo=False)
-            main.wait_stream(self.side)
-            for b in range(self._solo_from - 1, nst):
-                if has_solo(b) or b == nst - 1:
-                    self.flat.gather_grads(b)
 
     def _optim(self):
         self.step_count += 1

@@ -458,11 +458,6 @@ class _TrainPathMixin:
         order = ["trunk"] + ["srb%d" % i for i in range(k - 1, -1, -1)] + ["tp", "first", "stn"]
         return [(n, groups[n]) for n in order if groups[n]]
 
-    def solo_after_stage(self):
-        """Trainer protocol: the stage whose main lane submits a SOLO deferred closure -- the query GRU's backward chain (47 dependent
-        launches + its weight-gradient GEMMs), which the Trainer gives a lane of its own for the rest of the step.  None: no such chain."""
-        return "tp" if hasattr(self, "infoGen") else None
-
     def _bn_on_path(self):
         skip = () if getattr(self, "stn", False) else ("stn_head",)
         return [m for n, m in self.named_modules()

@@ -409,15 +409,9 @@ def test_single_rank_process_group_runs_the_staged_step(dev):
         for _ in range(3):
             tr.step(x.to(dev), tp.to(dev), hr.to(dev))
         assert tr.stages == ["trunk", "srb4", "srb3", "srb2", "srb1", "srb0", "tp", "first", "stn"]
-        # (round 4: the query GRU's backward has the second stream to itself from pass "first" to the end of the step, so the last two
-        # passes are ONE group: trunk + residual blocks after the TP pass, everything else behind the last pass)
-        assert tr._solo_from == 7
-        assert tr.reduce_log == [(6, 0, 5), (8, 6, 8)], tr.reduce_log
+        assert tr.reduce_log == [(6, 0, 5), (7, 6, 6), (8, 7, 8)], tr.reduce_log
         sizes = [e - s for s, e in tr.flat.ranges]
-        assert sizes[7] > 4.7e6 and len(tr._graphs["pass"]) == 2      # (the query GRU stays with block1: tatt_amd.tsrn.DP_QGRU_WITH_TP)
-        tr_old = Trainer(build("TSRN_TL_TRANS", dev, **STD).train(), use_graph=False, process_group=dist.group.WORLD, solo_tail=False)
-        tr_old.step(x.to(dev), tp.to(dev), hr.to(dev))
-        assert tr_old.reduce_log == [(6, 0, 5), (7, 6, 6), (8, 7, 8)], tr_old.reduce_log
+        assert sizes[7] > 4.7e6 and len(tr._graphs["pass"]) == 3      # (the query GRU stays with block1: tatt_amd.tsrn.DP_QGRU_WITH_TP)
     finally:
         dist.destroy_process_group()
     # (the flat layouts differ -- bucket order -- so compare through the module's own tensors)
