@@ -12,9 +12,17 @@
   greedy CTC decoding = utils/metrics.py:71-92, string filter = utils/util.py:12-32).
 * `collate_labels` / `collate_batch` produce the batch tuple the reference's loaders hand to the loop
   (dataset/dataset.py:1966-2077, alignCollate_realWTLAMask.__call__): images stacked, labels stretched to 26 steps and one-hot
-  encoded as the (B, 37, 1, 26) text prior, the per-character class list and the blank flags.  Image decoding / resizing / mask
-  synthesis (PIL, cv2, lmdb) stay outside: the adapter takes tensors that are already resized.
-torch.save / torch.load are file-format plumbing; all arithmetic stays in the HIP path.
+  encoded as the (B, 37, 1, 26) text prior, the per-character class list and the blank flags.
+* `resize_normalize` / `collate_pil_batch` are the image half of that collate (`resizeNormalize`, dataset/dataset.py:1266-1319; the
+  transform calls of :1987-2003): PIL bicubic resize to the HR / LR size, uint8 -> float / 255 in CHW, and the binarised mask channel
+  (gray < mean -> 1) as the fourth plane -- the (B, 4, H, W) tensors the generator reads.  Pinned by `tests/golden/collate.npz`,
+  generated from the reference's own collate (tools/gen_golden_collate.py).
+* `LmdbRecords` reads the reference's lmdb record layout (`lmdbDataset_real`, dataset/dataset.py:565-686): keys `num-samples`,
+  `label-%09d`, `image_hr-%09d`, `image_lr-%09d` (1-based), image bytes decoded by PIL to RGB, the label filtered by `str_filt`.
+  It takes any object with the lmdb transaction's `get(key)`; `open_lmdb` wraps a real environment when the `lmdb` package is there
+  (it is not in this image: the record logic is tested against an in-memory mapping).
+Host-side data plumbing (PIL / numpy), not part of the GPU path: torch.save / torch.load / PIL are file-format code; all arithmetic of
+the training step stays in the HIP kernels.
 """
 from __future__ import annotations
 
@@ -124,6 +132,108 @@ def collate_batch(samples, device=None, alphabet: str = ALPHABET):
         [torch.as_tensor(t) for t in ts], 0)
     vecs, masks, tics = collate_labels(labels, alphabet)
     return st(hr), None, st(lr), st(hry), st(lry), tuple(labels), (vecs.to(device) if device is not None else vecs), masks, tics
+
+
+def _to_tensor(img):
+    """torchvision.transforms.ToTensor for a uint8 PIL image: (H, W[, C]) uint8 -> (C, H, W) float32 in [0, 1]"""
+    import numpy as np
+    a = np.asarray(img)
+    if a.ndim == 2:
+        a = a[:, :, None]
+    return torch.from_numpy(np.array(a.transpose(2, 0, 1))).float().div(255)                  # (np.array: a writable, contiguous copy)
+
+
+def resize_normalize(img, size, mask: bool = False):
+    """reference `resizeNormalize(size, mask)(img)` (dataset/dataset.py:1266-1319, the ratio_keep / aug branches unused by the TATT
+    loaders): img: PIL image; size = (width, height).  Bicubic resize, ToTensor, and with `mask` a fourth plane that is 1 where the
+    gray value does not exceed the image's mean gray value (`mask.point(lambda x: 0 if x > thres else 255)`) -- dark text on a
+    bright background comes out as 1."""
+    import numpy as np
+    from PIL import Image
+    img = img.resize(tuple(size), Image.BICUBIC)
+    t = _to_tensor(img)
+    if mask:
+        m = img.convert("L")
+        thres = np.array(m).mean()
+        m = m.point(lambda v: 0 if v > thres else 255)
+        t = torch.cat((t, _to_tensor(m)), 0)
+    return t
+
+
+def collate_pil_batch(samples, imgH: int = 32, imgW: int = 128, down_sample_scale: int = 2, mask: bool = True, device=None,
+                      alphabet: str = ALPHABET):
+    """samples: iterable of (img_HR, img_lr, img_HRy, img_lry, label_str) with PIL images, as `lmdbDataset_real.__getitem__` yields
+    them -> the reference's batch tuple (alignCollate_realWTLAMask.__call__, dataset/dataset.py:1980-2077): HR images resized to
+    (imgW, imgH), LR images to (imgW, imgH) / down_sample_scale, each with its mask plane."""
+    hr_size, lr_size = (imgW, imgH), (imgW // down_sample_scale, imgH // down_sample_scale)
+    rows = [(resize_normalize(hr, hr_size, mask), resize_normalize(lr, lr_size, mask), resize_normalize(hry, hr_size, mask),
+             resize_normalize(lry, lr_size, mask), lab) for hr, lr, hry, lry, lab in samples]
+    return collate_batch(rows, device=device, alphabet=alphabet)
+
+
+def rgb_to_yuv_u8(rgb):
+    """cv2.cvtColor(img, cv2.COLOR_RGB2YUV) for uint8 (dataset/dataset.py:668-674: the `images_lry` / `images_HRy` members of a sample,
+    read by the loop only with --y_domain, which the TATT recipes do not set): Y = 0.299 R + 0.587 G + 0.114 B, U = 0.492 (B - Y) + 128,
+    V = 0.877 (R - Y) + 128, rounded and saturated.  (cv2 evaluates this in 14-bit fixed point; results may differ from it by one
+    count -- cv2 is not in this image, so this member is NOT pinned against the reference.)"""
+    import numpy as np
+    a = np.asarray(rgb).astype(np.float64)
+    y = 0.299 * a[..., 0] + 0.587 * a[..., 1] + 0.114 * a[..., 2]
+    u = 0.492 * (a[..., 2] - y) + 128.0
+    v = 0.877 * (a[..., 0] - y) + 128.0
+    return np.clip(np.rint(np.stack([y, u, v], -1)), 0, 255).astype(np.uint8)
+
+
+class LmdbRecords:
+    """The reference's lmdb record layout read through a transaction-like object (`get(bytes) -> bytes or None`), reference
+    `lmdbDataset_real` (dataset/dataset.py:565-686): `num-samples` holds the count, sample i (1-based) is `image_hr-%09d`,
+    `image_lr-%09d` (encoded image files) and `label-%09d` (utf-8).  __getitem__(index) -> (img_HR, img_lr, img_HRy, img_lry,
+    label_str) with PIL images, the label passed through `str_filt(word, voc_type)`; an unreadable image or an over-long label moves
+    on to the next record, as the reference does."""
+
+    def __init__(self, txn, voc_type: str = "upper", max_len: int = 100):
+        self.txn, self.voc_type, self.max_len = txn, voc_type, max_len
+        n = txn.get(b"num-samples")
+        if n is None:
+            raise KeyError("lmdb environment without a num-samples record")
+        self.n = int(n)
+
+    def __len__(self):
+        return self.n
+
+    def _image(self, key):
+        import io as _io
+        from PIL import Image
+        buf = self.txn.get(key)
+        if buf is None:
+            raise IOError("missing record %r" % key)
+        return Image.open(_io.BytesIO(buf)).convert("RGB")
+
+    def __getitem__(self, index):
+        from PIL import Image
+        if not 0 <= index < self.n:
+            raise IndexError(index)
+        for step in range(self.n):                               # (the reference recurses to index + 1 on a bad record)
+            i = (index + step) % self.n + 1
+            try:
+                hr, lr = self._image(b"image_hr-%09d" % i), self._image(b"image_lr-%09d" % i)
+            except (IOError, OSError):
+                continue
+            word = self.txn.get(b"label-%09d" % i)
+            word = " " if word is None else word.decode()
+            if len(word) > self.max_len:
+                continue
+            hry, lry = Image.fromarray(rgb_to_yuv_u8(hr)), Image.fromarray(rgb_to_yuv_u8(lr))
+            return hr, lr, hry, lry, str_filt(word, self.voc_type)
+        raise IOError("no readable record")
+
+
+def open_lmdb(root: str, **kw) -> LmdbRecords:
+    """`lmdbDataset_real(root)`: opens the environment read-only like the reference (dataset/dataset.py:576-583).  Needs the `lmdb`
+    package (absent from this image: ImportError says so)."""
+    import lmdb                                                  # noqa: F401 -- optional dependency of the data pipeline only
+    env = lmdb.open(root, max_readers=1, readonly=True, lock=False, readahead=False, meminit=False)
+    return LmdbRecords(env.begin(write=False), **kw)
 
 
 def ctc_greedy_decode(logits: torch.Tensor, alphabet: str = ALPHABET) -> list:

@@ -122,3 +122,61 @@ def test_evaluate_reports_recognition_accuracy(dev):
     res = io.evaluate(m, [(lr, hr, None, labels)], recognizer=rec)
     assert res["n_images"] == 4 and res["accuracy_hr"] == 0.75          # case and punctuation are filtered ('lower'), the third differs
     assert 0.0 <= res["accuracy"] <= 1.0 and 0.0 <= res["accuracy_lr"] <= 1.0 and res["psnr"] > 0.0
+
+
+def test_collate_images_and_labels_match_the_reference_fixture():
+    """tests/golden/collate.npz was produced by the reference's own `alignCollate_realWTLAMask(imgH=32, imgW=128, down_sample_scale=2,
+    mask=True)` (tools/gen_golden_collate.py): eight synthetic RGB images of assorted sizes and eight labels (empty, one character,
+    longer than 26, characters outside the alphabet).  The PIL resize + ToTensor + mask plane and every label tensor must match."""
+    import numpy as np
+    from PIL import Image
+    from tatt_amd import io
+    z = np.load("tests/golden/collate.npz")
+    n = int(z["n"])
+    alphabet = str(z["alphabet"])
+    samples = []
+    for i in range(n):
+        hr, lr = Image.fromarray(z["hr%d" % i], "RGB"), Image.fromarray(z["lr%d" % i], "RGB")
+        samples.append((hr, lr, hr, lr, io.str_filt(str(z["labels_in"][i]), "lower")))
+    out = io.collate_pil_batch(samples, imgH=32, imgW=128, down_sample_scale=2, mask=True, alphabet=alphabet)
+    images_HR, pseudo, images_lr, images_HRy, images_lry, label_strs, label_vecs, wmask, wtics = out
+    assert pseudo is None and list(label_strs) == [str(v) for v in z["label_strs"]]
+    assert tuple(images_HR.shape) == (n, 4, 32, 128) and tuple(images_lr.shape) == (n, 4, 16, 64)
+    assert torch.equal(images_HR, torch.from_numpy(z["images_HR"])) and torch.equal(images_lr, torch.from_numpy(z["images_lr"]))
+    assert set(images_HR[:, 3].unique().tolist()) <= {0.0, 1.0}                      # the mask plane is binary
+    assert torch.equal(label_vecs, torch.from_numpy(z["label_vecs"]))
+    assert torch.equal(wmask, torch.from_numpy(z["weighted_mask"])) and torch.equal(wtics, torch.from_numpy(z["weighted_tics"]))
+
+
+def test_lmdb_record_reader_on_an_in_memory_environment():
+    """`LmdbRecords` against the reference's record layout (dataset/dataset.py:565-686) with a dict standing in for the lmdb transaction:
+    1-based keys, PNG-encoded images decoded to RGB, labels filtered by voc_type, a missing label read as a blank, a broken record
+    skipped, and the batch it feeds to `collate_pil_batch`."""
+    import io as pyio
+    import numpy as np
+    from PIL import Image
+    from tatt_amd import io
+    rng = np.random.default_rng(1)
+
+    def png(w, h):
+        b = pyio.BytesIO()
+        Image.fromarray(rng.integers(0, 255, (h, w, 3), dtype=np.uint8), "RGB").save(b, format="PNG")
+        return b.getvalue()
+    db = {b"num-samples": b"3"}
+    for i, (lab, (w, h)) in enumerate(zip(("Ab-C!9", None, "second"), ((100, 30), (64, 20), (130, 40))), start=1):
+        db[b"image_hr-%09d" % i] = png(w, h)
+        db[b"image_lr-%09d" % i] = png(w // 2, h // 2)
+        if lab is not None:
+            db[b"label-%09d" % i] = lab.encode()
+    db[b"image_lr-%09d" % 2] = b"not an image"                     # record 2 is unreadable: the reader moves on to record 3
+    rec = io.LmdbRecords(db, voc_type="lower")
+    assert len(rec) == 3
+    hr, lr, hry, lry, lab = rec[0]
+    assert lab == "abc9" and hr.size == (100, 30) and lr.size == (50, 15) and hr.mode == "RGB" and hry.size == hr.size
+    assert rec[1][4] == "second" and rec[1][0].size == (130, 40)
+    batch = io.collate_pil_batch([rec[0], rec[2]])
+    assert tuple(batch[0].shape) == (2, 4, 32, 128) and tuple(batch[2].shape) == (2, 4, 16, 64) and batch[5] == ("abc9", "second")
+    y = io.rgb_to_yuv_u8(np.array([[[255, 255, 255], [0, 0, 0], [255, 0, 0]]], np.uint8))
+    assert y[0, 0].tolist() == [255, 128, 128] and y[0, 1].tolist() == [0, 128, 128] and y[0, 2, 0] == 76
+    with pytest.raises(ImportError):
+        io.open_lmdb("/nonexistent")
