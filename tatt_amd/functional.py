@@ -1102,45 +1102,56 @@ class QueryGruFn(Function):
         Hh = H // 2
         for d in range(2):
             ops.copy4d(hseq[d], q[:, d * Hh:], (B, W, Hh, C), (W * HID, HID, C, 1), (H * W * C, C, W * C, 1))
-        ctx.save_for_backward(emb, x, wih0, whh0, wih1, whh1, hbuf, gsave)
+        # W_hh^T of both directions for the backward recurrence (its B operand wants the 3*HID axis contiguous): parameters only, so
+        # the two transposes ride on this forked branch instead of opening the backward chain at the exposed end of the step
+        whhT = None
+        if any(ctx.needs_input_grad[:9]):
+            whhT = ops.new(dev, 2, HID, 3 * HID)
+            for d, whh in enumerate((whh0, whh1)):                 # (3*HID, HID) -> (HID, 3*HID)
+                ops.copy4d(whh, whhT[d], (1, 1, HID, 3 * HID), (0, 0, 1, HID), (0, 0, 3 * HID, 1))
+        ctx.save_for_backward(emb, x, wih0, whh0, wih1, whh1, hbuf, gsave, whhT)
         ctx.dims = (B, H, W, C, HID, IN)
         return q
 
     @staticmethod
     def backward(ctx, dq):
-        # every output of this backward is a parameter gradient (the embedding depends on parameters only): all of it is deferrable
+        # every output of this backward is a parameter gradient (the embedding depends on parameters only): all of it is deferrable.
+        # The recurrence (B - 1 dependent launches) is the longest thing left at the end of a training step; it is issued in two
+        # closures: the first QGRU_HEAD_STEPS steps carry no parameter and run with the side lane of the stage that produced dq (the TP
+        # interpreter's, which has room beside block1's backward), the rest -- filed under the bucket of the GRU's parameters -- follows
+        # one pass later beside the STN head's.
         dq = _c(dq)
         saved = ctx.saved_tensors
-        return tuple(SIDE.submit(ctx.leaves, lambda: QueryGruFn._backward(ctx, saved, dq), dq, saved)) + (None, None, None)
+        state = {}
+        B = ctx.dims[0]
+        head = max(0, min(QGRU_HEAD_STEPS, B - 1))
+        SIDE.submit((), lambda: QueryGruFn._bwd_chain(ctx, saved, dq, state, 0, head), dq, saved, state)
+        return tuple(SIDE.submit(ctx.leaves, lambda: QueryGruFn._bwd_rest(ctx, saved, dq, state, head), dq, saved, state)) + (None, None, None)
 
     @staticmethod
-    def _backward(ctx, saved, dq):
-        emb, x, wih0, whh0, wih1, whh1, hbuf, gsave = saved
+    def _bwd_chain(ctx, saved, dq, st, s_from, s_to):
+        """steps [s_from, s_to) of the backward sweep (step s visits time B-1-s in the forward direction and time s in the reverse one);
+        the first call also sets the sweep up (gradient layout, the gate gradients of the last time step) and leaves its state in `st`."""
+        emb, x, wih0, whh0, wih1, whh1, hbuf, gsave, whhT = saved
         B, H, W, C, HID, IN = ctx.dims
         hseq = (hbuf[0, 1:], hbuf[1, :B])
-        dq = _c(dq)
         dev = emb
-        Hh = H // 2
-        dhseq = ops.new(dev, 2, B, W, HID)
-        for d in range(2):
-            ops.copy4d(dq[:, d * Hh:], dhseq[d], (B, W, Hh, C), (H * W * C, C, W * C, 1), (W * HID, HID, C, 1))
-        dgh = ops.new(dev, 2, B, W, 3 * HID)
-        dgi_acc = ops.new(dev, 2, W, 3 * HID)
-        dhc = ops.new(dev, 2, W, HID)
-        whhT = []
-        for whh in (whh0, whh1):                     # (3*HID, HID) -> (HID, 3*HID) once per backward
-            tT = ops.new(dev, HID, 3 * HID)
-            ops.copy4d(whh, tT, (1, 1, HID, 3 * HID), (0, 0, 1, HID), (0, 0, 3 * HID, 1))
-            whhT.append(tT)
+
         def prev_h(t0, t1):
             return (hseq[0][t0 - 1] if t0 > 0 else None), (hseq[1][t1 + 1] if t1 < B - 1 else None)
-
-        # backward sweep: step s visits time B-1-s in the forward direction and time s in the reverse direction
-        hp0, hp1 = prev_h(B - 1, 0)
-        ops.call("tatt_qgru_bwd_gates", ops.P(dhseq[0, B - 1]), ops.P(dhseq[1, 0]), ops.P(gsave[0, B - 1]),
-                 ops.P(gsave[1, 0]), ops.P(hp0), ops.P(hp1), ops.P(dhc[0]), ops.P(dhc[1]), ops.P(dgi_acc[0]),
-                 ops.P(dgi_acc[1]), ops.P(dgh[0, B - 1]), ops.P(dgh[1, 0]), W, HID, 1, ops.stream())
-        for s in range(B - 1):
+        if "dgh" not in st:
+            Hh = H // 2
+            dhseq = ops.new(dev, 2, B, W, HID)
+            for d in range(2):
+                ops.copy4d(dq[:, d * Hh:], dhseq[d], (B, W, Hh, C), (H * W * C, C, W * C, 1), (W * HID, HID, C, 1))
+            st["dhseq"], st["dgh"] = dhseq, ops.new(dev, 2, B, W, 3 * HID)
+            st["dgi_acc"], st["dhc"] = ops.new(dev, 2, W, 3 * HID), ops.new(dev, 2, W, HID)
+            hp0, hp1 = prev_h(B - 1, 0)
+            ops.call("tatt_qgru_bwd_gates", ops.P(dhseq[0, B - 1]), ops.P(dhseq[1, 0]), ops.P(gsave[0, B - 1]),
+                     ops.P(gsave[1, 0]), ops.P(hp0), ops.P(hp1), ops.P(st["dhc"][0]), ops.P(st["dhc"][1]), ops.P(st["dgi_acc"][0]),
+                     ops.P(st["dgi_acc"][1]), ops.P(st["dgh"][0, B - 1]), ops.P(st["dgh"][1, 0]), W, HID, 1, ops.stream())
+        dhseq, dgh, dgi_acc, dhc = st["dhseq"], st["dgh"], st["dgi_acc"], st["dhc"]
+        for s in range(s_from, s_to):
             c0, c1 = B - 1 - s, s                # current step's time indices
             n0, n1 = c0 - 1, c1 + 1              # next step's
             hp0, hp1 = prev_h(n0, n1)
@@ -1148,6 +1159,15 @@ class QueryGruFn(Function):
                      ops.P(dhseq[0, n0]), ops.P(dhseq[1, n1]), ops.P(gsave[0, n0]), ops.P(gsave[1, n1]), ops.P(hp0),
                      ops.P(hp1), ops.P(dhc[0]), ops.P(dhc[1]), ops.P(dgi_acc[0]), ops.P(dgi_acc[1]),
                      ops.P(dgh[0, n0]), ops.P(dgh[1, n1]), W, HID, ops.stream())
+        return ()
+
+    @staticmethod
+    def _bwd_rest(ctx, saved, dq, st, head):
+        emb, x, wih0, whh0, wih1, whh1, hbuf, gsave, whhT = saved
+        B, H, W, C, HID, IN = ctx.dims
+        dev = emb
+        QueryGruFn._bwd_chain(ctx, saved, dq, st, head, B - 1)      # (sets the sweep up itself if the head closure has not)
+        dgh, dgi_acc = st["dgh"], st["dgi_acc"]
         grads = []
         dx = ops.new(dev, W, IN)
         for d, (wih, whh) in enumerate(((wih0, whh0), (wih1, whh1))):
@@ -1167,6 +1187,9 @@ class QueryGruFn(Function):
         ops.copy4d(dx, demb, (1, W, H, C), (0, IN, C, 1), (0, C, W * C, 1))
         (a0, b0, c0, d0), (a1, b1, c1, d1) = grads
         return demb, a0, b0, c0, d0, a1, b1, c1, d1
+
+
+QGRU_HEAD_STEPS = 5         # steps of the query GRU's backward recurrence issued with the TP stage's side lane (A/B hook; 0: all with the rest)
 
 
 def query_embedding(emb, gru, B, H, W):
