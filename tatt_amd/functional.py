@@ -1189,7 +1189,9 @@ class QueryGruFn(Function):
         return demb, a0, b0, c0, d0, a1, b1, c1, d1
 
 
-QGRU_HEAD_STEPS = 5         # steps of the query GRU's backward recurrence issued with the TP stage's side lane (A/B hook; 0: all with the rest)
+QGRU_HEAD_STEPS = 0         # steps of the query GRU's backward recurrence issued one pass early, with the TP stage's side lane (A/B hook).  Measured
+                            # (profiles/r04_m_ab.txt, same box): 0 / 5 / 10 / 16 steps -> 5.30 / 5.32 / 5.30 / 5.43 ms: that side lane has no room, a step
+                            # moved there lengthens its pass by what it saves in the next; 0 = the whole recurrence with the GRU's own bucket
 
 
 def query_embedding(emb, gru, B, H, W):
