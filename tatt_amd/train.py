@@ -206,9 +206,6 @@ class TssimRecipe:
         return loss if extra is None else loss + extra
 
 
-SIDE_PRIORITY = None
-
-
 class HipStepKernels:
     """The optimiser side of a step on the GPU: global-norm clip + Adam on flat buffers (tatt_l2norm, tatt_adam_step)."""
 
@@ -307,9 +304,7 @@ class Trainer:
             base = 0x1234ABCD5678EF01 if dropout_seed is None else int(dropout_seed)
             if self.dp or dropout_seed is not None:
                 Fh.set_seed(dev, rank_dropout_seed(base, self.rank) if self.dp else base)
-        # SIDE_PRIORITY: None = default; an int = the HIP stream priority of the side lane (A/B hook: the main lane is the critical path of
-        # the residual-block passes; a lower-priority side stream might cost it less)
-        self.side = (torch.cuda.Stream(device=dev) if SIDE_PRIORITY is None else torch.cuda.Stream(device=dev, priority=int(SIDE_PRIORITY))) if self.two_lanes else None
+        self.side = torch.cuda.Stream(device=dev) if self.two_lanes else None
         self._merge_last = len(self.stages) >= 2         # (also without a second stream: one pass structure everywhere)
         self._npass = len(self.stages) + (0 if self._merge_last else 1)
         self.gnorms = [torch.zeros(1, device=dev) for _ in self.groups]
