@@ -662,10 +662,10 @@ class GruBlockFn(Function):
         K = Wc.shape[1]
         x2 = x.reshape(-1, K1)
         xb2 = xb.reshape(-1, K - K1) if xb is not None else None
-        comp = _PRE.table.pop(conv_w.data_ptr(), None)          # composed at the start of this forward (gru_precompose)?
+        pre = _PRE.table.pop(conv_w.data_ptr(), None)           # composed at the start of this forward (gru_precompose)?
         Wfk = Wbk = None
-        if comp is not None and comp[2] == conv_w._version and comp[0].device == x.device:
-            Wp, bp, Wfk, Wbk = comp[0], comp[1], comp[3], comp[4]
+        if pre is not None and pre[2] == conv_w._version and pre[0].device == x.device:
+            Wp, bp, Wfk, Wbk = pre[0], pre[1], pre[3], pre[4]
         else:
             Wp = ops.new(x, 192, K)                              # composed projection  [W_ih_f; W_ih_r] @ W_c
             bp = ops.new(x, 192)
