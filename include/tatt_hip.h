@@ -379,12 +379,6 @@ int tatt_softmax_rows_bwd(const float* P, float* dP, long rows, int L, float pdr
  * (128, 192), (64, 192), (64, 64), (64, 128). */
 int tatt_tokgemm_sb(const float* X1, const float* X2, int K1, const float* Wp, const float* bias, float* Y1, float* Y2, int N1,
                     int M, int N, int K, hipStream_t st);
-/* tatt_tokgemm_sb with the producer's last element-wise step folded into the staging of X1 (reference model/tsrn.py:903-910: the
- * BatchNorm apply in front of gru1, the residual add in front of gru2): in_scale / in_shift (K1 floats each; both or neither):
- * x * in_scale + in_shift per column; X1add ((M, K1) or NULL): x + X1add; both: (x + X1add) * in_scale + in_shift */
-int tatt_tokgemm_sb_pre(const float* X1, const float* X2, int K1, const float* Wp, const float* bias, float* Y1, float* Y2,
-                        int N1, int M, int N, int K, const float* in_scale, const float* in_shift, const float* X1add,
-                        hipStream_t st);
 /* trans = 0: w(n, k) = W[n*ldw + k] (y = x W^T);  trans = 1: w(n, k) = W[k*ldw + n] (dx = dy W).  out: N*K words */
 int tatt_tokgemm_pack(const float* W, float* out, int N, int K, int ldw, int trans, hipStream_t st);
 /* n packs in one launch: ptrs = HOST array of n x 2 device pointers (W, out), dims = HOST array of n x 4 ints (N, K, ldw, trans) */

@@ -21,9 +21,6 @@ struct TokGemmP {
     const float* W; const float* bias;               // packed split-bf16 operand (tatt_tokgemm_pack), bias (N) or null
     float* Y1; float* Y2; int N1;                    // destinations: columns [0, N1) to Y1 (row pitch N1), [N1, N) to Y2 (row pitch N - N1)
     int M;
-    // round 4: the producer's last element-wise step folded into the staging of X1 (forward instances, template parameter PRE)
-    const float* in_scale; const float* in_shift;    // per column of X1 (K1 floats each): x * in_scale + in_shift  (a BatchNorm apply)
-    const float* X1add;                              // same shape as X1: x + X1add  (the residual add in front of the second GruBlock)
 };
 
 __device__ __forceinline__ void tg_split(f32x4 v, uint2& hi, uint2& lo) {
@@ -34,9 +31,8 @@ __device__ __forceinline__ void tg_split(f32x4 v, uint2& hi, uint2& lo) {
     lo = make_uint2(__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1));
 }
 
-// NCB: 16-column blocks per wave (N = 64 NCB); KS: k-steps of 32 (K = 32 KS); PRE: 0 = X1 as it is, 1 = x * in_scale + in_shift, 2 = x + X1add,
-// 3 = both: (x + X1add) * in_scale + in_shift  (compile-time: the backward instances carry no register for it)
-template <int NCB, int KS, int PRE>
+// NCB: 16-column blocks per wave (N = 64 NCB); KS: k-steps of 32 (K = 32 KS)
+template <int NCB, int KS>
 __global__ __launch_bounds__(512, 1) void tokgemm_sb_kernel(TokGemmP p) {
     constexpr int K = 32 * KS, N = 64 * NCB;
     constexpr int PW = K / 2 + 8;                            // tile pitch in 32-bit words (two bf16 each)
@@ -67,28 +63,14 @@ __global__ __launch_bounds__(512, 1) void tokgemm_sb_kernel(TokGemmP p) {
             const long m = (long)tl * 64 + row;
             r[i] = c4 < p.K1 ? *reinterpret_cast<const f32x4*>(p.X1 + m * p.K1 + c4)
                              : *reinterpret_cast<const f32x4*>(p.X2 + m * K2 + (c4 - p.K1));
-            if ((PRE & 2) && c4 < p.K1) r[i] += *reinterpret_cast<const f32x4*>(p.X1add + m * p.K1 + c4);
         }
     };
-    // affine coefficients: vector i of a thread covers columns 4 ((t + 512 i) mod K/4) = 4 (t mod K/4) when K/4 divides 512 (K = 64, 128:
-    // the forward instances) -- ONE pair per thread
-    static_assert(!(PRE & 1) || 512 % (K / 4) == 0, "affine staging needs K/4 | 512");
-    f32x4 asc = (f32x4){1.f, 1.f, 1.f, 1.f}, ash = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (PRE & 1) {
-        const int c4 = 4 * (t % (K / 4));
-        if (c4 < p.K1) { asc = *reinterpret_cast<const f32x4*>(p.in_scale + c4); ash = *reinterpret_cast<const f32x4*>(p.in_shift + c4); }
-    }
     auto stash = [&](unsigned* buf, const f32x4 (&r)[F4]) {
 #pragma unroll
         for (int i = 0; i < F4; ++i) {
             const int idx = t + 512 * i, row = idx / (K / 4), c4 = 4 * (idx - row * (K / 4));
             uint2 hi, lo;
-            f32x4 v = r[i];
-            if (PRE & 1) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], asc[e], ash[e]);
-            }
-            tg_split(v, hi, lo);
+            tg_split(r[i], hi, lo);
             unsigned* d = buf + row * PW + c4 / 2;
             *reinterpret_cast<uint2*>(d) = hi;
             *reinterpret_cast<uint2*>(d + IMG) = lo;
@@ -215,48 +197,28 @@ TATT_API int tatt_tokgemm_pack_batch(const float* const* ptrs, const int* dims, 
     return LAUNCH_CHECK();
 }
 
-template <int NCB, int KS, int PRE>
+template <int NCB, int KS>
 static int tg_launch(const TokGemmP& p, hipStream_t st) {
     constexpr int lds = 2 * 2 * 64 * (32 * KS / 2 + 8) * 4;
     static std::once_flag once;
     std::call_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tokgemm_sb_kernel<NCB, KS, PRE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tokgemm_sb_kernel<NCB, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     });
     const int ntiles = p.M / 64;
-    hipLaunchKernelGGL((tokgemm_sb_kernel<NCB, KS, PRE>), dim3(ntiles < 256 ? ntiles : 256), dim3(512), lds, st, p);
+    hipLaunchKernelGGL((tokgemm_sb_kernel<NCB, KS>), dim3(ntiles < 256 ? ntiles : 256), dim3(512), lds, st, p);
     return LAUNCH_CHECK();
-}
-static int tokgemm_dispatch(const TokGemmP& p, int N, int K, hipStream_t st) {
-    const int pre = (p.in_scale ? 1 : 0) | (p.X1add ? 2 : 0);
-    if (pre) {                                   // forward instances only (N = 192; K = 64 / 128)
-        if (N != 192 || (K != 64 && K != 128)) return 3;
-        if (K == 128) return pre == 1 ? tg_launch<3, 4, 1>(p, st) : (pre == 2 ? tg_launch<3, 4, 2>(p, st) : tg_launch<3, 4, 3>(p, st));
-        return pre == 1 ? tg_launch<3, 2, 1>(p, st) : (pre == 2 ? tg_launch<3, 2, 2>(p, st) : tg_launch<3, 2, 3>(p, st));
-    }
-    if (N == 192 && K == 128) return tg_launch<3, 4, 0>(p, st);
-    if (N == 192 && K == 64) return tg_launch<3, 2, 0>(p, st);
-    if (N == 128 && K == 192) return tg_launch<2, 6, 0>(p, st);
-    if (N == 64 && K == 192) return tg_launch<1, 6, 0>(p, st);
-    if (N == 64 && K == 64) return tg_launch<1, 2, 0>(p, st);
-    if (N == 64 && K == 128) return tg_launch<1, 4, 0>(p, st);
-    return 1;
 }
 // Y = [X1 | X2] Wp^T + bias with Wp from tatt_tokgemm_pack; X1 (M, K1), X2 (M, K - K1) (null when K1 == K); the first N1 output columns
 // go to Y1 (M, N1), the rest to Y2 (M, N - N1) (null when N1 == N).  M a multiple of 64; (N, K) in {64,128,192} x {64,128,192}.
 TATT_API int tatt_tokgemm_sb(const float* X1, const float* X2, int K1, const float* Wp, const float* bias, float* Y1, float* Y2, int N1,
                              int M, int N, int K, hipStream_t st) {
     if (M < 64 || M % 64 || K1 % 4 || (K - K1) % 4 || K1 < 0 || K1 > K || N1 < 0 || N1 > N || (K1 < K && !X2) || (N1 < N && !Y2)) return 1;
-    TokGemmP p = {X1, X2, K1, Wp, bias, Y1, Y2, N1, M, nullptr, nullptr, nullptr};
-    return tokgemm_dispatch(p, N, K, st);
-}
-// The same with the producer's last element-wise step applied while X1 is staged (reference model/tsrn.py:903-910: bn2 -> gru1 and
-// x + residual -> gru2): in_scale / in_shift (K1 floats each, both or neither): x * in_scale + in_shift per column of X1; X1add
-// ((M, K1) or null): x + X1add.  With both: (x + X1add) * in_scale + in_shift.  N = 192 and K in {64, 128} (the forward projections).
-TATT_API int tatt_tokgemm_sb_pre(const float* X1, const float* X2, int K1, const float* Wp, const float* bias, float* Y1, float* Y2,
-                                 int N1, int M, int N, int K, const float* in_scale, const float* in_shift, const float* X1add,
-                                 hipStream_t st) {
-    if (M < 64 || M % 64 || K1 % 4 || (K - K1) % 4 || K1 < 0 || K1 > K || N1 < 0 || N1 > N || (K1 < K && !X2) || (N1 < N && !Y2)) return 1;
-    if ((in_scale == nullptr) != (in_shift == nullptr)) return 2;
-    TokGemmP p = {X1, X2, K1, Wp, bias, Y1, Y2, N1, M, in_scale, in_shift, X1add};
-    return tokgemm_dispatch(p, N, K, st);
+    TokGemmP p = {X1, X2, K1, Wp, bias, Y1, Y2, N1, M};
+    if (N == 192 && K == 128) return tg_launch<3, 4>(p, st);
+    if (N == 192 && K == 64) return tg_launch<3, 2>(p, st);
+    if (N == 128 && K == 192) return tg_launch<2, 6>(p, st);
+    if (N == 64 && K == 192) return tg_launch<1, 6>(p, st);
+    if (N == 64 && K == 64) return tg_launch<1, 2>(p, st);
+    if (N == 64 && K == 128) return tg_launch<1, 4>(p, st);
+    return 1;
 }

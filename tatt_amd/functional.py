@@ -344,51 +344,6 @@ class BatchNormApplyFn(Function):
         return dx.reshape(x.shape), None, None, dg, db, None
 
 
-GRU_PRE_FUSED = True        # test / A-B hook: False -> bn2's apply and the residual add in front of the GruBlocks run as their own launches
-
-
-class BnApplyLazyFn(Function):
-    """BatchNormApplyFn whose forward applies NOTHING: the output aliases x, and the one consumer (a GruBlock's input projection,
-    tatt_tokgemm_sb_pre) applies x * scale + shift while it stages its tile.  The backward is the full train-mode BatchNorm backward
-    of the gradient that consumer returns for its (transformed) input."""
-
-    @staticmethod
-    def forward(ctx, x, mean, rstd, gamma, beta):
-        ctx.save_for_backward(x, mean, rstd, gamma, beta)
-        return x.view_as(x)
-
-    @staticmethod
-    def backward(ctx, dy):
-        x, mean, rstd, gamma, beta = ctx.saved_tensors
-        C = x.shape[-1]
-        dx, dg, db = ops.bn_bwd(x.reshape(-1, C), _c(dy).reshape(-1, C), mean, rstd, gamma, beta, ACT_NONE, True)
-        return dx.reshape(x.shape), None, None, dg, db
-
-
-class AddLazyFn(Function):
-    """a + b whose forward adds NOTHING: the output aliases a and carries b along for its one consumer (tatt_tokgemm_sb_pre adds while
-    staging).  Backward: the gradient goes to both."""
-
-    @staticmethod
-    def forward(ctx, a, b):
-        return a.view_as(a)
-
-    @staticmethod
-    def backward(ctx, dy):
-        return dy, dy
-
-
-def _materialize_pre(x, pre):
-    """the tensor a lazy producer stands for (fallback paths, and the weight-gradient pass on the side lane)"""
-    if pre is None:
-        return x
-    if pre[0] == "affine":
-        _, scale, shift, mean, rstd, gamma, beta = pre
-        C = x.shape[-1]
-        return ops.bn_apply(x.reshape(-1, C), mean, rstd, gamma, beta, ACT_NONE).reshape(x.shape)
-    return ops.axpby(x, pre[1], 1.0, 1.0)
-
-
 def conv_bn(x, conv, bn, prev=None):
     """conv: nn.Conv2d(64, 64, 3, padding=1), bn: its nn.BatchNorm2d (train mode), both parameter holders.
     prev = (y_prev's ConvBnFn statistics tuple, bn_prev, act): fold bn_prev + act of the producing layer into this convolution.
@@ -402,13 +357,7 @@ def conv_bn(x, conv, bn, prev=None):
     return out[0], tuple(out[1:])
 
 
-def bn_apply_stats(y, stats, bn, act=ACT_NONE, lazy=False):
-    """lazy (act none only): do not apply -- hand the consumer the raw map with the folded affine attached (`_tatt_pre`); ONLY for a
-    tensor whose single consumer is gru_block()."""
-    if lazy and act == ACT_NONE and GRU_PRE_FUSED and y.is_contiguous():
-        out = BnApplyLazyFn.apply(y, stats[0], stats[1], bn.weight, bn.bias)
-        out._tatt_pre = ("affine", stats[2], stats[3], stats[0], stats[1], bn.weight, bn.bias)
-        return out
+def bn_apply_stats(y, stats, bn, act=ACT_NONE):
     return BatchNormApplyFn.apply(y, stats[0], stats[1], bn.weight, bn.bias, act)
 
 
@@ -627,20 +576,13 @@ GRU_WGRAD_SB = True         # test / A-B hook: False -> three fp32-MFMA weight-g
 GRU_WGRAD_FRAG = True       # test / A-B hook: False -> tatt_gru_wgrad_sb from dgi / dgh / hprev (round 3) instead of the fragment stream
 
 
-def _tokgemm(X1, X2, Wpk, bias, N, K, N1=None, pre=None):
-    """[X1 | X2] (M, K) @ W^T (+ bias) through tatt_tokgemm_sb -> (Y1 (M, N1), Y2 (M, N - N1) or None).  pre: ("affine", scale, shift, ..)
-    or ("add", addend): the transform of X1 applied while it is staged (tatt_tokgemm_sb_pre)."""
+def _tokgemm(X1, X2, Wpk, bias, N, K, N1=None):
+    """[X1 | X2] (M, K) @ W^T (+ bias) through tatt_tokgemm_sb -> (Y1 (M, N1), Y2 (M, N - N1) or None)"""
     M, K1 = X1.shape
     N1 = N if N1 is None else N1
     Y1 = ops.new(X1, M, N1)
     Y2 = ops.new(X1, M, N - N1) if N1 < N else None
-    if pre is None:
-        ops.call("tatt_tokgemm_sb", ops.P(X1), ops.P(X2), K1, ops.P(Wpk), ops.P(bias), ops.P(Y1), ops.P(Y2), N1, M, N, K, ops.stream())
-    else:
-        sc, sh = (pre[1], pre[2]) if pre[0] == "affine" else (None, None)
-        ad = pre[1].reshape(M, K1) if pre[0] == "add" else None
-        ops.call("tatt_tokgemm_sb_pre", ops.P(X1), ops.P(X2), K1, ops.P(Wpk), ops.P(bias), ops.P(Y1), ops.P(Y2), N1, M, N, K, ops.P(sc),
-                 ops.P(sh), ops.P(ad), ops.stream())
+    ops.call("tatt_tokgemm_sb", ops.P(X1), ops.P(X2), K1, ops.P(Wpk), ops.P(bias), ops.P(Y1), ops.P(Y2), N1, M, N, K, ops.stream())
     return Y1, Y2
 
 
@@ -655,8 +597,7 @@ class GruBlockFn(Function):
     GEMMs for the weight gradients; the gradients of W_ih, W_c, b_c follow from the composed ones by tiny products."""
 
     @staticmethod
-    def forward(ctx, x, xb, conv_w, conv_b, wih_f, whh_f, bih_f, bhh_f, wih_r, whh_r, bih_r, bhh_r, vertical, pre=None):
-        # pre: the lazy producer of x (BnApplyLazyFn / AddLazyFn): x holds the RAW map, the projection applies the transform in staging
+    def forward(ctx, x, xb, conv_w, conv_b, wih_f, whh_f, bih_f, bhh_f, wih_r, whh_r, bih_r, bhh_r, vertical):
         B, H, W, K1 = x.shape
         Wc = conv_w.reshape(conv_w.shape[0], -1)                 # (64, K)
         K = Wc.shape[1]
@@ -672,22 +613,18 @@ class GruBlockFn(Function):
             ops.call("tatt_gru_compose", ops.P(wih_f), ops.P(wih_r), ops.P(bih_f), ops.P(bih_r), ops.P(Wc), ops.P(conv_b),
                      ops.P(Wp), ops.P(bp), K, ops.stream())
         use_tg = TOKGEMM_SB and x2.shape[0] % 64 == 0 and K in (64, 128) and K1 % 4 == 0
-        if pre is not None and not use_tg:                    # no kernel to fold it into: the ordinary tensor after all
-            x = _materialize_pre(x, pre)
-            x2, pre = x.reshape(-1, K1), None
         if use_tg and Wfk is None:
             Wfk, Wbk = ops.new(x, 192 * K), ops.new(x, 192 * K)
             ops.call("tatt_tokgemm_pack", ops.P(Wp), ops.P(Wfk), 192, K, K, 0, ops.stream())
             ops.call("tatt_tokgemm_pack", ops.P(Wp), ops.P(Wbk), K, 192, K, 1, ops.stream())
         if use_tg:
-            gi, _ = _tokgemm(x2, xb2, Wfk, bp, 192, K, pre=pre)
+            gi, _ = _tokgemm(x2, xb2, Wfk, bp, 192, K)
         else:
             gi = ops.linear_fwd(x2, Wp, bp, x2b=xb2)
             Wbk = None
         geom = ops.seq_geom(B, H, W, vertical)
         out, gates = ops.gru32_fwd(gi, whh_f, bhh_f, whh_r, bhh_r, geom, save=any(ctx.needs_input_grad))
         ctx.save_for_backward(x, xb, Wc, Wp, gates, out, wih_f, whh_f, wih_r, whh_r, conv_b, Wbk)
-        ctx.pre = pre                                          # (tensors of the producer's own graph: kept alive by it and by `pre`)
         ctx.geom = geom
         ctx.wshape = conv_w.shape
         ctx.leaves = (conv_w, conv_b, wih_f, whh_f, bih_f, bhh_f, wih_r, whh_r, bih_r, bhh_r)
@@ -722,13 +659,10 @@ class GruBlockFn(Function):
                 dxb = ops.linear_bwd_input(dgi, Wp, col0=K1, ncols=K - K1).reshape(xb.shape)
         geom = ctx.geom
 
-        pre = ctx.pre
-
         def param_grads():
             # weight-gradient GEMMs over the tokens; the bias gradients (column sums of dgi / dgh) ride along as a virtual ones column
             dbp, dbhh = ops.new(dgi, 192), ops.new(dgi, 192)
             dWp = ops.new(dgi, 192, K)
-            x2 = _materialize_pre(x, pre).reshape(-1, K1)       # the projection's actual input, rebuilt off the critical path
             if use_frag:
                 dWhh = ops.new(dgi, 192, 32)                          # compact: [forward; reverse]
                 ops.gru_wgrad_frag(frag, x2, xb2, geom, dWp, dWhh, dbp, dbhh)
@@ -748,17 +682,16 @@ class GruBlockFn(Function):
                      ops.P(wih_f), ops.P(wih_r), ops.P(dwih_f), ops.P(dwih_r), ops.P(dWc), ops.P(dbc), K, ops.P(dWhh),
                      ops.P(dwhh_f), ops.P(dwhh_r), ops.stream())
             return (dWc.reshape(ctx.wshape), dbc, dwih_f, dwhh_f, dbp[:96], dbhh[:96], dwih_r, dwhh_r, dbp[96:], dbhh[96:])
-        return (dx, dxb) + tuple(SIDE.submit(ctx.leaves, param_grads, dgi, dgh, hprev, frag, x, xb, Wp, Wc, pre)) + (None, None)
+        return (dx, dxb) + tuple(SIDE.submit(ctx.leaves, param_grads, dgi, dgh, hprev, frag, x, xb, Wp, Wc)) + (None,)
 
 
 def gru_block(x, blk, vertical, xb=None):
     """blk: a GruBlock parameter holder (conv1 = 1x1 nn.Conv2d, gru = nn.GRU(64, 32, bidirectional))."""
     g = blk.gru
-    pre = getattr(x, "_tatt_pre", None)                       # x comes from bn_apply_stats(lazy=True) / add_lazy: still to be transformed
     return GruBlockFn.apply(_c(x), None if xb is None else _c(xb), blk.conv1.weight, blk.conv1.bias,
                             g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0,
                             g.weight_ih_l0_reverse, g.weight_hh_l0_reverse, g.bias_ih_l0_reverse, g.bias_hh_l0_reverse,
-                            vertical, pre)
+                            vertical)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -770,15 +703,6 @@ class AddFn(Function):
     @staticmethod
     def backward(ctx, dy):
         return dy, dy
-
-
-def add_lazy(a, b):
-    """a + b for a tensor whose single consumer is gru_block(): no launch, the consumer adds while staging"""
-    if GRU_PRE_FUSED and a.is_contiguous() and b.is_contiguous() and a.shape == b.shape and getattr(a, "_tatt_pre", None) is None:
-        out = AddLazyFn.apply(a, b)
-        out._tatt_pre = ("add", b)
-        return out
-    return add(a, b)
 
 
 def add(a, b):

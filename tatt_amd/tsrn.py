@@ -287,15 +287,14 @@ def _srb(x, tp_map, blk: RecurrentResidualBlock):
         else:
             y1, st1 = Fh.conv_bn(x, blk.conv1, blk.bn1)
             y2, st2 = Fh.conv_bn(y1, blk.conv2, blk.bn2, prev=(st1, blk.bn1, ACT_MISH))
-            # bn2's apply is folded into gru1's input projection (r below is y2 with the affine map attached): one launch less
-            r = Fh.bn_apply_stats(y2, st2, blk.bn2, ACT_NONE, lazy=isinstance(blk.gru1, GruBlock))
+            r = Fh.bn_apply_stats(y2, st2, blk.bn2, ACT_NONE)
     else:
         r = Fh.conv2d(x, blk.conv1.weight, blk.conv1.bias)
         r = Fh.batch_norm_act(r, blk.bn1, ACT_MISH, False)
         r = Fh.conv2d(r, blk.conv2.weight, blk.conv2.bias)
         r = Fh.batch_norm_act(r, blk.bn2, ACT_NONE, False)
     r = _gru_block(r, blk.gru1, True, x_cat=tp_map)
-    return _gru_block(Fh.add_lazy(x, r), blk.gru2, False)   # (the residual add rides in gru2's input projection)
+    return _gru_block(Fh.add(x, r), blk.gru2, False)
 
 
 def _ffn(x, layer, training, site):

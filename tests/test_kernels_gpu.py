@@ -771,47 +771,6 @@ def test_conv_bn_folded_equals_operator_chain(dev, B, H, W):
     assert not bad, "\n".join(bad)
 
 
-@pytest.mark.parametrize("B,H,W,cat", [(2, 16, 64, True), (3, 8, 64, False), (48, 16, 64, True)])
-def test_srb_with_projection_prologues_equals_separate_launches(dev, B, H, W, cat):
-    """A whole RecurrentResidualBlock[TL] (reference model/tsrn.py:862-871, 892-910) with bn2's apply and the residual add folded into the
-    GruBlocks' input projections (BnApplyLazyFn / AddLazyFn -> tatt_tokgemm_sb_pre) == the same block with those two steps as launches of
-    their own: output, every gradient (input, text map, all parameters), BatchNorm running statistics."""
-    from tatt_amd import functional as Fh
-    from tatt_amd import tsrn
-    res = []
-    for fused in (True, False):
-        torch.manual_seed(9)
-        blk = tsrn.RecurrentResidualBlock(64, 64 if cat else 0).to(dev).train()
-        with torch.no_grad():
-            for bn in (blk.bn1, blk.bn2):
-                bn.weight.add_(0.3 * R(64).to(dev))
-                bn.bias.add_(0.3 * R(64, seed=1).to(dev))
-        x = (R(B, H, W, 64, seed=2) * 0.5).to(dev).requires_grad_(True)
-        tp = (R(B, H, W, 64, seed=4) * 0.5).to(dev).requires_grad_(True) if cat else None
-        Fh.GRU_PRE_FUSED = fused
-        try:
-            out = tsrn._srb(x, tp, blk)
-            (out * R(B, H, W, 64, seed=3).to(dev)).sum().backward()
-        finally:
-            Fh.GRU_PRE_FUSED = True
-        d = {"out": out, "dx": x.grad}
-        if cat:
-            d["dtp"] = tp.grad
-        for n, p_ in blk.named_parameters():
-            d["g." + n] = p_.grad
-        for n in ("bn1.running_mean", "bn1.running_var", "bn2.running_mean", "bn2.running_var"):
-            d[n] = blk.get_buffer(n)
-        res.append({k: v.detach().float().cpu().clone() for k, v in d.items()})
-    bad = []
-    for k in res[0]:
-        ref = float(res[1][k].abs().max()) + 1e-12
-        noise = k in ("g.conv1.bias", "g.conv2.bias")
-        err = float((res[0][k] - res[1][k]).abs().max()) / (1.0 if noise else ref)
-        if not err < (2e-7 * B * H * W + 1e-3 if noise else 1e-4):
-            bad.append("%s: %.3e" % (k, err))
-    assert not bad, "\n".join(bad)
-
-
 @pytest.mark.parametrize("B,H,W", [(2, 16, 64), (5, 3, 128), (48, 16, 64)])
 def test_srb_trunk_fused_backward_equals_operator_chain(dev, B, H, W):
     """SrbTrunkFn -- conv -> bn -> mish -> conv -> bn (reference model/tsrn.py:877-886) as one operator whose backward folds both
