@@ -11,6 +11,7 @@ include/tatt_hip.h).  No CPU fallback: see oracle/ for the CPU restatement used 
 from .tsrn import TSRN, TSRN_TL_TRANS  # noqa: F401
 from .tbsrn import TBSRN  # noqa: F401
 from .crnn import CRNN  # noqa: F401
+from . import torch_ops  # noqa: F401  (registers torch.ops.tatt_hip.*: the operator-registry view of the kernels)
 
 __all__ = ["TSRN", "TSRN_TL_TRANS", "TBSRN", "CRNN", "set_arithmetic", "get_arithmetic"]
 
