@@ -1115,43 +1115,35 @@ class QueryGruFn(Function):
 
     @staticmethod
     def backward(ctx, dq):
-        # every output of this backward is a parameter gradient (the embedding depends on parameters only): all of it is deferrable.
-        # The recurrence (B - 1 dependent launches) is the longest thing left at the end of a training step; it is issued in two
-        # closures: the first QGRU_HEAD_STEPS steps carry no parameter and run with the side lane of the stage that produced dq (the TP
-        # interpreter's, which has room beside block1's backward), the rest -- filed under the bucket of the GRU's parameters -- follows
-        # one pass later beside the STN head's.
+        # every output of this backward is a parameter gradient (the embedding depends on parameters only): all of it is deferrable
         dq = _c(dq)
         saved = ctx.saved_tensors
-        state = {}
-        B = ctx.dims[0]
-        head = max(0, min(QGRU_HEAD_STEPS, B - 1))
-        SIDE.submit((), lambda: QueryGruFn._bwd_chain(ctx, saved, dq, state, 0, head), dq, saved, state)
-        return tuple(SIDE.submit(ctx.leaves, lambda: QueryGruFn._bwd_rest(ctx, saved, dq, state, head), dq, saved, state)) + (None, None, None)
+        return tuple(SIDE.submit(ctx.leaves, lambda: QueryGruFn._backward(ctx, saved, dq), dq, saved)) + (None, None, None)
 
     @staticmethod
-    def _bwd_chain(ctx, saved, dq, st, s_from, s_to):
-        """steps [s_from, s_to) of the backward sweep (step s visits time B-1-s in the forward direction and time s in the reverse one);
-        the first call also sets the sweep up (gradient layout, the gate gradients of the last time step) and leaves its state in `st`."""
+    def _backward(ctx, saved, dq):
         emb, x, wih0, whh0, wih1, whh1, hbuf, gsave, whhT = saved
         B, H, W, C, HID, IN = ctx.dims
         hseq = (hbuf[0, 1:], hbuf[1, :B])
         dev = emb
+        Hh = H // 2
+        dhseq = ops.new(dev, 2, B, W, HID)
+        for d in range(2):
+            ops.copy4d(dq[:, d * Hh:], dhseq[d], (B, W, Hh, C), (H * W * C, C, W * C, 1), (W * HID, HID, C, 1))
+        dgh = ops.new(dev, 2, B, W, 3 * HID)
+        dgi_acc = ops.new(dev, 2, W, 3 * HID)
+        dhc = ops.new(dev, 2, W, HID)
 
         def prev_h(t0, t1):
             return (hseq[0][t0 - 1] if t0 > 0 else None), (hseq[1][t1 + 1] if t1 < B - 1 else None)
-        if "dgh" not in st:
-            Hh = H // 2
-            dhseq = ops.new(dev, 2, B, W, HID)
-            for d in range(2):
-                ops.copy4d(dq[:, d * Hh:], dhseq[d], (B, W, Hh, C), (H * W * C, C, W * C, 1), (W * HID, HID, C, 1))
-            st["dhseq"], st["dgh"] = dhseq, ops.new(dev, 2, B, W, 3 * HID)
-            st["dgi_acc"], st["dhc"] = ops.new(dev, 2, W, 3 * HID), ops.new(dev, 2, W, HID)
-            hp0, hp1 = prev_h(B - 1, 0)
-            ops.call("tatt_qgru_bwd_gates", ops.P(dhseq[0, B - 1]), ops.P(dhseq[1, 0]), ops.P(gsave[0, B - 1]),
-                     ops.P(gsave[1, 0]), ops.P(hp0), ops.P(hp1), ops.P(st["dhc"][0]), ops.P(st["dhc"][1]), ops.P(st["dgi_acc"][0]),
-                     ops.P(st["dgi_acc"][1]), ops.P(st["dgh"][0, B - 1]), ops.P(st["dgh"][1, 0]), W, HID, 1, ops.stream())
-        dhseq, dgh, dgi_acc, dhc = st["dhseq"], st["dgh"], st["dgi_acc"], st["dhc"]
-        for s in range(s_from, s_to):
+
+        # backward sweep: step s visits time B-1-s in the forward direction and time s in the reverse direction.  (Issuing the first
+        # steps one pass early, as a closure of their own beside block1's backward, was measured: no gain -- profiles/r04_m_ab.txt.)
+        hp0, hp1 = prev_h(B - 1, 0)
+        ops.call("tatt_qgru_bwd_gates", ops.P(dhseq[0, B - 1]), ops.P(dhseq[1, 0]), ops.P(gsave[0, B - 1]),
+                 ops.P(gsave[1, 0]), ops.P(hp0), ops.P(hp1), ops.P(dhc[0]), ops.P(dhc[1]), ops.P(dgi_acc[0]),
+                 ops.P(dgi_acc[1]), ops.P(dgh[0, B - 1]), ops.P(dgh[1, 0]), W, HID, 1, ops.stream())
+        for s in range(B - 1):
             c0, c1 = B - 1 - s, s                # current step's time indices
             n0, n1 = c0 - 1, c1 + 1              # next step's
             hp0, hp1 = prev_h(n0, n1)
@@ -1159,15 +1151,6 @@ class QueryGruFn(Function):
                      ops.P(dhseq[0, n0]), ops.P(dhseq[1, n1]), ops.P(gsave[0, n0]), ops.P(gsave[1, n1]), ops.P(hp0),
                      ops.P(hp1), ops.P(dhc[0]), ops.P(dhc[1]), ops.P(dgi_acc[0]), ops.P(dgi_acc[1]),
                      ops.P(dgh[0, n0]), ops.P(dgh[1, n1]), W, HID, ops.stream())
-        return ()
-
-    @staticmethod
-    def _bwd_rest(ctx, saved, dq, st, head):
-        emb, x, wih0, whh0, wih1, whh1, hbuf, gsave, whhT = saved
-        B, H, W, C, HID, IN = ctx.dims
-        dev = emb
-        QueryGruFn._bwd_chain(ctx, saved, dq, st, head, B - 1)      # (sets the sweep up itself if the head closure has not)
-        dgh, dgi_acc = st["dgh"], st["dgi_acc"]
         grads = []
         dx = ops.new(dev, W, IN)
         for d, (wih, whh) in enumerate(((wih0, whh0), (wih1, whh1))):
@@ -1187,11 +1170,6 @@ class QueryGruFn(Function):
         ops.copy4d(dx, demb, (1, W, H, C), (0, IN, C, 1), (0, C, W * C, 1))
         (a0, b0, c0, d0), (a1, b1, c1, d1) = grads
         return demb, a0, b0, c0, d0, a1, b1, c1, d1
-
-
-QGRU_HEAD_STEPS = 0         # steps of the query GRU's backward recurrence issued one pass early, with the TP stage's side lane (A/B hook).  Measured
-                            # (profiles/r04_m_ab.txt, same box): 0 / 5 / 10 / 16 steps -> 5.30 / 5.32 / 5.30 / 5.43 ms: that side lane has no room, a step
-                            # moved there lengthens its pass by what it saves in the next; 0 = the whole recurrence with the GRU's own bucket
 
 
 def query_embedding(emb, gru, B, H, W):

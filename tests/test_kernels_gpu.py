@@ -277,7 +277,15 @@ def test_conv3_wgrad_bias_gradient(dev):
     from tatt_amd import ops
     x, dy = R(3, 16, 64, 64).to(dev), R(3, 16, 64, 128, seed=1).to(dev)
     dw, db = ops.conv_wgrad(x, dy, 128, 3, 3, want_db=True)
-    check_close("db", db, dy.cpu().double().sum((0, 1, 2)).float(), rtol=1e-5, atol=1e-4)
+    # split-bf16 kernel (round 4): every dy operand keeps 16 mantissa bits (hi + lo), i.e. 2^-17 relative per term; the sum of M = 3072
+    # unit-scale terms carries ~2^-17 sqrt(M) = 4e-4 of absolute error (measured 3.2e-4) -- 6e-6 of the sum's natural scale sqrt(M)
+    check_close("db", db, dy.cpu().double().sum((0, 1, 2)).float(), rtol=1e-5, atol=2e-3)
+    ops.CONV3_WGRAD_SB = False
+    try:
+        _, db32 = ops.conv_wgrad(x, dy, 128, 3, 3, want_db=True)                   # the exact-fp32 kernel: round-off only
+    finally:
+        ops.CONV3_WGRAD_SB = True
+    check_close("db fp32", db32, dy.cpu().double().sum((0, 1, 2)).float(), rtol=1e-5, atol=1e-4)
     assert torch.equal(dw, ops.conv_wgrad(x, dy, 128, 3, 3))
 
 
@@ -821,7 +829,7 @@ def test_srb_trunk_fused_backward_equals_operator_chain(dev, B, H, W):
         noise = k in ("g.conv1.bias", "g.conv2.bias")          # mathematically zero (a bias in front of a BatchNorm): round-off only
         for name, got in (("fused", res[0]), ("deferred", res[1])):
             err = float((got[k] - res[2][k]).abs().max()) / (1.0 if noise else ref)
-            if not err < (2e-7 * B * H * W if noise else 2e-4):    # (noise: a sum of B H W round-offs of unit-scale terms)
+            if not err < (1e-6 * B * H * W + 1e-4 if noise else 2e-4):    # (noise: a sum of B H W round-offs of unit-scale terms)
                 bad.append("%s %s: %.3e" % (name, k, err))
     assert not bad, "\n".join(bad)
     for k in res[0]:
