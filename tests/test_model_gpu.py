@@ -330,10 +330,10 @@ def _flat_state(m, tr):
             "nbt": torch.stack([v.reshape(()) for k, v in sd.items() if k.endswith("num_batches_tracked")])}
 
 
-def _run_steps(dev, nsteps, B, dropout, **trainer_kw):
+def _run_steps(dev, nsteps, B, dropout, stn=True, **trainer_kw):
     from tatt_amd import functional as Fh
     from tatt_amd.train import Trainer
-    m = build("TSRN_TL_TRANS", dev, **STD).train()
+    m = build("TSRN_TL_TRANS", dev, **dict(STD, STN=stn)).train()
     m.infoGen.dropout_on = dropout
     Fh.set_seed(dev, 99)
     tr = Trainer(m, **trainer_kw)
@@ -345,14 +345,16 @@ def _run_steps(dev, nsteps, B, dropout, **trainer_kw):
     return [float(l) for l in losses], _flat_state(m, tr), int(Fh.seed_tensor(dev)), float(tr.last_grad_norm)
 
 
-@pytest.mark.parametrize("dropout,B", [(False, 4), (True, 4), (True, 48)])
-def test_graph_replay_equals_eager(dev, dropout, B):
+@pytest.mark.parametrize("dropout,B,stn", [(False, 4, True), (True, 4, True), (True, 48, True), (False, 3, False)])
+def test_graph_replay_equals_eager(dev, dropout, B, stn):
     """6 steps (2 eager + capture + 3 replays, fresh data every step) through Trainer(use_graph=True) next to the same 6 steps
     launched eagerly, from the same weights and dropout seed: same losses, weights, Adam moments, BatchNorm running
     statistics, num_batches_tracked and seed word.  The kernels and their order are identical, so the comparison is (near-)exact;
     with dropout ON it also proves that replays draw the masks the eager run draws."""
-    le, se, seed_e, gn_e = _run_steps(dev, 6, B, dropout, use_graph=False)
-    lg, sg, seed_g, gn_g = _run_steps(dev, 6, B, dropout, use_graph=True, warmup_eager=2)
+    # (STN off: "first" is the LAST stage, so its deferred closures run merged onto the main stream -- the layout in which a closure
+    # split across two lanes raced in round 4; kept as a case of its own)
+    le, se, seed_e, gn_e = _run_steps(dev, 6, B, dropout, stn=stn, use_graph=False)
+    lg, sg, seed_g, gn_g = _run_steps(dev, 6, B, dropout, stn=stn, use_graph=True, warmup_eager=2)
     assert len(set(lg)) == len(lg), "graph mode returned an aliased loss tensor"
     for a, b in zip(le, lg):
         assert abs(a - b) <= 1e-6 * abs(a), (le, lg)
