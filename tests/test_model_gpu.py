@@ -366,6 +366,27 @@ def test_graph_replay_equals_eager(dev, dropout, B, stn):
     assert abs(gn_e - gn_g) <= 1e-6 * gn_e
 
 
+def test_split_bf16_vs_fp32_training_drift(dev):
+    """Multi-step drift of the default arithmetic: 12 training steps (B = 8, STN on, dropout off, fresh data every step) with the
+    split-bf16 kernel families against the same steps with exact fp32 products (`tatt_amd.set_arithmetic`).  The single-step tests
+    bound each kernel; this one bounds what 12 optimiser steps make of it: the loss curves stay together to 2e-3 relative and the
+    weights to 4 x lr in max-abs (Adam's first steps turn ANY round-off on a near-zero gradient into +-lr per step -- the
+    eager-vs-eager fp32 noise floor of this comparison is the same order)."""
+    import tatt_amd
+    try:
+        tatt_amd.set_arithmetic("fp32")
+        l32, s32, _, g32 = _run_steps(dev, 12, 8, False, use_graph=False)
+    finally:
+        tatt_amd.set_arithmetic("split_bf16")
+    lsb, ssb, _, gsb = _run_steps(dev, 12, 8, False, use_graph=False)
+    rel = max(abs(a - b) / abs(a) for a, b in zip(l32, lsb))
+    dp = float((s32["p"] - ssb["p"]).abs().max())
+    rp = float((s32["p"] - ssb["p"]).norm() / s32["p"].norm())
+    print("split-bf16 vs fp32 after 12 steps: loss rel %.3e, weights max-abs %.3e, l2-rel %.3e" % (rel, dp, rp))
+    assert rel <= 2e-3, (l32, lsb)
+    assert dp <= 4e-3 and rp <= 1e-3, (dp, rp)
+
+
 @pytest.mark.parametrize("B", [6, 48])
 def test_staged_deferred_backward_equals_single_pass(dev, B):
     """Backward in eight stages (up-sampler, five SRBs, TP interpreter, block1 + STN) with the weight-gradient kernels and the

@@ -117,6 +117,25 @@ def test_packed_filter_sizes_come_from_the_library():
     assert _packed_numel((256, 64, 3, 3), 10) == 256 * 64 * 9
 
 
+def test_set_arithmetic_switches_every_split_kernel_family():
+    """`tatt_amd.set_arithmetic` is the documented switch between the split-bf16 default and exact fp32 products (INTEGRATION.md
+    "Arithmetic"): it must move all four kernel families together and refuse anything else."""
+    import tatt_amd
+    from tatt_amd import functional as Fh, ops
+    assert tatt_amd.get_arithmetic() == "split_bf16"
+    try:
+        tatt_amd.set_arithmetic("fp32")
+        assert not (ops.CONV3_SB or ops.CONV3_WGRAD_SB or Fh.TOKGEMM_SB or Fh.GRU_WGRAD_SB)
+        assert tatt_amd.get_arithmetic() == "fp32"
+        ops.CONV3_SB = True
+        assert tatt_amd.get_arithmetic() == "mixed"
+        with pytest.raises(ValueError):
+            tatt_amd.set_arithmetic("bf16")
+    finally:
+        tatt_amd.set_arithmetic("split_bf16")
+    assert ops.CONV3_SB and ops.CONV3_WGRAD_SB and Fh.TOKGEMM_SB and Fh.GRU_WGRAD_SB
+
+
 def test_bench_cpu_baseline_leg_runs_without_a_gpu():
     """`bench.py --cpu-baseline-only` (the child process of the cpu_baseline leg): bounded thread count, JSON contract."""
     import json
