@@ -350,6 +350,27 @@ int tatt_qgru_bwd_gates(const float* dhseq0, const float* dhseq1, const float* g
 int tatt_qgru_bwd_mm(const float* dgh0, const float* dgh1, const float* whhT0, const float* whhT1,
                      float* dhcarry0, float* dhcarry1, int Wb, int HID, hipStream_t st);
 
+/* The backward recurrence above as ONE persistent launch: fused steps s0 .. s1-1 of the T-1 (step s = tatt_qgru_bwd_fused with the
+ * forward direction at time T-1-s and the reverse direction at time s; model/transformer_v2.py:201-221 backward).  A work-group keeps
+ * its tile's W_hh^T slice, dhcarry and dgi accumulators in registers; dgh crosses work-groups per step through write-through (sc1)
+ * stores and per-(row block, direction) flag words -- no grid-wide barrier.  dgh* (T, Wb, 3*HID): slot T-1 (dir 0) / 0 (dir 1) filled
+ * by tatt_qgru_bwd_gates(first = 1), which also initialises dhcarry* and dgi_acc*; hbuf0 + t*Wb*HID = h_prev of time t (dir 0),
+ * hbuf1 + (t+1)*Wb*HID = h_prev of time t (dir 1); gsave* (T, 4, Wb, HID); dhseq* (T, Wb, HID).  sync: 1024 words (zeroed here when
+ * s0 == 0); sync[1023] != 0 afterwards: a wall-clock-bounded spin expired (results invalid).  Returns 1 for geometries it does not
+ * take (HID != 512, Wb % 16 != 0, more than 256 work-groups): use the per-step entry points then. */
+int tatt_qgru_bwd_chain(float* dgh0, float* dgh1, const float* whhT0, const float* whhT1, const float* dhseq0,
+                        const float* dhseq1, const float* gsave0, const float* gsave1, const float* hbuf0,
+                        const float* hbuf1, float* dhcarry0, float* dhcarry1, float* dgi_acc0, float* dgi_acc1,
+                        unsigned* sync, int T, int Wb, int HID, int s0, int s1, hipStream_t st);
+
+/* The forward recurrence (T calls of tatt_qgru_fwd_step) as one persistent launch, time steps s0 .. s1-1 (direction 0 at time s,
+ * direction 1 at time T-1-s), same hand-off as tatt_qgru_bwd_chain with h as the exchanged tensor.  hbuf* (T+1, Wb, HID): h of time t
+ * at slot t+1 (direction 0; slot 0 zero) / slot t (direction 1; slot T zero), zero slots filled by the caller; gsave* (T, 4, Wb, HID)
+ * or NULL; gi* (Wb, 3*HID) incl. b_ih.  model/transformer_v2.py:201-221. */
+int tatt_qgru_fwd_chain(const float* gi0, const float* gi1, const float* whh0, const float* whh1, const float* bhh0,
+                        const float* bhh1, float* hbuf0, float* hbuf1, float* gsave0, float* gsave1, unsigned* sync,
+                        int T, int Wb, int HID, int s0, int s1, hipStream_t st);
+
 /* ---- attention core ------------------------------------------------------------------------------------ */
 
 /* ctx = dropout(softmax(Q K^T)) V per head (E=64, 4 heads, S <= 32), wavg = head-mean of the dropped

@@ -833,6 +833,273 @@ TATT_API int tatt_qgru_bwd_fused(const float* dgh_cur0, const float* dgh_cur1, c
 }
 
 // ------------------------------------------------------------------------------------------------
+// backward recurrence of the query GRU as ONE persistent launch (steps s0 .. s1-1 of the T-1 fused steps above).
+//
+// The per-step launches above are bound by the launch boundary (9.4 us start to start for 0.2 GFLOP), 47 of them at the exposed end
+// of the training step.  Here a work-group keeps its (16 rows, 16 hidden units) tile for the whole chain: its slice of W_hh^T lives
+// in registers (48 per lane), dhcarry and the three dgi accumulators of its tile too; what crosses work-groups per step is only
+// dgh (this step's recurrent-side gate gradients): a tile's contraction needs the 16 x 3*HID rows its ROW BLOCK's HID/16 work-groups
+// produced one step earlier -- so synchronisation is per (row block, direction) GROUP of HID/16 members, not grid-wide.  Block b is
+// member b / NG of group b % NG: with NG = 8 groups (W = 64) a group's members are the blocks HIP places on ONE XCD (observed
+// placement b % 8, MI355X_MICROARCH.md) -- a speed bonus only; correctness uses the agent-scope forms of that guide:
+//   producer: 16-byte `sc1` (write-through) stores of its dgh tile -> s_waitcnt vmcnt(0) -> barrier -> ONE `sc1` flag store
+//             (flags[group][member] = number of steps published);
+//   consumer: wave 0 polls the group's flags (one 4-byte `sc1` load per lane = per member) -> barrier -> `sc1` loads of the rows.
+// Every spin is bounded by the wall clock: on expiry the kernel raises flags[QCH_ERR] and runs on without waiting (results are then
+// garbage but the launch ends); tatt_qgru_bwd_chain's caller reads the word when it next synchronises.
+// Residency: the NG * HID/16 <= 256 work-groups must be co-resident (one per CU at 512 threads / <= 128 VGPRs leaves room beside it).
+// ------------------------------------------------------------------------------------------------
+#define QCH_ERR 1023                       // index of the error word in the sync buffer (1024 words)
+#define QCH_SPIN_TICKS 3000000L            // 30 ms of the 100 MHz wall clock
+struct QChainP {
+    float* dgh[2]; const float* whhT[2]; const float* dhseq[2]; const float* gsave[2]; const float* hbuf[2];
+    float* dhcarry[2]; float* dgi_acc[2];
+    unsigned* flags;
+    int T, Wb, s0, s1;
+};
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(512) void qgru_bwd_chain_kernel(QChainP p) {
+    constexpr int HID = 512, K = 3 * HID, NM = HID / 16, KS = K / 8 / 16;      // KS = 12 sixteen-byte fragments per lane
+    __shared__ float red[8][16][17];
+    __shared__ __attribute__((aligned(16))) float stage[16][3][16];
+    __shared__ int s_dead;
+    const int NG = (p.Wb / 16) * 2;
+    const int grp = blockIdx.x % NG, mem = blockIdx.x / NG;
+    const int d = grp / (p.Wb / 16), m0 = (grp % (p.Wb / 16)) * 16, j0 = mem * 16;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int i = lane & 15, q = lane >> 4;
+    const long plane = (long)p.Wb * HID;
+    // W_hh^T rows j0 .. j0+15, this wave's eighth of the contraction: resident for the whole chain
+    f32x4 b[KS];
+    {
+        const float* bp = p.whhT[d] + (long)(j0 + i) * K + wave * (K / 8) + 4 * q;
+#pragma unroll
+        for (int u = 0; u < KS; ++u) b[u] = *reinterpret_cast<const f32x4*>(bp + 16 * u);
+    }
+    // epilogue ownership (threads 0..255): element (m0 + m, j0 + j)
+    const int m = (t >> 4) & 15, j = t & 15;
+    const long e = (long)(m0 + m) * HID + j0 + j, g3 = (long)(m0 + m) * K + j0 + j;
+    float dhc = 0.f, ga0 = 0.f, ga1 = 0.f, ga2 = 0.f;
+    if (t < 256) { dhc = p.dhcarry[d][e]; ga0 = p.dgi_acc[d][g3]; ga1 = p.dgi_acc[d][g3 + HID]; ga2 = p.dgi_acc[d][g3 + 2 * HID]; }
+    if (t == 0) s_dead = 0;
+    unsigned* flags = p.flags + grp * 64;
+    const int a_off = ((m0 + i) * K + wave * (K / 8) + 4 * q) * 4;             // byte offset of this lane's A fragments in a dgh step
+    for (int s = p.s0; s < p.s1; ++s) {
+        const int cur = d ? s : p.T - 1 - s, nxt = d ? s + 1 : p.T - 2 - s;
+        // inputs of the gate part do not depend on the chain: in flight before the wait
+        float in_dh = 0.f, r = 0.f, z = 0.f, n = 0.f, hn = 0.f, hp = 0.f;
+        if (t < 256) {
+            const float* gs = p.gsave[d] + (long)nxt * 4 * plane;
+            in_dh = p.dhseq[d][(long)nxt * plane + e];
+            r = gs[e]; z = gs[plane + e]; n = gs[2 * plane + e]; hn = gs[3 * plane + e];
+            hp = p.hbuf[d][(long)(d ? nxt + 1 : nxt) * plane + e];
+        }
+        if (s > p.s0) {                                                         // the group's members have published step s-1
+            if (wave == 0 && !s_dead) {
+                const long t0 = wall_clock64();
+                int it = 0;
+                for (;;) {
+                    const unsigned f = lane < NM ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+                    if (__builtin_amdgcn_ballot_w64(f < (unsigned)s) == 0) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if ((++it & 63) == 0 && wall_clock64() - t0 > QCH_SPIN_TICKS) {
+                        if (lane == 0) { s_dead = 1; __hip_atomic_store(p.flags + QCH_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        f32x4 a[KS];
+        {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.dgh[d] + (long)cur * p.Wb * K, 0, p.Wb * K * 4, 0x00020000);
+#pragma unroll
+            for (int u = 0; u < KS; ++u)
+                a[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, a_off + 64 * u, 0, 16 /* sc1 */));
+        }
+        __builtin_amdgcn_sched_barrier(0);                                      // all twelve loads in flight before the first MFMA
+        f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+        for (int u = 0; u < KS; ++u)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                if (v & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][v], b[u][v], acc1, 0, 0, 0);
+                else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][v], b[u][v], acc0, 0, 0, 0);
+            }
+        {
+            const int col = lane & 15, rb = (lane >> 4) * 4;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) red[wave][rb + rr][col] = acc0[rr] + acc1[rr];
+        }
+        __syncthreads();
+        if (t < 256) {
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) sum += red[w][m][j];
+            const float dh = in_dh + dhc + sum;
+            const float dn = dh * (1.f - z), dz = dh * (hp - n);
+            const float dnp = dn * (1.f - n * n);
+            const float drp = dnp * hn * r * (1.f - r);
+            const float dzp = dz * z * (1.f - z);
+            ga0 += drp; ga1 += dzp; ga2 += dnp;
+            stage[m][0][j] = drp; stage[m][1][j] = dzp; stage[m][2][j] = dnp * r;
+            dhc = dh * z;
+        }
+        __syncthreads();
+        if (t < 192) {                                                          // 16 rows x 3 gates x 4 sixteen-byte pieces
+            const int row = t / 12, gate = (t % 12) >> 2, j4 = (t & 3) * 4;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&stage[row][gate][j4]);
+            const __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc(p.dgh[d] + (long)nxt * p.Wb * K, 0, p.Wb * K * 4, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), ws, ((m0 + row) * K + gate * HID + j0 + j4) * 4, 0, 16 /* sc1 */);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        if (t == 0) __hip_atomic_store(flags + mem, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (t < 256) { p.dhcarry[d][e] = dhc; p.dgi_acc[d][g3] = ga0; p.dgi_acc[d][g3 + HID] = ga1; p.dgi_acc[d][g3 + 2 * HID] = ga2; }
+}
+// dgh (2 pointers: (T, Wb, 3*HID) per direction, the first step's slot filled by tatt_qgru_bwd_gates), hbuf* = h_prev of time t for
+// direction 0 at hbuf0 + t*Wb*HID and of time t for direction 1 at hbuf1 + (t+1)*Wb*HID (the zero-slot layout of the forward);
+// sync: 1024 words, zeroed here when s0 == 0; sync[1023] != 0 afterwards = a bounded spin expired (results invalid).
+// Returns 1 for geometries it does not take (HID != 512, Wb % 16, more than 256 work-groups): use the per-step entry points.
+TATT_API int tatt_qgru_bwd_chain(float* dgh0, float* dgh1, const float* whhT0, const float* whhT1, const float* dhseq0,
+                                 const float* dhseq1, const float* gsave0, const float* gsave1, const float* hbuf0,
+                                 const float* hbuf1, float* dhcarry0, float* dhcarry1, float* dgi_acc0, float* dgi_acc1,
+                                 unsigned* sync, int T, int Wb, int HID, int s0, int s1, hipStream_t st) {
+    if (HID != 512 || Wb % 16 || Wb <= 0 || (Wb / 16) * 2 * (HID / 16) > 256 || (Wb / 16) * 2 > 15) return 1;
+    if (s0 < 0 || s1 > T - 1 || s0 >= s1) return s0 == s1 ? 0 : 2;
+    if (s0 == 0 && hipMemsetAsync(sync, 0, 1024 * sizeof(unsigned), st) != hipSuccess) return 3;
+    QChainP p = {{dgh0, dgh1}, {whhT0, whhT1}, {dhseq0, dhseq1}, {gsave0, gsave1}, {hbuf0, hbuf1}, {dhcarry0, dhcarry1},
+                 {dgi_acc0, dgi_acc1}, sync, T, Wb, s0, s1};
+    hipLaunchKernelGGL(qgru_bwd_chain_kernel, dim3((Wb / 16) * 2 * (HID / 16)), dim3(512), 0, st, p);
+    return LAUNCH_CHECK();
+}
+
+// forward recurrence of the query GRU as one persistent launch (time steps s0 .. s1-1; direction 0 visits time s, direction 1 time
+// T-1-s): same groups, flags and hand-off forms as qgru_bwd_chain_kernel; what crosses work-groups per step is h (16 x HID rows per
+// group).  hbuf* is the zero-slot layout of the host: h of time t at hbuf0 + (t+1)*Wb*HID (slot 0 = zeros) for direction 0 and at
+// hbuf1 + t*Wb*HID (slot T = zeros) for direction 1, so h_prev of every step is a valid pointer.  The W_hh rows of the tile (3 gates x
+// 16 units, this wave's eighth of the contraction), the tile's gi, b_hh and its own h stay in registers.
+struct QFChainP {
+    const float* gi[2]; const float* whh[2]; const float* bhh[2]; float* hbuf[2]; float* gsave[2];
+    unsigned* flags;
+    int T, Wb, s0, s1;
+};
+__global__ __launch_bounds__(512) void qgru_fwd_chain_kernel(QFChainP p) {
+    constexpr int HID = 512, NM = HID / 16;
+    __shared__ float red[8][3][16][17];
+    __shared__ __attribute__((aligned(16))) float stage[16][16];
+    __shared__ int s_dead;
+    const int NG = (p.Wb / 16) * 2;
+    const int grp = blockIdx.x % NG, mem = blockIdx.x / NG;
+    const int d = grp / (p.Wb / 16), m0 = (grp % (p.Wb / 16)) * 16, j0 = mem * 16;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int i = lane & 15, q = lane >> 4;
+    const long plane = (long)p.Wb * HID;
+    f32x4 b[3][4];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            b[g][u] = *reinterpret_cast<const f32x4*>(p.whh[d] + ((long)g * HID + j0 + i) * HID + wave * 64 + 16 * u + 4 * q);
+    const int m = (t >> 4) & 15, j = t & 15;
+    const long e = (long)(m0 + m) * HID + j0 + j;
+    float gi0 = 0.f, gi1 = 0.f, gi2 = 0.f, bh0 = 0.f, bh1 = 0.f, bh2 = 0.f, hown = 0.f;
+    if (t < 256) {
+        const float* gi = p.gi[d] + (long)(m0 + m) * 3 * HID + j0 + j;
+        gi0 = gi[0]; gi1 = gi[HID]; gi2 = gi[2 * HID];
+        bh0 = p.bhh[d][j0 + j]; bh1 = p.bhh[d][HID + j0 + j]; bh2 = p.bhh[d][2 * HID + j0 + j];
+        const int tp = d ? p.T - 1 - p.s0 + 1 : p.s0;                           // slot of h_prev of the first step of this launch
+        hown = p.hbuf[d][(long)tp * plane + e];
+    }
+    if (t == 0) s_dead = 0;
+    unsigned* flags = p.flags + grp * 64;
+    const int a_off = ((m0 + i) * HID + wave * 64 + 4 * q) * 4;
+    for (int s = p.s0; s < p.s1; ++s) {
+        const int slot_prev = d ? p.T - s : s, slot_new = d ? p.T - 1 - s : s + 1, tcur = d ? p.T - 1 - s : s;
+        if (s > p.s0) {
+            if (wave == 0 && !s_dead) {
+                const long t0 = wall_clock64();
+                int it = 0;
+                for (;;) {
+                    const unsigned f = lane < NM ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+                    if (__builtin_amdgcn_ballot_w64(f < (unsigned)s) == 0) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if ((++it & 63) == 0 && wall_clock64() - t0 > QCH_SPIN_TICKS) {
+                        if (lane == 0) { s_dead = 1; __hip_atomic_store(p.flags + QCH_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        f32x4 a[4];
+        {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.hbuf[d] + (long)slot_prev * plane, 0, p.Wb * HID * 4, 0x00020000);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                a[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, a_off + 64 * u, 0, 16 /* sc1 */));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 acc[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+#pragma unroll
+                for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][v], b[g][u][v], acc[g], 0, 0, 0);
+        {
+            const int col = lane & 15, rb = (lane >> 4) * 4;
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) red[wave][g][rb + rr][col] = acc[g][rr];
+        }
+        __syncthreads();
+        if (t < 256) {
+            float gh0 = bh0, gh1 = bh1, gh2 = bh2;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) { gh0 += red[w][0][m][j]; gh1 += red[w][1][m][j]; gh2 += red[w][2][m][j]; }
+            const float r = sigmoid_fast(gi0 + gh0);
+            const float z = sigmoid_fast(gi1 + gh1);
+            const float n = tanh_fast(gi2 + r * gh2);
+            const float h = (1.f - z) * n + z * hown;
+            hown = h;
+            stage[m][j] = h;
+            float* gs = p.gsave[d];
+            if (gs) {
+                gs += (long)tcur * 4 * plane;
+                gs[e] = r; gs[plane + e] = z; gs[2 * plane + e] = n; gs[3 * plane + e] = gh2;
+            }
+        }
+        __syncthreads();
+        if (t < 64) {                                                           // 16 rows x 4 sixteen-byte pieces
+            const int row = t >> 2, j4 = (t & 3) * 4;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&stage[row][j4]);
+            const __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc(p.hbuf[d] + (long)slot_new * plane, 0, p.Wb * HID * 4, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), ws, ((m0 + row) * HID + j0 + j4) * 4, 0, 16 /* sc1 */);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        if (t == 0) __hip_atomic_store(flags + mem, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// gi* (Wb, 3*HID) incl. b_ih; whh* (3*HID, HID); hbuf* (T+1, Wb, HID) with the zero slots already zeroed; gsave* (T, 4, Wb, HID) or
+// NULL; sync as for tatt_qgru_bwd_chain.  Returns 1 for geometries it does not take.
+TATT_API int tatt_qgru_fwd_chain(const float* gi0, const float* gi1, const float* whh0, const float* whh1, const float* bhh0,
+                                 const float* bhh1, float* hbuf0, float* hbuf1, float* gsave0, float* gsave1, unsigned* sync,
+                                 int T, int Wb, int HID, int s0, int s1, hipStream_t st) {
+    if (HID != 512 || Wb % 16 || Wb <= 0 || (Wb / 16) * 2 * (HID / 16) > 256 || (Wb / 16) * 2 > 15) return 1;
+    if (s0 < 0 || s1 > T || s0 >= s1) return s0 == s1 ? 0 : 2;
+    if (s0 == 0 && hipMemsetAsync(sync, 0, 1024 * sizeof(unsigned), st) != hipSuccess) return 3;
+    QFChainP p = {{gi0, gi1}, {whh0, whh1}, {bhh0, bhh1}, {hbuf0, hbuf1}, {gsave0, gsave1}, sync, T, Wb, s0, s1};
+    hipLaunchKernelGGL(qgru_fwd_chain_kernel, dim3((Wb / 16) * 2 * (HID / 16)), dim3(512), 0, st, p);
+    return LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------------------------
 // GruBlock glue (reference GruBlock = 1x1 conv + BiGRU, model/tsrn.py:1067-1084): the 1x1 conv W_c (64 x K), b_c and the
 // GRU input projections W_ih (2 x 96 x 64), b_ih are composed into ONE projection  W' = W_ih W_c (192 x K),
 // b' = W_ih b_c + b_ih  applied to the token matrix by a single GEMM; `tail` maps the gradients of the composed

@@ -1061,6 +1061,30 @@ class TPStackFn(Function):
 
 
 # --------------------------------------------------------------------------------------------------
+# Query GRU recurrences as persistent launches (tatt_qgru_fwd_chain / tatt_qgru_bwd_chain) instead of one launch per time step.  Every spin in them is bounded
+# by the wall clock; qgru_chain_check() reads the error words of the most recent launches (synchronises: call it outside a capture).
+QGRU_CHAIN_FWD = True
+QGRU_CHAIN_BWD = True
+QGRU_CHAIN_SYNC = []
+
+
+def _qgru_chain_takes(W, HID):
+    return HID == 512 and W % 16 == 0 and (W // 16) * 2 * (HID // 16) <= 256
+
+
+def _qgru_chain_sync(ref):
+    sync = torch.empty(1024, device=ref.device, dtype=torch.int32)
+    QGRU_CHAIN_SYNC.append(sync)
+    del QGRU_CHAIN_SYNC[:-8]
+    return sync
+
+
+def qgru_chain_check():
+    for s in QGRU_CHAIN_SYNC:
+        if int(s[1023].item()) != 0:
+            raise RuntimeError("tatt_amd: a persistent query-GRU launch gave up waiting for its neighbours (work-groups not co-resident?)")
+
+
 class QueryGruFn(Function):
     """Query positional embedding: init_factor (H*W, C) -> BiGRU(C*H -> C*H/2 per direction) whose TIME axis is
     the sample axis (reference quirk) -> (B, H, W, C)."""
@@ -1090,7 +1114,12 @@ class QueryGruFn(Function):
         hbuf[1, B].zero_()
         hseq = (hbuf[0, 1:], hbuf[1, :B])
         gsave = ops.new(dev, 2, B, 4, W, HID)
-        for s in range(B):
+        chain = QGRU_CHAIN_FWD and _qgru_chain_takes(W, HID)
+        if chain:
+            ops.call("tatt_qgru_fwd_chain", ops.P(gi[0]), ops.P(gi[1]), ops.P(whh0), ops.P(whh1), ops.P(bhh0), ops.P(bhh1),
+                     ops.P(hbuf[0]), ops.P(hbuf[1]), ops.P(gsave[0]), ops.P(gsave[1]), ops.P(_qgru_chain_sync(dev)), B, W, HID,
+                     0, B, ops.stream())
+        for s in range(0 if chain else B):
             t0, t1 = s, B - 1 - s
             hp0 = hseq[0][t0 - 1] if s > 0 else None
             hp1 = hseq[1][t1 + 1] if s > 0 else None
@@ -1143,7 +1172,14 @@ class QueryGruFn(Function):
         ops.call("tatt_qgru_bwd_gates", ops.P(dhseq[0, B - 1]), ops.P(dhseq[1, 0]), ops.P(gsave[0, B - 1]),
                  ops.P(gsave[1, 0]), ops.P(hp0), ops.P(hp1), ops.P(dhc[0]), ops.P(dhc[1]), ops.P(dgi_acc[0]),
                  ops.P(dgi_acc[1]), ops.P(dgh[0, B - 1]), ops.P(dgh[1, 0]), W, HID, 1, ops.stream())
-        for s in range(B - 1):
+        chain = QGRU_CHAIN_BWD and _qgru_chain_takes(W, HID) and B > 1
+        if chain:
+            # the remaining B-1 steps as ONE persistent launch (work-groups exchange dgh through write-through stores and flag words)
+            sync = _qgru_chain_sync(dev)
+            ops.call("tatt_qgru_bwd_chain", ops.P(dgh[0]), ops.P(dgh[1]), ops.P(whhT[0]), ops.P(whhT[1]), ops.P(dhseq[0]),
+                     ops.P(dhseq[1]), ops.P(gsave[0]), ops.P(gsave[1]), ops.P(hbuf[0]), ops.P(hbuf[1]), ops.P(dhc[0]),
+                     ops.P(dhc[1]), ops.P(dgi_acc[0]), ops.P(dgi_acc[1]), ops.P(sync), B, W, HID, 0, B - 1, ops.stream())
+        for s in range(0 if chain else B - 1):
             c0, c1 = B - 1 - s, s                # current step's time indices
             n0, n1 = c0 - 1, c1 + 1              # next step's
             hp0, hp1 = prev_h(n0, n1)

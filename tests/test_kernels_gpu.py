@@ -424,6 +424,59 @@ def test_query_gru(dev, B):
                grtol=1e-3)
 
 
+def _qgru_run(dev, B, fwd_chain, bwd_chain, seed=5):
+    from tatt_amd import functional as Fh
+    H, W, C = 16, 64, 64                     # the published geometry: GRU(1024 -> 2 x 512), 64 rows
+    g = torch.nn.GRU(C * H, C * H // 2, bidirectional=True, batch_first=True)
+    torch.manual_seed(seed)
+    for p in g.parameters():
+        torch.nn.init.uniform_(p, -0.05, 0.05)
+    names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0", "weight_ih_l0_reverse",
+             "weight_hh_l0_reverse", "bias_ih_l0_reverse", "bias_hh_l0_reverse"]
+    leaves = [R(H * W, C).to(dev).requires_grad_()] + [getattr(g, n).detach().to(dev).requires_grad_() for n in names]
+    dq = R(B, H, W, C, seed=3).to(dev)
+    old = Fh.QGRU_CHAIN_FWD, Fh.QGRU_CHAIN_BWD
+    Fh.QGRU_CHAIN_FWD, Fh.QGRU_CHAIN_BWD = fwd_chain, bwd_chain
+    try:
+        q = Fh.QueryGruFn.apply(*leaves, B, H, W)
+        grads = torch.autograd.grad(q, leaves, dq)
+        torch.cuda.synchronize()
+        Fh.qgru_chain_check()
+    finally:
+        Fh.QGRU_CHAIN_FWD, Fh.QGRU_CHAIN_BWD = old
+    return (q.detach(),) + tuple(grads)
+
+
+@pytest.mark.parametrize("B", [2, 5, 48])
+def test_query_gru_persistent_chain_matches_stepwise(dev, B):
+    """tatt_qgru_fwd_chain / tatt_qgru_bwd_chain (one persistent launch per recurrence; work-groups hand h / dgh to their group through
+    write-through stores and flag words) against the per-step launches on the same inputs (model/transformer_v2.py:201-221): the
+    backward chain runs the same arithmetic in the same order, the forward chain splits the contraction over 8 waves instead of 4."""
+    ref = _qgru_run(dev, B, False, False)
+    for fwd_chain, bwd_chain in ((True, False), (False, True), (True, True)):
+        out = _qgru_run(dev, B, fwd_chain, bwd_chain)
+        for k, (a, b) in enumerate(zip(ref, out)):
+            err = float((a - b).abs().max() / (a.abs().max() + 1e-20))
+            assert err < 1e-5, (fwd_chain, bwd_chain, k, err)
+
+
+def test_query_gru_persistent_chain_under_load(dev):
+    """The hand-off between work-groups must hold when the chip is busy and the consumers' caches are warm from the previous run
+    (MI355X_MICROARCH.md: test every hand-off under uneven load, checking every word): 30 runs of the B = 48 chains beside a second
+    stream that keeps streaming kernels in flight, every output word against the first run."""
+    ref = _qgru_run(dev, 48, True, True)
+    side = torch.cuda.Stream()
+    x = torch.randn(64 << 20, device=dev)
+    for rep in range(30):
+        with torch.cuda.stream(side):
+            for _ in range(1 + rep % 4):
+                x.mul_(1.0001)
+        out = _qgru_run(dev, 48, True, True)
+        for k, (a, b) in enumerate(zip(ref, out)):
+            assert torch.equal(a, b), (rep, k, float((a - b).abs().max()))
+    torch.cuda.synchronize()
+
+
 # ------------------------------------------------------------------------------------------- attention
 @pytest.mark.parametrize("Lq,S", [(1024, 26), (26, 26), (70, 5)])
 def test_mha(dev, Lq, S):

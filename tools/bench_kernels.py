@@ -272,4 +272,50 @@ def timeit_graph(name, fn, iters=20):
 
 
 timeit_graph("qgru_fwd_chain_graph", _qgru_fwd)
+
+
+# ---- the recurrences alone: 48 / 47 per-step launches (as a hipGraph: no host cost between them) vs ONE persistent launch -----------
+def _with(fwd, bwd, fn):
+    def run():
+        old = Fh.QGRU_CHAIN_FWD, Fh.QGRU_CHAIN_BWD
+        Fh.QGRU_CHAIN_FWD, Fh.QGRU_CHAIN_BWD = fwd, bwd
+        try:
+            return fn()
+        finally:
+            Fh.QGRU_CHAIN_FWD, Fh.QGRU_CHAIN_BWD = old
+    return run
+
+
+timeit_graph("qgru_fwd_stepwise_graph", _with(False, False, _qgru_fwd))
+timeit_graph("qgru_fwd_persistent_graph", _with(True, True, _qgru_fwd))
+timeit("qgru_bwd_stepwise_eager", _with(False, False, _qgru_bwd))
+timeit("qgru_bwd_persistent_eager", _with(True, True, _qgru_bwd))
+_T, _W, _HID = B, 64, 512
+_gi = [R(_W, 3 * _HID) * 0.3 for _ in range(2)]
+_whh = [R(3 * _HID, _HID) * 0.03 for _ in range(2)]
+_whhT = [w_.t().contiguous() for w_ in _whh]
+_bhh = [R(3 * _HID) * 0.1 for _ in range(2)]
+_hbuf = torch.zeros(2, _T + 1, _W, _HID, device=dev)
+_gsave = torch.empty(2, _T, 4, _W, _HID, device=dev)
+_sync = torch.zeros(1024, device=dev, dtype=torch.int32)
+_dgh = torch.zeros(2, _T, _W, 3 * _HID, device=dev)
+_dhseq = R(2, _T, _W, _HID) * 0.1
+_dhc = torch.zeros(2, _W, _HID, device=dev)
+_dgia = torch.zeros(2, _W, 3 * _HID, device=dev)
+
+
+def _fwd_chain_only():
+    ops.call("tatt_qgru_fwd_chain", ops.P(_gi[0]), ops.P(_gi[1]), ops.P(_whh[0]), ops.P(_whh[1]), ops.P(_bhh[0]), ops.P(_bhh[1]),
+             ops.P(_hbuf[0]), ops.P(_hbuf[1]), ops.P(_gsave[0]), ops.P(_gsave[1]), ops.P(_sync), _T, _W, _HID, 0, _T, ops.stream())
+
+
+def _bwd_chain_only():
+    ops.call("tatt_qgru_bwd_chain", ops.P(_dgh[0]), ops.P(_dgh[1]), ops.P(_whhT[0]), ops.P(_whhT[1]), ops.P(_dhseq[0]), ops.P(_dhseq[1]),
+             ops.P(_gsave[0]), ops.P(_gsave[1]), ops.P(_hbuf[0]), ops.P(_hbuf[1]), ops.P(_dhc[0]), ops.P(_dhc[1]), ops.P(_dgia[0]),
+             ops.P(_dgia[1]), ops.P(_sync), _T, _W, _HID, 0, _T - 1, ops.stream())
+
+
+timeit("qgru_fwd_persistent_launch", _fwd_chain_only)           # / 48 = per time step
+timeit("qgru_bwd_persistent_launch", _bwd_chain_only)           # / 47
+print("   persistent launches: error word %d" % int(_sync[1023].item()), flush=True)
 # (the backward chain allocates its split-K workspaces through torch outside a Trainer: not capturable on its own)
