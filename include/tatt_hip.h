@@ -371,6 +371,36 @@ int tatt_qgru_fwd_chain(const float* gi0, const float* gi1, const float* whh0, c
                         const float* bhh1, float* hbuf0, float* hbuf1, float* gsave0, float* gsave1, unsigned* sync,
                         int T, int Wb, int HID, int s0, int s1, hipStream_t st);
 
+/* ---- STN head glue (model/stn_head.py:25-106): everything between two of its convolutions as ONE launch ------------------------
+ * The launches below synchronise their (<= 128) work-groups INSIDE the launch: partial sums leave through write-through stores, each
+ * work-group raises a flag word and waits for the others'.  `sync` is a 256-word buffer per call site, zeroed ONCE by the caller when
+ * it is allocated and then reused (word 254 = epoch, word 255 = error: a wall-clock-bounded spin expired, results invalid); launches
+ * that share a sync buffer must not overlap. */
+
+/* A (B,H/ph,W/pw,C) = maxpool_{ph x pw}(relu(batchnorm_train(X))), X (B,H,W,C) contiguous; mean, rstd (C) out; running statistics
+ * updated (NULL: not); part >= 128*2*C doubles.  nn.BatchNorm2d + nn.ReLU + nn.MaxPool2d of stn_head.py:9-15,33-49.  ph, pw in {1,2},
+ * C in {32, 64, 128, 256} and at most 128 * 4 * 1024 / C pool windows, else 1. */
+int tatt_stn_bn_pool_fwd(const float* X, float* A, const float* gamma, const float* beta, float* mean, float* rstd,
+                         float* running_mean, float* running_var, double* part, unsigned* sync, int B, int H, int W, int C,
+                         int ph, int pw, float eps, float momentum, hipStream_t st);
+/* its backward: dA -> dX (gradient w.r.t. X), dgamma, dbeta, dbias = column sums of dX (the producing convolution's bias gradient;
+ * NULL: skipped).  The pooled gradient goes to the first maximum of its window (tatt_maxpool_bwd's rule).  part >= 128*3*C doubles. */
+int tatt_stn_bn_pool_bwd(const float* X, const float* dA, const float* gamma, const float* beta, const float* mean,
+                         const float* rstd, float* dX, float* dgamma, float* dbeta, float* dbias, double* part,
+                         unsigned* sync, int B, int H, int W, int C, int ph, int pw, hipStream_t st);
+/* x.view(B,-1) of the (B,256,1,2) map [given NHWC: A6 (B,2,256)] -> Linear(512,512) -> BatchNorm1d(train) -> ReLU -> x0.1 ->
+ * Linear(512,NO): U (B,512) = first Linear's output, S (B,512) = the second Linear's input, ctrl (B,NO); W1 (512,512), W2 (NO,512)
+ * row-major [out][in]; part >= 32*B*NO floats.  stn_head.py:51-58,96-106.  B <= 64, NO % 4 == 0, NO <= 64, else 1. */
+int tatt_stn_fc_fwd(const float* A6, const float* W1, const float* b1, const float* g1, const float* be1, float* rm1,
+                    float* rv1, const float* W2, const float* b2, float* U, float* mean1, float* rstd1, float* S,
+                    float* ctrl, float* part, unsigned* sync, int B, int NO, float eps, float momentum, hipStream_t st);
+/* its backward incl. every parameter gradient: dW2 (NO,512), db2, dgamma1, dbeta1, dW1 (512,512), db1, dA6 (B,2,256); dU (B,512)
+ * is workspace (the tensor the work-groups exchange). */
+int tatt_stn_fc_bwd(const float* dctrl, const float* W2, const float* S, const float* U, const float* mean1,
+                    const float* rstd1, const float* g1, const float* W1, const float* A6, float* dW2, float* db2,
+                    float* dg1, float* dbe1, float* dW1, float* db1, float* dU, float* dA6, unsigned* sync, int B, int NO,
+                    hipStream_t st);
+
 /* ---- attention core ------------------------------------------------------------------------------------ */
 
 /* ctx = dropout(softmax(Q K^T)) V per head (E=64, 4 heads, S <= 32), wavg = head-mean of the dropped

@@ -1063,8 +1063,8 @@ class TPStackFn(Function):
 # --------------------------------------------------------------------------------------------------
 # Query GRU recurrences as persistent launches (tatt_qgru_fwd_chain / tatt_qgru_bwd_chain) instead of one launch per time step.  Every spin in them is bounded
 # by the wall clock; qgru_chain_check() reads the error words of the most recent launches (synchronises: call it outside a capture).
-QGRU_CHAIN_FWD = True
-QGRU_CHAIN_BWD = True
+QGRU_CHAIN_FWD = False
+QGRU_CHAIN_BWD = False
 QGRU_CHAIN_SYNC = []
 
 
@@ -1212,6 +1212,130 @@ def query_embedding(emb, gru, B, H, W):
     return QueryGruFn.apply(emb, gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0,
                             gru.weight_ih_l0_reverse, gru.weight_hh_l0_reverse, gru.bias_ih_l0_reverse,
                             gru.bias_hh_l0_reverse, B, H, W)
+
+
+# --------------------------------------------------------------------------------------------------
+# STN head as a few launches (csrc/stnhead.hip): one Function for the whole head.  Convolutions (forward, data and weight gradients) go
+# through the ordinary entry points; everything between them is one launch per layer and direction, and the fully connected end is one
+# launch each way.  53 -> 19 launches forward, 62 -> about 30 backward, at both exposed ends of the training step.
+# --------------------------------------------------------------------------------------------------
+STN_SYNC = []            # every sync buffer handed to those launches (sync_check reads their error words)
+
+
+def _stn_sync(holder, site, ref):
+    """the 256-word sync buffer of one call site: zeroed once, reused by every later launch of that site"""
+    table = holder.__dict__.setdefault("_tatt_sync", {})
+    key = (site, ref.device)
+    if key not in table:
+        table[key] = torch.zeros(256, device=ref.device, dtype=torch.int32)
+        STN_SYNC.append(table[key])
+    return table[key]
+
+
+def sync_check():
+    """Raise if a launch that synchronises its work-groups in flight gave up waiting (every such spin is bounded by the wall clock).
+    Synchronises the device: call it outside a capture."""
+    qgru_chain_check()
+    for s in STN_SYNC:
+        if int(s[255].item()) != 0:
+            raise RuntimeError("tatt_amd: an STN-head launch gave up waiting for its neighbours (work-groups not co-resident?)")
+
+
+def stn_head_fusable(x, stn, B):
+    bns = [stn.stn_convnet[i][1] for i in (0, 2, 4, 6, 8, 10)] + [stn.stn_fc1[1]]
+    if not all(bn.training and bn.momentum is not None and bn.affine and bn.track_running_stats for bn in bns):
+        return False
+    H, W = x.shape[1], x.shape[2]
+    return B <= 64 and H == 16 and W % 32 == 0 and (W // 32) * 256 == stn.stn_fc1[0].in_features == 512 \
+        and stn.stn_fc2.out_features % 4 == 0 and stn.stn_fc2.out_features <= 64
+
+
+class StnHeadFn(Function):
+    """STNHead.forward in training mode (model/stn_head.py:92-106) on the NHWC-indexed view x (B,H,W,Cin): control points (B, NO).
+    args: x, then (conv.weight, conv.bias, bn.weight, bn.bias) x 6, fc1.weight, fc1.bias, bn1.weight, bn1.bias, fc2.weight,
+    fc2.bias, then the STNHead module (running statistics, sync buffers)."""
+    POOLS = ((2, 2), (2, 2), (2, 2), (2, 2), (1, 2), (1, 1))
+
+    @staticmethod
+    def forward(ctx, x, *args):
+        stn = args[-1]
+        pr = args[:-1]
+        B = x.shape[0]
+        saved, geoms = [], []
+        a = x
+        for L in range(6):
+            w, b, ga, be = pr[4 * L:4 * L + 4]
+            bn = stn.stn_convnet[2 * L][1]
+            xc = ops.conv2d_forward(a, w, b, ACT_NONE)
+            _, H, W, C = xc.shape
+            ph, pw = StnHeadFn.POOLS[L]
+            A = ops.new(xc, B, H // ph, W // pw, C)
+            mean, rstd = ops.new(xc, C), ops.new(xc, C)
+            part = ops.new(xc, 128 * 3 * C, dtype=torch.float64)
+            ops.call("tatt_stn_bn_pool_fwd", ops.P(xc), ops.P(A), ops.P(ga), ops.P(be), ops.P(mean), ops.P(rstd),
+                     ops.P(bn.running_mean), ops.P(bn.running_var), ops.P(part), ops.P(_stn_sync(stn, "f%d" % L, xc)), B, H, W, C,
+                     ph, pw, float(bn.eps), float(bn.momentum), ops.stream())
+            saved += [a, xc, mean, rstd]
+            geoms.append((H, W, C, ph, pw))
+            a = A
+        w1, b1, g1, be1, w2, b2 = pr[24:30]
+        bn1 = stn.stn_fc1[1]
+        NO = w2.shape[0]
+        U, S = ops.new(a, B, 512), ops.new(a, B, 512)
+        mean1, rstd1 = ops.new(a, 512), ops.new(a, 512)
+        ctrl = ops.new(a, B, NO)
+        part = ops.new(a, 32 * B * NO)
+        ops.call("tatt_stn_fc_fwd", ops.P(a), ops.P(w1), ops.P(b1), ops.P(g1), ops.P(be1), ops.P(bn1.running_mean),
+                 ops.P(bn1.running_var), ops.P(w2), ops.P(b2), ops.P(U), ops.P(mean1), ops.P(rstd1), ops.P(S), ops.P(ctrl), ops.P(part),
+                 ops.P(_stn_sync(stn, "ffc", a)), B, NO, float(bn1.eps), float(bn1.momentum), ops.stream())
+        ctx.save_for_backward(*saved, a, U, S, mean1, rstd1, *pr)
+        ctx.geoms, ctx.stn, ctx.NO = geoms, stn, NO
+        return ctrl
+
+    @staticmethod
+    def backward(ctx, dctrl):
+        t = ctx.saved_tensors
+        saved, (a6, U, S, mean1, rstd1), pr = t[:24], t[24:29], t[29:]
+        stn, NO = ctx.stn, ctx.NO
+        B = a6.shape[0]
+        dctrl = _c(dctrl)
+        w1, b1, g1, be1, w2, b2 = pr[24:30]
+        dW2, db2 = torch.empty_like(w2), torch.empty_like(b2)
+        dg1, dbe1, db1, dW1 = torch.empty_like(g1), torch.empty_like(be1), torch.empty_like(b1), torch.empty_like(w1)
+        dU, dA = ops.new(a6, B, 512), torch.empty_like(a6)
+        ops.call("tatt_stn_fc_bwd", ops.P(dctrl), ops.P(w2), ops.P(S), ops.P(U), ops.P(mean1), ops.P(rstd1), ops.P(g1), ops.P(w1),
+                 ops.P(a6), ops.P(dW2), ops.P(db2), ops.P(dg1), ops.P(dbe1), ops.P(dW1), ops.P(db1), ops.P(dU), ops.P(dA),
+                 ops.P(_stn_sync(stn, "bfc", a6)), B, NO, ops.stream())
+        grads = [None] * 24
+        for L in range(5, -1, -1):
+            a_in, xc, mean, rstd = saved[4 * L:4 * L + 4]
+            w, b, ga, be = pr[4 * L:4 * L + 4]
+            H, W, C, ph, pw = ctx.geoms[L]
+            dX = torch.empty_like(xc)
+            dga, dbe, dbias = torch.empty_like(ga), torch.empty_like(be), torch.empty_like(b)
+            part = ops.new(xc, 128 * 3 * C, dtype=torch.float64)
+            ops.call("tatt_stn_bn_pool_bwd", ops.P(xc), ops.P(dA), ops.P(ga), ops.P(be), ops.P(mean), ops.P(rstd), ops.P(dX),
+                     ops.P(dga), ops.P(dbe), ops.P(dbias), ops.P(part), ops.P(_stn_sync(stn, "b%d" % L, xc)), B, H, W, C, ph, pw,
+                     ops.stream())
+            if L > 0:
+                dA = ops.conv2d_dgrad(dX, w)
+            Cout = w.shape[0]
+            (dw,) = SIDE.submit((w,), (lambda a_in=a_in, dX=dX, Cout=Cout: (ops.conv_wgrad(a_in, dX, Cout, 3, 3),)), a_in, dX)
+            grads[4 * L:4 * L + 4] = [dw, dbias, dga, dbe]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv2d_dgrad(dX, pr[0])
+        return (dx,) + tuple(grads) + (dW1, db1, dg1, dbe1, dW2, db2, None)
+
+
+def stn_head(x, stn):
+    ps = []
+    for L in range(6):
+        conv, bn = stn.stn_convnet[2 * L][0], stn.stn_convnet[2 * L][1]
+        ps += [conv.weight, conv.bias, bn.weight, bn.bias]
+    fc1, bn1 = stn.stn_fc1[0], stn.stn_fc1[1]
+    ps += [fc1.weight, fc1.bias, bn1.weight, bn1.bias, stn.stn_fc2.weight, stn.stn_fc2.bias]
+    return StnHeadFn.apply(x, *ps, stn)
 
 
 # --------------------------------------------------------------------------------------------------

@@ -243,9 +243,19 @@ def _require_gpu(x):
                            "fallback (the CPU restatement lives in oracle/ and is test infrastructure)." % x.device)
 
 
+# the STN head as one launch per layer and direction + one per direction for its fully connected end (csrc/stnhead.hip); False: operator
+# by operator (test hook; also taken for geometries the fused launches do not cover)
+STN_FUSED = True
+
+
 def _stn_forward(x_nchw, stn: STNHead, count=True):
     """STNHead.forward (model/stn_head.py:92-106): control points (B, N, 2)."""
     h = x_nchw.permute(0, 2, 3, 1)                    # NHWC-indexed view of the NCHW image
+    if STN_FUSED and Fh.stn_head_fusable(h, stn, h.shape[0]):
+        if count:
+            for bn in [stn.stn_convnet[i][1] for i in (0, 2, 4, 6, 8, 10)] + [stn.stn_fc1[1]]:
+                bn.num_batches_tracked += 1
+        return Fh.stn_head(h, stn).reshape(h.shape[0], stn.num_ctrlpoints, 2)
     pools = {0: (2, 2), 2: (2, 2), 4: (2, 2), 6: (2, 2), 8: (1, 2)}
     for i in (0, 2, 4, 6, 8, 10):
         conv, bn = stn.stn_convnet[i][0], stn.stn_convnet[i][1]

@@ -13,7 +13,9 @@ dev = torch.device("cuda:0")
 x, tp, hr = bench.make_batch(48, 0, dev)
 
 
-def run(stn, fwd, bwd, steps=30):
+def run(stn, fwd, bwd, fused=True, steps=30):
+    import tatt_amd.tsrn as T
+    T.STN_FUSED = fused
     Fh.QGRU_CHAIN_FWD, Fh.QGRU_CHAIN_BWD = fwd, bwd
     torch.manual_seed(0)
     m = tatt_amd.TSRN_TL_TRANS(scale_factor=2, width=128, height=32, STN=stn, mask=True, srb_nums=5, hidden_units=32).to(dev).train()
@@ -25,11 +27,12 @@ def run(stn, fwd, bwd, steps=30):
     for _ in range(steps):
         tr.step(x, tp, hr)
     torch.cuda.synchronize()
-    Fh.qgru_chain_check()
+    Fh.sync_check()
     return (time.perf_counter() - t0) / steps * 1e3
 
 
 for rep in range(2):
-    for stn in (True, False):
-        for fwd, bwd in ((False, False), (False, True), (True, True)):
-            print("STN %-5s chain fwd %-5s bwd %-5s  %.3f ms/step" % (stn, fwd, bwd, run(stn, fwd, bwd)), flush=True)
+    for stn, fused in ((True, False), (True, True), (False, True)):
+        for fwd, bwd in ((False, False), (False, True), (True, False), (True, True)):
+            print("STN %-5s fused head %-5s chain fwd %-5s bwd %-5s  %.3f ms/step" % (stn, fused, fwd, bwd, run(stn, fwd, bwd, fused)),
+                  flush=True)
