@@ -257,6 +257,8 @@ int tatt_dropout(const float* x, float* y, long n, float p, const unsigned long 
 /* advance the device-resident seed word and (snap != NULL) copy the new value to `snap`: one call per TRAINING FORWARD; every
    dropout site of that forward and of its backward reads the snapshot (graph-replay safe; several forwards may be in flight) */
 int tatt_bump_seed(unsigned long long* seed, unsigned long long* snap, hipStream_t st);
+/* out[0] = 100 MHz wall clock at this point of the stream (a one-thread launch): timelines inside a replayed hipGraph (tooling) */
+int tatt_stamp(unsigned long long* out, hipStream_t st);
 /* dst[i0*d0+i1*d1+i2*d2+i3*d3] = src[i0*s0+...] + beta*dst  (layout changes, parameter gathers) */
 int tatt_copy4d(const float* src, float* dst, int n0, int n1, int n2, int n3, long s0, long s1, long s2,
                 long s3, long d0, long d1, long d2, long d3, float beta, hipStream_t st);
@@ -357,19 +359,27 @@ int tatt_qgru_bwd_mm(const float* dgh0, const float* dgh1, const float* whhT0, c
  * by tatt_qgru_bwd_gates(first = 1), which also initialises dhcarry* and dgi_acc*; hbuf0 + t*Wb*HID = h_prev of time t (dir 0),
  * hbuf1 + (t+1)*Wb*HID = h_prev of time t (dir 1); gsave* (T, 4, Wb, HID); dhseq* (T, Wb, HID).  sync: 1024 words (zeroed here when
  * s0 == 0); sync[1023] != 0 afterwards: a wall-clock-bounded spin expired (results invalid).  Returns 1 for geometries it does not
- * take (HID != 512, Wb % 16 != 0, more than 256 work-groups): use the per-step entry points then. */
+ * take (HID != 512, Wb % 16 != 0, more than 256 work-groups): use the per-step entry points then.  whhT*: W_hh^T (HID, 3*HID) with
+ * transposed != 0, W_hh itself (3*HID, HID) with 0 (no transposition launch needed: the slices are read once per launch).
+ * xch* non-NULL (workspace of T*Wb*3*HID floats per direction): the recurrent product runs on the bf16 matrix cores with split operands
+ * (hi hi + hi lo + lo hi, fp32 accumulation) and the exchanged tensor travels in operand form; NULL: exact fp32 products. */
 int tatt_qgru_bwd_chain(float* dgh0, float* dgh1, const float* whhT0, const float* whhT1, const float* dhseq0,
                         const float* dhseq1, const float* gsave0, const float* gsave1, const float* hbuf0,
                         const float* hbuf1, float* dhcarry0, float* dhcarry1, float* dgi_acc0, float* dgi_acc1,
-                        unsigned* sync, int T, int Wb, int HID, int s0, int s1, hipStream_t st);
+                        unsigned* sync, int T, int Wb, int HID, int s0, int s1, int transposed, float* xch0, float* xch1,
+                        hipStream_t st);
 
 /* The forward recurrence (T calls of tatt_qgru_fwd_step) as one persistent launch, time steps s0 .. s1-1 (direction 0 at time s,
  * direction 1 at time T-1-s), same hand-off as tatt_qgru_bwd_chain with h as the exchanged tensor.  hbuf* (T+1, Wb, HID): h of time t
  * at slot t+1 (direction 0; slot 0 zero) / slot t (direction 1; slot T zero), zero slots filled by the caller; gsave* (T, 4, Wb, HID)
- * or NULL; gi* (Wb, 3*HID) incl. b_ih.  model/transformer_v2.py:201-221. */
+ * or NULL; gi* (Wb, 3*HID) incl. b_ih, or NULL: the launch computes the projection itself from x (Wb, IN), wih* (3*HID, IN), bih*
+ * (IN % 1024 == 0); q (T, 2*HID/C, Wb, C) or NULL: h also in the (sample, H, W, C) layout of the query embedding.
+ * xch* non-NULL (workspace of (T+1)*Wb*HID floats per direction, s0 == 0): split-bf16 form as for tatt_qgru_bwd_chain.
+ * model/transformer_v2.py:201-221. */
 int tatt_qgru_fwd_chain(const float* gi0, const float* gi1, const float* whh0, const float* whh1, const float* bhh0,
                         const float* bhh1, float* hbuf0, float* hbuf1, float* gsave0, float* gsave1, unsigned* sync,
-                        int T, int Wb, int HID, int s0, int s1, hipStream_t st);
+                        int T, int Wb, int HID, int s0, int s1, const float* x, const float* wih0, const float* wih1,
+                        const float* bih0, const float* bih1, int IN, float* q, int C, float* xch0, float* xch1, hipStream_t st);
 
 /* ---- STN head glue (model/stn_head.py:25-106): everything between two of its convolutions as ONE launch ------------------------
  * The launches below synchronise their (<= 128) work-groups INSIDE the launch: partial sums leave through write-through stores, each

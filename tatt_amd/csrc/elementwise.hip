@@ -263,6 +263,14 @@ TATT_API int tatt_bump_seed(unsigned long long* seed, unsigned long long* snap, 
     return LAUNCH_CHECK();
 }
 
+// out[0] = the 100 MHz wall clock when this point of the stream is reached: a timeline that is valid INSIDE a replayed hipGraph
+// (rocprofv3 serialises graph nodes; this does not).  Measurement tooling only (tatt_amd.functional.stamp).
+__global__ void stamp_kernel(unsigned long long* out) { out[0] = wall_clock64(); }
+TATT_API int tatt_stamp(unsigned long long* out, hipStream_t st) {
+    hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, st, out);
+    return LAUNCH_CHECK();
+}
+
 // ---- generic 4-D strided copy (layout changes: NCHW<->NHWC, parameter gathers) ------------------------
 __global__ void copy4d_kernel(const float* __restrict__ src, float* __restrict__ dst, int n0, int n1, int n2, int n3,
                               long s0, long s1, long s2, long s3, long d0, long d1, long d2, long d3, float beta) {

@@ -855,13 +855,36 @@ struct QChainP {
     float* dgh[2]; const float* whhT[2]; const float* dhseq[2]; const float* gsave[2]; const float* hbuf[2];
     float* dhcarry[2]; float* dgi_acc[2];
     unsigned* flags;
-    int T, Wb, s0, s1;
+    int T, Wb, s0, s1, transposed;
+    float* xch[2];      // SB: the exchanged tensor in matrix-core operand form, (T, Wb, 3*HID / 8) x {8 bf16 hi, 8 bf16 lo}
 };
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 qc_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void qc_split8(const float* v, qc_bf16x8& hi, qc_bf16x8& lo) {
+    hi = __builtin_bit_cast(qc_bf16x8, gr_split8(v, false));
+    lo = __builtin_bit_cast(qc_bf16x8, gr_split8(v, true));
+}
+__device__ __forceinline__ f32x4 qc_mma3(const qc_bf16x8& ah, const qc_bf16x8& al, const qc_bf16x8& bh, const qc_bf16x8& bl, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
+}
+__device__ __forceinline__ void qc_split1(float x, unsigned short& hi, unsigned short& lo) {
+    const __bf16 h = (__bf16)x;
+    hi = __builtin_bit_cast(unsigned short, h);
+    lo = __builtin_bit_cast(unsigned short, (__bf16)(x - (float)h));
+}
+// SB = true: the recurrent product on the bf16 matrix cores with split operands (a = hi + lo, a b ~ hi hi + hi lo + lo hi, fp32
+// accumulation: 2^-16 relative per product).  The fp32 MFMA form of this product costs a third of the CHIP's fp32 matrix throughput
+// for the duration of the chain (0.2 GFLOP per step on 256 CUs) and slows whatever runs beside it; the split form needs a fifth of
+// the matrix-core time.  What the work-groups exchange is then already in operand form: the producer of an element splits it ONCE and
+// publishes 8-element groups as {8 bf16 hi, 8 bf16 lo} (the same 4 bytes per element), consumers load fragments with no conversion.
+template <bool SB>
 __global__ __launch_bounds__(512) void qgru_bwd_chain_kernel(QChainP p) {
     constexpr int HID = 512, K = 3 * HID, NM = HID / 16, KS = K / 8 / 16;      // KS = 12 sixteen-byte fragments per lane
     __shared__ float red[8][16][17];
     __shared__ __attribute__((aligned(16))) float stage[16][3][16];
+    __shared__ __attribute__((aligned(16))) unsigned short stage_h[SB ? 16 : 1][3][16], stage_l[SB ? 16 : 1][3][16];
     __shared__ int s_dead;
     const int NG = (p.Wb / 16) * 2;
     const int grp = blockIdx.x % NG, mem = blockIdx.x / NG;
@@ -870,11 +893,35 @@ __global__ __launch_bounds__(512) void qgru_bwd_chain_kernel(QChainP p) {
     const int i = lane & 15, q = lane >> 4;
     const long plane = (long)p.Wb * HID;
     // W_hh^T rows j0 .. j0+15, this wave's eighth of the contraction: resident for the whole chain
-    f32x4 b[KS];
-    {
+    f32x4 b[SB ? 1 : KS];
+    qc_bf16x8 bh[SB ? 6 : 1], bl[SB ? 6 : 1];
+    if constexpr (SB) {
+        // operand blocks of 32 k: lane (i, q) holds k = wave * 192 + 32 t + 8 q .. + 7 of column j0 + i
+#pragma unroll
+        for (int tt = 0; tt < 6; ++tt) {
+            float v[8];
+            const int k0 = wave * (K / 8) + 32 * tt + 8 * q;
+            if (p.transposed) {
+                const f32x4 lo4 = *reinterpret_cast<const f32x4*>(p.whhT[d] + (long)(j0 + i) * K + k0);
+                const f32x4 hi4 = *reinterpret_cast<const f32x4*>(p.whhT[d] + (long)(j0 + i) * K + k0 + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = lo4[e]; v[4 + e] = hi4[e]; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = p.whhT[d][(long)(k0 + e) * HID + j0 + i];
+            }
+            qc_split8(v, bh[tt], bl[tt]);
+        }
+    } else if (p.transposed) {
         const float* bp = p.whhT[d] + (long)(j0 + i) * K + wave * (K / 8) + 4 * q;
 #pragma unroll
         for (int u = 0; u < KS; ++u) b[u] = *reinterpret_cast<const f32x4*>(bp + 16 * u);
+    } else {                                                        // W_hh as the parameter stores it (3*HID, HID): column j0 + i
+        const float* bp = p.whhT[d] + (long)(wave * (K / 8) + 4 * q) * HID + j0 + i;
+#pragma unroll
+        for (int u = 0; u < KS; ++u)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) b[u][v] = bp[(long)(16 * u + v) * HID];
     }
     // epilogue ownership (threads 0..255): element (m0 + m, j0 + j)
     const int m = (t >> 4) & 15, j = t & 15;
@@ -910,22 +957,57 @@ __global__ __launch_bounds__(512) void qgru_bwd_chain_kernel(QChainP p) {
             }
             __syncthreads();
         }
-        f32x4 a[KS];
-        {
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.dgh[d] + (long)cur * p.Wb * K, 0, p.Wb * K * 4, 0x00020000);
+        f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+        if constexpr (SB) {
+            qc_bf16x8 ah[6], al[6];
+            if (s == 0) {
+                // the first step's dgh comes from tatt_qgru_bwd_gates in fp32 only: split here, once
+                const float* src = p.dgh[d] + (long)cur * p.Wb * K + (long)(m0 + i) * K + wave * (K / 8) + 8 * q;
+                f32x4 raw[12];
+#pragma unroll
+                for (int tt = 0; tt < 6; ++tt) {
+                    raw[2 * tt] = *reinterpret_cast<const f32x4*>(src + 32 * tt);
+                    raw[2 * tt + 1] = *reinterpret_cast<const f32x4*>(src + 32 * tt + 4);
+                }
+#pragma unroll
+                for (int tt = 0; tt < 6; ++tt) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] = raw[2 * tt][e]; v[4 + e] = raw[2 * tt + 1][e]; }
+                    qc_split8(v, ah[tt], al[tt]);
+                }
+            } else {
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.xch[d] + (long)cur * p.Wb * K, 0, p.Wb * K * 4, 0x00020000);
+                const int off = (m0 + i) * K * 4 + (wave * 24 + q) * 32;
+#pragma unroll
+                for (int tt = 0; tt < 6; ++tt) {
+                    ah[tt] = __builtin_bit_cast(qc_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, off + 128 * tt, 0, 16 /* sc1 */));
+                    al[tt] = __builtin_bit_cast(qc_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, off + 128 * tt + 16, 0, 16 /* sc1 */));
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tt = 0; tt < 6; ++tt) {
+                if (tt & 1) acc1 = qc_mma3(ah[tt], al[tt], bh[tt], bl[tt], acc1);
+                else acc0 = qc_mma3(ah[tt], al[tt], bh[tt], bl[tt], acc0);
+            }
+        } else {
+            f32x4 a[KS];
+            {
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.dgh[d] + (long)cur * p.Wb * K, 0, p.Wb * K * 4, 0x00020000);
+#pragma unroll
+                for (int u = 0; u < KS; ++u)
+                    a[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, a_off + 64 * u, 0, 16 /* sc1 */));
+            }
+            __builtin_amdgcn_sched_barrier(0);                                  // all twelve loads in flight before the first MFMA
 #pragma unroll
             for (int u = 0; u < KS; ++u)
-                a[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, a_off + 64 * u, 0, 16 /* sc1 */));
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    if (v & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][v], b[u][v], acc1, 0, 0, 0);
+                    else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][v], b[u][v], acc0, 0, 0, 0);
+                }
         }
-        __builtin_amdgcn_sched_barrier(0);                                      // all twelve loads in flight before the first MFMA
-        f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-#pragma unroll
-        for (int u = 0; u < KS; ++u)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                if (v & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][v], b[u][v], acc1, 0, 0, 0);
-                else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][v], b[u][v], acc0, 0, 0, 0);
-            }
         {
             const int col = lane & 15, rb = (lane >> 4) * 4;
 #pragma unroll
@@ -942,15 +1024,31 @@ __global__ __launch_bounds__(512) void qgru_bwd_chain_kernel(QChainP p) {
             const float drp = dnp * hn * r * (1.f - r);
             const float dzp = dz * z * (1.f - z);
             ga0 += drp; ga1 += dzp; ga2 += dnp;
-            stage[m][0][j] = drp; stage[m][1][j] = dzp; stage[m][2][j] = dnp * r;
+            const float g0 = drp, g1 = dzp, g2 = dnp * r;
+            if constexpr (SB) {
+                qc_split1(g0, stage_h[m][0][j], stage_l[m][0][j]);
+                qc_split1(g1, stage_h[m][1][j], stage_l[m][1][j]);
+                qc_split1(g2, stage_h[m][2][j], stage_l[m][2][j]);
+                float* dg = p.dgh[d] + (long)nxt * p.Wb * K + g3;              // fp32 copy: the W_hh gradient GEMM reads it later
+                dg[0] = g0; dg[HID] = g1; dg[2 * HID] = g2;
+            } else {
+                stage[m][0][j] = g0; stage[m][1][j] = g1; stage[m][2][j] = g2;
+            }
             dhc = dh * z;
         }
         __syncthreads();
         if (t < 192) {                                                          // 16 rows x 3 gates x 4 sixteen-byte pieces
-            const int row = t / 12, gate = (t % 12) >> 2, j4 = (t & 3) * 4;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(&stage[row][gate][j4]);
-            const __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc(p.dgh[d] + (long)nxt * p.Wb * K, 0, p.Wb * K * 4, 0x00020000);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), ws, ((m0 + row) * K + gate * HID + j0 + j4) * 4, 0, 16 /* sc1 */);
+            if constexpr (SB) {
+                const int row = t / 12, gate = (t % 12) >> 2, grp8 = (t >> 1) & 1, hl = t & 1;
+                const u32x4_t v = *reinterpret_cast<const u32x4_t*>(hl ? &stage_l[row][gate][grp8 * 8] : &stage_h[row][gate][grp8 * 8]);
+                const __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc(p.xch[d] + (long)nxt * p.Wb * K, 0, p.Wb * K * 4, 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b128(v, ws, (m0 + row) * K * 4 + ((gate * HID + j0) / 8 + grp8) * 32 + hl * 16, 0, 16 /* sc1 */);
+            } else {
+                const int row = t / 12, gate = (t % 12) >> 2, j4 = (t & 3) * 4;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(&stage[row][gate][j4]);
+                const __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc(p.dgh[d] + (long)nxt * p.Wb * K, 0, p.Wb * K * 4, 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), ws, ((m0 + row) * K + gate * HID + j0 + j4) * 4, 0, 16 /* sc1 */);
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
@@ -961,17 +1059,22 @@ __global__ __launch_bounds__(512) void qgru_bwd_chain_kernel(QChainP p) {
 // dgh (2 pointers: (T, Wb, 3*HID) per direction, the first step's slot filled by tatt_qgru_bwd_gates), hbuf* = h_prev of time t for
 // direction 0 at hbuf0 + t*Wb*HID and of time t for direction 1 at hbuf1 + (t+1)*Wb*HID (the zero-slot layout of the forward);
 // sync: 1024 words, zeroed here when s0 == 0; sync[1023] != 0 afterwards = a bounded spin expired (results invalid).
+// whhT*: transposed != 0: W_hh^T (HID, 3*HID); 0: W_hh itself (3*HID, HID) -- the slices are read once per launch either way.
+// xch* non-NULL ((T, Wb, 3*HID) floats of workspace per direction): the split-bf16 form (see the kernel); NULL: exact fp32 products.
 // Returns 1 for geometries it does not take (HID != 512, Wb % 16, more than 256 work-groups): use the per-step entry points.
 TATT_API int tatt_qgru_bwd_chain(float* dgh0, float* dgh1, const float* whhT0, const float* whhT1, const float* dhseq0,
                                  const float* dhseq1, const float* gsave0, const float* gsave1, const float* hbuf0,
                                  const float* hbuf1, float* dhcarry0, float* dhcarry1, float* dgi_acc0, float* dgi_acc1,
-                                 unsigned* sync, int T, int Wb, int HID, int s0, int s1, hipStream_t st) {
+                                 unsigned* sync, int T, int Wb, int HID, int s0, int s1, int transposed, float* xch0, float* xch1,
+                                 hipStream_t st) {
     if (HID != 512 || Wb % 16 || Wb <= 0 || (Wb / 16) * 2 * (HID / 16) > 256 || (Wb / 16) * 2 > 15) return 1;
     if (s0 < 0 || s1 > T - 1 || s0 >= s1) return s0 == s1 ? 0 : 2;
+    if ((xch0 == nullptr) != (xch1 == nullptr)) return 1;
     if (s0 == 0 && hipMemsetAsync(sync, 0, 1024 * sizeof(unsigned), st) != hipSuccess) return 3;
     QChainP p = {{dgh0, dgh1}, {whhT0, whhT1}, {dhseq0, dhseq1}, {gsave0, gsave1}, {hbuf0, hbuf1}, {dhcarry0, dhcarry1},
-                 {dgi_acc0, dgi_acc1}, sync, T, Wb, s0, s1};
-    hipLaunchKernelGGL(qgru_bwd_chain_kernel, dim3((Wb / 16) * 2 * (HID / 16)), dim3(512), 0, st, p);
+                 {dgi_acc0, dgi_acc1}, sync, T, Wb, s0, s1, transposed, {xch0, xch1}};
+    if (xch0) hipLaunchKernelGGL(qgru_bwd_chain_kernel<true>, dim3((Wb / 16) * 2 * (HID / 16)), dim3(512), 0, st, p);
+    else hipLaunchKernelGGL(qgru_bwd_chain_kernel<false>, dim3((Wb / 16) * 2 * (HID / 16)), dim3(512), 0, st, p);
     return LAUNCH_CHECK();
 }
 
@@ -984,11 +1087,18 @@ struct QFChainP {
     const float* gi[2]; const float* whh[2]; const float* bhh[2]; float* hbuf[2]; float* gsave[2];
     unsigned* flags;
     int T, Wb, s0, s1;
+    // gi == NULL: the input projection is computed here, once per launch: gi = x W_ih^T + b_ih for the tile (x (Wb, IN), wih (3*HID, IN))
+    const float* x; const float* wih[2]; const float* bih[2]; int IN;
+    // q != NULL: h also leaves in the layout the TP interpreter reads, q[n][d*Hh + j / C][w][j % C] (n = time, w = row, j = unit)
+    float* q; int C;
+    float* xch[2];      // SB: h in matrix-core operand form, (T+1 slots as hbuf, Wb, HID / 8) x {8 bf16 hi, 8 bf16 lo}
 };
+template <bool SB>
 __global__ __launch_bounds__(512) void qgru_fwd_chain_kernel(QFChainP p) {
     constexpr int HID = 512, NM = HID / 16;
     __shared__ float red[8][3][16][17];
     __shared__ __attribute__((aligned(16))) float stage[16][16];
+    __shared__ __attribute__((aligned(16))) unsigned short stage_h[SB ? 16 : 1][16], stage_l[SB ? 16 : 1][16];
     __shared__ int s_dead;
     const int NG = (p.Wb / 16) * 2;
     const int grp = blockIdx.x % NG, mem = blockIdx.x / NG;
@@ -996,18 +1106,71 @@ __global__ __launch_bounds__(512) void qgru_fwd_chain_kernel(QFChainP p) {
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int i = lane & 15, q = lane >> 4;
     const long plane = (long)p.Wb * HID;
-    f32x4 b[3][4];
-#pragma unroll
-    for (int g = 0; g < 3; ++g)
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            b[g][u] = *reinterpret_cast<const f32x4*>(p.whh[d] + ((long)g * HID + j0 + i) * HID + wave * 64 + 16 * u + 4 * q);
     const int m = (t >> 4) & 15, j = t & 15;
     const long e = (long)(m0 + m) * HID + j0 + j;
     float gi0 = 0.f, gi1 = 0.f, gi2 = 0.f, bh0 = 0.f, bh1 = 0.f, bh2 = 0.f, hown = 0.f;
+    if (!p.gi[0]) {
+        // input projection of this tile: 16 rows x (3 gates x 16 units), contraction over IN split over the 8 waves in trips of 128
+        f32x4 acc[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int IN = p.IN, span = IN / 8;
+        for (int kb = wave * span; kb < (wave + 1) * span; kb += 128) {
+            f32x4 a[8], w[3][8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                a[u] = *reinterpret_cast<const f32x4*>(p.x + (long)(m0 + i) * IN + kb + 16 * u + 4 * q);
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+                    w[g][u] = *reinterpret_cast<const f32x4*>(p.wih[d] + ((long)g * HID + j0 + i) * IN + kb + 16 * u + 4 * q);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][v], w[g][u][v], acc[g], 0, 0, 0);
+        }
+        const int col = lane & 15, rb = (lane >> 4) * 4;
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) red[wave][g][rb + rr][col] = acc[g][rr];
+        __syncthreads();
+        if (t < 256) {
+            gi0 = p.bih[d][j0 + j]; gi1 = p.bih[d][HID + j0 + j]; gi2 = p.bih[d][2 * HID + j0 + j];
+#pragma unroll
+            for (int w = 0; w < 8; ++w) { gi0 += red[w][0][m][j]; gi1 += red[w][1][m][j]; gi2 += red[w][2][m][j]; }
+        }
+        __syncthreads();
+    }
+    f32x4 b[SB ? 1 : 3][4];
+    qc_bf16x8 bh[SB ? 3 : 1][2], bl[SB ? 3 : 1][2];
+    if constexpr (SB) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {                        // operand blocks of 32 k: lane (i, q) holds k = wave*64 + 32 tt + 8 q .. + 7
+                const float* src = p.whh[d] + ((long)g * HID + j0 + i) * HID + wave * 64 + 32 * tt + 8 * q;
+                const f32x4 lo4 = *reinterpret_cast<const f32x4*>(src), hi4 = *reinterpret_cast<const f32x4*>(src + 4);
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = lo4[e]; v[4 + e] = hi4[e]; }
+                qc_split8(v, bh[g][tt], bl[g][tt]);
+            }
+    } else {
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                b[g][u] = *reinterpret_cast<const f32x4*>(p.whh[d] + ((long)g * HID + j0 + i) * HID + wave * 64 + 16 * u + 4 * q);
+    }
     if (t < 256) {
-        const float* gi = p.gi[d] + (long)(m0 + m) * 3 * HID + j0 + j;
-        gi0 = gi[0]; gi1 = gi[HID]; gi2 = gi[2 * HID];
+        if (p.gi[0]) {
+            const float* gi = p.gi[d] + (long)(m0 + m) * 3 * HID + j0 + j;
+            gi0 = gi[0]; gi1 = gi[HID]; gi2 = gi[2 * HID];
+        }
         bh0 = p.bhh[d][j0 + j]; bh1 = p.bhh[d][HID + j0 + j]; bh2 = p.bhh[d][2 * HID + j0 + j];
         const int tp = d ? p.T - 1 - p.s0 + 1 : p.s0;                           // slot of h_prev of the first step of this launch
         hown = p.hbuf[d][(long)tp * plane + e];
@@ -1033,23 +1196,41 @@ __global__ __launch_bounds__(512) void qgru_fwd_chain_kernel(QFChainP p) {
             }
             __syncthreads();
         }
-        f32x4 a[4];
-        {
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.hbuf[d] + (long)slot_prev * plane, 0, p.Wb * HID * 4, 0x00020000);
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                a[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, a_off + 64 * u, 0, 16 /* sc1 */));
-        }
-        __builtin_amdgcn_sched_barrier(0);
         f32x4 acc[3];
 #pragma unroll
         for (int g = 0; g < 3; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if constexpr (SB) {
+            if (s > 0) {                                                        // (h_prev of the first time step is zero: nothing to add)
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.xch[d] + (long)slot_prev * plane, 0, p.Wb * HID * 4, 0x00020000);
+                const int off = (m0 + i) * HID * 4 + (wave * 8 + q) * 32;
+                qc_bf16x8 ah[2], al[2];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+                for (int tt = 0; tt < 2; ++tt) {
+                    ah[tt] = __builtin_bit_cast(qc_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, off + 128 * tt, 0, 16 /* sc1 */));
+                    al[tt] = __builtin_bit_cast(qc_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, off + 128 * tt + 16, 0, 16 /* sc1 */));
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int v = 0; v < 4; ++v)
+                for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-                for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][v], b[g][u][v], acc[g], 0, 0, 0);
+                    for (int g = 0; g < 3; ++g) acc[g] = qc_mma3(ah[tt], al[tt], bh[g][tt], bl[g][tt], acc[g]);
+            }
+        } else {
+            f32x4 a[4];
+            {
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.hbuf[d] + (long)slot_prev * plane, 0, p.Wb * HID * 4, 0x00020000);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    a[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, a_off + 64 * u, 0, 16 /* sc1 */));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][v], b[g][u][v], acc[g], 0, 0, 0);
+        }
         {
             const int col = lane & 15, rb = (lane >> 4) * 4;
 #pragma unroll
@@ -1067,7 +1248,16 @@ __global__ __launch_bounds__(512) void qgru_fwd_chain_kernel(QFChainP p) {
             const float n = tanh_fast(gi2 + r * gh2);
             const float h = (1.f - z) * n + z * hown;
             hown = h;
-            stage[m][j] = h;
+            if constexpr (SB) {
+                qc_split1(h, stage_h[m][j], stage_l[m][j]);
+                p.hbuf[d][(long)slot_new * plane + e] = h;                      // fp32 copy: the backward and the W_hh gradient read it
+            } else {
+                stage[m][j] = h;
+            }
+            if (p.q) {
+                const int Hh = HID / p.C, jj = j0 + j;
+                p.q[(((long)tcur * 2 * Hh + d * Hh + jj / p.C) * p.Wb + m0 + m) * p.C + jj % p.C] = h;
+            }
             float* gs = p.gsave[d];
             if (gs) {
                 gs += (long)tcur * 4 * plane;
@@ -1076,26 +1266,43 @@ __global__ __launch_bounds__(512) void qgru_fwd_chain_kernel(QFChainP p) {
         }
         __syncthreads();
         if (t < 64) {                                                           // 16 rows x 4 sixteen-byte pieces
-            const int row = t >> 2, j4 = (t & 3) * 4;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(&stage[row][j4]);
-            const __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc(p.hbuf[d] + (long)slot_new * plane, 0, p.Wb * HID * 4, 0x00020000);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), ws, ((m0 + row) * HID + j0 + j4) * 4, 0, 16 /* sc1 */);
+            if constexpr (SB) {
+                const int row = t >> 2, grp8 = (t >> 1) & 1, hl = t & 1;
+                const u32x4_t v = *reinterpret_cast<const u32x4_t*>(hl ? &stage_l[row][grp8 * 8] : &stage_h[row][grp8 * 8]);
+                const __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc(p.xch[d] + (long)slot_new * plane, 0, p.Wb * HID * 4, 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b128(v, ws, (m0 + row) * HID * 4 + (j0 / 8 + grp8) * 32 + hl * 16, 0, 16 /* sc1 */);
+            } else {
+                const int row = t >> 2, j4 = (t & 3) * 4;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(&stage[row][j4]);
+                const __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc(p.hbuf[d] + (long)slot_new * plane, 0, p.Wb * HID * 4, 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), ws, ((m0 + row) * HID + j0 + j4) * 4, 0, 16 /* sc1 */);
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
         if (t == 0) __hip_atomic_store(flags + mem, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
-// gi* (Wb, 3*HID) incl. b_ih; whh* (3*HID, HID); hbuf* (T+1, Wb, HID) with the zero slots already zeroed; gsave* (T, 4, Wb, HID) or
-// NULL; sync as for tatt_qgru_bwd_chain.  Returns 1 for geometries it does not take.
+// gi* (Wb, 3*HID) incl. b_ih -- or NULL with x (Wb, IN), wih* (3*HID, IN), bih*: the projection is then computed by the launch itself
+// (IN a multiple of 1024); whh* (3*HID, HID); hbuf* (T+1, Wb, HID) with the zero slots already zeroed; gsave* (T, 4, Wb, HID) or NULL;
+// q (T, 2*HID/C, Wb, C) or NULL: h in the (sample, H, W, C) layout of the TP interpreter's query embedding; sync as for
+// tatt_qgru_bwd_chain.  xch* non-NULL ((T+1, Wb, HID) floats of workspace per direction): the split-bf16 form (s0 must be 0).
+// Returns 1 for geometries it does not take.
 TATT_API int tatt_qgru_fwd_chain(const float* gi0, const float* gi1, const float* whh0, const float* whh1, const float* bhh0,
                                  const float* bhh1, float* hbuf0, float* hbuf1, float* gsave0, float* gsave1, unsigned* sync,
-                                 int T, int Wb, int HID, int s0, int s1, hipStream_t st) {
+                                 int T, int Wb, int HID, int s0, int s1, const float* x, const float* wih0, const float* wih1,
+                                 const float* bih0, const float* bih1, int IN, float* q, int C, float* xch0, float* xch1,
+                                 hipStream_t st) {
     if (HID != 512 || Wb % 16 || Wb <= 0 || (Wb / 16) * 2 * (HID / 16) > 256 || (Wb / 16) * 2 > 15) return 1;
     if (s0 < 0 || s1 > T || s0 >= s1) return s0 == s1 ? 0 : 2;
+    if (!gi0 && (!x || !wih0 || !wih1 || !bih0 || !bih1 || IN % 1024)) return 1;
+    if (q && (C <= 0 || HID % C)) return 1;
     if (s0 == 0 && hipMemsetAsync(sync, 0, 1024 * sizeof(unsigned), st) != hipSuccess) return 3;
-    QFChainP p = {{gi0, gi1}, {whh0, whh1}, {bhh0, bhh1}, {hbuf0, hbuf1}, {gsave0, gsave1}, sync, T, Wb, s0, s1};
-    hipLaunchKernelGGL(qgru_fwd_chain_kernel, dim3((Wb / 16) * 2 * (HID / 16)), dim3(512), 0, st, p);
+    if ((xch0 == nullptr) != (xch1 == nullptr) || (xch0 && s0 != 0)) return 1;      // (the split form runs the whole chain in one launch)
+    QFChainP p = {{gi0, gi1}, {whh0, whh1}, {bhh0, bhh1}, {hbuf0, hbuf1}, {gsave0, gsave1}, sync, T, Wb, s0, s1,
+                  x, {wih0, wih1}, {bih0, bih1}, IN, q, C, {xch0, xch1}};
+    if (xch0) hipLaunchKernelGGL(qgru_fwd_chain_kernel<true>, dim3((Wb / 16) * 2 * (HID / 16)), dim3(512), 0, st, p);
+    else hipLaunchKernelGGL(qgru_fwd_chain_kernel<false>, dim3((Wb / 16) * 2 * (HID / 16)), dim3(512), 0, st, p);
     return LAUNCH_CHECK();
 }
 

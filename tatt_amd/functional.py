@@ -1063,8 +1063,11 @@ class TPStackFn(Function):
 # --------------------------------------------------------------------------------------------------
 # Query GRU recurrences as persistent launches (tatt_qgru_fwd_chain / tatt_qgru_bwd_chain) instead of one launch per time step.  Every spin in them is bounded
 # by the wall clock; qgru_chain_check() reads the error words of the most recent launches (synchronises: call it outside a capture).
-QGRU_CHAIN_FWD = False
-QGRU_CHAIN_BWD = False
+QGRU_CHAIN_FWD = True
+QGRU_CHAIN_BWD = True
+# their recurrent products on the bf16 matrix cores with split operands (hi hi + hi lo + lo hi, fp32 accumulation) instead of fp32 MFMA:
+# the fp32 form takes a third of the chip's fp32 matrix throughput while the chain runs and slows the lane beside it
+QGRU_CHAIN_SB = True
 QGRU_CHAIN_SYNC = []
 
 
@@ -1103,9 +1106,9 @@ class QueryGruFn(Function):
         assert IN == H * C and 2 * HID == H * C
         dev = emb
         # x[w, h*C + c] = emb[h*W + w, c]
+        stamp("qgru fwd: branch start", emb)
         x = ops.new(dev, W, IN)
         ops.copy4d(emb, x, (1, W, H, C), (0, C, W * C, 1), (0, IN, C, 1))
-        gi = [ops.linear_fwd(x, wih0, bih0), ops.linear_fwd(x, wih1, bih1)]       # (W, 3*HID) each
         # h of both directions with ONE zero time slot: in front of the forward direction's sequence, behind the reverse one's -- so
         # that "h_prev of every step" is one contiguous (B*W, HID) matrix per direction (the W_hh gradient GEMM then covers all rows
         # and its row sums are the hidden-bias gradient: no separate column-sum pass)
@@ -1114,30 +1117,36 @@ class QueryGruFn(Function):
         hbuf[1, B].zero_()
         hseq = (hbuf[0, 1:], hbuf[1, :B])
         gsave = ops.new(dev, 2, B, 4, W, HID)
-        chain = QGRU_CHAIN_FWD and _qgru_chain_takes(W, HID)
-        if chain:
-            ops.call("tatt_qgru_fwd_chain", ops.P(gi[0]), ops.P(gi[1]), ops.P(whh0), ops.P(whh1), ops.P(bhh0), ops.P(bhh1),
-                     ops.P(hbuf[0]), ops.P(hbuf[1]), ops.P(gsave[0]), ops.P(gsave[1]), ops.P(_qgru_chain_sync(dev)), B, W, HID,
-                     0, B, ops.stream())
-        for s in range(0 if chain else B):
-            t0, t1 = s, B - 1 - s
-            hp0 = hseq[0][t0 - 1] if s > 0 else None
-            hp1 = hseq[1][t1 + 1] if s > 0 else None
-            ops.call("tatt_qgru_fwd_step", ops.P(gi[0]), ops.P(gi[1]), ops.P(whh0), ops.P(whh1), ops.P(bhh0),
-                     ops.P(bhh1), ops.P(hp0), ops.P(hp1), ops.P(hseq[0][t0]), ops.P(hseq[1][t1]),
-                     ops.P(gsave[0, t0]), ops.P(gsave[1, t1]), W, HID, ops.stream())
-        # q[n, h, w, c] = hseq[d][n][w][(h % (H/2))*C + c], d = h // (H/2)
         q = ops.new(dev, B, H, W, C)
         Hh = H // 2
-        for d in range(2):
-            ops.copy4d(hseq[d], q[:, d * Hh:], (B, W, Hh, C), (W * HID, HID, C, 1), (H * W * C, C, W * C, 1))
-        # W_hh^T of both directions for the backward recurrence (its B operand wants the 3*HID axis contiguous): parameters only, so
-        # the two transposes ride on this forked branch instead of opening the backward chain at the exposed end of the step
+        chain = QGRU_CHAIN_FWD and _qgru_chain_takes(W, HID) and IN % 1024 == 0
+        if chain:
+            # ONE persistent launch: the input projection of each tile, the B time steps of both directions, h written in both layouts
+            xch = ops.new(dev, 2, B + 1, W, HID) if QGRU_CHAIN_SB else None      # h in matrix-core operand form (split-bf16 recurrence)
+            ops.call("tatt_qgru_fwd_chain", None, None, ops.P(whh0), ops.P(whh1), ops.P(bhh0), ops.P(bhh1), ops.P(hbuf[0]),
+                     ops.P(hbuf[1]), ops.P(gsave[0]), ops.P(gsave[1]), ops.P(_qgru_chain_sync(dev)), B, W, HID, 0, B, ops.P(x),
+                     ops.P(wih0), ops.P(wih1), ops.P(bih0), ops.P(bih1), IN, ops.P(q), C,
+                     ops.P(xch[0]) if xch is not None else None, ops.P(xch[1]) if xch is not None else None, ops.stream())
+        else:
+            gi = [ops.linear_fwd(x, wih0, bih0), ops.linear_fwd(x, wih1, bih1)]       # (W, 3*HID) each
+            for s in range(B):
+                t0, t1 = s, B - 1 - s
+                hp0 = hseq[0][t0 - 1] if s > 0 else None
+                hp1 = hseq[1][t1 + 1] if s > 0 else None
+                ops.call("tatt_qgru_fwd_step", ops.P(gi[0]), ops.P(gi[1]), ops.P(whh0), ops.P(whh1), ops.P(bhh0),
+                         ops.P(bhh1), ops.P(hp0), ops.P(hp1), ops.P(hseq[0][t0]), ops.P(hseq[1][t1]),
+                         ops.P(gsave[0, t0]), ops.P(gsave[1, t1]), W, HID, ops.stream())
+            # q[n, h, w, c] = hseq[d][n][w][(h % (H/2))*C + c], d = h // (H/2)
+            for d in range(2):
+                ops.copy4d(hseq[d], q[:, d * Hh:], (B, W, Hh, C), (W * HID, HID, C, 1), (H * W * C, C, W * C, 1))
+        # W_hh^T of both directions for the per-step backward kernels (their B operand wants the 3*HID axis contiguous): parameters
+        # only, so the two transposes ride on this forked branch.  The persistent backward launch reads W_hh as it is stored.
         whhT = None
-        if any(ctx.needs_input_grad[:9]):
+        if any(ctx.needs_input_grad[:9]) and not (QGRU_CHAIN_BWD and _qgru_chain_takes(W, HID) and B > 1):
             whhT = ops.new(dev, 2, HID, 3 * HID)
             for d, whh in enumerate((whh0, whh1)):                 # (3*HID, HID) -> (HID, 3*HID)
                 ops.copy4d(whh, whhT[d], (1, 1, HID, 3 * HID), (0, 0, 1, HID), (0, 0, 3 * HID, 1))
+        stamp("qgru fwd: branch end", emb)
         ctx.save_for_backward(emb, x, wih0, whh0, wih1, whh1, hbuf, gsave, whhT)
         ctx.dims = (B, H, W, C, HID, IN)
         return q
@@ -1156,6 +1165,7 @@ class QueryGruFn(Function):
         hseq = (hbuf[0, 1:], hbuf[1, :B])
         dev = emb
         Hh = H // 2
+        stamp("qgru bwd: start", emb)
         dhseq = ops.new(dev, 2, B, W, HID)
         for d in range(2):
             ops.copy4d(dq[:, d * Hh:], dhseq[d], (B, W, Hh, C), (H * W * C, C, W * C, 1), (W * HID, HID, C, 1))
@@ -1172,13 +1182,18 @@ class QueryGruFn(Function):
         ops.call("tatt_qgru_bwd_gates", ops.P(dhseq[0, B - 1]), ops.P(dhseq[1, 0]), ops.P(gsave[0, B - 1]),
                  ops.P(gsave[1, 0]), ops.P(hp0), ops.P(hp1), ops.P(dhc[0]), ops.P(dhc[1]), ops.P(dgi_acc[0]),
                  ops.P(dgi_acc[1]), ops.P(dgh[0, B - 1]), ops.P(dgh[1, 0]), W, HID, 1, ops.stream())
-        chain = QGRU_CHAIN_BWD and _qgru_chain_takes(W, HID) and B > 1
+        chain = (QGRU_CHAIN_BWD or whhT is None) and _qgru_chain_takes(W, HID) and B > 1
+        if whhT is None and not chain and B > 1:
+            raise RuntimeError("tatt_amd: QGRU_CHAIN_BWD was switched off between a forward and its backward")
         if chain:
             # the remaining B-1 steps as ONE persistent launch (work-groups exchange dgh through write-through stores and flag words)
             sync = _qgru_chain_sync(dev)
-            ops.call("tatt_qgru_bwd_chain", ops.P(dgh[0]), ops.P(dgh[1]), ops.P(whhT[0]), ops.P(whhT[1]), ops.P(dhseq[0]),
+            wt = (whhT[0], whhT[1], 1) if whhT is not None else (whh0, whh1, 0)
+            xch = ops.new(dev, 2, B, W, 3 * HID) if QGRU_CHAIN_SB else None      # dgh in matrix-core operand form
+            ops.call("tatt_qgru_bwd_chain", ops.P(dgh[0]), ops.P(dgh[1]), ops.P(wt[0]), ops.P(wt[1]), ops.P(dhseq[0]),
                      ops.P(dhseq[1]), ops.P(gsave[0]), ops.P(gsave[1]), ops.P(hbuf[0]), ops.P(hbuf[1]), ops.P(dhc[0]),
-                     ops.P(dhc[1]), ops.P(dgi_acc[0]), ops.P(dgi_acc[1]), ops.P(sync), B, W, HID, 0, B - 1, ops.stream())
+                     ops.P(dhc[1]), ops.P(dgi_acc[0]), ops.P(dgi_acc[1]), ops.P(sync), B, W, HID, 0, B - 1, wt[2],
+                     ops.P(xch[0]) if xch is not None else None, ops.P(xch[1]) if xch is not None else None, ops.stream())
         for s in range(0 if chain else B - 1):
             c0, c1 = B - 1 - s, s                # current step's time indices
             n0, n1 = c0 - 1, c1 + 1              # next step's
@@ -1187,6 +1202,7 @@ class QueryGruFn(Function):
                      ops.P(dhseq[0, n0]), ops.P(dhseq[1, n1]), ops.P(gsave[0, n0]), ops.P(gsave[1, n1]), ops.P(hp0),
                      ops.P(hp1), ops.P(dhc[0]), ops.P(dhc[1]), ops.P(dgi_acc[0]), ops.P(dgi_acc[1]),
                      ops.P(dgh[0, n0]), ops.P(dgh[1, n1]), W, HID, ops.stream())
+        stamp("qgru bwd: recurrence done", emb)
         grads = []
         dx = ops.new(dev, W, IN)
         for d, (wih, whh) in enumerate(((wih0, whh0), (wih1, whh1))):
@@ -1204,6 +1220,7 @@ class QueryGruFn(Function):
         ops.reduce_flush()
         demb = torch.empty_like(emb)
         ops.copy4d(dx, demb, (1, W, H, C), (0, IN, C, 1), (0, C, W * C, 1))
+        stamp("qgru bwd: end", emb)
         (a0, b0, c0, d0), (a1, b1, c1, d1) = grads
         return demb, a0, b0, c0, d0, a1, b1, c1, d1
 
@@ -1212,6 +1229,23 @@ def query_embedding(emb, gru, B, H, W):
     return QueryGruFn.apply(emb, gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0,
                             gru.weight_ih_l0_reverse, gru.weight_hh_l0_reverse, gru.bias_ih_l0_reverse,
                             gru.bias_hh_l0_reverse, B, H, W)
+
+
+# --------------------------------------------------------------------------------------------------
+# Timeline inside a replayed hipGraph (tools/step_stamps.py): with STAMPS a list, stamp(name) launches a one-thread kernel that writes
+# the 100 MHz wall clock when the current stream reaches that point; the stamps are graph nodes like any other launch and are
+# re-written by every replay.  rocprofv3 serialises graph nodes; this shows the overlap as it happens.
+# --------------------------------------------------------------------------------------------------
+STAMPS = None
+
+
+def stamp(name, ref=None):
+    if STAMPS is None:
+        return
+    dev = ref.device if ref is not None else torch.device("cuda", torch.cuda.current_device())
+    t = torch.zeros(1, device=dev, dtype=torch.int64)
+    STAMPS.append((name, t))
+    ops.call("tatt_stamp", ops.P(t), ops.stream())
 
 
 # --------------------------------------------------------------------------------------------------
@@ -1299,6 +1333,7 @@ class StnHeadFn(Function):
         stn, NO = ctx.stn, ctx.NO
         B = a6.shape[0]
         dctrl = _c(dctrl)
+        stamp("stn bwd: start", dctrl)
         w1, b1, g1, be1, w2, b2 = pr[24:30]
         dW2, db2 = torch.empty_like(w2), torch.empty_like(b2)
         dg1, dbe1, db1, dW1 = torch.empty_like(g1), torch.empty_like(be1), torch.empty_like(b1), torch.empty_like(w1)
@@ -1325,6 +1360,7 @@ class StnHeadFn(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = ops.conv2d_dgrad(dX, pr[0])
+        stamp("stn bwd: activation chain done", dctrl)
         return (dx,) + tuple(grads) + (dW1, db1, dg1, dbe1, dW2, db2, None)
 
 

@@ -379,17 +379,22 @@ class Trainer:
         merge_last = self._merge_last
         if merge_last and k == nst:
             return
+        name = self.stages[k] if k < nst and isinstance(self.stages[k], str) else str(k)
+        Fh.stamp("pass %s: start" % name)
         if k >= 1:
             if self.two_lanes:
                 self.side.wait_stream(main)
                 with torch.cuda.stream(self.side):
                     self._side_lane(k - 1)
+                    Fh.stamp("pass %s: side lane done" % name)
             else:
                 self._side_lane(k - 1)
         if k < nst:
             self._main_lane(k, x, tp, hr)
+            Fh.stamp("pass %s: main lane done" % name)
         if merge_last and k == nst - 1:
             self._side_lane(k)
+            Fh.stamp("pass %s: merged side work done" % name)
         if k >= 1 and self.two_lanes:
             main.wait_stream(self.side)          # (without this per-pass join the side lanes form one long branch, which the
                                                  #  hipGraph executor does not overlap with the main lane: 8.98 ms instead of 7.86)

@@ -337,6 +337,8 @@ def _dec_params(dec):
 # block1's short backward and lengthens that pass by 0.47 ms -- more than the ~0.3 ms the 19 MB all-reduce costs when it trails the
 # last pass.  Off by default; tools/ab_bench.py tatt_amd.tsrn.DP_QGRU_WITH_TP=1 re-measures.
 DP_QGRU_WITH_TP = False
+# where the 9x9 output convolution's weight gradient is filed (see grad_buckets): "srb0" = beside the TP interpreter's backward
+OUTCONV_BUCKET = "srb0"
 TP_FUSED = True          # test hook: False walks the operator-by-operator path for every geometry (tests compare the two)
 
 
@@ -381,7 +383,9 @@ def _tp_interpreter(feat, tp, ig: TPInterpreter, training, qpos=None):
     pd = lambda v: float(v) if drop else 0.0
     cfg = Fh.TPStackCfg((2,), pd(enc.self_attn.dropout), pd(enc.p), pd(enc.p), False, False, True, enc.norm1.eps)
     memory, _ = Fh.TPStackFn.apply(_cc(src), _cc(pos), src, pos, cfg, *_enc_params(enc))
+    Fh.stamp("fwd: tp waits for qpos", feat)
     Fh.FWD_FORK.join(feat.device)              # the query embedding may have been a parallel branch until here
+    Fh.stamp("fwd: tp has qpos", feat)
     decs = list(tr.decoder.layers)
     d0 = decs[0]
     cfg = Fh.TPStackCfg([10 + 10 * i for i in range(len(decs))], pd(d0.multihead_attn.dropout), pd(d0.p), pd(d0.p), True, True,
@@ -460,7 +464,7 @@ class _TrainPathMixin:
                 groups["srb%d" % (int(top[5:]) - 2)].append(p)
             elif top.startswith("block") and int(top[5:]) > k + 1:
                 out_conv = int(top[5:]) == k + 3 and name.split(".")[1] == str(len(getattr(self, top)) - 1)
-                groups["srb0" if (out_conv and hasattr(self, "infoGen") and k > 0) else "trunk"].append(p)
+                groups[OUTCONV_BUCKET if (out_conv and hasattr(self, "infoGen") and k > 0) else "trunk"].append(p)
             elif top == "stn_head":
                 groups["stn"].append(p)
             else:                                  # block1, (TBSRN's unused conv / bn)
@@ -535,26 +539,30 @@ class _GeneratorBase(_TrainPathMixin, nn.Module):
         k = self.srb_nums
         cuts = self._grad_cuts if training else None
         qpos = None
+        if use_tp:
+            # first of all: the query embedding depends on parameters only (no dropout in it) and is the longest dependent chain of
+            # the forward's head -- its forked branch starts before anything else is issued
+            qpos = _query_pos(self.infoGen, x.shape[0], x.shape[2], x.shape[3])
         if training:
             Fh.begin_training_forward(x.device)                  # fresh dropout masks for this call (and its backward)
             self._bump_bn_counters()
+        if use_tp and text_emb is None:
+            text_emb = torch.zeros(1, 37, 1, 26, device=x.device)         # reference :653-654
         if k > 0 and isinstance(getattr(self, "block2").gru1, GruBlock):
             # the composed 1x1-conv x GRU-input projections of every residual block: parameters only, one launch for all of them
             Fh.gru_precompose([g for i in range(k) for g in (getattr(self, "block%d" % (i + 2)).gru1,
                                                              getattr(self, "block%d" % (i + 2)).gru2)])
-        if use_tp:
-            if text_emb is None:
-                text_emb = torch.zeros(1, 37, 1, 26, device=x.device)     # reference :653-654
-            qpos = _query_pos(self.infoGen, x.shape[0], x.shape[2], x.shape[3])
         if self.stn and training:
             ctrl = _stn_forward(x, self.stn_head, False)
             if cuts:
                 ctrl = cuts.cut("stn", ctrl)                     # the STN head's backward is a stage of its own
+            Fh.stamp("fwd: stn head done", x)
             xin, _ = _tps_forward(x, ctrl, self.tps)             # NHWC
         else:
             xin = x.permute(0, 2, 3, 1)                          # NHWC-indexed view, read through strides
         c1 = self.block1[0]
         b1 = Fh.prelu(Fh.conv2d(xin, c1.weight, c1.bias), self.block1[1].weight)
+        Fh.stamp("fwd: block1 done", x)
         feats = {"1": b1}
         tp_map = pr_weights = None
         b1_trunk = b1
@@ -571,7 +579,10 @@ class _GeneratorBase(_TrainPathMixin, nn.Module):
                 tp_in = cuts.cut("tp", tp_map) if tp_map is not None else None
             else:
                 h_in, tp_in = h, tp_map
+            if i == 0:
+                Fh.stamp("fwd: tp done", x)
             h = _srb(h_in, tp_in, getattr(self, "block%d" % (i + 2)))
+            Fh.stamp("fwd: srb%d done" % i, x)
             feats[str(i + 2)] = h
         if cuts and k > 0:
             h = cuts.cut("srb%d" % (k - 1), h)
@@ -592,6 +603,7 @@ class _GeneratorBase(_TrainPathMixin, nn.Module):
         u = Fh.conv2d(u, last.weight, last.bias)
         feats[str(k + 3)] = u
         sr = Fh.ActFn.apply(u, ACT_TANH)                         # reference :675
+        Fh.stamp("fwd: sr done", x)
         Fh.gru_precompose_done()                                 # composed projections no block consumed do not outlive the forward
         self.block = {kk: _nchw(v) for kk, v in feats.items()}
         return _nchw(sr), tp_ret, pr_weights, b1

@@ -424,7 +424,7 @@ def test_query_gru(dev, B):
                grtol=1e-3)
 
 
-def _qgru_run(dev, B, fwd_chain, bwd_chain, seed=5):
+def _qgru_run(dev, B, fwd_chain, bwd_chain, seed=5, sb=False):
     from tatt_amd import functional as Fh
     H, W, C = 16, 64, 64                     # the published geometry: GRU(1024 -> 2 x 512), 64 rows
     g = torch.nn.GRU(C * H, C * H // 2, bidirectional=True, batch_first=True)
@@ -435,15 +435,15 @@ def _qgru_run(dev, B, fwd_chain, bwd_chain, seed=5):
              "weight_hh_l0_reverse", "bias_ih_l0_reverse", "bias_hh_l0_reverse"]
     leaves = [R(H * W, C).to(dev).requires_grad_()] + [getattr(g, n).detach().to(dev).requires_grad_() for n in names]
     dq = R(B, H, W, C, seed=3).to(dev)
-    old = Fh.QGRU_CHAIN_FWD, Fh.QGRU_CHAIN_BWD
-    Fh.QGRU_CHAIN_FWD, Fh.QGRU_CHAIN_BWD = fwd_chain, bwd_chain
+    old = Fh.QGRU_CHAIN_FWD, Fh.QGRU_CHAIN_BWD, Fh.QGRU_CHAIN_SB
+    Fh.QGRU_CHAIN_FWD, Fh.QGRU_CHAIN_BWD, Fh.QGRU_CHAIN_SB = fwd_chain, bwd_chain, sb
     try:
         q = Fh.QueryGruFn.apply(*leaves, B, H, W)
         grads = torch.autograd.grad(q, leaves, dq)
         torch.cuda.synchronize()
         Fh.qgru_chain_check()
     finally:
-        Fh.QGRU_CHAIN_FWD, Fh.QGRU_CHAIN_BWD = old
+        Fh.QGRU_CHAIN_FWD, Fh.QGRU_CHAIN_BWD, Fh.QGRU_CHAIN_SB = old
     return (q.detach(),) + tuple(grads)
 
 
@@ -458,20 +458,28 @@ def test_query_gru_persistent_chain_matches_stepwise(dev, B):
         for k, (a, b) in enumerate(zip(ref, out)):
             err = float((a - b).abs().max() / (a.abs().max() + 1e-20))
             assert err < 1e-5, (fwd_chain, bwd_chain, k, err)
+    # the split-bf16 form of the recurrent products (default): 2^-16 relative per product, carried through B dependent steps
+    out = _qgru_run(dev, B, True, True, sb=True)
+    worst = 0.0
+    for k, (a, b) in enumerate(zip(ref, out)):
+        err = float((a - b).abs().max() / (a.abs().max() + 1e-20))
+        worst = max(worst, err)
+        assert err < 1e-4, ("split-bf16", k, err)
+    print("B = %d: split-bf16 chains vs fp32 per-step launches: worst relative error %.2e" % (B, worst))
 
 
 def test_query_gru_persistent_chain_under_load(dev):
     """The hand-off between work-groups must hold when the chip is busy and the consumers' caches are warm from the previous run
     (MI355X_MICROARCH.md: test every hand-off under uneven load, checking every word): 30 runs of the B = 48 chains beside a second
     stream that keeps streaming kernels in flight, every output word against the first run."""
-    ref = _qgru_run(dev, 48, True, True)
+    ref = _qgru_run(dev, 48, True, True, sb=True)
     side = torch.cuda.Stream()
     x = torch.randn(64 << 20, device=dev)
     for rep in range(30):
         with torch.cuda.stream(side):
             for _ in range(1 + rep % 4):
                 x.mul_(1.0001)
-        out = _qgru_run(dev, 48, True, True)
+        out = _qgru_run(dev, 48, True, True, sb=True)
         for k, (a, b) in enumerate(zip(ref, out)):
             assert torch.equal(a, b), (rep, k, float((a - b).abs().max()))
     torch.cuda.synchronize()

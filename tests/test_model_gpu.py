@@ -369,22 +369,34 @@ def test_graph_replay_equals_eager(dev, dropout, B, stn):
 def test_split_bf16_vs_fp32_training_drift(dev):
     """Multi-step drift of the default arithmetic: 12 training steps (B = 8, STN on, dropout off, fresh data every step) with the
     split-bf16 kernel families against the same steps with exact fp32 products (`tatt_amd.set_arithmetic`).  The single-step tests
-    bound each kernel; this one bounds what 12 optimiser steps make of it: the loss curves stay together to 2e-3 relative and the
-    weights to 4 x lr in max-abs (Adam's first steps turn ANY round-off on a near-zero gradient into +-lr per step -- the
-    eager-vs-eager fp32 noise floor of this comparison is the same order)."""
+    bound each kernel; this one bounds what 12 optimiser steps make of it.  At the recipe's learning rate (1e-3) the first steps of a
+    freshly initialised model are chaotic (the loss goes 37 -> 12 -> 15 -> 22 -> 31: ANY perturbation, fp32 summation order
+    included, is amplified a hundredfold within five steps), so the drift is measured where the dynamics do not amplify it:
+    lr = 1e-5.  There the two arithmetics must stay together: losses to 1e-4 relative, weights to 1e-4 of their l2 norm; in max-abs a
+    weight may differ by up to 12 x lr (a parameter whose true gradient is zero -- a convolution bias in front of a BatchNorm --
+    receives round-off as gradient, and Adam turns round-off of either sign into a full +-lr step, in any arithmetic).  At lr = 1e-3
+    only the first two steps are compared (before the amplification sets in)."""
     import tatt_amd
-    try:
-        tatt_amd.set_arithmetic("fp32")
-        l32, s32, _, g32 = _run_steps(dev, 12, 8, False, use_graph=False)
-    finally:
-        tatt_amd.set_arithmetic("split_bf16")
-    lsb, ssb, _, gsb = _run_steps(dev, 12, 8, False, use_graph=False)
+
+    def both(**kw):
+        try:
+            tatt_amd.set_arithmetic("fp32")
+            a = _run_steps(dev, kw.pop("n"), 8, False, use_graph=False, **kw)
+        finally:
+            tatt_amd.set_arithmetic("split_bf16")
+        return a, _run_steps(dev, len(a[0]), 8, False, use_graph=False, **kw)
+
+    (l32, s32, _, _), (lsb, ssb, _, _) = both(n=12, lr=1e-5)
     rel = max(abs(a - b) / abs(a) for a, b in zip(l32, lsb))
     dp = float((s32["p"] - ssb["p"]).abs().max())
     rp = float((s32["p"] - ssb["p"]).norm() / s32["p"].norm())
-    print("split-bf16 vs fp32 after 12 steps: loss rel %.3e, weights max-abs %.3e, l2-rel %.3e" % (rel, dp, rp))
-    assert rel <= 2e-3, (l32, lsb)
-    assert dp <= 4e-3 and rp <= 1e-3, (dp, rp)
+    print("split-bf16 vs fp32, 12 steps at lr 1e-5: loss rel %.3e, weights max-abs %.3e, l2-rel %.3e" % (rel, dp, rp))
+    assert rel <= 1e-4, (l32, lsb)
+    assert dp <= 12 * 1e-5 * 1.01 and rp <= 1e-4, (dp, rp)
+    (l32, _, _, _), (lsb, _, _, _) = both(n=2, lr=1e-3)
+    rel = max(abs(a - b) / abs(a) for a, b in zip(l32, lsb))
+    print("split-bf16 vs fp32, first 2 steps at lr 1e-3: loss rel %.3e" % rel)
+    assert rel <= 1e-4, (l32, lsb)
 
 
 @pytest.mark.parametrize("B", [6, 48])

@@ -125,7 +125,7 @@ def test_set_arithmetic_switches_every_split_kernel_family():
     assert tatt_amd.get_arithmetic() == "split_bf16"
     try:
         tatt_amd.set_arithmetic("fp32")
-        assert not (ops.CONV3_SB or ops.CONV3_WGRAD_SB or Fh.TOKGEMM_SB or Fh.GRU_WGRAD_SB)
+        assert not (ops.CONV3_SB or ops.CONV3_WGRAD_SB or Fh.TOKGEMM_SB or Fh.GRU_WGRAD_SB or Fh.QGRU_CHAIN_SB)
         assert tatt_amd.get_arithmetic() == "fp32"
         ops.CONV3_SB = True
         assert tatt_amd.get_arithmetic() == "mixed"
@@ -133,7 +133,7 @@ def test_set_arithmetic_switches_every_split_kernel_family():
             tatt_amd.set_arithmetic("bf16")
     finally:
         tatt_amd.set_arithmetic("split_bf16")
-    assert ops.CONV3_SB and ops.CONV3_WGRAD_SB and Fh.TOKGEMM_SB and Fh.GRU_WGRAD_SB
+    assert ops.CONV3_SB and ops.CONV3_WGRAD_SB and Fh.TOKGEMM_SB and Fh.GRU_WGRAD_SB and Fh.QGRU_CHAIN_SB
 
 
 def test_bench_cpu_baseline_leg_runs_without_a_gpu():

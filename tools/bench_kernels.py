@@ -306,16 +306,21 @@ _dgia = torch.zeros(2, _W, 3 * _HID, device=dev)
 
 def _fwd_chain_only():
     ops.call("tatt_qgru_fwd_chain", ops.P(_gi[0]), ops.P(_gi[1]), ops.P(_whh[0]), ops.P(_whh[1]), ops.P(_bhh[0]), ops.P(_bhh[1]),
-             ops.P(_hbuf[0]), ops.P(_hbuf[1]), ops.P(_gsave[0]), ops.P(_gsave[1]), ops.P(_sync), _T, _W, _HID, 0, _T, ops.stream())
+             ops.P(_hbuf[0]), ops.P(_hbuf[1]), ops.P(_gsave[0]), ops.P(_gsave[1]), ops.P(_sync), _T, _W, _HID, 0, _T, None, None, None,
+             None, None, 0, None, 0, ops.P(_xf[0]) if _sb else None, ops.P(_xf[1]) if _sb else None, ops.stream())
 
 
 def _bwd_chain_only():
     ops.call("tatt_qgru_bwd_chain", ops.P(_dgh[0]), ops.P(_dgh[1]), ops.P(_whhT[0]), ops.P(_whhT[1]), ops.P(_dhseq[0]), ops.P(_dhseq[1]),
              ops.P(_gsave[0]), ops.P(_gsave[1]), ops.P(_hbuf[0]), ops.P(_hbuf[1]), ops.P(_dhc[0]), ops.P(_dhc[1]), ops.P(_dgia[0]),
-             ops.P(_dgia[1]), ops.P(_sync), _T, _W, _HID, 0, _T - 1, ops.stream())
+             ops.P(_dgia[1]), ops.P(_sync), _T, _W, _HID, 0, _T - 1, 1, ops.P(_xb[0]) if _sb else None, ops.P(_xb[1]) if _sb else None,
+             ops.stream())
 
 
-timeit("qgru_fwd_persistent_launch", _fwd_chain_only)           # / 48 = per time step
-timeit("qgru_bwd_persistent_launch", _bwd_chain_only)           # / 47
+_xf = torch.zeros(2, _T + 1, _W, _HID, device=dev)
+_xb = torch.zeros(2, _T, _W, 3 * _HID, device=dev)
+for _sb in (False, True):
+    timeit("qgru_fwd_persistent_launch%s" % ("_sb" if _sb else ""), _fwd_chain_only)           # / 48 = per time step
+    timeit("qgru_bwd_persistent_launch%s" % ("_sb" if _sb else ""), _bwd_chain_only)           # / 47
 print("   persistent launches: error word %d" % int(_sync[1023].item()), flush=True)
 # (the backward chain allocates its split-K workspaces through torch outside a Trainer: not capturable on its own)
