@@ -432,7 +432,7 @@ def main():
     loss_v = float(loss)
     assert loss_v == loss_v, "loss is NaN"
     from tatt_amd import functional as _Fh
-    _Fh.qgru_chain_check()                           # the persistent query-GRU launches bound every spin: an expired one voids the run
+    _Fh.sync_check()                                 # launches that synchronise their work-groups in flight bound every spin: an expired one voids the run
 
     if rank == 0:
         ms = dt / a.steps * 1e3

@@ -13,7 +13,7 @@ from .tbsrn import TBSRN  # noqa: F401
 from .crnn import CRNN  # noqa: F401
 from . import torch_ops  # noqa: F401  (registers torch.ops.tatt_hip.*: the operator-registry view of the kernels)
 
-__all__ = ["TSRN", "TSRN_TL_TRANS", "TBSRN", "CRNN", "set_arithmetic", "get_arithmetic"]
+__all__ = ["TSRN", "TSRN_TL_TRANS", "TBSRN", "CRNN", "set_arithmetic", "get_arithmetic", "sync_check"]
 
 
 def set_arithmetic(mode: str) -> None:
@@ -39,3 +39,12 @@ def get_arithmetic() -> str:
     from . import functional as _F, ops as _ops
     flags = (_ops.CONV3_SB, _ops.CONV3_WGRAD_SB, _F.TOKGEMM_SB, _F.GRU_WGRAD_SB, _F.QGRU_CHAIN_SB)
     return "split_bf16" if all(flags) else ("fp32" if not any(flags) else "mixed")
+
+
+def sync_check() -> None:
+    """Some launches of the path synchronise their work-groups in flight (the persistent query-GRU recurrences, the STN head's
+    BatchNorm launches): every such wait is bounded by the wall clock (30 ms) and raises an error word instead of hanging when it
+    expires (work-groups that never became co-resident).  This reads those words and raises RuntimeError if one is set -- results of
+    that launch are then invalid.  It synchronises the device: call it where the training loop synchronises anyway (logging, eval)."""
+    from . import functional as _F
+    _F.sync_check()

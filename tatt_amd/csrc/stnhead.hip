@@ -520,7 +520,8 @@ struct SnFcBwdP {
     float* dW2; float* db2; float* dg1; float* dbe1; float* dW1; float* db1; float* dU; float* dA6; unsigned* sync;
     int B, NO;
 };
-__global__ __launch_bounds__(512) void stn_fc_bwd_kernel(SnFcBwdP p) {
+// (96 registers: two of its waves per SIMD fit beside the two of a resident query-GRU recurrence work-group with room to spare)
+__global__ __launch_bounds__(512, 5) void stn_fc_bwd_kernel(SnFcBwdP p) {
     __shared__ float red[8][4][16][17];
     __shared__ float dcs[64][65];
     __shared__ __attribute__((aligned(16))) float w2s[64][16];

@@ -1342,6 +1342,7 @@ class StnHeadFn(Function):
                  ops.P(a6), ops.P(dW2), ops.P(db2), ops.P(dg1), ops.P(dbe1), ops.P(dW1), ops.P(db1), ops.P(dU), ops.P(dA),
                  ops.P(_stn_sync(stn, "bfc", a6)), B, NO, ops.stream())
         grads = [None] * 24
+        stamp("stn bwd: fc done", dctrl)
         for L in range(5, -1, -1):
             a_in, xc, mean, rstd = saved[4 * L:4 * L + 4]
             w, b, ga, be = pr[4 * L:4 * L + 4]
@@ -1352,8 +1353,10 @@ class StnHeadFn(Function):
             ops.call("tatt_stn_bn_pool_bwd", ops.P(xc), ops.P(dA), ops.P(ga), ops.P(be), ops.P(mean), ops.P(rstd), ops.P(dX),
                      ops.P(dga), ops.P(dbe), ops.P(dbias), ops.P(part), ops.P(_stn_sync(stn, "b%d" % L, xc)), B, H, W, C, ph, pw,
                      ops.stream())
+            stamp("stn bwd: layer %d BatchNorm done" % (L + 1), dctrl)
             if L > 0:
                 dA = ops.conv2d_dgrad(dX, w)
+                stamp("stn bwd: layer %d data gradient done" % (L + 1), dctrl)
             Cout = w.shape[0]
             (dw,) = SIDE.submit((w,), (lambda a_in=a_in, dX=dX, Cout=Cout: (ops.conv_wgrad(a_in, dX, Cout, 3, 3),)), a_in, dX)
             grads[4 * L:4 * L + 4] = [dw, dbias, dga, dbe]

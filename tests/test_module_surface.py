@@ -147,3 +147,36 @@ def test_bench_cpu_baseline_leg_runs_without_a_gpu():
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert set(d) == {"value", "unit", "cores", "kind", "sample"}
     assert d["kind"] == "port" and d["unit"] == "LR images/s" and d["value"] > 0 and 1 <= d["cores"] <= 32
+
+
+def test_sync_kernels_fit_beside_each_other():
+    """The persistent query-GRU launches occupy EVERY CU (256 work-groups of 8 waves) while the STN head's launches -- which also wait
+    for their own work-groups in flight -- run on the other lane.  A kernel of one family whose waves do not fit into the registers a
+    resident work-group of the other leaves on a SIMD (512 VGPRs per lane, allocated in blocks of 8) would have to wait for it: the lane
+    stalls for the length of the recurrence, and two half-resident launches could wait for each other until their wall-clock bound
+    expires.  Checked at build time from hipcc's resource report: 2 waves/SIMD of a chain kernel + the waves/SIMD of each STN kernel."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def vgprs(src):
+        out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast",
+                              "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(root, "tatt_amd", "csrc", src), "-o", "/dev/null"],
+                             capture_output=True, text=True).stderr
+        res, name = {}, None
+        for line in out.splitlines():
+            m = re.search(r"Function Name: (\S+)", line)
+            if m:
+                name = m.group(1)
+            m = re.search(r" VGPRs: (\d+)", line)
+            if m and name:
+                res[name] = max(res.get(name, 0), int(m.group(1)))
+        return res
+    up8 = lambda v: (v + 7) // 8 * 8
+    gru, stn = vgprs("gru.hip"), vgprs("stnhead.hip")
+    chains = {k: v for k, v in gru.items() if "chain_kernel" in k}
+    assert len(chains) == 4 and len(stn) >= 8, (chains, stn)
+    for k, v in stn.items():
+        direction = "fwd" if "fwd" in k else "bwd"                  # the head's forward runs beside the forward recurrence, ...
+        chain = max(2 * up8(c) for n, c in chains.items() if direction + "_chain" in n)      # 512 threads = 2 waves per SIMD
+        per_simd = (2 if "_fc_" in k else 1) * up8(v)               # the fc launches have 512 threads, the map launches 256
+        assert chain + per_simd <= 512, (k, v, chains)

@@ -14,4 +14,6 @@ b dp_selftest --dp-selftest --no-cpu-baseline
 tools/gpu_quick.sh ${tag}_final none "prof:" > /dev/null 2>&1
 head -3 gpurun_out/${tag}_final_timeline.txt
 timeout 300 python tools/bench_kernels.py > gpurun_out/${tag}_kernel_microbench.txt 2>&1; tail -3 gpurun_out/${tag}_kernel_microbench.txt
-timeout 900 python -m pytest tests -m gpu -q --timeout=600 --durations=15 2>&1 | tail -30 > gpurun_out/${tag}_tests.log; tail -4 gpurun_out/${tag}_tests.log
+timeout 200 python tools/step_stamps.py > gpurun_out/${tag}_step_stamps.txt 2>&1; tail -2 gpurun_out/${tag}_step_stamps.txt
+timeout 100 python tools/stn_head_bench.py > gpurun_out/${tag}_stn_head_bench.txt 2>&1
+timeout 1150 python -m pytest tests -m gpu -q --timeout=600 --durations=15 2>&1 | tail -30 > gpurun_out/${tag}_tests.log; tail -4 gpurun_out/${tag}_tests.log
