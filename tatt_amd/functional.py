@@ -221,6 +221,12 @@ class Conv2dFn(Function):
             dw = ops.conv_wgrad(x, dy, Cout, KH, KW) if want_dw else None
             db = ops.colsum(dy.reshape(-1, Cout)) if want_db else None
             return dw, db
+        wleaf, bleaf = ctx.leaves
+        if want_dw and want_db and SIDE.enabled and SIDE.due_of.get(id(wleaf)) != SIDE.due_of.get(id(bleaf)):
+            # weight and bias filed under different stages (tsrn.OUTCONV_*): two closures, each with its own stage's side lane
+            (dw,) = SIDE.submit((wleaf,), lambda: (ops.conv_wgrad(x, dy, Cout, KH, KW),), x, dy)
+            (db,) = SIDE.submit((bleaf,), lambda: (ops.colsum(dy.reshape(-1, Cout)),), dy)
+            return dx, dw, db, None
         dw, db = SIDE.submit(ctx.leaves, param_grads, x, dy)
         return dx, dw, db, None
 

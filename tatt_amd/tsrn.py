@@ -339,6 +339,10 @@ def _dec_params(dec):
 DP_QGRU_WITH_TP = False
 # where the 9x9 output convolution's weight gradient is filed (see grad_buckets): "srb0" = beside the TP interpreter's backward
 OUTCONV_BUCKET = "srb0"
+# ... and its bias gradient (a column sum over the 196,608 HR pixels of a 4-channel map): beside the TP layers' backward it waits for
+# their work-groups to leave the CUs (156 us in the step, 15 alone) on a side lane that is the longer one of that pass; filed with its
+# own stage it runs in a pass whose side lane has room
+OUTCONV_BIAS_BUCKET = "trunk"
 TP_FUSED = True          # test hook: False walks the operator-by-operator path for every geometry (tests compare the two)
 
 
@@ -464,7 +468,11 @@ class _TrainPathMixin:
                 groups["srb%d" % (int(top[5:]) - 2)].append(p)
             elif top.startswith("block") and int(top[5:]) > k + 1:
                 out_conv = int(top[5:]) == k + 3 and name.split(".")[1] == str(len(getattr(self, top)) - 1)
-                groups[OUTCONV_BUCKET if (out_conv and hasattr(self, "infoGen") and k > 0) else "trunk"].append(p)
+                late = out_conv and hasattr(self, "infoGen") and k > 0
+                if late and name.endswith(".bias"):
+                    groups[OUTCONV_BIAS_BUCKET].append(p)
+                else:
+                    groups[OUTCONV_BUCKET if late else "trunk"].append(p)
             elif top == "stn_head":
                 groups["stn"].append(p)
             else:                                  # block1, (TBSRN's unused conv / bn)
