@@ -468,7 +468,9 @@ def main():
             "metric": "LR images/s (train fwd+bwd+clip+Adam) at %dx%d->%dx%d" % (tile["H"], tile["W"], 2 * tile["H"], 2 * tile["W"]),
             "value": round(ips, 2), "unit": "LR images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "fp32" + (" (split-bf16 MFMA operands in conv3 / conv3-wgrad / tokgemm / gru-wgrad)" if _ops.CONV3_SB else ""),
+            "dtype": "fp32" + (" (split-bf16 MFMA operands in conv3 / conv3-wgrad / tokgemm / gru-wgrad%s)"
+                               % (" / query-GRU recurrence" if _Fh.QGRU_CHAIN_SB and a.arch in ("tatt", "tatt_tpg") and a.tile == "std" else "")
+                               if _ops.CONV3_SB else ""),
             "data": "synthetic",
             "config": {"workload": "TATT (TSRN_TL_TRANS, STN %s, dropout on) train step, batch %d/GPU, %dx%d LR -> %dx%d SR, "
                                    "ImageLoss + clip 0.25 + Adam(1e-3,(0.5,0.999))" % (
@@ -479,9 +481,11 @@ def main():
                        "launch": ("hipGraph replay" if graph_ok else "eager") + ("" if a.no_defer else ", staged backward" + ("" if a.no_side_stream else " on 2 streams")), "final_loss": round(loss_v, 5),
                        "host_issue_ms_per_step": round(t_issue / a.steps * 1e3, 3), "known_answer": kat,
                        "arithmetic": "fp32 storage, accumulation and results throughout (the reference's arithmetic)"
-                                     + ("; the 3x3 convolutions, the GruBlock input projections and the GruBlock weight gradients evaluate "
+                                     + ("; the 3x3 convolutions, the GruBlock input projections, the GruBlock weight gradients and "
+                                        "the recurrent products of the query GRU's persistent launches evaluate "
                                         "every fp32 product as three bf16 matrix-core products of hi/lo operand halves (2^-16 relative, "
-                                        "measured 1e-6 on SR: profiles/r03_split_bf16_probe.txt)" if _ops.CONV3_SB else ""),
+                                        "measured 1e-6 on SR: profiles/r03_split_bf16_probe.txt; query GRU 5e-6 of the fp32 result: "
+                                        "tests/test_kernels_gpu.py)" if _ops.CONV3_SB else ""),
                        # algorithmic = the reference graph's FLOP count; executed = minus the query-GRU input projection
                        # the build hoists out of the recurrence
                        "whole_step_tflops": ({"algorithmic": round(ips * tile["flop_per_image"] / 1e12, 2),
