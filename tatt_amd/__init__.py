@@ -43,7 +43,7 @@ def get_arithmetic() -> str:
 
 def sync_check() -> None:
     """Some launches of the path synchronise their work-groups in flight (the persistent query-GRU recurrences, the STN head's
-    BatchNorm launches): every such wait is bounded by the wall clock (30 ms) and raises an error word instead of hanging when it
+    BatchNorm launches): every such wait is bounded by the wall clock (2 s) and raises an error word instead of hanging when it
     expires (work-groups that never became co-resident).  This reads those words and raises RuntimeError if one is set -- results of
     that launch are then invalid.  It synchronises the device: call it where the training loop synchronises anyway (logging, eval)."""
     from . import functional as _F

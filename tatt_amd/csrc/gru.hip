@@ -850,7 +850,7 @@ TATT_API int tatt_qgru_bwd_fused(const float* dgh_cur0, const float* dgh_cur1, c
 // Residency: the NG * HID/16 <= 256 work-groups must be co-resident (one per CU at 512 threads / <= 128 VGPRs leaves room beside it).
 // ------------------------------------------------------------------------------------------------
 #define QCH_ERR 1023                       // index of the error word in the sync buffer (1024 words)
-#define QCH_SPIN_TICKS 3000000L            // 30 ms of the 100 MHz wall clock
+#define QCH_SPIN_TICKS 200000000L          // 2 s of the 100 MHz wall clock: far beyond any stall another launch (a collective waiting for a late rank) can cause
 struct QChainP {
     float* dgh[2]; const float* whhT[2]; const float* dhseq[2]; const float* gsave[2]; const float* hbuf[2];
     float* dhcarry[2]; float* dgi_acc[2];

@@ -22,7 +22,7 @@ typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 #define SN_WORDS 256                      // words of a site's sync buffer: flags 0 .. SN_MAXG-1, epoch, error
 #define SN_EPOCH 254
 #define SN_ERR 255
-#define SN_SPIN_TICKS 3000000L            // 30 ms of the 100 MHz wall clock
+#define SN_SPIN_TICKS 200000000L          // 2 s of the 100 MHz wall clock
 #define SN_MAXG 128
 #define SN_MAXW 4                         // pool windows per thread (they stay in registers between the two passes over the map)
 
