@@ -180,3 +180,23 @@ def test_sync_kernels_fit_beside_each_other():
         chain = max(2 * up8(c) for n, c in chains.items() if direction + "_chain" in n)      # 512 threads = 2 waves per SIMD
         per_simd = (2 if "_fc_" in k else 1) * up8(v)               # the fc launches have 512 threads, the map launches 256
         assert chain + per_simd <= 512, (k, v, chains)
+
+
+def test_fused_path_predicates_choose_the_fallbacks():
+    """Host logic of the launches that only take the published geometry: the STN head's fused launches (B <= 64, 16-row input,
+    BatchNorms in training mode with a momentum) and the persistent query-GRU launches (hidden 512, rows % 16 == 0, <= 256 tiles);
+    everything else must be routed to the operator-by-operator / per-step paths."""
+    import tatt_amd.tsrn as T
+    from tatt_amd import functional as Fh
+    stn = T.STNHead(4, 20, "none").train()
+    x = torch.zeros(3, 16, 64, 4)                                  # NHWC-indexed view shape
+    assert Fh.stn_head_fusable(x, stn, 3) and Fh.stn_head_fusable(x, stn, 64)
+    assert not Fh.stn_head_fusable(x, stn, 65)                     # the fully connected launch holds <= 64 samples
+    assert not Fh.stn_head_fusable(torch.zeros(3, 32, 128, 4), stn, 3)
+    stn.stn_convnet[4][1].momentum = None                          # cumulative-average BatchNorm: not handled by the fused launch
+    assert not Fh.stn_head_fusable(x, stn, 3)
+    stn.stn_convnet[4][1].momentum = 0.1
+    stn.eval()
+    assert not Fh.stn_head_fusable(x, stn, 3)
+    assert Fh._qgru_chain_takes(64, 512)
+    assert not Fh._qgru_chain_takes(128, 1024) and not Fh._qgru_chain_takes(60, 512) and not Fh._qgru_chain_takes(144, 512)
