@@ -1257,7 +1257,7 @@ def stamp(name, ref=None):
 # --------------------------------------------------------------------------------------------------
 # STN head as a few launches (csrc/stnhead.hip): one Function for the whole head.  Convolutions (forward, data and weight gradients) go
 # through the ordinary entry points; everything between them is one launch per layer and direction, and the fully connected end is one
-# launch each way.  53 -> 19 launches forward, 62 -> about 30 backward, at both exposed ends of the training step.
+# launch each way.  53 -> 17 launches forward, 62 -> 23 backward, at both exposed ends of the training step.
 # --------------------------------------------------------------------------------------------------
 STN_SYNC = []            # every sync buffer handed to those launches (sync_check reads their error words)
 
