@@ -361,11 +361,15 @@ def _tp_fusable(ig: TPInterpreter, L):
     return True
 
 
-def _tp_interpreter(feat, tp, ig: TPInterpreter, training, qpos=None):
-    """TPInterpreter.forward (model/tsrn.py:194-224) + InfoTransformer.forward (model/transformer_v2.py:198-244).
-    feat (B,H,W,C) NHWC block1 output; tp (B,37,1,26).  Returns tp_map (B,H,W,C), pr_weights (B,H*W,26)."""
-    B, H, W, C = feat.shape
-    L = tp.shape[3]
+# A/B hook: the text side of the TP interpreter (prior -> tokens -> encoder layer: depends on the prior and on parameters only) issued on
+# the forward's forked branch, behind the query embedding, instead of on the main lane between block1 and the decoder layers
+TEXT_ON_FORK = False
+
+
+def _tp_text_side(tp, ig: TPInterpreter, training):
+    """The text side of the TP interpreter (model/tsrn.py:194-216, transformer_v2.py:268-276): -> (src, pos, memory); memory is None
+    when the encoder layer has to run operator by operator (the caller does that)."""
+    B, L, C = tp.shape[0], tp.shape[3], ig.fc_in.weight.shape[0]
     x = Fh.Permute4dFn.apply(tp, (0, 3, 2, 1)).reshape(B, L, tp.shape[1])               # (B,26,37); differentiable: the prior may
                                                                                        # come from a trainable recogniser (tatt_amd.crnn)
     x = Fh.prelu(Fh.linear(x, ig.fc_in.weight, ig.fc_in.bias), ig.activation.weight)   # (B,26,64)
@@ -377,16 +381,32 @@ def _tp_interpreter(feat, tp, ig: TPInterpreter, training, qpos=None):
         pos = Fh.dropout(pe.unsqueeze(0).expand(B, L, C).contiguous(), ig.pe.p, True, 1)
     else:
         pos = pe
-    if qpos is None:
-        qpos = _query_pos(ig, B, H, W)
-    tgt = feat.reshape(B, H * W, C)
     src = Fh.ScaleFn.apply(x, 2.0)               # the encoder layer is fed with output + src = 2*src (transformer_v2.py:274)
     if not _tp_fusable(ig, L):
-        return _tp_layers_unfused(src, pos, tgt, qpos, tr, drop, (B, H, W, C))
+        return src, pos, None
     enc = tr.encoder.layers[0]
     pd = lambda v: float(v) if drop else 0.0
     cfg = Fh.TPStackCfg((2,), pd(enc.self_attn.dropout), pd(enc.p), pd(enc.p), False, False, True, enc.norm1.eps)
     memory, _ = Fh.TPStackFn.apply(_cc(src), _cc(pos), src, pos, cfg, *_enc_params(enc))
+    return src, pos, memory
+
+
+def _tp_interpreter(feat, tp, ig: TPInterpreter, training, qpos=None, text=None):
+    """TPInterpreter.forward (model/tsrn.py:194-224) + InfoTransformer.forward (model/transformer_v2.py:198-244).
+    feat (B,H,W,C) NHWC block1 output; tp (B,37,1,26).  Returns tp_map (B,H,W,C), pr_weights (B,H*W,26)."""
+    B, H, W, C = feat.shape
+    L = tp.shape[3]
+    tr = ig.transformer
+    drop = training and ig.dropout_on
+    pd = lambda v: float(v) if drop else 0.0
+    if text is None:
+        text = _tp_text_side(tp, ig, training)
+    src, pos, memory = text
+    if qpos is None:
+        qpos = _query_pos(ig, B, H, W)
+    tgt = feat.reshape(B, H * W, C)
+    if memory is None:
+        return _tp_layers_unfused(src, pos, tgt, qpos, tr, drop, (B, H, W, C))
     Fh.stamp("fwd: tp waits for qpos", feat)
     Fh.FWD_FORK.join(feat.device)              # the query embedding may have been a parallel branch until here
     Fh.stamp("fwd: tp has qpos", feat)
@@ -556,6 +576,10 @@ class _GeneratorBase(_TrainPathMixin, nn.Module):
             self._bump_bn_counters()
         if use_tp and text_emb is None:
             text_emb = torch.zeros(1, 37, 1, 26, device=x.device)         # reference :653-654
+        text_side = None
+        if use_tp and TEXT_ON_FORK and training and _tp_fusable(self.infoGen, text_emb.shape[3]):
+            tpf = text_emb.float()
+            text_side = Fh.FWD_FORK.run(tpf, lambda: _tp_text_side(tpf, self.infoGen, training))
         if k > 0 and isinstance(getattr(self, "block2").gru1, GruBlock):
             # the composed 1x1-conv x GRU-input projections of every residual block: parameters only, one launch for all of them
             Fh.gru_precompose([g for i in range(k) for g in (getattr(self, "block%d" % (i + 2)).gru1,
@@ -576,7 +600,7 @@ class _GeneratorBase(_TrainPathMixin, nn.Module):
         b1_trunk = b1
         if use_tp:
             tp_map, pr_weights = _tp_interpreter(cuts.cut("first", b1) if cuts else b1, text_emb.float(), self.infoGen, training,
-                                                 qpos)
+                                                 qpos, text_side)
         tp_ret = tp_map
         if cuts:                                 # backward stages: "trunk" (from the loss), "srb4" ... "srb0", "tp", "first"
             b1_trunk = cuts.cut("first", b1)
