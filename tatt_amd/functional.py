@@ -8,6 +8,8 @@ from __future__ import annotations
 import math
 from typing import Optional
 
+import weakref
+
 import torch
 from torch.autograd import Function
 
@@ -1268,7 +1270,8 @@ def _stn_sync(holder, site, ref):
     key = (site, ref.device)
     if key not in table:
         table[key] = torch.zeros(256, device=ref.device, dtype=torch.int32)
-        STN_SYNC.append(table[key])
+        STN_SYNC[:] = [r for r in STN_SYNC if r() is not None]      # (the buffers belong to their module and go with it)
+        STN_SYNC.append(weakref.ref(table[key]))
     return table[key]
 
 
@@ -1276,8 +1279,9 @@ def sync_check():
     """Raise if a launch that synchronises its work-groups in flight gave up waiting (every such spin is bounded by the wall clock).
     Synchronises the device: call it outside a capture."""
     qgru_chain_check()
-    for s in STN_SYNC:
-        if int(s[255].item()) != 0:
+    for r in STN_SYNC:
+        s = r()
+        if s is not None and int(s[255].item()) != 0:
             raise RuntimeError("tatt_amd: an STN-head launch gave up waiting for its neighbours (work-groups not co-resident?)")
 
 
