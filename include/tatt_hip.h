@@ -477,6 +477,14 @@ int tatt_tplayer_fwd(const float* x, const float* qpos, long qbs, const float* K
                      const float* lnB_b, const float* lnF_w, const float* lnF_b, float fin_scale, int fin_both, float* xout,
                      float* fin, float* wavg, int B, int L, int S, float p_attn, float p_res, float p_ffn,
                      const unsigned long long* seed, unsigned site0, float eps, hipStream_t st);
+/* the same launch, additionally leaving the relu-and-kept bits of the FFN's hidden layer (B*L 64-bit words; L % 32 == 0) for
+ * tatt_tplayer2_bwd, whose split-bf16 recomputation could otherwise flip a relu whose pre-activation is within ~1e-5 of zero */
+int tatt_tplayer_fwd_m(const float* x, const float* qpos, long qbs, const float* K, const float* V, const float* in_w,
+                       const float* in_b, const float* out_w, const float* out_b, const float* w1, const float* b1,
+                       const float* w2, const float* b2, const float* lnA_w, const float* lnA_b, const float* lnB_w,
+                       const float* lnB_b, const float* lnF_w, const float* lnF_b, float fin_scale, int fin_both, float* xout,
+                       float* fin, float* wavg, unsigned long long* hmask, int B, int L, int S, float p_attn, float p_res,
+                       float p_ffn, const unsigned long long* seed, unsigned site0, float eps, hipStream_t st);
 /* Backward of the layer, recomputed from x (the forward saves nothing else): upstream gradients dxout (of xout), dfin (of fin;
  * required when lnF_w != NULL), dwavg (of wavg) -- each nullable; dqacc (nullable) is added to dqpos (the next layer's dqpos).
  * Writes dx (B,L,64), dqpos (B,L,64; nullable), and partial records: kvpart (dK / dV per work-group and sample) and ppart
@@ -497,6 +505,33 @@ int tatt_tplayer_reduce_kv(const float* kvpart, float* dK, float* dV, int B, int
 int tatt_tplayer_reduce_params(const float* ppart, int B, int L, float* d_in_w, float* d_in_b, float* d_out_w, float* d_out_b,
                                float* d_w1, float* d_b1, float* d_w2, float* d_b2, float* d_lnA_w, float* d_lnA_b,
                                float* d_lnB_w, float* d_lnB_b, float* d_lnF_w, float* d_lnF_b, float betaF, hipStream_t st);
+
+/* the same reduction over G records (the second-generation backward below has its own work-group count) */
+int tatt_tplayer_reduce_params_g(const float* ppart, int G, float* d_in_w, float* d_in_b, float* d_out_w, float* d_out_b,
+                                 float* d_w1, float* d_b1, float* d_w2, float* d_b2, float* d_lnA_w, float* d_lnA_b,
+                                 float* d_lnB_w, float* d_lnB_b, float* d_lnF_w, float* d_lnF_b, float betaF, hipStream_t st);
+
+/* ---- second-generation backward of the layer (csrc/tplayer2.hip): split-bf16 products on the bf16 matrix cores, a wave owns 16
+ * tokens and chains every product in registers (transposed MFMA orientation), weight gradients shared by the four waves of a
+ * work-group.  Same inputs, outputs and dropout masks as tatt_tplayer_bwd; takes L % 64 == 0, S <= 32 (tatt_tplayer2_geom says). */
+/* host-side: out[0] = 1 if the geometry is taken, out[1] = work-groups, out[2] = floats of kvpart, out[3] = floats of ppart,
+ * out[4] = ints of kvflags, out[5] = 32-bit words of wimg, out[6] = 32-bit words of kvf */
+int tatt_tplayer2_geom(int B, int L, int S, int* out);
+/* packed operands: wimg = the four 64x64 matrices (in_w: query rows of the packed in-projection) as MFMA A fragments, forward and
+ * transposed, bf16 hi / lo; kvf = K, V (B,S,64) as the four fragment forms of the attention products */
+int tatt_tplayer2_prep(const float* in_w, const float* out_w, const float* w1, const float* w2, const float* K, const float* V,
+                       unsigned* wimg, unsigned* kvf, int B, int S, hipStream_t st);
+/* arguments as tatt_tplayer_bwd with the matrices / K / V replaced by their packed forms; kvflags: which sample the dK / dV
+ * records of a work-group belong to (read by tatt_tplayer2_reduce_kv); ppart is summed by tatt_tplayer_reduce_params_g;
+ * hmask: the bits tatt_tplayer_fwd_m left (nullable: the relu is then decided by the recomputation) */
+int tatt_tplayer2_bwd(const float* x, const float* qpos, long qbs, const unsigned* wimg, const unsigned* kvf, const float* in_b,
+                      const float* out_b, const float* b1, const float* b2, const float* lnA_w, const float* lnA_b,
+                      const float* lnB_w, const float* lnB_b, const float* lnF_w, const float* lnF_b, float fin_scale,
+                      int fin_both, const float* dxout, const float* dfin, const float* dwavg, const float* dqacc, float* dx,
+                      float* dqpos, float* kvpart, float* ppart, int* kvflags, const unsigned long long* hmask, int B, int L, int S,
+                      float p_attn, float p_res, float p_ffn, const unsigned long long* seed, unsigned site0, float eps,
+                      hipStream_t st);
+int tatt_tplayer2_reduce_kv(const float* kvpart, const int* kvflags, float* dK, float* dV, int B, int L, int S, hipStream_t st);
 
 /* ---- TPS rectification ---------------------------------------------------------------------------------- */
 

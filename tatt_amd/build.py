@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libtatt_hip.so")
-SOURCES = ["gemm.hip", "conv3.hip", "conv3w.hip", "conv9.hip", "norm.hip", "elementwise.hip", "gru.hip", "attn.hip", "sattn.hip", "tplayer.hip", "tokgemm.hip", "gruwgrad.hip", "tps.hip", "loss.hip", "lstm.hip", "ssim.hip", "stnhead.hip"]
+SOURCES = ["gemm.hip", "conv3.hip", "conv3w.hip", "conv9.hip", "norm.hip", "elementwise.hip", "gru.hip", "attn.hip", "sattn.hip", "tplayer.hip", "tplayer2.hip", "tokgemm.hip", "gruwgrad.hip", "tps.hip", "loss.hip", "lstm.hip", "ssim.hip", "stnhead.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-ffp-contract=fast"]
 
 

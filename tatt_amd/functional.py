@@ -985,17 +985,21 @@ class TPStackFn(Function):
         seed = current_seed(x.device) if drop else None
         kin = ops.axpby(mem, pos, 1.0, 1.0) if pos.dim() == 3 else ops.add_rowbcast(mem, pos, pos.shape[0])
         kin2, mem2 = kin.reshape(-1, E), mem.reshape(-1, E)
-        xs, Ks, Vs = [x], [], []
+        xs, Ks, Vs, hms = [x], [], [], []
         out = wavg = None
+        # the second-generation backward (csrc/tplayer2.hip) takes the FFN's relu bits from the forward launch
+        want_bits = any(ctx.needs_input_grad) and ops.TPLAYER_BWD2 and ops.tplayer2_geom(B, L, S)[0] == 1
         for l, lp in enumerate(lps):
             in_w, in_b = lp[0], lp[1]
             K = ops.linear_fwd(kin2, in_w[E:2 * E], in_b[E:2 * E]).reshape(B, S, E)
             V = ops.linear_fwd(mem2, in_w[2 * E:], in_b[2 * E:]).reshape(B, S, E)
             last = l == n - 1
             fin_here = cfg.fin and last
+            hm = torch.empty(B * L, dtype=torch.int64, device=x.device) if want_bits else None
+            hms.append(hm)
             xout, fin, w = ops.tplayer_fwd(xs[l], qpos, K, V, lp, lnF if fin_here else None, 1.0 / n, int(n == 2), cfg.p_attn,
                                            cfg.p_res, cfg.p_ffn, seed, cfg.sites[l], cfg.eps, not fin_here,
-                                           cfg.need_wavg and last)
+                                           cfg.need_wavg and last, hmask=hm)
             if last:
                 out, wavg = (fin if fin_here else xout), w
             else:
@@ -1003,7 +1007,7 @@ class TPStackFn(Function):
             Ks.append(K)
             Vs.append(V)
         ctx.save_for_backward(qpos, mem, kin, *xs, *Ks, *Vs, *params)
-        ctx.cfg, ctx.seed = cfg, seed
+        ctx.cfg, ctx.seed, ctx.hms = cfg, seed, hms
         ctx.set_materialize_grads(False)          # an unused `wavg` must not cost a zero-filled (B,L,S) gradient
         return out, wavg
 
@@ -1030,11 +1034,18 @@ class TPStackFn(Function):
             lp = lps[l]
             last = l == n - 1
             fin_here = cfg.fin and last
-            dx, dq, kvpart, ppart = ops.tplayer_bwd(xs[l], qpos, Ks[l], Vs[l], lp, lnF if fin_here else None, 1.0 / n, int(n == 2),
-                                                    cfg.p_attn, cfg.p_res, cfg.p_ffn, ctx.seed, cfg.sites[l], cfg.eps,
-                                                    None if fin_here else up, up if fin_here else None, dwavg if last else None,
-                                                    dq, want_dq)
-            dK, dV = ops.tplayer_reduce_kv(kvpart, B, L, S)
+            # second generation (split-bf16, csrc/tplayer2.hip) where it takes the geometry, else the exact-fp32 first generation
+            gen2 = ops.TPLAYER_BWD2 and ops.tplayer2_geom(B, L, S)[0] == 1 and ctx.hms[l] is not None
+            bargs = (xs[l], qpos, Ks[l], Vs[l], lp, lnF if fin_here else None, 1.0 / n, int(n == 2), cfg.p_attn, cfg.p_res, cfg.p_ffn,
+                     ctx.seed, cfg.sites[l], cfg.eps, None if fin_here else up, up if fin_here else None, dwavg if last else None,
+                     dq, want_dq)
+            G2 = 0
+            if gen2:
+                dx, dq, kvpart, kvflags, ppart, G2 = ops.tplayer2_bwd(*bargs, hmask=ctx.hms[l])
+                dK, dV = ops.tplayer2_reduce_kv(kvpart, kvflags, B, L, S)
+            else:
+                dx, dq, kvpart, ppart = ops.tplayer_bwd(*bargs)
+                dK, dV = ops.tplayer_reduce_kv(kvpart, B, L, S)
             dK2, dV2 = dK.reshape(-1, E), dV.reshape(-1, E)
             in_w = lp[0]
             if want_dmem:
@@ -1048,11 +1059,14 @@ class TPStackFn(Function):
                     ops.linear_bwd_input(dK2, in_w[E:2 * E], out=dmem2, beta=1.0)
                 ops.linear_bwd_input(dV2, in_w[2 * E:], out=dmem2, beta=1.0)
 
-            def param_grads(lp=lp, ppart=ppart, dK2=dK2, dV2=dV2, fin_here=fin_here):
+            def param_grads(lp=lp, ppart=ppart, dK2=dK2, dV2=dV2, fin_here=fin_here, G2=G2):
                 g = [ops.new(dK2, *t.shape) for t in lp]
                 gF = [ops.new(dK2, *t.shape) for t in lnF] if fin_here else [None, None]
-                ops.tplayer_reduce_params(ppart, B, L, [g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], g[9], g[10], g[11],
-                                                        gF[0], gF[1]])
+                dsts = [g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], g[9], g[10], g[11], gF[0], gF[1]]
+                if G2:
+                    ops.tplayer_reduce_params_g(ppart, G2, dsts)
+                else:
+                    ops.tplayer_reduce_params(ppart, B, L, dsts)
                 ops.linear_bwd_weight(dK2, kin2, out=g[0][E:2 * E], out_ld=E, rowsum=g[1][E:2 * E])
                 ops.linear_bwd_weight(dV2, mem2, out=g[0][2 * E:], out_ld=E, rowsum=g[1][2 * E:])
                 return tuple(g) + (tuple(gF) if fin_here else ())

@@ -823,8 +823,9 @@ def _tpl_weights(lp, lnF):
     return [P(t) for t in lp] + [P(lnF[0]) if lnF else None, P(lnF[1]) if lnF else None]
 
 
-def tplayer_fwd(x, qpos, K, V, lp, lnF, fin_scale, fin_both, p_attn, p_res, p_ffn, seed, site0, eps, want_xout, want_wavg):
+def tplayer_fwd(x, qpos, K, V, lp, lnF, fin_scale, fin_both, p_attn, p_res, p_ffn, seed, site0, eps, want_xout, want_wavg, hmask=None):
     """One fused transformer layer (see tatt_tplayer_fwd).  x (B,L,64); qpos (B,L,64) or (L,64); K, V (B,S,64).
+    hmask (int64, B*L words; L % 32 == 0): receives the relu-and-kept bits of the FFN for tplayer2_bwd (tatt_tplayer_fwd_m).
     -> (xout or None, fin or None, wavg or None)"""
     _check_dev(x)
     B, L, E = x.shape
@@ -834,8 +835,13 @@ def tplayer_fwd(x, qpos, K, V, lp, lnF, fin_scale, fin_both, p_attn, p_res, p_ff
     xout = torch.empty_like(x) if want_xout else None
     fin = torch.empty_like(x) if lnF else None
     wavg = new(x, B, L, S) if want_wavg else None
-    call("tatt_tplayer_fwd", P(x), P(qpos), qbs, P(K), P(V), *_tpl_weights(lp, lnF), float(fin_scale), int(fin_both), P(xout), P(fin),
-         P(wavg), B, L, S, float(p_attn), float(p_res), float(p_ffn), P(seed), int(site0), float(eps), stream())
+    if hmask is not None:
+        assert hmask.dtype == torch.int64 and hmask.numel() == B * L and L % 32 == 0
+        call("tatt_tplayer_fwd_m", P(x), P(qpos), qbs, P(K), P(V), *_tpl_weights(lp, lnF), float(fin_scale), int(fin_both), P(xout),
+             P(fin), P(wavg), P(hmask), B, L, S, float(p_attn), float(p_res), float(p_ffn), P(seed), int(site0), float(eps), stream())
+    else:
+        call("tatt_tplayer_fwd", P(x), P(qpos), qbs, P(K), P(V), *_tpl_weights(lp, lnF), float(fin_scale), int(fin_both), P(xout),
+             P(fin), P(wavg), B, L, S, float(p_attn), float(p_res), float(p_ffn), P(seed), int(site0), float(eps), stream())
     return xout, fin, wavg
 
 
@@ -864,6 +870,53 @@ def tplayer_reduce_kv(kvpart, B, L, S):
 def tplayer_reduce_params(ppart, B, L, dsts, betaF=0.0):
     """dsts: 14 tensors or None in the order of tatt_tplayer_reduce_params."""
     call("tatt_tplayer_reduce_params", P(ppart), B, L, *[P(t) for t in dsts], float(betaF), stream())
+
+
+# second-generation backward of the fused layer (csrc/tplayer2.hip): split-bf16 on the bf16 matrix cores, a wave owns 16 tokens.
+# False (tatt_amd.set_arithmetic("fp32"), tests) keeps the exact-fp32 first generation for every geometry.
+TPLAYER_BWD2 = True
+
+
+def tplayer2_geom(B, L, S):
+    """-> (taken, work-groups, floats of kvpart, floats of ppart, ints of kvflags, words of wimg, words of kvf)"""
+    out = (ctypes.c_int * 7)()
+    call("tatt_tplayer2_geom", int(B), int(L), int(S), out)
+    return tuple(out[i] for i in range(7))
+
+
+def tplayer2_bwd(x, qpos, K, V, lp, lnF, fin_scale, fin_both, p_attn, p_res, p_ffn, seed, site0, eps, dxout, dfin, dwavg, dqacc,
+                 want_dqpos, hmask=None):
+    """tatt_tplayer2_prep + tatt_tplayer2_bwd -> dx, dqpos (or None), kvpart, kvflags, ppart, work-groups.
+    hmask: the relu bits tplayer_fwd left (None: the recomputation decides the relu itself -- may flip kinks, see csrc/tplayer2.hip)"""
+    B, L, E = x.shape
+    S = K.shape[1]
+    qbs = L * 64 if qpos.dim() == 3 else 0
+    taken, G, nkv, npp, nfl, nw, nkf = tplayer2_geom(B, L, S)
+    assert taken
+    wimg = torch.empty(nw, dtype=torch.int32, device=x.device)
+    kvf = torch.empty(nkf, dtype=torch.int32, device=x.device)
+    in_w, in_b, out_w, out_b, w1, b1, w2, b2, lnA_w, lnA_b, lnB_w, lnB_b = lp
+    call("tatt_tplayer2_prep", P(in_w), P(out_w), P(w1), P(w2), P(K), P(V), P(wimg), P(kvf), B, S, stream())
+    dx = torch.empty_like(x)
+    dqpos = torch.empty_like(x) if want_dqpos else None
+    kvpart, ppart = new(x, nkv), new(x, npp)
+    kvflags = torch.empty(nfl, dtype=torch.int32, device=x.device)
+    call("tatt_tplayer2_bwd", P(x), P(qpos), qbs, P(wimg), P(kvf), P(in_b), P(out_b), P(b1), P(b2), P(lnA_w), P(lnA_b), P(lnB_w),
+         P(lnB_b), P(lnF[0]) if lnF else None, P(lnF[1]) if lnF else None, float(fin_scale), int(fin_both), P(dxout), P(dfin),
+         P(dwavg), P(dqacc), P(dx), P(dqpos), P(kvpart), P(ppart), P(kvflags), P(hmask), B, L, S, float(p_attn), float(p_res),
+         float(p_ffn), P(seed), int(site0), float(eps), stream())
+    return dx, dqpos, kvpart, kvflags, ppart, G
+
+
+def tplayer2_reduce_kv(kvpart, kvflags, B, L, S):
+    dK, dV = new(kvpart, B, S, 64), new(kvpart, B, S, 64)
+    call("tatt_tplayer2_reduce_kv", P(kvpart), P(kvflags), P(dK), P(dV), B, L, S, stream())
+    return dK, dV
+
+
+def tplayer_reduce_params_g(ppart, G, dsts, betaF=0.0):
+    """dsts: 14 tensors or None in the order of tatt_tplayer_reduce_params; G: records in ppart."""
+    call("tatt_tplayer_reduce_params_g", P(ppart), int(G), *[P(t) for t in dsts], float(betaF), stream())
 
 
 def tps_grid_fwd(ctrl, inv, pad, repr_):

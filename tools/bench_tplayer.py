@@ -37,13 +37,46 @@ def layer_case(dev, B, L, S, p, fin):
     bwd = lambda: ops.tplayer_bwd(x, qpos, K, V, lp, lnF, 0.5, int(fin), p, p, p, seed, 10, 1e-5, None if fin else up, up if fin else None,
                                   None, None, True)
     tf, tb = timed(fwd), timed(bwd)
+    tb2 = tprep = float("nan")
+    if ops.tplayer2_geom(B, L, S)[0]:
+        args = (x, qpos, K, V, lp, lnF, 0.5, int(fin), p, p, p, seed, 10, 1e-5, None if fin else up, up if fin else None, None, None, True)
+        hm = torch.empty(B * L, dtype=torch.int64, device=dev)
+        ops.tplayer_fwd(x, qpos, K, V, lp, lnF, 0.5, int(fin), p, p, p, seed, 10, 1e-5, not fin, fin, hmask=hm)
+        bwd2 = lambda: ops.tplayer2_bwd(*args, hmask=hm)
+        tb2 = timed(bwd2)
+        nw, nkf = ops.tplayer2_geom(B, L, S)[5:7]
+        wimg = torch.empty(nw, dtype=torch.int32, device=dev)
+        kvf = torch.empty(nkf, dtype=torch.int32, device=dev)
+        prep = lambda: ops.call("tatt_tplayer2_prep", ops.P(lp[0]), ops.P(lp[2]), ops.P(lp[4]), ops.P(lp[6]), ops.P(K), ops.P(V), ops.P(wimg),
+                                ops.P(kvf), B, S, ops.stream())
+        tprep = timed(prep)
+        # kernel-level parity: second generation (split bf16) against the first (exact fp32), every output after its reducer
+        dx1, dq1, kv1, pp1 = ops.tplayer_bwd(*args)
+        dK1, dV1 = ops.tplayer_reduce_kv(kv1, B, L, S)
+        dx2, dq2, kv2, fl2, pp2, G2 = ops.tplayer2_bwd(*args, hmask=hm)
+        dK2, dV2 = ops.tplayer2_reduce_kv(kv2, fl2, B, L, S)
+        names = ["in_w", "in_b", "out_w", "out_b", "w1", "b1", "w2", "b2", "lnA_w", "lnA_b", "lnB_w", "lnB_b", "lnF_w", "lnF_b"]
+        shp = [(64, 64), (64,), (64, 64), (64,), (64, 64), (64,), (64, 64), (64,), (64,), (64,), (64,), (64,), (64,), (64,)]
+        g1 = [torch.zeros(*sh, device=dev) for sh in shp]
+        g2 = [torch.zeros(*sh, device=dev) for sh in shp]
+        if not fin:
+            g1[12] = g1[13] = g2[12] = g2[13] = None
+        ops.tplayer_reduce_params(pp1, B, L, g1)
+        ops.tplayer_reduce_params_g(pp2, G2, g2)
+        torch.cuda.synchronize()
+        worst = []
+        for n, a, b in [("dx", dx2, dx1), ("dqpos", dq2, dq1), ("dK", dK2, dK1), ("dV", dV2, dV1)] + [(n, a, b) for n, a, b in zip(names, g2, g1) if a is not None]:
+            e = float((a - b).abs().max()) / (float(b.abs().max()) + 1e-20)
+            worst.append((e, n))
+        worst.sort(reverse=True)
+        print("   gen2 vs gen1 (rel-max err): " + ", ".join("%s %.1e" % (n, e) for e, n in worst[:6]) + ("   ALL <= 1e-4" if worst[0][0] <= 1e-4 else "   MISMATCH"))
     tok = B * L
     f_fwd = tok * (4 * 2 * 64 * 64 + 2 * 2 * S * 64)                 # four 64x64 products + QK^T + PV per token
     f_bwd = tok * (12 * 2 * 64 * 64 + 6 * 2 * S * 64)                # recompute + data gradients + weight gradients
     b_fwd = tok * 64 * 4 * 3 + (tok * S * 4 if fin else 0)           # x, qpos in; one map out (+ weights map)
     b_bwd = tok * 64 * 4 * 5                                         # x, qpos, upstream in; dx, dqpos out
-    print("tplayer B=%d L=%d S=%d p=%.1f fin=%d: fwd %7.1f us %6.1f TFLOP/s %6.0f GB/s | bwd %7.1f us %6.1f TFLOP/s %6.0f GB/s" % (
-        B, L, S, p, fin, tf, f_fwd / tf / 1e6, b_fwd / tf / 1e3, tb, f_bwd / tb / 1e6, b_bwd / tb / 1e3))
+    print("tplayer B=%d L=%d S=%d p=%.1f fin=%d: fwd %7.1f us %6.1f TFLOP/s %6.0f GB/s | bwd %7.1f us %6.1f TFLOP/s %6.0f GB/s | bwd2 (prep + kernel) %7.1f us, prep alone %5.1f us" % (
+        B, L, S, p, fin, tf, f_fwd / tf / 1e6, b_fwd / tf / 1e3, tb, f_bwd / tb / 1e6, b_bwd / tb / 1e3, tb2, tprep))
     return tf, tb
 
 
@@ -51,6 +84,8 @@ def main():
     from __graft_entry__ import build
     build()
     dev = torch.device("cuda:0")
+    layer_case(dev, 2, 64, 26, 0.0, False)         # one work-group, one round: smallest case the second generation takes
+    layer_case(dev, 3, 128, 26, 0.1, True)
     for p in (0.0, 0.1):
         layer_case(dev, 48, 1024, 26, p, False)
         layer_case(dev, 48, 1024, 26, p, True)
