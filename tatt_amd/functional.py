@@ -75,6 +75,8 @@ class _DeferredParamGrads:
         self.enabled = False
         self.stage = 0                   # index of the backward stage whose main lane is running (set by the Trainer)
         self.due_of = {}                 # id(parameter) -> index of the stage (= gradient bucket) its gradient belongs to
+        self.immediate = frozenset()     # id(parameter): run the closure AT ONCE on `side_stream`, beside the main lane that produced it
+        self.side_stream = None          # the Trainer's second stream while a stage's main lane runs with two lanes
         self._pending = []
         self._keep = []
 
@@ -103,6 +105,17 @@ class _DeferredParamGrads:
         convolution's 0.4 ms weight gradient are filed under later buckets, where the main lane beside them has room)."""
         if not self.enabled or any(p is not None and not p.is_leaf for p in params):
             return self._run(fn)
+        if (self.side_stream is not None and lag == 0 and any(p is not None and id(p) in self.immediate for p in params)
+                and all(p is None or self.due_of.get(id(p), 0) <= self.stage for p in params)):
+            # lag 0: a side lane of the producing stage's OWN pass (the 9x9 output convolution's weight gradient is available at the
+            # first kernel of the backward and pass "trunk" has no other side work).  Same stream as every later side lane, so the
+            # gather of the bucket (next pass, that stream) and the per-pass join order it; operands stay referenced until release().
+            main = torch.cuda.current_stream(self.side_stream.device)
+            self.side_stream.wait_stream(main)
+            with torch.cuda.stream(self.side_stream):
+                self._assign(params, self._run(fn))
+            self._keep.append(keep)
+            return (None,) * len(params)
         due = self.stage + lag
         for p in params:                 # a parameter filed under a LATER bucket: its kernels run with that stage's side lane
             if p is not None:
@@ -224,7 +237,8 @@ class Conv2dFn(Function):
             db = ops.colsum(dy.reshape(-1, Cout)) if want_db else None
             return dw, db
         wleaf, bleaf = ctx.leaves
-        if want_dw and want_db and SIDE.enabled and SIDE.due_of.get(id(wleaf)) != SIDE.due_of.get(id(bleaf)):
+        if want_dw and want_db and SIDE.enabled and (SIDE.due_of.get(id(wleaf)) != SIDE.due_of.get(id(bleaf))
+                                                     or (id(wleaf) in SIDE.immediate) != (id(bleaf) in SIDE.immediate)):
             # weight and bias filed under different stages (tsrn.OUTCONV_*): two closures, each with its own stage's side lane
             (dw,) = SIDE.submit((wleaf,), lambda: (ops.conv_wgrad(x, dy, Cout, KH, KW),), x, dy)
             (db,) = SIDE.submit((bleaf,), lambda: (ops.colsum(dy.reshape(-1, Cout)),), dy)

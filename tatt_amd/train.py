@@ -289,6 +289,7 @@ class Trainer:
         # id(parameter) -> its bucket: a deferred weight-gradient closure runs with the side lane of that stage (or of the stage
         # that produced it, whichever is later), so that the bucket is complete when that side lane gathers it
         self._due = {id(p): k for k, (_, ps) in enumerate(buckets or []) for p in ps}
+        self._immediate = frozenset(id(p) for p in model.immediate_grad_params()) if hasattr(model, "immediate_grad_params") else frozenset()
         # installed on the model only while a step's forward runs (_main_lane): a forward made outside the Trainer -- a plain
         # loss.backward() loop, a gradient check -- sees an ordinary, uncut graph
         self.cuts = GradCuts() if staged and len(self.stages) > 1 else None
@@ -340,6 +341,8 @@ class Trainer:
         Fh.FWD_FORK.enabled = self.two_lanes
         Fh.SIDE.stage = k
         Fh.SIDE.due_of = self._due
+        Fh.SIDE.immediate = self._immediate
+        Fh.SIDE.side_stream = self.side if self.two_lanes and len(self.stages) > 1 else None
         try:
             if k == 0:
                 for p in self.params:
@@ -362,6 +365,7 @@ class Trainer:
                 self.cuts.run(self.stages[k])
         finally:
             Fh.SIDE.enabled = False
+            Fh.SIDE.side_stream = None
             Fh.FWD_FORK.enabled = False
             if k == 0 and self.cuts is not None:
                 self.model.set_grad_cuts(None)

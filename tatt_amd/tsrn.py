@@ -337,7 +337,12 @@ def _dec_params(dec):
 # block1's short backward and lengthens that pass by 0.47 ms -- more than the ~0.3 ms the 19 MB all-reduce costs when it trails the
 # last pass.  Off by default; tools/ab_bench.py tatt_amd.tsrn.DP_QGRU_WITH_TP=1 re-measures.
 DP_QGRU_WITH_TP = False
-# where the 9x9 output convolution's weight gradient is filed (see grad_buckets): "srb0" = beside the TP interpreter's backward
+# where the query GRU's backward (one persistent recurrence launch + four GEMMs since round 4) is filed: "first" = it runs beside the STN
+# head's backward (the last pass), "tp" = one pass earlier, beside block1's backward
+QGRU_BUCKET = "first"
+# where the 9x9 output convolution's weight gradient is filed (see grad_buckets): "srb0" = beside the TP interpreter's backward (rounds
+# 2-4), "trunk" = with its own stage (the side lane of the NEXT pass), "now" = its own stage's bucket AND issued at once on the second
+# stream, beside the backward from the loss that produced its operands (a pass with no other side work)
 OUTCONV_BUCKET = "srb0"
 # ... and its bias gradient (a column sum over the 196,608 HR pixels of a 4-channel map): beside the TP layers' backward it waits for
 # their work-groups to leave the CUs (156 us in the step, 15 alone) on a side lane that is the longer one of that pass; filed with its
@@ -483,7 +488,7 @@ class _TrainPathMixin:
             top = name.split(".", 1)[0]
             if top == "infoGen":
                 is_q = name.startswith("infoGen.transformer.gru_encoding.") or name.startswith("infoGen.init_factor.")
-                groups["first" if (is_q and not (dp and DP_QGRU_WITH_TP)) else "tp"].append(p)
+                groups[QGRU_BUCKET if (is_q and not (dp and DP_QGRU_WITH_TP)) else "tp"].append(p)
             elif top.startswith("block") and 2 <= int(top[5:]) <= k + 1:
                 groups["srb%d" % (int(top[5:]) - 2)].append(p)
             elif top.startswith("block") and int(top[5:]) > k + 1:
@@ -492,13 +497,21 @@ class _TrainPathMixin:
                 if late and name.endswith(".bias"):
                     groups[OUTCONV_BIAS_BUCKET].append(p)
                 else:
-                    groups[OUTCONV_BUCKET if late else "trunk"].append(p)
+                    groups[("trunk" if OUTCONV_BUCKET == "now" else OUTCONV_BUCKET) if late else "trunk"].append(p)
             elif top == "stn_head":
                 groups["stn"].append(p)
             else:                                  # block1, (TBSRN's unused conv / bn)
                 groups["first"].append(p)
         order = ["trunk"] + ["srb%d" % i for i in range(k - 1, -1, -1)] + ["tp", "first", "stn"]
         return [(n, groups[n]) for n in order if groups[n]]
+
+    def immediate_grad_params(self):
+        """Parameters whose gradient kernels run on the side lane of the very pass that produces them (OUTCONV_BUCKET = "now": the
+        9x9 output convolution's weight -- its operands exist at the first kernel of the backward, and that pass has no side work)."""
+        if OUTCONV_BUCKET != "now" or not hasattr(self, "infoGen") or self.srb_nums == 0:
+            return []
+        b8 = getattr(self, "block%d" % (self.srb_nums + 3))
+        return [b8[len(b8) - 1].weight]
 
     def _bn_on_path(self):
         skip = () if getattr(self, "stn", False) else ("stn_head",)

@@ -3,7 +3,7 @@
 # table, the kernel micro-benchmarks, then the whole -m gpu suite.  usage: tools/final_round.sh <tag>
 tag=${1:-r04}
 mkdir -p gpurun_out; export TMPDIR=/tmp
-b() { name=$1; shift; timeout 300 python bench.py --steps 30 --warmup 10 "$@" > gpurun_out/${tag}_bench_${name}.json 2> gpurun_out/${tag}_bench_${name}.err; echo "bench $name rc=$? $(cut -c1-200 gpurun_out/${tag}_bench_${name}.json)"; }
+b() { name=$1; shift; timeout 300 python bench.py --steps 50 --warmup 10 "$@" > gpurun_out/${tag}_bench_${name}.json 2> gpurun_out/${tag}_bench_${name}.err; echo "bench $name rc=$? $(cut -c1-200 gpurun_out/${tag}_bench_${name}.json)"; }
 b std
 b large --tile large
 b tsrn --arch tsrn --no-cpu-baseline

@@ -10,7 +10,7 @@ for cfg in "$@"; do
   name=${cfg%%:*}; flags=${cfg#*:}
   if [ "$name" == "prof" ]; then
     cd /tmp
-    timeout 240 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/${tag}_prof -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 5 --no-cpu-baseline $flags > $GRAFT_REPO_ROOT/gpurun_out/${tag}_prof.log 2>&1
+    timeout 240 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/${tag}_prof -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 5 --no-cpu-baseline --sustain 0 --no-exact-fp32 $flags > $GRAFT_REPO_ROOT/gpurun_out/${tag}_prof.log 2>&1
     cd $GRAFT_REPO_ROOT
     db=$(find gpurun_out/${tag}_prof -name "*.db" | head -1)
     python tools/prof_summary.py $db 15 > gpurun_out/${tag}_kernel_stats.txt 2>&1
