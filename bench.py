@@ -475,8 +475,6 @@ def main():
     graph_ok = use_graph                        # a failed hipGraph capture raises: the line below never reports eager as graph
     for _ in range(a.warmup):
         tr.step(x, tp, hr)
-    if pg is not None:
-        tr.profile_collectives = True               # event pairs around every wait for a collective: the time the step stream was blocked
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -493,9 +491,18 @@ def main():
     from tatt_amd import functional as _Fh
     _Fh.sync_check()                                 # launches that synchronise their work-groups in flight bound every spin: an expired one voids the run
     # after the timed region: a long replay (>= 2 s of GPU time: clocks and thermals settle, the driver's busy sampler sees it) ...
+    coll = None
+    if pg is not None:
+        # collectives profiled OUTSIDE the timed region, over a bounded number of steps: an event pair around every wait for a collective
+        # (the time the step's stream sat blocked behind it) and around every pass group
+        tr.profile_collectives = True
+        for _ in range(min(20, a.steps)):
+            tr.step(x, tp, hr)
+        barrier()
+        coll = tr.collective_report()
+        tr.profile_collectives = False
     sustained = None
     if a.sustain > 0:
-        tr.profile_collectives = False
         barrier()
         t1 = time.perf_counter()
         for _ in range(a.sustain):
@@ -601,8 +608,8 @@ def main():
             out[roof_other[0]] = roof_other[1]
         if attn is not None:
             out["roofline_attn"] = attn
-        if pg is not None:
-            out["collectives"] = tr.collective_report()
+        if coll is not None:
+            out["collectives"] = coll
         if world == 1 and not a.no_cpu_baseline and a.arch != "tatt_tpg":
             out["cpu_baseline"] = cpu_baseline(a.arch, a.cpu_batch if a.tile == "std" else min(a.cpu_batch, a.batch), a.tile)
         line = json.dumps(out)

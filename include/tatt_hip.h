@@ -533,6 +533,29 @@ int tatt_tplayer2_bwd(const float* x, const float* qpos, long qbs, const unsigne
                       hipStream_t st);
 int tatt_tplayer2_reduce_kv(const float* kvpart, const int* kvflags, float* dK, float* dV, int B, int L, int S, hipStream_t st);
 
+/* ---- launches that synchronise their work-groups in flight: residency and the sticky error word -------------------------------- */
+
+/* The persistent query-GRU recurrences (tatt_qgru_fwd_chain / _bwd_chain) and the STN-head launches (tatt_stn_*) exchange data between
+ * work-groups INSIDE a launch: their whole grid must be resident at once.  These report, for the CURRENT device, how many work-groups of
+ * each kernel fit (hipOccupancyMaxActiveBlocksPerMultiprocessor x the CUs the process sees), so that a caller on a partitioned or
+ * CU-masked device takes the per-step / operator-chain path instead:
+ *   tatt_qgru_chain_capacity: out[0] forward split-bf16, out[1] forward fp32, out[2] backward split-bf16, out[3] backward fp32
+ *                             (a launch needs (Wb / 16) * 2 * (HID / 16) work-groups);
+ *   tatt_stn_capacity:        out[0] the map launches (need <= 128), out[1] the fully connected launches (need 32). */
+int tatt_qgru_chain_capacity(int* out);
+int tatt_stn_capacity(int* out);
+/* Every wait inside those launches is bounded by the wall clock (2 s); one that expires raises the launch's own error word AND ORs a code
+ * (1: query GRU, 2: STN head) into the device's sticky word -- one zero-initialised 32-bit word in device memory registered here, which the
+ * library never resets (NULL unregisters). */
+int tatt_set_sticky(unsigned* word);
+/* One-thread launch that traps (GPU exception: the process dies) if the sticky word is non-zero; no-op without a registered word.  Issued
+ * in front of the optimiser kernels it keeps gradients of a launch that gave up waiting from ever reaching the weights. */
+int tatt_sync_guard(hipStream_t st);
+
+/* diagnostic: `groups` work-groups of 512 threads (lds_bytes of LDS each, <= 64 KB) that stay resident for `ticks` of the 100 MHz wall
+ * clock (<= 1 s) and do nothing else -- a stand-in for a collective's channel kernels in the residency tests; sink: any device word */
+int tatt_cu_holder(int groups, long ticks, int lds_bytes, unsigned* sink, hipStream_t st);
+
 /* ---- TPS rectification ---------------------------------------------------------------------------------- */
 
 /* src[b,p,:] = repr[p,:] @ (inv @ [ctrl[b]; pad])  (model/tps_spatial_transformer.py:103-105); N ctrl points, P pixels */

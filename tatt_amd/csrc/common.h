@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 
 #define TATT_API extern "C" __attribute__((visibility("default")))
 
@@ -11,6 +12,28 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define LAUNCH_CHECK() (int)hipGetLastError()
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Run `f` once per DEVICE at a call site (hipFuncSetAttribute and friends are per device: a process-wide std::once_flag would leave a
+// second GPU of the same process without the attribute).  `f` runs under the site's lock, so a concurrent caller on the same device
+// cannot launch before the attribute is set.
+struct TattPerDevice { std::mutex mu; bool done[64] = {}; };
+template <class F>
+static inline void tatt_per_device(TattPerDevice& s, F f) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { f(); return; }
+    std::lock_guard<std::mutex> lk(s.mu);
+    if (!s.done[dev]) { f(); s.done[dev] = true; }
+}
+
+// Sticky error word of the launches that synchronise their work-groups in flight (persistent query-GRU recurrences, STN-head launches):
+// one word per device, registered once by the host (tatt_set_sticky), never reset by the library.  A bounded spin that expires ORs a
+// code into it (besides the launch's own error word); tatt_sync_guard traps on it.  Defined in elementwise.hip; null until registered.
+unsigned* tatt_sticky_ptr();
+#define TATT_STICKY_QGRU 1u
+#define TATT_STICKY_STN 2u
+__device__ __forceinline__ void tatt_raise_sticky(unsigned* sticky, unsigned code) {
+    if (sticky) __hip_atomic_fetch_or(sticky, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // ---- activations ------------------------------------------------------------------------
 // mish(x) = x * tanh(softplus(x)), softplus threshold 20  (reference model/tsrn.py:1056-1064)

@@ -202,8 +202,8 @@ TATT_API int tatt_conv3_c64_fwd_t(const float* x, const float* wt, const float* 
                                   int Cout, int act, float beta, hipStream_t st) {
     if (Cin % 64 || Cout % 64 || W % C3_PX) return 1;
     Conv3P p = {x, wt, bias, y, B, H, W, Cin, Cout, act, beta};
-    static std::once_flag attr_once;                 // C++11 call_once: safe if several host threads launch
-    std::call_once(attr_once, [&] {
+    static TattPerDevice attr_once;                 // once per device, under the site lock (common.h)
+    tatt_per_device(attr_once, [&] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_fwd_v5_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   C5<32>::LDS);
     });
@@ -382,8 +382,8 @@ TATT_API int tatt_conv3_c64_fwd_ws16_bn(const float* x, const float* wl, const f
     if (stats && (Cout != 64 || act != ACT_NONE || beta != 0.f)) return 2;
     if (in_scale && (!in_shift || in_act == ACT_TANH)) return 3;
     Conv3P p = {x, wl, bias, y, B, H, W, 64, Cout, act, beta, in_scale, in_shift, in_act, stats};
-    static std::once_flag attr_once;                 // C++11 call_once: safe if several host threads launch
-    std::call_once(attr_once, [&] {
+    static TattPerDevice attr_once;                 // once per device, under the site lock (common.h)
+    tatt_per_device(attr_once, [&] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_ws16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W16_LDS);
     });
     const int cob = Cout / 64, npt = B * H * (W / C3_PX);
@@ -590,8 +590,8 @@ __global__ __launch_bounds__(512, 1) void conv3_c64_sb_kernel(Conv3SB q) {
 // gradient): chunk c of a mode-10/11 buffer starts c * Cout * 576 words in.  BatchNorm folding arguments as tatt_conv3_c64_fwd_ws16_bn.
 static int conv3_sb_launch(const Conv3SB& q, hipStream_t st) {
     const Conv3P& p = q.c;
-    static std::once_flag attr_once;
-    std::call_once(attr_once, [&] {
+    static TattPerDevice attr_once;
+    tatt_per_device(attr_once, [&] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_sb_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SB_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_sb_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SB_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_sb_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SB_LDS);
@@ -806,8 +806,8 @@ TATT_API int tatt_conv3_c64_wgrad_partial(const float* x, const float* dy, float
     if (Cin % 64 || Cout % 64 || W % C3_PX) return 1;
     const int nseg = B * H * (W / C3_PX);
     Conv3WP p = {x, dy, part, B, H, W, Cin, Cout, nseg, pdb};
-    static std::once_flag attr_once;                 // C++11 call_once: safe if several host threads launch
-    std::call_once(attr_once, [&] {
+    static TattPerDevice attr_once;                 // once per device, under the site lock (common.h)
+    tatt_per_device(attr_once, [&] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   C3_WG_LDS);
     });

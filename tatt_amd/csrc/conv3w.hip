@@ -1,5 +1,7 @@
-// Weight gradient of the 3x3 64-channel convolutions on the bf16 matrix cores by operand splitting -- NOT YET VALIDATED ON A GPU
-// (written at the end of round 3 without GPU time left; not in build.py's SOURCES, not bound in tatt_hip.h).
+// Weight gradient of the 3x3 64-channel convolutions on the bf16 matrix cores by operand splitting (tatt_conv3_c64_wgrad_partial_sb).
+// Written in round 3, validated on the GPU and made the default in round 4 (ops.CONV3_WGRAD_SB = True): against fp64 at all four
+// shapes of the step + the bias gradient (tests/test_kernels_gpu.py::test_conv3_wgrad_split_bf16_vs_fp64, ::test_conv3_wgrad_bias_gradient),
+// inside the model-level fp64 yardsticks (tests/test_model_gpu.py), and in tools/emulate_conv3w.py (CPU emulation of the fragment algebra).
 //   dW[tap][ci][co] = sum over pixels of x[px + tap - 1][ci] * dy[px][co]        (+ db[co] = sum of dy[px][co])
 // Same arithmetic as tatt_conv3_c64_fwd_sb / tatt_gru_wgrad_sb: a = hi + lo (bf16 each), a*b = hi hi + hi lo + lo hi, fp32
 // accumulation.  The contraction runs over PIXELS, so an MFMA operand (v_mfma_f32_16x16x32_bf16) needs 8 consecutive pixels of one
@@ -184,8 +186,8 @@ TATT_API int tatt_conv3_c64_wgrad_partial_sb(const float* x, const float* dy, fl
     if (Cin % 64 || Cout % 64 || W % CW_PX) return 1;
     const int nseg = B * H * (W / CW_PX);
     Conv3WSP p = {x, dy, part, B, H, W, Cin, Cout, nseg, pdb};
-    static std::once_flag attr_once;
-    std::call_once(attr_once, [&] {
+    static TattPerDevice attr_once;
+    tatt_per_device(attr_once, [&] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_wgrad_sb_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS);
     });
     hipLaunchKernelGGL(conv3_c64_wgrad_sb_kernel, dim3(G, (Cin / 64) * (Cout / 64)), dim3(512), CW_LDS, st, p);

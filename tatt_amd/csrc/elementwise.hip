@@ -370,3 +370,57 @@ TATT_API int tatt_adam_step(float* p, const float* g, float* m, float* v, long n
     hipLaunchKernelGGL(adam_kernel, EW_GRID((n >> 2) + 1), 0, st, p, g, m, v, n, lr, b1, b2, eps, gnorm, max_norm, gscale, step);
     return LAUNCH_CHECK();
 }
+
+// ---- sticky error word + guard (see common.h) ---------------------------------------------------------------------------------------
+#include <mutex>
+static std::mutex g_sticky_mu;
+static unsigned* g_sticky[64] = {};
+unsigned* tatt_sticky_ptr() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lk(g_sticky_mu);
+    return g_sticky[dev];
+}
+// word: one zero-initialised 32-bit word in the CURRENT device's memory that outlives every launch (NULL: unregister)
+TATT_API int tatt_set_sticky(unsigned* word) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 1;
+    std::lock_guard<std::mutex> lk(g_sticky_mu);
+    g_sticky[dev] = word;
+    return 0;
+}
+__global__ void sync_guard_kernel(const unsigned* word) {
+    if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) __builtin_trap();
+}
+// One-thread launch that TRAPS (the process dies with a GPU exception) if a launch that synchronises its work-groups in flight has given
+// up waiting since the word was registered: issued in front of the optimiser, it keeps invalid gradients from ever reaching the weights.
+// Returns 0 without launching when no word is registered.
+TATT_API int tatt_sync_guard(hipStream_t st) {
+    unsigned* w = tatt_sticky_ptr();
+    if (!w) return 0;
+    hipLaunchKernelGGL(sync_guard_kernel, dim3(1), dim3(1), 0, st, w);
+    return LAUNCH_CHECK();
+}
+
+// ---- a resident "CU holder" (diagnostic) -----------------------------------------------------------------------------------------------
+// `groups` work-groups of 512 threads that do nothing but stay resident for `ticks` of the 100 MHz wall clock: what a collective's channel
+// kernels look like to the launches that need their whole grid co-resident (RCCL keeps one work-group per channel on a CU for the length
+// of the collective).  lds_bytes of dynamic LDS per group are touched so that the allocation is real.  The tests launch it on a second
+// stream beside the persistent query-GRU chains and the STN-head launches.
+__global__ __launch_bounds__(512) void cu_holder_kernel(long ticks, unsigned* sink, int lds_words) {
+    extern __shared__ unsigned hold_lds[];
+    for (int i = threadIdx.x; i < lds_words; i += 512) hold_lds[i] = i;
+    __syncthreads();
+    const long t0 = wall_clock64();
+    unsigned acc = 0;
+    while (wall_clock64() - t0 < ticks) {
+        acc += lds_words ? hold_lds[(threadIdx.x + acc) % lds_words] : 1u;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    if (acc == 0xffffffffu && sink) sink[0] = acc;            // (keeps the loop alive for the compiler)
+}
+TATT_API int tatt_cu_holder(int groups, long ticks, int lds_bytes, unsigned* sink, hipStream_t st) {
+    if (groups < 1 || groups > 1024 || ticks < 0 || ticks > 100000000L || lds_bytes < 0 || lds_bytes > 65536) return 1;
+    hipLaunchKernelGGL(cu_holder_kernel, dim3(groups), dim3(512), lds_bytes, st, ticks, sink, lds_bytes / 4);
+    return LAUNCH_CHECK();
+}

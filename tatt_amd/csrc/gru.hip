@@ -857,6 +857,7 @@ struct QChainP {
     unsigned* flags;
     int T, Wb, s0, s1, transposed;
     float* xch[2];      // SB: the exchanged tensor in matrix-core operand form, (T, Wb, 3*HID / 8) x {8 bf16 hi, 8 bf16 lo}
+    unsigned* sticky;   // the device's sticky error word (common.h), may be null
 };
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 typedef __bf16 qc_bf16x8 __attribute__((ext_vector_type(8)));
@@ -950,7 +951,7 @@ __global__ __launch_bounds__(512) void qgru_bwd_chain_kernel(QChainP p) {
                     if (__builtin_amdgcn_ballot_w64(f < (unsigned)s) == 0) break;
                     __builtin_amdgcn_s_sleep(1);
                     if ((++it & 63) == 0 && wall_clock64() - t0 > QCH_SPIN_TICKS) {
-                        if (lane == 0) { s_dead = 1; __hip_atomic_store(p.flags + QCH_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                        if (lane == 0) { s_dead = 1; __hip_atomic_store(p.flags + QCH_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); tatt_raise_sticky(p.sticky, TATT_STICKY_QGRU); }
                         break;
                     }
                 }
@@ -1072,7 +1073,7 @@ TATT_API int tatt_qgru_bwd_chain(float* dgh0, float* dgh1, const float* whhT0, c
     if ((xch0 == nullptr) != (xch1 == nullptr)) return 1;
     if (s0 == 0 && hipMemsetAsync(sync, 0, 1024 * sizeof(unsigned), st) != hipSuccess) return 3;
     QChainP p = {{dgh0, dgh1}, {whhT0, whhT1}, {dhseq0, dhseq1}, {gsave0, gsave1}, {hbuf0, hbuf1}, {dhcarry0, dhcarry1},
-                 {dgi_acc0, dgi_acc1}, sync, T, Wb, s0, s1, transposed, {xch0, xch1}};
+                 {dgi_acc0, dgi_acc1}, sync, T, Wb, s0, s1, transposed, {xch0, xch1}, tatt_sticky_ptr()};
     if (xch0) hipLaunchKernelGGL(qgru_bwd_chain_kernel<true>, dim3((Wb / 16) * 2 * (HID / 16)), dim3(512), 0, st, p);
     else hipLaunchKernelGGL(qgru_bwd_chain_kernel<false>, dim3((Wb / 16) * 2 * (HID / 16)), dim3(512), 0, st, p);
     return LAUNCH_CHECK();
@@ -1092,6 +1093,7 @@ struct QFChainP {
     // q != NULL: h also leaves in the layout the TP interpreter reads, q[n][d*Hh + j / C][w][j % C] (n = time, w = row, j = unit)
     float* q; int C;
     float* xch[2];      // SB: h in matrix-core operand form, (T+1 slots as hbuf, Wb, HID / 8) x {8 bf16 hi, 8 bf16 lo}
+    unsigned* sticky;   // the device's sticky error word (common.h), may be null
 };
 template <bool SB>
 __global__ __launch_bounds__(512) void qgru_fwd_chain_kernel(QFChainP p) {
@@ -1189,7 +1191,7 @@ __global__ __launch_bounds__(512) void qgru_fwd_chain_kernel(QFChainP p) {
                     if (__builtin_amdgcn_ballot_w64(f < (unsigned)s) == 0) break;
                     __builtin_amdgcn_s_sleep(1);
                     if ((++it & 63) == 0 && wall_clock64() - t0 > QCH_SPIN_TICKS) {
-                        if (lane == 0) { s_dead = 1; __hip_atomic_store(p.flags + QCH_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                        if (lane == 0) { s_dead = 1; __hip_atomic_store(p.flags + QCH_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); tatt_raise_sticky(p.sticky, TATT_STICKY_QGRU); }
                         break;
                     }
                 }
@@ -1300,10 +1302,27 @@ TATT_API int tatt_qgru_fwd_chain(const float* gi0, const float* gi1, const float
     if (s0 == 0 && hipMemsetAsync(sync, 0, 1024 * sizeof(unsigned), st) != hipSuccess) return 3;
     if ((xch0 == nullptr) != (xch1 == nullptr) || (xch0 && s0 != 0)) return 1;      // (the split form runs the whole chain in one launch)
     QFChainP p = {{gi0, gi1}, {whh0, whh1}, {bhh0, bhh1}, {hbuf0, hbuf1}, {gsave0, gsave1}, sync, T, Wb, s0, s1,
-                  x, {wih0, wih1}, {bih0, bih1}, IN, q, C, {xch0, xch1}};
+                  x, {wih0, wih1}, {bih0, bih1}, IN, q, C, {xch0, xch1}, tatt_sticky_ptr()};
     if (xch0) hipLaunchKernelGGL(qgru_fwd_chain_kernel<true>, dim3((Wb / 16) * 2 * (HID / 16)), dim3(512), 0, st, p);
     else hipLaunchKernelGGL(qgru_fwd_chain_kernel<false>, dim3((Wb / 16) * 2 * (HID / 16)), dim3(512), 0, st, p);
     return LAUNCH_CHECK();
+}
+
+// Work-groups of each persistent launch that can be resident on the CURRENT device at once (occupancy per CU x CUs the process sees):
+// out[0] forward split-bf16, out[1] forward fp32, out[2] backward split-bf16, out[3] backward fp32.  The chains need their whole grid
+// ((Wb / 16) * 2 * (HID / 16) work-groups) co-resident: on a partitioned / CU-masked device the caller takes the per-step launches.
+TATT_API int tatt_qgru_chain_capacity(int* out) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 1;
+    const void* k[4] = {reinterpret_cast<const void*>(qgru_fwd_chain_kernel<true>), reinterpret_cast<const void*>(qgru_fwd_chain_kernel<false>),
+                        reinterpret_cast<const void*>(qgru_bwd_chain_kernel<true>), reinterpret_cast<const void*>(qgru_bwd_chain_kernel<false>)};
+    for (int i = 0; i < 4; ++i) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k[i], 512, 0) != hipSuccess) return 2;
+        out[i] = n * prop.multiProcessorCount;
+    }
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -192,8 +192,8 @@ TATT_API int tatt_gru_wgrad_sb(const float* dgi, const float* dgh, const float* 
     if (M <= 0 || M % GW_TOK) return 1;
     const int nchunks = M / GW_TOK;
     if (G < 1 || G > nchunks || G > 256) return 2;
-    static std::once_flag attr_once;
-    std::call_once(attr_once, [&] {
+    static TattPerDevice attr_once;
+    tatt_per_device(attr_once, [&] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gru_wgrad_sb_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, GW_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gru_wgrad_sb_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, GW_LDS);
     });

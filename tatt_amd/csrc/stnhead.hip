@@ -43,7 +43,7 @@ __device__ __forceinline__ void sn_publish(unsigned* sync, int g, unsigned val) 
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(sync + g, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void sn_wait(unsigned* sync, int G, unsigned val, int* s_dead) {
+__device__ __forceinline__ void sn_wait(unsigned* sync, int G, unsigned val, int* s_dead, unsigned* sticky) {
     if (threadIdx.x < 64 && !*s_dead) {
         const int lane = threadIdx.x;
         const long t0 = wall_clock64();
@@ -54,7 +54,7 @@ __device__ __forceinline__ void sn_wait(unsigned* sync, int G, unsigned val, int
             if (__builtin_amdgcn_ballot_w64((int)(f0 - val) < 0 || (int)(f1 - val) < 0) == 0) break;
             __builtin_amdgcn_s_sleep(1);
             if ((++it & 63) == 0 && wall_clock64() - t0 > SN_SPIN_TICKS) {
-                if (lane == 0) { *s_dead = 1; __hip_atomic_store(sync + SN_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                if (lane == 0) { *s_dead = 1; __hip_atomic_store(sync + SN_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); tatt_raise_sticky(sticky, TATT_STICKY_STN); }
                 break;
             }
         }
@@ -97,7 +97,7 @@ __device__ __forceinline__ void sn_allsum(double (*red)[4][64], double* v, int c
 // ---------------------------------------------------------------------------------------------------------------------------------
 struct SnFwdP {
     const float* X; float* A; const float* gamma; const float* beta; float* mean; float* rstd; float* running_mean; float* running_var;
-    double* part; unsigned* sync; SnGeom g; float eps, momentum;
+    double* part; unsigned* sync; SnGeom g; float eps, momentum; unsigned* sticky;
 };
 template <int PH, int PW>
 __global__ __launch_bounds__(256) void stn_bn_pool_fwd_kernel(SnFwdP p) {
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void stn_bn_pool_fwd_kernel(SnFwdP p) {
         v[0] = acc[6]; v[1] = acc[7]; st16_sc1(p.part, d + C * 8 + 16, v);
     }
     sn_publish(p.sync, g, ep * 4 + 1);
-    sn_wait(p.sync, G, ep * 4 + 1, &s_dead);
+    sn_wait(p.sync, G, ep * 4 + 1, &s_dead, p.sticky);
     if (g == 0 && t == 0) __hip_atomic_store(p.sync + SN_EPOCH, ep + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // totals: every work-group adds the G partials in the same order (row lane rl takes partials rl, rl + RL, ...; then sn_allsum)
 #pragma unroll
@@ -212,7 +212,7 @@ TATT_API int tatt_stn_bn_pool_fwd(const float* X, float* A, const float* gamma, 
                                   int ph, int pw, float eps, float momentum, hipStream_t st) {
     if (!sn_geom_ok(B, H, W, C, ph, pw)) return 1;
     SnGeom g = {B, H, W, C, sn_groups((long)B * (H / ph) * (W / pw), C)};
-    SnFwdP p = {X, A, gamma, beta, mean, rstd, running_mean, running_var, part, sync, g, eps, momentum};
+    SnFwdP p = {X, A, gamma, beta, mean, rstd, running_mean, running_var, part, sync, g, eps, momentum, tatt_sticky_ptr()};
     if (ph == 2) hipLaunchKernelGGL((stn_bn_pool_fwd_kernel<2, 2>), dim3(g.G), dim3(256), 0, st, p);
     else if (pw == 2) hipLaunchKernelGGL((stn_bn_pool_fwd_kernel<1, 2>), dim3(g.G), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((stn_bn_pool_fwd_kernel<1, 1>), dim3(g.G), dim3(256), 0, st, p);
@@ -226,7 +226,7 @@ TATT_API int tatt_stn_bn_pool_fwd(const float* X, float* A, const float* gamma, 
 // ---------------------------------------------------------------------------------------------------------------------------------
 struct SnBwdP {
     const float* X; const float* dA; const float* gamma; const float* beta; const float* mean; const float* rstd;
-    float* dX; float* dgamma; float* dbeta; float* dbias; double* part; unsigned* sync; SnGeom g;
+    float* dX; float* dgamma; float* dbeta; float* dbias; double* part; unsigned* sync; SnGeom g; unsigned* sticky;
 };
 template <int PH, int PW>
 __global__ __launch_bounds__(256) void stn_bn_pool_bwd_kernel(SnBwdP p) {
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void stn_bn_pool_bwd_kernel(SnBwdP p) {
         v[0] = acc[6]; v[1] = acc[7]; st16_sc1(p.part, d + C * 8 + 16, v);
     }
     sn_publish(p.sync, g, ep * 4 + 1);
-    sn_wait(p.sync, G, ep * 4 + 1, &s_dead);
+    sn_wait(p.sync, G, ep * 4 + 1, &s_dead, p.sticky);
     if (g == 0 && t == 0) __hip_atomic_store(p.sync + SN_EPOCH, ep + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0;
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) void stn_bn_pool_bwd_kernel(SnBwdP p) {
     }
     sn_publish(p.sync, g, ep * 4 + 2);
     if (g != 0) return;
-    sn_wait(p.sync, G, ep * 4 + 2, &s_dead);
+    sn_wait(p.sync, G, ep * 4 + 2, &s_dead, p.sticky);
     double s[4] = {0, 0, 0, 0};
     for (int gg = rl; gg < G; gg += RL) {
         const int d = (gg * 3 * C + 2 * C + cq * 4) * 8;
@@ -364,7 +364,7 @@ TATT_API int tatt_stn_bn_pool_bwd(const float* X, const float* dA, const float* 
                                   unsigned* sync, int B, int H, int W, int C, int ph, int pw, hipStream_t st) {
     if (!sn_geom_ok(B, H, W, C, ph, pw)) return 1;
     SnGeom g = {B, H, W, C, sn_groups((long)B * (H / ph) * (W / pw), C)};
-    SnBwdP p = {X, dA, gamma, beta, mean, rstd, dX, dgamma, dbeta, dbias, part, sync, g};
+    SnBwdP p = {X, dA, gamma, beta, mean, rstd, dX, dgamma, dbeta, dbias, part, sync, g, tatt_sticky_ptr()};
     if (ph == 2) hipLaunchKernelGGL((stn_bn_pool_bwd_kernel<2, 2>), dim3(g.G), dim3(256), 0, st, p);
     else if (pw == 2) hipLaunchKernelGGL((stn_bn_pool_bwd_kernel<1, 2>), dim3(g.G), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((stn_bn_pool_bwd_kernel<1, 1>), dim3(g.G), dim3(256), 0, st, p);
@@ -383,7 +383,7 @@ TATT_API int tatt_stn_bn_pool_bwd(const float* X, const float* dA, const float* 
 struct SnFcFwdP {
     const float* A6; const float* W1; const float* b1; const float* g1; const float* be1; float* rm1; float* rv1;
     const float* W2; const float* b2; float* U; float* mean1; float* rstd1; float* S; float* ctrl; float* part; unsigned* sync;
-    int B, NO; float eps, momentum;
+    int B, NO; float eps, momentum; unsigned* sticky;
 };
 __global__ __launch_bounds__(512) void stn_fc_fwd_kernel(SnFcFwdP p) {
     __shared__ float red[8][4][16][17];
@@ -488,7 +488,7 @@ __global__ __launch_bounds__(512) void stn_fc_fwd_kernel(SnFcFwdP p) {
     }
     sn_publish(p.sync, g, ep * 4 + 1);
     if (g != 0) return;
-    sn_wait(p.sync, 32, ep * 4 + 1, &s_dead);
+    sn_wait(p.sync, 32, ep * 4 + 1, &s_dead, p.sticky);
     if (t == 0) __hip_atomic_store(p.sync + SN_EPOCH, ep + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int idx = t; idx < nq; idx += 512) {
         const int o = (idx * 4) % NO;
@@ -506,7 +506,7 @@ TATT_API int tatt_stn_fc_fwd(const float* A6, const float* W1, const float* b1, 
                              float* rv1, const float* W2, const float* b2, float* U, float* mean1, float* rstd1, float* S,
                              float* ctrl, float* part, unsigned* sync, int B, int NO, float eps, float momentum, hipStream_t st) {
     if (B < 1 || B > 64 || NO % 4 || NO < 4 || NO > 64) return 1;
-    SnFcFwdP p = {A6, W1, b1, g1, be1, rm1, rv1, W2, b2, U, mean1, rstd1, S, ctrl, part, sync, B, NO, eps, momentum};
+    SnFcFwdP p = {A6, W1, b1, g1, be1, rm1, rv1, W2, b2, U, mean1, rstd1, S, ctrl, part, sync, B, NO, eps, momentum, tatt_sticky_ptr()};
     hipLaunchKernelGGL(stn_fc_fwd_kernel, dim3(32), dim3(512), 0, st, p);
     return LAUNCH_CHECK();
 }
@@ -518,7 +518,7 @@ struct SnFcBwdP {
     const float* dctrl; const float* W2; const float* S; const float* U; const float* mean1; const float* rstd1; const float* g1;
     const float* W1; const float* A6;
     float* dW2; float* db2; float* dg1; float* dbe1; float* dW1; float* db1; float* dU; float* dA6; unsigned* sync;
-    int B, NO;
+    int B, NO; unsigned* sticky;
 };
 // (96 registers: two of its waves per SIMD fit beside the two of a resident query-GRU recurrence work-group with room to spare)
 __global__ __launch_bounds__(512, 5) void stn_fc_bwd_kernel(SnFcBwdP p) {
@@ -620,7 +620,7 @@ __global__ __launch_bounds__(512, 5) void stn_fc_bwd_kernel(SnFcBwdP p) {
 #pragma unroll
         for (int jj = 0; jj < 16; ++jj) p.dW1[(long)(j0 + jj) * FC_H + t] = a[jj];
     }
-    sn_wait(p.sync, 32, ep * 4 + 1, &s_dead);
+    sn_wait(p.sync, 32, ep * 4 + 1, &s_dead, p.sticky);
     if (g == 0 && t == 0) __hip_atomic_store(p.sync + SN_EPOCH, ep + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // phase B: dF[b][k] = sum_j dU[b][j] W1[j][k] for k = 16 g + n
     f32x4 acc[4];
@@ -667,7 +667,35 @@ TATT_API int tatt_stn_fc_bwd(const float* dctrl, const float* W2, const float* S
                              float* dg1, float* dbe1, float* dW1, float* db1, float* dU, float* dA6, unsigned* sync, int B, int NO,
                              hipStream_t st) {
     if (B < 1 || B > 64 || NO % 4 || NO < 4 || NO > 64) return 1;
-    SnFcBwdP p = {dctrl, W2, S, U, mean1, rstd1, g1, W1, A6, dW2, db2, dg1, dbe1, dW1, db1, dU, dA6, sync, B, NO};
+    SnFcBwdP p = {dctrl, W2, S, U, mean1, rstd1, g1, W1, A6, dW2, db2, dg1, dbe1, dW1, db1, dU, dA6, sync, B, NO, tatt_sticky_ptr()};
     hipLaunchKernelGGL(stn_fc_bwd_kernel, dim3(32), dim3(512), 0, st, p);
     return LAUNCH_CHECK();
+}
+
+// Work-groups of each launch above that can be resident on the CURRENT device at once (occupancy per CU x CUs the process sees), the
+// smallest over the kernels of a kind: out[0] the map launches (need g.G <= SN_MAXG = 128 co-resident), out[1] the fully connected
+// launches (need 32).  On a partitioned / CU-masked device that cannot hold them the caller walks the operator chain instead.
+TATT_API int tatt_stn_capacity(int* out) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 1;
+    const void* km[6] = {reinterpret_cast<const void*>(stn_bn_pool_fwd_kernel<2, 2>), reinterpret_cast<const void*>(stn_bn_pool_fwd_kernel<1, 2>),
+                         reinterpret_cast<const void*>(stn_bn_pool_fwd_kernel<1, 1>), reinterpret_cast<const void*>(stn_bn_pool_bwd_kernel<2, 2>),
+                         reinterpret_cast<const void*>(stn_bn_pool_bwd_kernel<1, 2>), reinterpret_cast<const void*>(stn_bn_pool_bwd_kernel<1, 1>)};
+    const void* kf[2] = {reinterpret_cast<const void*>(stn_fc_fwd_kernel), reinterpret_cast<const void*>(stn_fc_bwd_kernel)};
+    int lo = 1 << 30;
+    for (int i = 0; i < 6; ++i) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, km[i], 256, 0) != hipSuccess) return 2;
+        lo = n * prop.multiProcessorCount < lo ? n * prop.multiProcessorCount : lo;
+    }
+    out[0] = lo;
+    lo = 1 << 30;
+    for (int i = 0; i < 2; ++i) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kf[i], 512, 0) != hipSuccess) return 2;
+        lo = n * prop.multiProcessorCount < lo ? n * prop.multiProcessorCount : lo;
+    }
+    out[1] = lo;
+    return 0;
 }

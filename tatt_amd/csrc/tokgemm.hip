@@ -200,8 +200,8 @@ TATT_API int tatt_tokgemm_pack_batch(const float* const* ptrs, const int* dims, 
 template <int NCB, int KS>
 static int tg_launch(const TokGemmP& p, hipStream_t st) {
     constexpr int lds = 2 * 2 * 64 * (32 * KS / 2 + 8) * 4;
-    static std::once_flag once;
-    std::call_once(once, [] {
+    static TattPerDevice once;
+    tatt_per_device(once, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tokgemm_sb_kernel<NCB, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     });
     const int ntiles = p.M / 64;

@@ -597,8 +597,8 @@ static inline TLGeom tl_geom(int B, int L) {
     return g;
 }
 static void tl_set_attr() {
-    static std::once_flag once;
-    std::call_once(once, [] {
+    static TattPerDevice once;
+    tatt_per_device(once, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tplayer_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, TL_LDS_BYTES);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tplayer_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, TL_LDS_BYTES);
     });

@@ -846,17 +846,10 @@ TATT_API int tatt_tplayer2_bwd(const float* x, const float* qpos, long qbs, cons
     p.p_attn = p_attn; p.p_res = p_res; p.p_ffn = p_ffn; p.seed = seed; p.site0 = site0; p.eps = eps;
     p.dxout = dxout; p.dfin = dfin; p.dwavg = dwavg; p.dqacc = dqacc;
     p.dx = dx; p.dqpos = dqpos; p.kvpart = kvpart; p.ppart = ppart; p.kvflags = kvflags; p.hmask = hmask;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    static std::mutex mu;
-    static bool done[64] = {};
-    {
-        std::lock_guard<std::mutex> lk(mu);                  // the attribute is per device
-        if (dev >= 0 && dev < 64 && !done[dev]) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tplayer2_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS_BYTES);
-            done[dev] = true;
-        }
-    }
+    static TattPerDevice attr;
+    tatt_per_device(attr, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tplayer2_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS_BYTES);
+    });
     hipLaunchKernelGGL(tplayer2_bwd_kernel, dim3(g.G), dim3(T2_NT), T2_LDS_BYTES, st, p);
     return LAUNCH_CHECK();
 }

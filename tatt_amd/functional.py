@@ -1107,11 +1107,57 @@ QGRU_CHAIN_SB = True
 QGRU_CHAIN_SYNC = []
 
 
-def _qgru_chain_takes(W, HID):
-    return HID == 512 and W % 16 == 0 and (W // 16) * 2 * (HID // 16) <= 256
+# ---- residency and the sticky error word of the launches that synchronise their work-groups in flight --------------------------------
+_CAPACITY = {}           # device index -> (query-GRU chain capacities x4, STN map launches, STN fully connected launches)
+_STICKY = {}             # device index -> the device's sticky error word (int32 x 4; word 0 is registered with the library)
+
+
+def _has_gpu():
+    return torch.cuda.is_available()
+
+
+def sync_capacity(device=None):
+    """Work-groups of each in-flight-synchronising kernel that fit on the device at once (tatt_qgru_chain_capacity, tatt_stn_capacity:
+    occupancy per CU x the CUs this process sees), asked once per device.  Those launches are only correct with their whole grid
+    resident: on a partitioned or CU-masked GPU the callers below take the per-step / operator-chain paths instead."""
+    idx = torch.cuda.current_device() if device is None else torch.device(device).index
+    if idx not in _CAPACITY:
+        import ctypes
+        q, s = (ctypes.c_int * 4)(), (ctypes.c_int * 2)()
+        with torch.cuda.device(idx):
+            ops.call("tatt_qgru_chain_capacity", q)
+            ops.call("tatt_stn_capacity", s)
+        _CAPACITY[idx] = (q[0], q[1], q[2], q[3], s[0], s[1])
+    return _CAPACITY[idx]
+
+
+def sticky_word(device):
+    """The device's sticky error word: allocated (zero) and registered with the library on first use -- outside any capture, so that no
+    replayed fill ever resets it (the Trainer asks for it when it is built).  A wait that expires in any query-GRU chain or STN-head
+    launch ORs a code into it; nothing but a new process clears it."""
+    idx = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if idx not in _STICKY:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("tatt_amd: the sticky error word must be allocated outside a graph capture (build the Trainer first)")
+        w = torch.zeros(4, dtype=torch.int32, device=torch.device("cuda", idx))
+        with torch.cuda.device(idx):
+            ops.call("tatt_set_sticky", ops.P(w))
+        _STICKY[idx] = w
+    return _STICKY[idx]
+
+
+def _qgru_chain_takes(W, HID, bwd=False):
+    if not (HID == 512 and W % 16 == 0 and (W // 16) * 2 * (HID // 16) <= 256):
+        return False
+    if not _has_gpu():                           # (host-only callers: the geometry predicate alone)
+        return True
+    cap = sync_capacity()
+    return (W // 16) * 2 * (HID // 16) <= cap[(2 if bwd else 0) + (0 if QGRU_CHAIN_SB else 1)]
 
 
 def _qgru_chain_sync(ref):
+    if not torch.cuda.is_current_stream_capturing():
+        sticky_word(ref.device)                  # (registered before the first launch that could raise it)
     sync = torch.empty(1024, device=ref.device, dtype=torch.int32)
     QGRU_CHAIN_SYNC.append(sync)
     del QGRU_CHAIN_SYNC[:-8]
@@ -1178,7 +1224,7 @@ class QueryGruFn(Function):
         # W_hh^T of both directions for the per-step backward kernels (their B operand wants the 3*HID axis contiguous): parameters
         # only, so the two transposes ride on this forked branch.  The persistent backward launch reads W_hh as it is stored.
         whhT = None
-        if any(ctx.needs_input_grad[:9]) and not (QGRU_CHAIN_BWD and _qgru_chain_takes(W, HID) and B > 1):
+        if any(ctx.needs_input_grad[:9]) and not (QGRU_CHAIN_BWD and _qgru_chain_takes(W, HID, True) and B > 1):
             whhT = ops.new(dev, 2, HID, 3 * HID)
             for d, whh in enumerate((whh0, whh1)):                 # (3*HID, HID) -> (HID, 3*HID)
                 ops.copy4d(whh, whhT[d], (1, 1, HID, 3 * HID), (0, 0, 1, HID), (0, 0, 3 * HID, 1))
@@ -1218,7 +1264,7 @@ class QueryGruFn(Function):
         ops.call("tatt_qgru_bwd_gates", ops.P(dhseq[0, B - 1]), ops.P(dhseq[1, 0]), ops.P(gsave[0, B - 1]),
                  ops.P(gsave[1, 0]), ops.P(hp0), ops.P(hp1), ops.P(dhc[0]), ops.P(dhc[1]), ops.P(dgi_acc[0]),
                  ops.P(dgi_acc[1]), ops.P(dgh[0, B - 1]), ops.P(dgh[1, 0]), W, HID, 1, ops.stream())
-        chain = (QGRU_CHAIN_BWD or whhT is None) and _qgru_chain_takes(W, HID) and B > 1
+        chain = (QGRU_CHAIN_BWD or whhT is None) and _qgru_chain_takes(W, HID, True) and B > 1
         if whhT is None and not chain and B > 1:
             raise RuntimeError("tatt_amd: QGRU_CHAIN_BWD was switched off between a forward and its backward")
         if chain:
@@ -1297,15 +1343,25 @@ def _stn_sync(holder, site, ref):
     table = holder.__dict__.setdefault("_tatt_sync", {})
     key = (site, ref.device)
     if key not in table:
+        if not torch.cuda.is_current_stream_capturing():
+            sticky_word(ref.device)
         table[key] = torch.zeros(256, device=ref.device, dtype=torch.int32)
+    buf = table[key]
+    if not any(r() is buf for r in STN_SYNC):        # registered on LOOKUP: a deep-copied / unpickled module brings its buffers unregistered
         STN_SYNC[:] = [r for r in STN_SYNC if r() is not None]      # (the buffers belong to their module and go with it)
-        STN_SYNC.append(weakref.ref(table[key]))
-    return table[key]
+        STN_SYNC.append(weakref.ref(buf))
+    return buf
 
 
 def sync_check():
     """Raise if a launch that synchronises its work-groups in flight gave up waiting (every such spin is bounded by the wall clock).
     Synchronises the device: call it outside a capture."""
+    for idx, w in _STICKY.items():               # the sticky word first: it also remembers launches whose own words are gone
+        code = int(w[0].item())
+        if code:
+            raise RuntimeError("tatt_amd: a launch that synchronises its work-groups in flight gave up waiting on cuda:%d (%s): its "
+                               "results -- and everything computed from them since -- are invalid (work-groups not co-resident?)" % (
+                                   idx, " + ".join(n for b, n in ((1, "query-GRU chain"), (2, "STN head")) if code & b)))
     qgru_chain_check()
     for r in STN_SYNC:
         s = r()
@@ -1318,8 +1374,13 @@ def stn_head_fusable(x, stn, B):
     if not all(bn.training and bn.momentum is not None and bn.affine and bn.track_running_stats for bn in bns):
         return False
     H, W = x.shape[1], x.shape[2]
-    return B <= 64 and H == 16 and W % 32 == 0 and (W // 32) * 256 == stn.stn_fc1[0].in_features == 512 \
-        and stn.stn_fc2.out_features % 4 == 0 and stn.stn_fc2.out_features <= 64
+    if not (B <= 64 and H == 16 and W % 32 == 0 and (W // 32) * 256 == stn.stn_fc1[0].in_features == 512
+            and stn.stn_fc2.out_features % 4 == 0 and stn.stn_fc2.out_features <= 64):
+        return False
+    if not (_has_gpu() and x.is_cuda):           # (host-only callers: the geometry predicate alone)
+        return True
+    cap = sync_capacity(x.device)                # the launches need up to 128 / 32 work-groups resident at once
+    return cap[4] >= 128 and cap[5] >= 32
 
 
 class StnHeadFn(Function):

@@ -188,8 +188,12 @@ class LmdbRecords:
     """The reference's lmdb record layout read through a transaction-like object (`get(bytes) -> bytes or None`), reference
     `lmdbDataset_real` (dataset/dataset.py:565-686): `num-samples` holds the count, sample i (1-based) is `image_hr-%09d`,
     `image_lr-%09d` (encoded image files) and `label-%09d` (utf-8).  __getitem__(index) -> (img_HR, img_lr, img_HRy, img_lry,
-    label_str) with PIL images, the label passed through `str_filt(word, voc_type)`; an unreadable image or an over-long label moves
-    on to the next record, as the reference does."""
+    label_str) with PIL images, the label passed through `str_filt(word, voc_type)`.
+    Bad records, exactly as the reference behaves (dataset/dataset.py:640-686): its `except IOError or len(word) > self.max_len` catches
+    IOError ONLY (the `or` picks the class), so an over-long label is RETURNED, not skipped (`max_len` is kept as an attribute, unused as
+    upstream); on an unreadable image it returns `self[index + 1]` AFTER `index += 1`, i.e. 0-based item i falls through to item i + 2 --
+    one record further than it looks.  Running past the last record raises IndexError (upstream: an assertion / a missing key).
+    NOT exercised against a real lmdb environment: the `lmdb` package is absent from this image (tests use an in-memory mapping)."""
 
     def __init__(self, txn, voc_type: str = "upper", max_len: int = 100):
         self.txn, self.voc_type, self.max_len = txn, voc_type, max_len
@@ -213,19 +217,18 @@ class LmdbRecords:
         from PIL import Image
         if not 0 <= index < self.n:
             raise IndexError(index)
-        for step in range(self.n):                               # (the reference recurses to index + 1 on a bad record)
-            i = (index + step) % self.n + 1
+        while index < self.n:
+            i = index + 1                                            # 1-based record
             try:
                 hr, lr = self._image(b"image_hr-%09d" % i), self._image(b"image_lr-%09d" % i)
             except (IOError, OSError):
+                index += 2                                           # the reference's `return self[index + 1]` after `index += 1`
                 continue
             word = self.txn.get(b"label-%09d" % i)
             word = " " if word is None else word.decode()
-            if len(word) > self.max_len:
-                continue
             hry, lry = Image.fromarray(rgb_to_yuv_u8(hr)), Image.fromarray(rgb_to_yuv_u8(lr))
             return hr, lr, hry, lry, str_filt(word, self.voc_type)
-        raise IOError("no readable record")
+        raise IndexError("no readable record at or after the requested index")
 
 
 def open_lmdb(root: str, **kw) -> LmdbRecords:

@@ -216,6 +216,10 @@ class HipStepKernels:
         ops.call("tatt_adam_step", ops.P(p), ops.P(g), ops.P(m), ops.P(v), p.numel(), lr, b1, b2, eps, ops.P(gnorm), max_norm,
                  gscale, ops.P(step), ops.stream())
 
+    def guard(self):
+        """In front of the optimiser: trap if a launch that synchronises its work-groups in flight gave up waiting (tatt_sync_guard)."""
+        ops.call("tatt_sync_guard", ops.stream())
+
     def after_update(self, device):
         """The weights moved behind torch's back (raw-pointer kernel): rebuild the cached packed filter layouts, one launch."""
         ops.PACKED.refresh(device)
@@ -309,6 +313,8 @@ class Trainer:
             if self.dp or dropout_seed is not None:
                 Fh.set_seed(dev, rank_dropout_seed(base, self.rank) if self.dp else base)
         self.side = torch.cuda.Stream(device=dev) if self.two_lanes else None
+        if self.cuda and isinstance(self.kernels, HipStepKernels):
+            Fh.sticky_word(dev)                      # allocated and registered now: never inside the capture of a step
         self._merge_last = len(self.stages) >= 2         # (also without a second stream: one pass structure everywhere)
         self._npass = len(self.stages) + (0 if self._merge_last else 1)
         self.gnorms = [torch.zeros(1, device=dev) for _ in self.groups]
@@ -410,6 +416,8 @@ class Trainer:
                                                  #  hipGraph executor does not overlap with the main lane: 8.98 ms instead of 7.86)
 
     def _optim(self):
+        if self.cuda and hasattr(self.kernels, "guard"):
+            self.kernels.guard()                     # (a one-thread launch: invalid gradients never reach the weights silently)
         self.step_count += 1
         b1, b2 = self.betas
         for (s, e, max_norm), gn in zip(self.groups, self.gnorms):
@@ -447,13 +455,18 @@ class Trainer:
                 w.wait()
                 e1.record()
                 self._coll_events.append((i, e0, e1))
+                del self._coll_events[:-self.PROFILE_KEEP]       # bounded: a long profiled run keeps the latest steps only
             else:
                 w.wait()
         self._works = []
 
+    PROFILE_KEEP = 256                               # event pairs kept while `profile_collectives` is on (each step adds a handful)
+
     def collective_report(self):
         """What the data-parallel step sent and what it cost, for the bench line: the world size as the process group's backend reports it,
-        the all-reduces of one step (bytes, the pass they were issued after) and -- if profiled -- the average exposed time of each."""
+        the all-reduces of one step (bytes, the pass they were issued after) and -- if profiled -- the average exposed time of each.
+        Profiling costs an event pair per collective and per pass group inside the step: profile a bounded number of steps OUTSIDE a
+        timed region (bench.py does); the report resets the buffers."""
         if not self.dp:
             return None
         rep = {"backend": torch.distributed.get_backend(self.pg), "world_size": torch.distributed.get_world_size(self.pg),
@@ -479,6 +492,7 @@ class Trainer:
                 cnt[i] += 1
             rep["pass_groups"] = [{"passes": [self.stages[k] if k < len(self.stages) else "side(%s)" % self.stages[-1] for k in g],
                                    "gpu_ms": round(tot[i] / max(cnt[i], 1), 4)} for i, g in enumerate(self._groups)]
+        self._coll_events, self._group_events = [], []
         return rep
 
     @property
@@ -523,6 +537,7 @@ class Trainer:
                 g1 = torch.cuda.Event(enable_timing=True)
                 g1.record()
                 self._group_events.append((gi, g0, g1))
+                del self._group_events[:-self.PROFILE_KEEP]
             done = self._buckets_done_by(group[-1])
             self._reduce(sent + 1, done, group[-1])  # what this group completed: on the wire while the next group computes
             sent = max(sent, done)

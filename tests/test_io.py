@@ -182,18 +182,27 @@ def test_lmdb_record_reader_on_an_in_memory_environment():
         b = pyio.BytesIO()
         Image.fromarray(rng.integers(0, 255, (h, w, 3), dtype=np.uint8), "RGB").save(b, format="PNG")
         return b.getvalue()
-    db = {b"num-samples": b"3"}
-    for i, (lab, (w, h)) in enumerate(zip(("Ab-C!9", None, "second"), ((100, 30), (64, 20), (130, 40))), start=1):
+    long_label = "x" * 150                                           # longer than max_len = 100
+    db = {b"num-samples": b"5"}
+    for i, (lab, (w, h)) in enumerate(zip(("Ab-C!9", None, "second", long_label, "fifth"),
+                                          ((100, 30), (64, 20), (130, 40), (90, 28), (80, 24))), start=1):
         db[b"image_hr-%09d" % i] = png(w, h)
         db[b"image_lr-%09d" % i] = png(w // 2, h // 2)
         if lab is not None:
             db[b"label-%09d" % i] = lab.encode()
-    db[b"image_lr-%09d" % 2] = b"not an image"                     # record 2 is unreadable: the reader moves on to record 3
+    db[b"image_lr-%09d" % 2] = b"not an image"                     # record 2 (item 1) is unreadable
     rec = io.LmdbRecords(db, voc_type="lower")
-    assert len(rec) == 3
+    assert len(rec) == 5
     hr, lr, hry, lry, lab = rec[0]
     assert lab == "abc9" and hr.size == (100, 30) and lr.size == (50, 15) and hr.mode == "RGB" and hry.size == hr.size
-    assert rec[1][4] == "second" and rec[1][0].size == (130, 40)
+    # the reference's `return self[index + 1]` after `index += 1`: item 1 falls through to item 3 (record 4), NOT to item 2
+    assert rec[1][0].size == (90, 28)
+    # ... and its `except IOError or len(word) > self.max_len` catches IOError only: the over-long label of record 4 is returned
+    assert rec[3][4] == long_label and rec[1][4] == long_label
+    assert rec[2][4] == "second" and rec[2][0].size == (130, 40)
+    db[b"image_hr-%09d" % 4] = b"broken"                           # item 3 unreadable: falls through to item 5, past the end
+    with pytest.raises(IndexError):
+        rec[3]
     batch = io.collate_pil_batch([rec[0], rec[2]])
     assert tuple(batch[0].shape) == (2, 4, 32, 128) and tuple(batch[2].shape) == (2, 4, 16, 64) and batch[5] == ("abc9", "second")
     y = io.rgb_to_yuv_u8(np.array([[[255, 255, 255], [0, 0, 0], [255, 0, 0]]], np.uint8))

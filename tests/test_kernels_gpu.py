@@ -485,6 +485,41 @@ def test_query_gru_persistent_chain_under_load(dev):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("groups,lds", [(32, 0), (64, 0), (64, 65536)])
+def test_query_gru_persistent_chain_beside_a_cu_holder(dev, groups, lds):
+    """the chains had shared the chip with streaming kernels and a co-running process, never with a kernel that HOLDS
+    CUs the way a collective's channel kernels do.  Here 32 / 64 work-groups of 512 threads (with and without 64 KB of LDS each) sit
+    resident for ~1 ms on a second stream while the B = 48 forward and backward chains (256 work-groups, one per CU) run: every output
+    word must equal the unloaded run, no wait may expire (launch word and the device's sticky word stay 0), and the stall is printed."""
+    from tatt_amd import ops, functional as Fh
+    ref = _qgru_run(dev, 48, True, True, sb=True)
+    sticky = Fh.sticky_word(dev)
+    side = torch.cuda.Stream()
+    sink = torch.zeros(4, dtype=torch.int32, device=dev)
+
+    def timed(load):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        if load:
+            with torch.cuda.stream(side):
+                ops.call("tatt_cu_holder", groups, 100000, lds, ops.P(sink), ops.stream())      # 1 ms
+        e0.record()
+        out = _qgru_run(dev, 48, True, True, sb=True)
+        e1.record()
+        torch.cuda.synchronize()
+        return out, e0.elapsed_time(e1)
+    _, t_alone = timed(False)
+    worst = 0.0
+    for rep in range(6):
+        out, t = timed(True)
+        worst = max(worst, t)
+        for k, (a, b) in enumerate(zip(ref, out)):
+            assert torch.equal(a, b), (rep, k, float((a - b).abs().max()))
+    Fh.qgru_chain_check()
+    assert int(sticky[0].item()) == 0
+    print("query-GRU chains beside %d resident work-groups (%d KB LDS each): %.3f ms alone, worst %.3f ms" % (groups, lds // 1024, t_alone, worst))
+
+
 # ------------------------------------------------------------------------------------------- attention
 @pytest.mark.parametrize("Lq,S", [(1024, 26), (26, 26), (70, 5)])
 def test_mha(dev, Lq, S):

@@ -200,3 +200,27 @@ def test_fused_path_predicates_choose_the_fallbacks():
     assert not Fh.stn_head_fusable(x, stn, 3)
     assert Fh._qgru_chain_takes(64, 512)
     assert not Fh._qgru_chain_takes(128, 1024) and not Fh._qgru_chain_takes(60, 512) and not Fh._qgru_chain_takes(144, 512)
+
+
+def test_residency_gate_routes_a_partitioned_device_to_the_fallbacks(monkeypatch):
+    """The launches that synchronise their work-groups in flight need their whole grid resident (256 work-groups for the query-GRU chains
+    at W = 64, up to 128 / 32 for the STN head).  With the occupancy query reporting less -- a partitioned or CU-masked GPU -- the
+    predicates must choose the per-step / operator-chain paths (nothing on the host checked this)."""
+    import tatt_amd.tsrn as T
+    from tatt_amd import functional as Fh
+
+    class _X:                                                       # a "device tensor" for the predicate: shape + is_cuda + device
+        shape, is_cuda, device = (3, 16, 64, 4), True, torch.device("cpu")
+    stn = T.STNHead(4, 20, "none").train()
+    monkeypatch.setattr(Fh, "_has_gpu", lambda: True)
+    monkeypatch.setattr(Fh, "sync_capacity", lambda device=None: (256, 256, 256, 256, 512, 512))     # a whole MI355X
+    assert Fh._qgru_chain_takes(64, 512) and Fh._qgru_chain_takes(64, 512, True) and Fh.stn_head_fusable(_X, stn, 3)
+    monkeypatch.setattr(Fh, "sync_capacity", lambda device=None: (128, 128, 128, 128, 256, 256))     # half the CUs
+    assert not Fh._qgru_chain_takes(64, 512) and not Fh._qgru_chain_takes(64, 512, True)
+    assert Fh._qgru_chain_takes(32, 512)                           # 128 tiles still fit
+    assert Fh.stn_head_fusable(_X, stn, 3)
+    monkeypatch.setattr(Fh, "sync_capacity", lambda device=None: (256, 256, 256, 128, 96, 24))       # the backward fp32 chain and the STN launches do not fit
+    assert Fh._qgru_chain_takes(64, 512) and Fh._qgru_chain_takes(64, 512, True)                    # (split-bf16 is the default form)
+    monkeypatch.setattr(Fh, "QGRU_CHAIN_SB", False)
+    assert Fh._qgru_chain_takes(64, 512) and not Fh._qgru_chain_takes(64, 512, True)
+    assert not Fh.stn_head_fusable(_X, stn, 3)

@@ -114,6 +114,40 @@ def test_stn_head_fused_is_deterministic_under_load(dev):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("groups,lds", [(32, 0), (64, 65536)])
+def test_stn_head_fused_beside_a_cu_holder(dev, groups, lds):
+    """The fused head's launches (<= 128 work-groups exchanging BatchNorm partial sums in flight) beside resident work-groups that hold
+    CUs for ~1 ms on a second stream -- what a collective's channel kernels do: bit-identical to the unloaded run, no expired wait."""
+    from tatt_amd import ops, functional as Fh
+    stn0 = _head()
+    x, dctrl = _inputs(48)
+    ref = _run_hip(stn0, x, dctrl, True, dev)
+    sticky = Fh.sticky_word(dev)
+    side = torch.cuda.Stream()
+    sink = torch.zeros(4, dtype=torch.int32, device=dev)
+    for rep in range(6):
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            ops.call("tatt_cu_holder", groups, 100000, lds, ops.P(sink), ops.stream())
+        out = _run_hip(stn0, x, dctrl, True, dev)
+        for k in ref:
+            assert torch.equal(ref[k], out[k]), (rep, k)
+    torch.cuda.synchronize()
+    Fh.sync_check()
+    assert int(sticky[0].item()) == 0
+
+
+def test_sync_guard_is_silent_on_a_clean_device_and_capacity_covers_the_grids(dev):
+    """tatt_sync_guard launches and returns on a clean sticky word (a raised word would kill the process: not exercised here); the
+    occupancy query says the whole MI355X holds the grids of every in-flight-synchronising launch."""
+    from tatt_amd import ops, functional as Fh
+    Fh.sticky_word(dev)
+    ops.call("tatt_sync_guard", ops.stream())
+    torch.cuda.synchronize()
+    cap = Fh.sync_capacity(dev)
+    assert min(cap[:4]) >= 256 and cap[4] >= 128 and cap[5] >= 32, cap
+
+
 def test_stn_head_falls_back_for_other_geometries(dev):
     """B > 64 (the fully connected launch holds <= 64 samples) runs operator by operator, silently and correctly."""
     import tatt_amd.tsrn as T
