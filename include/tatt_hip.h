@@ -556,6 +556,15 @@ int tatt_sync_guard(hipStream_t st);
  * clock (<= 1 s) and do nothing else -- a stand-in for a collective's channel kernels in the residency tests; sink: any device word */
 int tatt_cu_holder(int groups, long ticks, int lds_bytes, unsigned* sink, hipStream_t st);
 
+/* ---- small launches that keep the replayed step free of framework kernels ------------------------------------------------------------ */
+/* dst[offs[k] .. + ns[k]) <- srcs[k] (zeros where srcs[k] == NULL) for k < count: one bucket of the flat gradient buffer gathered from
+ * the parameters' gradient tensors in ONE launch.  srcs / offs / ns are HOST arrays; the table travels in the kernel arguments. */
+int tatt_gather_grads(const float* const* srcs, const long* offs, const int* ns, int count, float* dst, hipStream_t st);
+/* v[i] += 1 for n 64-bit counters */
+int tatt_inc_i64(long long* v, int n, hipStream_t st);
+/* y[0 .. n) = 0 */
+int tatt_zero_f32(float* y, long n, hipStream_t st);
+
 /* ---- TPS rectification ---------------------------------------------------------------------------------- */
 
 /* src[b,p,:] = repr[p,:] @ (inv @ [ctrl[b]; pad])  (model/tps_spatial_transformer.py:103-105); N ctrl points, P pixels */

@@ -424,3 +424,60 @@ TATT_API int tatt_cu_holder(int groups, long ticks, int lds_bytes, unsigned* sin
     hipLaunchKernelGGL(cu_holder_kernel, dim3(groups), dim3(512), lds_bytes, st, ticks, sink, lds_bytes / 4);
     return LAUNCH_CHECK();
 }
+
+// ---- gradient gather: one bucket of the flat gradient buffer <- the parameters' fresh gradient tensors ----------------------------------
+// (replaces a fill + a multi-tensor ATen copy per bucket: one launch, descriptor table in the kernel arguments -- fixed at hipGraph
+// capture like the tables of the split-K reducer).  An entry without a source writes zeros (a parameter that received no gradient).
+#define GG_MAX 112
+struct GGEntry { const float* src; long off; int n; int block0; };
+struct GGTable { GGEntry e[GG_MAX]; float* dst; int n; };
+__global__ __launch_bounds__(256) void gather_grads_kernel(GGTable t) {
+    int k = 0;
+    while (k + 1 < t.n && (int)blockIdx.x >= t.e[k + 1].block0) ++k;
+    const GGEntry& e = t.e[k];
+    const int i = (((int)blockIdx.x - e.block0) * 256 + threadIdx.x) * 4;
+    if (i >= e.n) return;
+    float* d = t.dst + e.off + i;
+    const bool vec = i + 4 <= e.n && (((uintptr_t)d | (e.src ? (uintptr_t)(e.src + i) : 0)) & 15) == 0;
+    if (vec) {
+        *reinterpret_cast<f32x4*>(d) = e.src ? *reinterpret_cast<const f32x4*>(e.src + i) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    } else {
+        for (int j = 0; j < 4 && i + j < e.n; ++j) d[j] = e.src ? e.src[i + j] : 0.f;
+    }
+}
+// srcs: HOST array of `count` device pointers (NULL: zeros), offs / ns: HOST arrays (element offset into dst, element count)
+TATT_API int tatt_gather_grads(const float* const* srcs, const long* offs, const int* ns, int count, float* dst, hipStream_t st) {
+    for (int base = 0; base < count; base += GG_MAX) {
+        GGTable t;
+        t.dst = dst;
+        t.n = count - base < GG_MAX ? count - base : GG_MAX;
+        int blocks = 0;
+        for (int k = 0; k < t.n; ++k) {
+            if (ns[base + k] < 0) return 1;
+            t.e[k] = {srcs[base + k], offs[base + k], ns[base + k], blocks};
+            blocks += cdiv(ns[base + k], 1024);
+        }
+        if (blocks) hipLaunchKernelGGL(gather_grads_kernel, dim3(blocks), dim3(256), 0, st, t);
+    }
+    return LAUNCH_CHECK();
+}
+// v[i] += 1 for n 64-bit counters (the optimiser's step count, the BatchNorms' num_batches_tracked group)
+__global__ void inc_i64_kernel(long long* v, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] += 1;
+}
+TATT_API int tatt_inc_i64(long long* v, int n, hipStream_t st) {
+    if (n < 1) return 0;
+    hipLaunchKernelGGL(inc_i64_kernel, dim3(cdiv(n, 64)), dim3(64), 0, st, v, n);
+    return LAUNCH_CHECK();
+}
+// y[i] = 0 (n floats): the zero time slots of the query GRU's state buffer and other small clears, without an ATen fill
+__global__ void zero_f32_kernel(float* y, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = 0.f;
+}
+TATT_API int tatt_zero_f32(float* y, long n, hipStream_t st) {
+    if (n < 1) return 0;
+    hipLaunchKernelGGL(zero_f32_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, y, n);
+    return LAUNCH_CHECK();
+}

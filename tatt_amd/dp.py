@@ -77,6 +77,19 @@ class FlatParams:
     def gather_grads(self, k: int):
         """Bucket k of the flat gradient buffer <- the parameters' fresh `.grad` tensors (zeros where a parameter got none):
         one fill + one multi-tensor copy instead of one accumulate kernel per parameter."""
+        if self.g.is_cuda:
+            # one launch of the library (descriptor table in the kernel arguments); the alignment padding between parameters is zero
+            # since the buffer was allocated and is never written
+            from . import ops
+            ent = []
+            for p in self.bucket_params[k]:
+                off, n = self.offsets[id(p)]
+                g = p.grad
+                if g is not None and (g.dtype != torch.float32 or not g.is_contiguous()):
+                    g = g.float().contiguous()
+                ent.append((g, off, n))
+            ops.gather_grads(self.g, ent)
+            return
         s, e = self.ranges[k]
         self.g[s:e].zero_()
         have = [p for p in self.bucket_params[k] if p.grad is not None]
@@ -108,7 +121,7 @@ class GradCuts:
             gs = [d.grad for d in reversed(copies) if d.grad is not None]   # later consumers first, like the single-pass engine
             g = None
             if gs:
-                if len(gs) > 2 and gs[0].is_cuda and len(gs) <= 8 and gs[0].dtype == torch.float32:
+                if len(gs) >= 2 and gs[0].is_cuda and len(gs) <= 8 and gs[0].dtype == torch.float32:
                     from . import ops
                     g = ops.add_n(gs)                # one launch, same left-to-right order as the chain of adds below
                 else:

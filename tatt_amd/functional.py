@@ -95,7 +95,12 @@ class _DeferredParamGrads:
     def _assign(params, grads):
         for p, g in zip(params, grads):
             if p is not None and g is not None:
-                p.grad = g if p.grad is None else p.grad + g
+                if p.grad is None:
+                    p.grad = g
+                elif g.is_cuda and g.dtype == torch.float32 and p.grad.shape == g.shape:
+                    p.grad = ops.add_n([p.grad, g])          # (a second forward of the same step: the shipped recipe)
+                else:
+                    p.grad = p.grad + g
 
     def submit(self, params, fn, *keep, lag=0):
         """params: tuple of leaf tensors (or None); fn() -> tuple of their gradients (or None), same order (or a generator that
@@ -731,6 +736,27 @@ def add(a, b):
     return AddFn.apply(_c(a), _c(b))
 
 
+class Fork2Fn(Function):
+    """x -> (x, x) for a tensor with two consumers: the two gradients are summed by ONE launch of the library (ops.add_n) instead of the
+    autograd engine's own accumulation kernel (a + b either way: bit-identical)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        if ga is None or gb is None:
+            return ga if gb is None else gb
+        if ga.is_cuda and ga.dtype == torch.float32 and ga.shape == gb.shape:
+            return ops.add_n([_c(ga), _c(gb)])
+        return ga + gb
+
+
+def fork2(x):
+    return Fork2Fn.apply(x) if (x.requires_grad and torch.is_grad_enabled()) else (x, x)
+
+
 class AddRowBcastFn(Function):
     """a (B,L,C) + b (L,C) broadcast over B; b carries no gradient (positional-encoding buffer)."""
 
@@ -1195,8 +1221,8 @@ class QueryGruFn(Function):
         # that "h_prev of every step" is one contiguous (B*W, HID) matrix per direction (the W_hh gradient GEMM then covers all rows
         # and its row sums are the hidden-bias gradient: no separate column-sum pass)
         hbuf = ops.new(dev, 2, B + 1, W, HID)
-        hbuf[0, 0].zero_()
-        hbuf[1, B].zero_()
+        ops.zero_f32(hbuf[0, 0])
+        ops.zero_f32(hbuf[1, B])
         hseq = (hbuf[0, 1:], hbuf[1, :B])
         gsave = ops.new(dev, 2, B, 4, W, HID)
         q = ops.new(dev, B, H, W, C)

@@ -660,6 +660,29 @@ def add_n(ts):
     return y
 
 
+def gather_grads(dst_flat, entries):
+    """dst_flat[off : off + n] <- src (zeros where src is None) for every (src, off, n) of `entries`: one launch per 112 entries
+    (tatt_gather_grads: the bucket gather of the data-parallel flat gradient buffer without framework kernels)."""
+    m = len(entries)
+    if not m:
+        return
+    srcs = (ctypes.c_void_p * m)(*[None if s is None else s.data_ptr() for s, _, _ in entries])
+    offs = (ctypes.c_long * m)(*[int(o) for _, o, _ in entries])
+    ns = (ctypes.c_int * m)(*[int(n) for _, _, n in entries])
+    call("tatt_gather_grads", srcs, offs, ns, m, P(dst_flat), stream())
+
+
+def inc_i64(t):
+    """t += 1 for an int64 tensor (contiguous), one small launch."""
+    assert t.dtype == torch.int64 and t.is_contiguous()
+    call("tatt_inc_i64", P(t), t.numel(), stream())
+
+
+def zero_f32(t):
+    assert t.dtype == torch.float32 and t.is_contiguous()
+    call("tatt_zero_f32", P(t), t.numel(), stream())
+
+
 def add_rowbcast(a2, b2, period):
     y = torch.empty_like(a2)
     rows = a2.numel() // a2.shape[-1]

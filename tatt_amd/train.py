@@ -216,6 +216,9 @@ class HipStepKernels:
         ops.call("tatt_adam_step", ops.P(p), ops.P(g), ops.P(m), ops.P(v), p.numel(), lr, b1, b2, eps, ops.P(gnorm), max_norm,
                  gscale, ops.P(step), ops.stream())
 
+    def inc(self, counter):
+        ops.inc_i64(counter)
+
     def guard(self):
         """In front of the optimiser: trap if a launch that synchronises its work-groups in flight gave up waiting (tatt_sync_guard)."""
         ops.call("tatt_sync_guard", ops.stream())
@@ -324,6 +327,7 @@ class Trainer:
         self.use_graph = use_graph and self.cuda
         self.warmup_eager = warmup_eager
         self._graphs = None
+        self._one = None
         self._static = None
         self._nsteps = 0
         self._works = []
@@ -365,7 +369,9 @@ class Trainer:
                     extra = self.model.extra_loss(hr) if hasattr(self.model, "extra_loss") else None
                     if extra is not None:
                         loss = loss + extra
-                loss.backward()
+                if self._one is None or self._one.device != loss.device or self._one.dtype != loss.dtype:
+                    self._one = torch.ones_like(loss)            # (allocated once: the engine would fill a fresh one per step)
+                loss.backward(self._one)
                 self.last_loss = loss.detach()
             else:
                 self.cuts.run(self.stages[k])
@@ -418,7 +424,10 @@ class Trainer:
     def _optim(self):
         if self.cuda and hasattr(self.kernels, "guard"):
             self.kernels.guard()                     # (a one-thread launch: invalid gradients never reach the weights silently)
-        self.step_count += 1
+        if hasattr(self.kernels, "inc"):
+            self.kernels.inc(self.step_count)
+        else:
+            self.step_count += 1
         b1, b2 = self.betas
         for (s, e, max_norm), gn in zip(self.groups, self.gnorms):
             if max_norm > 0.0:

@@ -289,6 +289,7 @@ def _gru_block(x, blk: GruBlock, vertical, x_cat=None):
 
 def _srb(x, tp_map, blk: RecurrentResidualBlock):
     """RecurrentResidualBlock[TL].forward (model/tsrn.py:862-871, 892-910).  (num_batches_tracked: bumped by the generator.)"""
+    x, x_res = Fh.fork2(x)                       # two consumers (conv1 and the residual sum): their gradients meet in one library launch
     if blk.bn1.training and blk.bn2.training and ops.conv3_bn_fusable(x, blk.conv1.weight, blk.bn1) and ops.conv3_bn_fusable(x, blk.conv2.weight, blk.bn2):
         # conv(+stats) | finish | conv(+bn1, mish on the way in, +stats) | finish | apply bn2: 5 launches instead of 8, and the
         # normalised + activated map between the two convolutions never exists in HBM
@@ -304,7 +305,7 @@ def _srb(x, tp_map, blk: RecurrentResidualBlock):
         r = Fh.conv2d(r, blk.conv2.weight, blk.conv2.bias)
         r = Fh.batch_norm_act(r, blk.bn2, ACT_NONE, False)
     r = _gru_block(r, blk.gru1, True, x_cat=tp_map)
-    return _gru_block(Fh.add(x, r), blk.gru2, False)
+    return _gru_block(Fh.add(x_res, r), blk.gru2, False)
 
 
 def _ffn(x, layer, training, site):
@@ -537,7 +538,10 @@ class _TrainPathMixin:
                 bn._buffers["num_batches_tracked"] = grp[i]
             object.__setattr__(self, "_nbt_group", grp)
         if all(bn.training for bn in bns):
-            grp += 1
+            if grp.is_cuda:
+                ops.inc_i64(grp)
+            else:
+                grp += 1
         else:                                    # some BatchNorms frozen by the caller: only the live ones count
             for bn in bns:
                 if bn.training:

@@ -165,6 +165,13 @@ timeit("tplayer_fwd", lambda: ops.tplayer_fwd(tx, tq, tK, tV, lp, lnF, 0.5, 1, 0
 timeit("tplayer_bwd", lambda: ops.tplayer_bwd(tx, tq, tK, tV, lp, lnF, 0.5, 1, 0.1, 0.1, 0.1, sd, 10, 1e-5, None, tup, None, None, True),
        B * L * (12 * 2 * 64 * 64 + 2 * 2 * 26 * 64), B * L * 64 * 4 * 5)
 
+# second generation of the backward (csrc/tplayer2.hip): prep (operand packing) + kernel, the relu bits from the forward launch
+if ops.tplayer2_geom(B, L, 26)[0]:
+    thm = torch.empty(B * L, dtype=torch.int64, device=dev)
+    ops.tplayer_fwd(tx, tq, tK, tV, lp, lnF, 0.5, 1, 0.1, 0.1, 0.1, sd, 10, 1e-5, False, True, hmask=thm)
+    timeit("tplayer2_bwd", lambda: ops.tplayer2_bwd(tx, tq, tK, tV, lp, lnF, 0.5, 1, 0.1, 0.1, 0.1, sd, 10, 1e-5, None, tup, None, None, True, hmask=thm),
+           B * L * (12 * 2 * 64 * 64 + 8 * 2 * 26 * 64), B * L * 64 * 4 * 5)
+
 # ---- TBSRN score-free self-attention (csrc/sattn.hip): P = 1024 tokens, 4 heads x 32 ----
 sQ, sK, sV, sdO = (R(B, 1024, 128) for _ in range(4))
 sO, slse, sws = torch.empty_like(sQ), torch.empty(B, 4, 1024, device=dev), torch.empty(B, 4, 1024, device=dev)
