@@ -268,10 +268,11 @@ def roofline_block(name, k, per_step_us, launches, shape_key):
 
 def time_tp_layer(dev, B, L, S=26):
     """The attention path: one fused TP-interpreter decoder layer (last layer: final norms + attention weights out), forward and backward,
-    dropout on, at the benchmark's token count, as the step runs it: forward = tplayer_kernel<fwd> (csrc/tplayer.hip, fp32 MFMA 16x16x4,
-    vector-ALU softmax); backward = tplayer2_bwd_kernel (csrc/tplayer2.hip: every product -- projections, 26-key attention, weight / key /
-    value gradients -- as split-bf16 on the bf16 matrix cores, operands packed by tplayer2_prep_kernel) or, with
-    tatt_amd.set_arithmetic("fp32"), the first generation tplayer_kernel<bwd>.  -> dict for the bench line (`roofline_attn`)."""
+    dropout on, at the benchmark's token count, as the training step runs it: csrc/tplayer2.hip -- operand packing (tplayer2_prep_kernel,
+    timed with the forward), tplayer2_fwd_kernel (exact fp32 MFMA: the relu decisions must stay inside fp32 round-off of the reference),
+    tplayer2_bwd_kernel (every product -- projections, 26-key attention, weight / key / value gradients -- as split-bf16 on the bf16 matrix
+    cores) -- or, with tatt_amd.set_arithmetic("fp32"), the first generation tplayer_kernel (csrc/tplayer.hip, fp32 MFMA 16x16x4,
+    vector-ALU softmax).  -> dict for the bench line (`roofline_attn`)."""
     from tatt_amd import ops, functional as Fh
     g = torch.Generator().manual_seed(0)
     r = lambda *s: (torch.randn(*s, generator=g) * 0.3).to(dev)
@@ -285,29 +286,31 @@ def time_tp_layer(dev, B, L, S=26):
     fw, bw = [], []
     for _ in range(_nsets(b_bwd)):
         x, qpos, K, V, up = r(B, L, 64), r(B, L, 64), r(B, S, 64), r(B, S, 64), r(B, L, 64)
-        hm = torch.empty(B * L, dtype=torch.int64, device=dev) if gen2 else None
-        fw.append(lambda x=x, qpos=qpos, K=K, V=V, hm=hm: ops.tplayer_fwd(x, qpos, K, V, lp, lnF, 0.5, 1, 0.1, 0.1, 0.1, seed, 10, 1e-5, False, True,
-                                                                         hmask=hm))
         if gen2:
-            bw.append(lambda x=x, qpos=qpos, K=K, V=V, up=up, hm=hm: ops.tplayer2_bwd(x, qpos, K, V, lp, lnF, 0.5, 1, 0.1, 0.1, 0.1, seed, 10, 1e-5,
-                                                                                      None, up, None, None, True, hmask=hm))
+            pk = ops.tplayer2_prep(lp, K, V)
+            f = lambda x=x, qpos=qpos, pk=pk: ops.tplayer2_fwd(x, qpos, pk, lp, lnF, 0.5, 1, 0.1, 0.1, 0.1, seed, 10, 1e-5, False, True, S)
+            hm = f()[3]
+            fw.append(lambda K=K, V=V, f=f: (ops.tplayer2_prep(lp, K, V), f()))         # the operand packing belongs to the layer's forward
+            bw.append(lambda x=x, qpos=qpos, pk=pk, up=up, hm=hm: ops.tplayer2_bwd(x, qpos, pk, lp, lnF, 0.5, 1, 0.1, 0.1, 0.1, seed, 10, 1e-5,
+                                                                                   None, up, None, None, True, S, hmask=hm))
         else:
+            fw.append(lambda x=x, qpos=qpos, K=K, V=V: ops.tplayer_fwd(x, qpos, K, V, lp, lnF, 0.5, 1, 0.1, 0.1, 0.1, seed, 10, 1e-5, False, True))
             bw.append(lambda x=x, qpos=qpos, K=K, V=V, up=up: ops.tplayer_bwd(x, qpos, K, V, lp, lnF, 0.5, 1, 0.1, 0.1, 0.1, seed, 10, 1e-5, None, up,
                                                                               None, None, True))
     tf = _timed_ms(fw, 30, 3)
     tb = _timed_ms(bw, 30, 3)
     f_fwd = tok * (4 * 2 * 64 * 64 + (2 * 2 * S * 64 if gen2 else 0))     # the four projections (+ QK^T and PV where they run on the matrix cores)
     f_bwd = tok * (12 * 2 * 64 * 64 + (8 if gen2 else 2) * 2 * S * 64)     # recompute + data gradients + weight gradients (+ attention fwd/bwd) + dK / dV
-    f_fwd_mfma = tok * (4 * 2 * 64 * 64)                                   # the forward kernel's softmax / PV stay on the vector ALU
-    ach = (f_fwd_mfma + f_bwd) / ((tf + tb) * 1e-3) / 1e12
-    out = {"kernel": "tplayer_kernel<fwd> + %s (fused cross-attention + LayerNorm + FFN layer, %d x %d query tokens, %d keys)" % (
-               "tplayer2_prep_kernel + tplayer2_bwd_kernel" if gen2 else "tplayer_kernel<bwd>", B, L, S),
+    ach = (f_fwd + f_bwd) / ((tf + tb) * 1e-3) / 1e12
+    peak = PEAK_BF16_MFMA_TFLOPS if gen2 else PEAK_FP32_MFMA_TFLOPS
+    pipe = "bf16 MFMA, split operands (3 products per fp32 product)" if gen2 else "fp32 MFMA"
+    out = {"kernel": "%s (fused cross-attention + LayerNorm + FFN layer, %d x %d query tokens, %d keys)" % (
+               "tplayer2_prep_kernel + tplayer2_fwd_kernel + tplayer2_bwd_kernel" if gen2 else "tplayer_kernel<fwd> + tplayer_kernel<bwd>", B, L, S),
            "bound": "mfma", "unit": "TFLOP/s", "achieved": round(ach, 2), "fwd_ms": round(tf, 4), "bwd_ms": round(tb, 4),
-           "fwd": {"tflops": round(f_fwd_mfma / (tf * 1e-3) / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                   "frac": round(f_fwd_mfma / (tf * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4), "pipe": "fp32 MFMA"},
-           "bwd": {"tflops": round(f_bwd / (tb * 1e-3) / 1e12, 2), "peak": PEAK_BF16_MFMA_TFLOPS if gen2 else PEAK_FP32_MFMA_TFLOPS,
-                   "frac": round(f_bwd / (tb * 1e-3) / 1e12 / (PEAK_BF16_MFMA_TFLOPS if gen2 else PEAK_FP32_MFMA_TFLOPS), 4),
-                   "pipe": "bf16 MFMA, split operands (3 products per fp32 product)" if gen2 else "fp32 MFMA"},
+           # the forward's products are exact fp32 in both generations (v_mfma_f32_16x16x4_f32)
+           "fwd": {"tflops": round(f_fwd / (tf * 1e-3) / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                   "frac": round(f_fwd / (tf * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4), "pipe": "fp32 MFMA"},
+           "bwd": {"tflops": round(f_bwd / (tb * 1e-3) / 1e12, 2), "peak": peak, "frac": round(f_bwd / (tb * 1e-3) / 1e12 / peak, 4), "pipe": pipe},
            # continuity with rounds 3-4: fp32-equivalent MFMA work of forward + backward against the fp32 MFMA peak
            "peak": PEAK_FP32_MFMA_TFLOPS, "mfma_util": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
            "hbm_gbps": round((b_fwd + b_bwd) / ((tf + tb) * 1e-3) / 1e9, 1),

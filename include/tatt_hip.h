@@ -477,14 +477,6 @@ int tatt_tplayer_fwd(const float* x, const float* qpos, long qbs, const float* K
                      const float* lnB_b, const float* lnF_w, const float* lnF_b, float fin_scale, int fin_both, float* xout,
                      float* fin, float* wavg, int B, int L, int S, float p_attn, float p_res, float p_ffn,
                      const unsigned long long* seed, unsigned site0, float eps, hipStream_t st);
-/* the same launch, additionally leaving the relu-and-kept bits of the FFN's hidden layer (B*L 64-bit words; L % 32 == 0) for
- * tatt_tplayer2_bwd, whose split-bf16 recomputation could otherwise flip a relu whose pre-activation is within ~1e-5 of zero */
-int tatt_tplayer_fwd_m(const float* x, const float* qpos, long qbs, const float* K, const float* V, const float* in_w,
-                       const float* in_b, const float* out_w, const float* out_b, const float* w1, const float* b1,
-                       const float* w2, const float* b2, const float* lnA_w, const float* lnA_b, const float* lnB_w,
-                       const float* lnB_b, const float* lnF_w, const float* lnF_b, float fin_scale, int fin_both, float* xout,
-                       float* fin, float* wavg, unsigned long long* hmask, int B, int L, int S, float p_attn, float p_res,
-                       float p_ffn, const unsigned long long* seed, unsigned site0, float eps, hipStream_t st);
 /* Backward of the layer, recomputed from x (the forward saves nothing else): upstream gradients dxout (of xout), dfin (of fin;
  * required when lnF_w != NULL), dwavg (of wavg) -- each nullable; dqacc (nullable) is added to dqpos (the next layer's dqpos).
  * Writes dx (B,L,64), dqpos (B,L,64; nullable), and partial records: kvpart (dK / dV per work-group and sample) and ppart
@@ -515,15 +507,27 @@ int tatt_tplayer_reduce_params_g(const float* ppart, int G, float* d_in_w, float
  * tokens and chains every product in registers (transposed MFMA orientation), weight gradients shared by the four waves of a
  * work-group.  Same inputs, outputs and dropout masks as tatt_tplayer_bwd; takes L % 64 == 0, S <= 32 (tatt_tplayer2_geom says). */
 /* host-side: out[0] = 1 if the geometry is taken, out[1] = work-groups, out[2] = floats of kvpart, out[3] = floats of ppart,
- * out[4] = ints of kvflags, out[5] = 32-bit words of wimg, out[6] = 32-bit words of kvf */
+ * out[4] = ints of kvflags, out[5] = 32-bit words of wimg, out[6] = 32-bit words of kvf, out[7] = floats of wimg32, out[8] = floats of
+ * kvf32 */
 int tatt_tplayer2_geom(int B, int L, int S, int* out);
-/* packed operands: wimg = the four 64x64 matrices (in_w: query rows of the packed in-projection) as MFMA A fragments, forward and
- * transposed, bf16 hi / lo; kvf = K, V (B,S,64) as the four fragment forms of the attention products */
+/* packed operands of one layer, one launch: wimg = the four 64x64 matrices (in_w: query rows of the packed in-projection) as MFMA A
+ * fragments, forward and transposed, bf16 hi / lo, and kvf = K, V (B,S,64) as the four fragment forms of the attention products (the
+ * backward's split-bf16 operands); wimg32 / kvf32 = the forward's exact-fp32 operands (one float per lane and v_mfma_f32_16x16x4_f32 step) */
 int tatt_tplayer2_prep(const float* in_w, const float* out_w, const float* w1, const float* w2, const float* K, const float* V,
-                       unsigned* wimg, unsigned* kvf, int B, int S, hipStream_t st);
+                       unsigned* wimg, unsigned* kvf, float* wimg32, float* kvf32, int B, int S, hipStream_t st);
+/* the layer's forward in the same organisation (training mode), exact fp32 products (v_mfma_f32_16x16x4_f32): arguments as tatt_tplayer_fwd
+ * with the matrices / K / V replaced by wimg32 / kvf32; hmask (B*L 64-bit words, nullable) receives the relu-and-kept bits of the FFN's hidden layer -- word [16-token tile][channel
+ * block][r], bit = lane -- which tatt_tplayer2_bwd reads instead of re-deciding the relu (a recomputation that differs from the forward in
+ * the last bits flips a relu whose pre-activation is within ~1e-5 of zero: O(1) error on that token's gradients) */
+int tatt_tplayer2_fwd(const float* x, const float* qpos, long qbs, const float* wimg32, const float* kvf32, const float* in_b,
+                      const float* out_b, const float* b1, const float* b2, const float* lnA_w, const float* lnA_b,
+                      const float* lnB_w, const float* lnB_b, const float* lnF_w, const float* lnF_b, float fin_scale,
+                      int fin_both, float* xout, float* fin, float* wavg, unsigned long long* hmask, int B, int L, int S,
+                      float p_attn, float p_res, float p_ffn, const unsigned long long* seed, unsigned site0, float eps,
+                      hipStream_t st);
 /* arguments as tatt_tplayer_bwd with the matrices / K / V replaced by their packed forms; kvflags: which sample the dK / dV
  * records of a work-group belong to (read by tatt_tplayer2_reduce_kv); ppart is summed by tatt_tplayer_reduce_params_g;
- * hmask: the bits tatt_tplayer_fwd_m left (nullable: the relu is then decided by the recomputation) */
+ * hmask: the bits tatt_tplayer2_fwd left (nullable: the relu is then decided by the recomputation) */
 int tatt_tplayer2_bwd(const float* x, const float* qpos, long qbs, const unsigned* wimg, const unsigned* kvf, const float* in_b,
                       const float* out_b, const float* b1, const float* b2, const float* lnA_w, const float* lnA_b,
                       const float* lnB_w, const float* lnB_b, const float* lnF_w, const float* lnF_b, float fin_scale,

@@ -47,7 +47,6 @@ struct TLP {
     float p_attn, p_res, p_ffn; const unsigned long long* seed; unsigned site0; float eps;
     const float* dxout; const float* dfin; const float* dwavg; const float* dqacc;   // backward inputs (nullable)
     float* dx; float* dqpos; float* kvpart; float* ppart; int span;
-    unsigned long long* hmask;                                   // forward: relu-and-kept bits for tplayer2.hip's backward (nullable)
 };
 
 __device__ __forceinline__ float tl_sum16(float v) { return row16_sum(v); }      // the 16 lanes of a token = one DPP row
@@ -341,10 +340,6 @@ __global__ __launch_bounds__(TL_NT, 1) void tplayer_kernel(TLP p) {
                 float h = fmaxf(acc[r] + bj, 0.f);
                 if (p.p_ffn > 0.f) h = dropout_keep(sd, p.site0 + 2, (uint64_t)((row0 + row) * 64 + col), th_ffn) ? h * sc_ffn : 0.f;
                 T4[row * TL_P + col] = h;
-                if (!BWD && p.hmask) {                        // word [16-token tile][channel block cb][token & 3]: bit 16 (token >> 2) + channel
-                    const unsigned long long m = __ballot(h > 0.f);
-                    if (lane == 0) p.hmask[(((long)tile * 2 + rb) * 4 + cb) * 4 + r] = m;
-                }
             }
         }
         __syncthreads();                                     // (S6)
@@ -629,40 +624,20 @@ static TLP tl_params(const float* x, const float* qpos, long qbs, const float* K
     return p;
 }
 
-static int tl_fwd_impl(const float* x, const float* qpos, long qbs, const float* K, const float* V, const float* in_w,
-                       const float* in_b, const float* out_w, const float* out_b, const float* w1, const float* b1,
-                       const float* w2, const float* b2, const float* lnA_w, const float* lnA_b, const float* lnB_w,
-                       const float* lnB_b, const float* lnF_w, const float* lnF_b, float fin_scale, int fin_both, float* xout,
-                       float* fin, float* wavg, unsigned long long* hmask, int B, int L, int S, float p_attn, float p_res, float p_ffn,
-                       const unsigned long long* seed, unsigned site0, float eps, hipStream_t st) {
-    if (S < 1 || S > 32 || B < 1 || L < 1) return 1;
-    if ((p_attn > 0.f || p_res > 0.f || p_ffn > 0.f) && !seed) return 2;
-    if (hmask && L % 32) return 4;                            // the bit words are laid out per whole 16-token tile
-    TLP p = tl_params(x, qpos, qbs, K, V, in_w, in_b, out_w, out_b, w1, b1, w2, b2, lnA_w, lnA_b, lnB_w, lnB_b, lnF_w, lnF_b,
-                      fin_scale, fin_both, B, L, S, p_attn, p_res, p_ffn, seed, site0, eps);
-    p.xout = xout; p.fin = fin; p.wavg = wavg; p.hmask = hmask;
-    tl_set_attr();
-    hipLaunchKernelGGL(tplayer_kernel<false>, dim3(tl_geom(B, L).G), dim3(TL_NT), TL_LDS_BYTES, st, p);
-    return LAUNCH_CHECK();
-}
 TATT_API int tatt_tplayer_fwd(const float* x, const float* qpos, long qbs, const float* K, const float* V, const float* in_w,
                               const float* in_b, const float* out_w, const float* out_b, const float* w1, const float* b1,
                               const float* w2, const float* b2, const float* lnA_w, const float* lnA_b, const float* lnB_w,
                               const float* lnB_b, const float* lnF_w, const float* lnF_b, float fin_scale, int fin_both, float* xout,
                               float* fin, float* wavg, int B, int L, int S, float p_attn, float p_res, float p_ffn,
                               const unsigned long long* seed, unsigned site0, float eps, hipStream_t st) {
-    return tl_fwd_impl(x, qpos, qbs, K, V, in_w, in_b, out_w, out_b, w1, b1, w2, b2, lnA_w, lnA_b, lnB_w, lnB_b, lnF_w, lnF_b, fin_scale,
-                       fin_both, xout, fin, wavg, nullptr, B, L, S, p_attn, p_res, p_ffn, seed, site0, eps, st);
-}
-// the same launch, leaving the relu-and-kept bits of the FFN's hidden layer for tatt_tplayer2_bwd: hmask = B L 64-bit words (L % 32 == 0)
-TATT_API int tatt_tplayer_fwd_m(const float* x, const float* qpos, long qbs, const float* K, const float* V, const float* in_w,
-                                const float* in_b, const float* out_w, const float* out_b, const float* w1, const float* b1,
-                                const float* w2, const float* b2, const float* lnA_w, const float* lnA_b, const float* lnB_w,
-                                const float* lnB_b, const float* lnF_w, const float* lnF_b, float fin_scale, int fin_both, float* xout,
-                                float* fin, float* wavg, unsigned long long* hmask, int B, int L, int S, float p_attn, float p_res,
-                                float p_ffn, const unsigned long long* seed, unsigned site0, float eps, hipStream_t st) {
-    return tl_fwd_impl(x, qpos, qbs, K, V, in_w, in_b, out_w, out_b, w1, b1, w2, b2, lnA_w, lnA_b, lnB_w, lnB_b, lnF_w, lnF_b, fin_scale,
-                       fin_both, xout, fin, wavg, hmask, B, L, S, p_attn, p_res, p_ffn, seed, site0, eps, st);
+    if (S < 1 || S > 32 || B < 1 || L < 1) return 1;
+    if ((p_attn > 0.f || p_res > 0.f || p_ffn > 0.f) && !seed) return 2;
+    TLP p = tl_params(x, qpos, qbs, K, V, in_w, in_b, out_w, out_b, w1, b1, w2, b2, lnA_w, lnA_b, lnB_w, lnB_b, lnF_w, lnF_b,
+                      fin_scale, fin_both, B, L, S, p_attn, p_res, p_ffn, seed, site0, eps);
+    p.xout = xout; p.fin = fin; p.wavg = wavg;
+    tl_set_attr();
+    hipLaunchKernelGGL(tplayer_kernel<false>, dim3(tl_geom(B, L).G), dim3(TL_NT), TL_LDS_BYTES, st, p);
+    return LAUNCH_CHECK();
 }
 
 TATT_API int tatt_tplayer_bwd(const float* x, const float* qpos, long qbs, const float* K, const float* V, const float* in_w,

@@ -422,14 +422,14 @@ __global__ __launch_bounds__(T2_NT, 1) void tplayer2_bwd_kernel(T2P p) {
                 t2_pack16(x1, X1);
             }
             gemm16(2, X1, acc);
-            // bit 4 nb + r: relu active and kept.  Taken from the FORWARD launch when it left them (tatt_tplayer_fwd_m): the forward's
-            // exact-fp32 pre-activation and this recomputation (2^-16 products) can disagree on the sign of a pre-activation within
-            // ~1e-5 of zero, and a flipped relu moves that token's gradients by O(1) (measured: 4 of 49,152 tokens).
+            // bit 4 nb + r: relu active and kept.  Taken from the FORWARD launch (tplayer2_fwd_kernel leaves them): a forward and a
+            // recomputation that differ in the last bits (first version: exact-fp32 forward, 2^-16 products here) can disagree on the sign of a
+            // pre-activation within ~1e-5 of zero, and a flipped relu moves that token's gradients by O(1) (measured: 4 of 49,152 tokens).
             unsigned hmask = 0;
             if (p.hmask) {
-                const unsigned long long* hm = p.hmask + (long)tile * 16 + (am & 3);        // word [tile][nb][token & 3], bit 16 (token >> 2) + channel
+                const unsigned long long* hm = p.hmask + (long)tile * 16;                    // word [tile][nb][r], bit `lane` (tplayer2_fwd_kernel)
 #pragma unroll
-                for (int nb = 0; nb < 4; ++nb) hmask |= ((unsigned)(hm[4 * nb] >> (16 * (am >> 2) + 4 * kq)) & 0xFu) << (4 * nb);
+                for (int i = 0; i < 16; ++i) hmask |= ((unsigned)(hm[i] >> lane) & 1u) << i;
             }
             {
                 f32x4 hd[4];
@@ -735,12 +735,276 @@ __global__ __launch_bounds__(T2_NT, 1) void tplayer2_bwd_kernel(T2P p) {
     if (tid == 0) { p.kvflags[blockIdx.x * 2] = split < nrd ? b0 : -1; p.kvflags[blockIdx.x * 2 + 1] = split < nrd ? b0 + 1 : b0; }
 }
 
+
+// ---- forward of the layer in the same organisation, EXACT fp32 (training mode: it leaves the FFN's relu bits for the backward above) -------
+// A wave owns 16 tokens and chains Q projection -> scores -> softmax -> PV -> out projection -> LN_A -> FFN -> LN_B (-> final norm) in
+// registers: v_mfma_f32_16x16x4_f32 takes ONE f32 per lane as its B operand, k = lane group kq, so step c of a product consumes the lane's
+// own value (block c >> 2, element c & 3) when the contraction index is enumerated as channel 16 (c >> 2) + 4 kq + (c & 3) -- the weight
+// images are packed in that order.  Nothing is shared between waves: no barrier after the prologue.  Eight waves per work-group (two per
+// SIMD); the four fp32 weight images (64 KB) are the only LDS.  A work-group takes T consecutive tiles, wave w the tiles w, w + 8, ...: with
+// T = 12 (B = 48) every SIMD hosts one wave with two tiles and one with one.
+// Why not split-bf16 like the backward: it was built first (22.6 us per decoder layer, the same as this one -- the kernel is bound by its
+// vector-ALU epilogues, not by the matrix pipe) and agrees with the exact forward to 1e-5, but a forward that differs from the reference's
+// fp32 arithmetic by 1e-5 decides a handful of relus (pre-activation within 1e-5 of zero: ~4 of 49,152 tokens per layer) the other way, and
+// the gradients of those tokens then differ by O(1) from the reference's.  Products in fp32 keep the forward inside fp32 round-off of the
+// reference; the backward takes the relu decisions from here (hmask), so ITS 2^-16 products cannot flip one.
+struct T2F {
+    const float* x; const float* qpos; long qbs;
+    const float* wimg32; const float* kvf32;
+    const float* bv[4]; const float* lnw[3]; const float* lnb[3];
+    float fin_scale; int fin_both;
+    int B, L, S, tps, ntiles, T;
+    float p_attn, p_res, p_ffn; const unsigned long long* seed; unsigned site0; float eps;
+    float* xout; float* fin; float* wavg; unsigned long long* hmask;
+};
+#define T2F_NT 512
+#define T2F_WIMG_FLOATS (4 * 4096)               // 4 images x [4 nb][4 c4][64 lanes][4 floats]
+#define T2F_KVF_FLOATS 4096                      // per sample: KF1f [4 h][2 sb][64][4], VTFf [4 h][2 c4][64][4]
+#define T2F_LDS_BYTES (T2F_WIMG_FLOATS * 4 + 10 * 64 * 4)
+
+__global__ __launch_bounds__(T2F_NT) void tplayer2_fwd_kernel(T2F p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char t2_smem[];
+    const f32x4* const Wl = reinterpret_cast<const f32x4*>(t2_smem);
+    float* const Vec = reinterpret_cast<float*>(t2_smem + T2F_WIMG_FLOATS * 4);
+    const int tid = threadIdx.x, wave = tid >> 6;
+    int lane = tid & 63;
+    int am = lane & 15, kq = lane >> 4;
+    const bool fin_on = p.lnw[2] != nullptr;
+    const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(p.wimg32);
+        f32x4* dst = reinterpret_cast<f32x4*>(t2_smem);
+#pragma unroll 8
+        for (int i = tid; i < T2F_WIMG_FLOATS / 4; i += T2F_NT) dst[i] = src[i];
+        for (int i = tid; i < 10 * 64; i += T2F_NT) {
+            const int v = i >> 6, c = i & 63;
+            const float* s = v < 4 ? p.bv[v] : (((v - 4) & 1) ? p.lnb[(v - 4) >> 1] : p.lnw[(v - 4) >> 1]);
+            Vec[i] = s ? s[c] : 0.f;
+        }
+    }
+    __syncthreads();
+    auto vec4 = [&](int v, int nb) __attribute__((always_inline)) -> f32x4 { return t2_ld4(Vec + v * 64 + 16 * nb + 4 * kq); };
+    // D^T = W X^T, exact fp32: acc[nb] rows = output channels 16 nb .., columns = the wave's 16 tokens; X: the lane's 16 values of its token
+    auto gemm16 = [&](int im, const f32x4 (&X)[4], f32x4 (&acc)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) acc[nb] = z4;
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            f32x4 a[4];
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) a[nb] = Wl[((im * 4 + nb) * 4 + c4) * 64 + lane];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[nb][u], X[c4][u], acc[nb], 0, 0, 0);
+        }
+    };
+    auto ln_fwd = [&](const f32x4 (&v)[4], f32x4 (&xh)[4], float& rstd) __attribute__((always_inline)) {
+        const float mean = t2_allkq((t2_sum4(v[0]) + t2_sum4(v[1])) + (t2_sum4(v[2]) + t2_sum4(v[3]))) * (1.f / 64.f);
+        float q = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) { xh[nb] = v[nb] - mean; q += t2_sum4(xh[nb] * xh[nb]); }
+        rstd = __builtin_amdgcn_rsqf(t2_allkq(q) * (1.f / 64.f) + p.eps);
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) xh[nb] = xh[nb] * rstd;
+    };
+    const bool any_drop = p.p_attn > 0.f || p.p_res > 0.f || p.p_ffn > 0.f;
+    const uint64_t sd = any_drop ? p.seed[0] : 0ull;
+    const uint32_t th_attn = dropout_thresh(p.p_attn), th_res = dropout_thresh(p.p_res), th_ffn = dropout_thresh(p.p_ffn);
+    const float sc_attn = p.p_attn > 0.f ? 1.f / (1.f - p.p_attn) : 1.f;
+    const float sc_res = p.p_res > 0.f ? 1.f / (1.f - p.p_res) : 1.f;
+    const float sc_ffn = p.p_ffn > 0.f ? 1.f / (1.f - p.p_ffn) : 1.f;
+    auto key0 = [&](unsigned site) __attribute__((always_inline)) -> uint32_t { return (uint32_t)sd ^ (site * 0x9E3779B9u); };
+    auto key1 = [&](unsigned site) __attribute__((always_inline)) -> uint32_t { return (uint32_t)(sd >> 32) + site * 0x85EBCA77u; };
+    const uint32_t ka0 = key0(p.site0), ka1 = key1(p.site0);
+    const uint32_t kr0 = key0(p.site0 + 1), kr1 = key1(p.site0 + 1);
+    const uint32_t kf0 = key0(p.site0 + 2), kf1 = key1(p.site0 + 2);
+    const uint32_t ks0 = key0(p.site0 + 3), ks1 = key1(p.site0 + 3);
+
+    const int wg0 = blockIdx.x * p.T, wg1 = min(p.ntiles, wg0 + p.T);
+    for (int tile = wg0 + wave; tile < wg1; tile += 8) {
+        asm volatile("" : "+v"(lane));                       // (see tplayer2_bwd_kernel: keeps lane-dependent addresses out of loop-invariant registers)
+        am = lane & 15; kq = lane >> 4;
+        const int b = tile / p.tps, tok0 = (tile - b * p.tps) * 16;
+        const long row = (long)b * p.L + tok0 + am;
+        const float* const xrow = p.x + row * 64 + 4 * kq;
+        const float* const qrow = p.qpos + (long)b * p.qbs + (long)(tok0 + am) * 64 + 4 * kq;
+        const f32x4* const kvf = reinterpret_cast<const f32x4*>(p.kvf32 + (long)b * T2F_KVF_FLOATS);
+        const uint32_t ridx = (uint32_t)(row * 64) + 4 * kq;
+        const uint32_t aidx = (uint32_t)(((long)b * 4 * p.L + tok0 + am) * p.S) + 4 * kq;
+        const uint32_t hstep = (uint32_t)p.L * (uint32_t)p.S;
+        f32x4 acc[4], Q[4];
+        {
+            f32x4 xq[4];
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) xq[nb] = t2_ld4(xrow + 16 * nb) + t2_ld4(qrow + 16 * nb);
+            gemm16(0, xq, acc);
+        }
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) Q[nb] = (acc[nb] + vec4(0, nb)) * 0.25f;
+        f32x4 ctx[4], wsum[2] = {z4, z4};                    // wsum: head sum of the dropped probabilities (the layer's attention-weight output)
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const f32x4 kf0v = kvf[(h * 2 + 0) * 64 + lane], kf1v = kvf[(h * 2 + 1) * 64 + lane];        // K[16 sb + am][16 h + 4 kq + j]
+            const f32x4 vt0 = kvf[512 + (h * 2 + 0) * 64 + lane], vt1 = kvf[512 + (h * 2 + 1) * 64 + lane];   // V[16 c4 + 4 kq + u][16 h + am]
+            f32x4 sc[2] = {z4, z4};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                    // head dims 4 kq + j
+                sc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf0v[j], Q[h][j], sc[0], 0, 0, 0);
+                sc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf1v[j], Q[h][j], sc[1], 0, 0, 0);
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool live = 16 * sb + 4 * kq + r < p.S;
+                    sc[sb][r] = live ? sc[sb][r] : -INFINITY;
+                    mx = fmaxf(mx, sc[sb][r]);
+                }
+            mx = t2_maxkq(mx);
+            float sum = 0.f;
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = (16 * sb + 4 * kq + r < p.S) ? __expf(sc[sb][r] - mx) : 0.f;
+                    sc[sb][r] = e; sum += e;
+                }
+            const float inv = __builtin_amdgcn_rcpf(t2_allkq(sum));
+            f32x4 pd[2];
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float d = sc[sb][r] * inv;
+                    if (p.p_attn > 0.f) d = t2_keep(ka0, ka1, aidx + (uint32_t)h * hstep + 16 * sb + r, th_attn) ? d * sc_attn : 0.f;
+                    pd[sb][r] = d;
+                }
+            wsum[0] += pd[0]; wsum[1] += pd[1];
+            f32x4 a0 = z4, a1 = z4;                          // two accumulator chains: keys 0-15 and 16-31
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(vt0[u], pd[0][u], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vt1[u], pd[1][u], a1, 0, 0, 0);
+            }
+            ctx[h] = a0 + a1;
+        }
+        if (p.wavg) {
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int s = 16 * sb + 4 * kq + r;
+                    if (s < p.S) p.wavg[row * p.S + s] = 0.25f * wsum[sb][r];
+                }
+        }
+        f32x4 xh1[4];
+        float rstd1;
+        {
+            gemm16(1, ctx, acc);
+            f32x4 y1[4];
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                f32x4 a = acc[nb] + vec4(1, nb);
+                if (p.p_res > 0.f) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a[r] = t2_keep(kr0, kr1, ridx + 16 * nb + r, th_res) ? a[r] * sc_res : 0.f;
+                }
+                y1[nb] = t2_ld4(xrow + 16 * nb) + a;
+            }
+            ln_fwd(y1, xh1, rstd1);
+        }
+        f32x4 x1[4];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) x1[nb] = xh1[nb] * vec4(4, nb) + vec4(5, nb);
+        gemm16(2, x1, acc);
+        f32x4 hd[4];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            const f32x4 bj = vec4(2, nb);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float h = fmaxf(acc[nb][r] + bj[r], 0.f);
+                if (p.p_ffn > 0.f) h = t2_keep(kf0, kf1, ridx + 16 * nb + r, th_ffn) ? h * sc_ffn : 0.f;
+                hd[nb][r] = h;
+                if (p.hmask) {                               // word [tile][nb][r]: bit `lane` = relu active and kept for (token am, channel 16 nb + 4 kq + r)
+                    const unsigned long long m = __ballot(h > 0.f);
+                    if (lane == 0) p.hmask[(long)tile * 16 + 4 * nb + r] = m;
+                }
+            }
+        }
+        gemm16(3, hd, acc);
+        f32x4 xh2[4];
+        float rstd2;
+        {
+            f32x4 y2[4];
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                f32x4 f = acc[nb] + vec4(3, nb);
+                if (p.p_res > 0.f) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) f[r] = t2_keep(ks0, ks1, ridx + 16 * nb + r, th_res) ? f[r] * sc_res : 0.f;
+                }
+                y2[nb] = x1[nb] + f;
+            }
+            ln_fwd(y2, xh2, rstd2);
+        }
+        f32x4 x2[4];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            x2[nb] = xh2[nb] * vec4(6, nb) + vec4(7, nb);
+            if (p.xout) t2_st4(p.xout + row * 64 + 4 * kq + 16 * nb, x2[nb]);
+        }
+        if (fin_on && p.fin) {
+            f32x4 xf[4], o[4];
+            float rf;
+            ln_fwd(x2, xf, rf);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) o[nb] = xf[nb] * vec4(8, nb) + vec4(9, nb);
+            if (p.fin_both) {
+                f32x4 xv[4], xh[4];
+                float rs;
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) xv[nb] = t2_ld4(xrow + 16 * nb);
+                ln_fwd(xv, xh, rs);
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) o[nb] += xh[nb] * vec4(8, nb) + vec4(9, nb);
+            }
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) t2_st4(p.fin + row * 64 + 4 * kq + 16 * nb, o[nb] * p.fin_scale);
+        }
+    }
+}
+
 // ---- packed operands: weight images in k-slot order, K / V as MFMA fragments -------------------------------------------------------------
 // k-slot order of the 16x16x32 products: slot j of k-step ks in lane group kq <-> index 16 (2 ks + (j >> 2)) + 4 kq + (j & 3)
 __device__ __forceinline__ int t2_kslot(int ks, int kq, int j) { return 16 * (2 * ks + (j >> 2)) + 4 * kq + (j & 3); }
-struct T2Prep { const float* W[4]; const float* K; const float* V; unsigned* wimg; unsigned* kvf; int B, S; };
+struct T2Prep { const float* W[4]; const float* K; const float* V; unsigned* wimg; unsigned* kvf; float* wimg32; float* kvf32; int B, S; };
 __global__ __launch_bounds__(256) void tplayer2_prep_kernel(T2Prep p) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long nb16 = T2_WIMG_WORDS + (long)p.B * T2_KVF_WORDS;
+    if (idx >= nb16) {
+        // ---- the forward's exact-fp32 operands (tplayer2_fwd_kernel): one float per lane and MFMA step ----------------------------------
+        long j = idx - nb16;
+        if (j < T2F_WIMG_FLOATS) {
+            // [im][nb][c4][lane][u]: W[16 nb + am][16 c4 + 4 kq + u]   (step c = 4 c4 + u of v_mfma_f32_16x16x4_f32, k = kq)
+            const int u = j & 3, lane = (j >> 2) & 63, c4 = (j >> 8) & 3, nb = (j >> 10) & 3, im = (int)(j >> 12);
+            p.wimg32[j] = p.W[im][(16 * nb + (lane & 15)) * 64 + 16 * c4 + 4 * (lane >> 4) + u];
+            return;
+        }
+        j -= T2F_WIMG_FLOATS;
+        if (j >= (long)p.B * T2F_KVF_FLOATS) return;
+        const int b = (int)(j / T2F_KVF_FLOATS), w = (int)(j % T2F_KVF_FLOATS);
+        const int u = w & 3, lane = (w >> 2) & 63, i2 = (w >> 8) & 1, h = (w >> 9) & 3, form = w >> 11;
+        const int am = lane & 15, kq = lane >> 4;
+        int s_, c_;
+        if (form == 0) { s_ = 16 * i2 + am; c_ = 16 * h + 4 * kq + u; }               // KF1f [h][sb][lane][j]: K[16 sb + am][16 h + 4 kq + j]
+        else { s_ = 16 * i2 + 4 * kq + u; c_ = 16 * h + am; }                            // VTFf [h][c4][lane][u]: V[16 c4 + 4 kq + u][16 h + am]
+        const float* src = (form == 0 ? p.K : p.V) + (long)b * p.S * 64;
+        p.kvf32[j] = s_ < p.S ? src[s_ * 64 + c_] : 0.f;
+        return;
+    }
     float v0, v1;
     unsigned* dst;
     int hl;
@@ -756,7 +1020,6 @@ __global__ __launch_bounds__(256) void tplayer2_prep_kernel(T2Prep p) {
         dst = p.wimg + idx;
     } else {
         const long j = idx - T2_WIMG_WORDS;
-        if (j >= (long)p.B * T2_KVF_WORDS) return;
         const int b = (int)(j / T2_KVF_WORDS), w = (int)(j % T2_KVF_WORDS);
         const int form = w >> 11, u = w & 2047;              // 0: KF1, 1: VF1, 2: VTF, 3: KTF
         const float* src = ((form == 0 || form == 3) ? p.K : p.V) + (long)b * p.S * 64;
@@ -806,21 +1069,21 @@ static inline int t2_takes(int B, int L, int S) {
     return 1;
 }
 // out[0] = 1 if the geometry is taken, out[1] = work-groups, out[2] = floats of kvpart, out[3] = floats of ppart, out[4] = ints of
-// kvflags, out[5] = words of wimg, out[6] = words of kvf
+// kvflags, out[5] = words of wimg, out[6] = words of kvf, out[7] = floats of wimg32, out[8] = floats of kvf32
 TATT_API int tatt_tplayer2_geom(int B, int L, int S, int* out) {
     out[0] = t2_takes(B, L, S);
     const T2Geom g = out[0] ? t2_geom(B, L) : T2Geom{0, 0, 0, 0};
     out[1] = g.G; out[2] = g.G * 5 * T2_KVREC; out[3] = g.G * T2_PREC; out[4] = g.G * 2;
-    out[5] = T2_WIMG_WORDS; out[6] = B * T2_KVF_WORDS;
+    out[5] = T2_WIMG_WORDS; out[6] = B * T2_KVF_WORDS; out[7] = T2F_WIMG_FLOATS; out[8] = B * T2F_KVF_FLOATS;
     return 0;
 }
 
 // in_w: the packed in-projection (192, 64) -- its first 64 rows are the query projection
 TATT_API int tatt_tplayer2_prep(const float* in_w, const float* out_w, const float* w1, const float* w2, const float* K, const float* V,
-                                unsigned* wimg, unsigned* kvf, int B, int S, hipStream_t st) {
+                                unsigned* wimg, unsigned* kvf, float* wimg32, float* kvf32, int B, int S, hipStream_t st) {
     if (B < 1 || S < 1 || S > 32) return 1;
-    T2Prep p = {{in_w, out_w, w1, w2}, K, V, wimg, kvf, B, S};
-    const long n = T2_WIMG_WORDS + (long)B * T2_KVF_WORDS;
+    T2Prep p = {{in_w, out_w, w1, w2}, K, V, wimg, kvf, wimg32, kvf32, B, S};
+    const long n = T2_WIMG_WORDS + (long)B * T2_KVF_WORDS + T2F_WIMG_FLOATS + (long)B * T2F_KVF_FLOATS;
     hipLaunchKernelGGL(tplayer2_prep_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, p);
     return LAUNCH_CHECK();
 }
@@ -851,6 +1114,37 @@ TATT_API int tatt_tplayer2_bwd(const float* x, const float* qpos, long qbs, cons
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tplayer2_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS_BYTES);
     });
     hipLaunchKernelGGL(tplayer2_bwd_kernel, dim3(g.G), dim3(T2_NT), T2_LDS_BYTES, st, p);
+    return LAUNCH_CHECK();
+}
+
+
+// Forward of the layer (training), exact fp32: arguments as tatt_tplayer_fwd with the matrices / K / V replaced by the fp32 operand images of
+// tatt_tplayer2_prep (wimg32, kvf32); hmask (B L 64-bit words, nullable) receives the relu-and-kept bits of the FFN's hidden layer
+TATT_API int tatt_tplayer2_fwd(const float* x, const float* qpos, long qbs, const float* wimg32, const float* kvf32, const float* in_b,
+                               const float* out_b, const float* b1, const float* b2, const float* lnA_w, const float* lnA_b,
+                               const float* lnB_w, const float* lnB_b, const float* lnF_w, const float* lnF_b, float fin_scale,
+                               int fin_both, float* xout, float* fin, float* wavg, unsigned long long* hmask, int B, int L, int S,
+                               float p_attn, float p_res, float p_ffn, const unsigned long long* seed, unsigned site0, float eps,
+                               hipStream_t st) {
+    if (!t2_takes(B, L, S)) return 1;
+    if ((p_attn > 0.f || p_res > 0.f || p_ffn > 0.f) && !seed) return 2;
+    T2F p = {};
+    p.x = x; p.qpos = qpos; p.qbs = qbs; p.wimg32 = wimg32; p.kvf32 = kvf32;
+    p.bv[0] = in_b; p.bv[1] = out_b; p.bv[2] = b1; p.bv[3] = b2;
+    p.lnw[0] = lnA_w; p.lnw[1] = lnB_w; p.lnw[2] = lnF_w;
+    p.lnb[0] = lnA_b; p.lnb[1] = lnB_b; p.lnb[2] = lnF_b;
+    p.fin_scale = fin_scale; p.fin_both = fin_both;
+    const int tps = L / 16, ntiles = B * tps;
+    const int G0 = cdiv(ntiles, 8) < 256 ? cdiv(ntiles, 8) : 256;
+    const int T = cdiv(ntiles, G0), G = cdiv(ntiles, T);
+    p.B = B; p.L = L; p.S = S; p.tps = tps; p.ntiles = ntiles; p.T = T;
+    p.p_attn = p_attn; p.p_res = p_res; p.p_ffn = p_ffn; p.seed = seed; p.site0 = site0; p.eps = eps;
+    p.xout = xout; p.fin = fin; p.wavg = wavg; p.hmask = hmask;
+    static TattPerDevice attr;
+    tatt_per_device(attr, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tplayer2_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, T2F_LDS_BYTES);
+    });
+    hipLaunchKernelGGL(tplayer2_fwd_kernel, dim3(G), dim3(T2F_NT), T2F_LDS_BYTES, st, p);
     return LAUNCH_CHECK();
 }
 

@@ -1025,21 +1025,29 @@ class TPStackFn(Function):
         seed = current_seed(x.device) if drop else None
         kin = ops.axpby(mem, pos, 1.0, 1.0) if pos.dim() == 3 else ops.add_rowbcast(mem, pos, pos.shape[0])
         kin2, mem2 = kin.reshape(-1, E), mem.reshape(-1, E)
-        xs, Ks, Vs, hms = [x], [], [], []
+        xs, Ks, Vs, hms, packs = [x], [], [], [], []
         out = wavg = None
-        # the second-generation backward (csrc/tplayer2.hip) takes the FFN's relu bits from the forward launch
-        want_bits = any(ctx.needs_input_grad) and ops.TPLAYER_BWD2 and ops.tplayer2_geom(B, L, S)[0] == 1
+        # training (a backward will follow): the second generation of the layer (csrc/tplayer2.hip) where it takes the geometry -- its
+        # forward leaves the FFN's relu bits and the packed operands for its backward
+        gen2 = any(ctx.needs_input_grad) and ops.TPLAYER_BWD2 and ops.tplayer2_geom(B, L, S)[0] == 1
         for l, lp in enumerate(lps):
             in_w, in_b = lp[0], lp[1]
             K = ops.linear_fwd(kin2, in_w[E:2 * E], in_b[E:2 * E]).reshape(B, S, E)
             V = ops.linear_fwd(mem2, in_w[2 * E:], in_b[2 * E:]).reshape(B, S, E)
             last = l == n - 1
             fin_here = cfg.fin and last
-            hm = torch.empty(B * L, dtype=torch.int64, device=x.device) if want_bits else None
+            if gen2:
+                pk = ops.tplayer2_prep(lp, K, V)
+                xout, fin, w, hm = ops.tplayer2_fwd(xs[l], qpos, pk, lp, lnF if fin_here else None, 1.0 / n, int(n == 2), cfg.p_attn,
+                                                    cfg.p_res, cfg.p_ffn, seed, cfg.sites[l], cfg.eps, not fin_here,
+                                                    cfg.need_wavg and last, S)
+            else:
+                pk = hm = None
+                xout, fin, w = ops.tplayer_fwd(xs[l], qpos, K, V, lp, lnF if fin_here else None, 1.0 / n, int(n == 2), cfg.p_attn,
+                                               cfg.p_res, cfg.p_ffn, seed, cfg.sites[l], cfg.eps, not fin_here,
+                                               cfg.need_wavg and last)
             hms.append(hm)
-            xout, fin, w = ops.tplayer_fwd(xs[l], qpos, K, V, lp, lnF if fin_here else None, 1.0 / n, int(n == 2), cfg.p_attn,
-                                           cfg.p_res, cfg.p_ffn, seed, cfg.sites[l], cfg.eps, not fin_here,
-                                           cfg.need_wavg and last, hmask=hm)
+            packs.append(pk)
             if last:
                 out, wavg = (fin if fin_here else xout), w
             else:
@@ -1047,7 +1055,7 @@ class TPStackFn(Function):
             Ks.append(K)
             Vs.append(V)
         ctx.save_for_backward(qpos, mem, kin, *xs, *Ks, *Vs, *params)
-        ctx.cfg, ctx.seed, ctx.hms = cfg, seed, hms
+        ctx.cfg, ctx.seed, ctx.hms, ctx.packs = cfg, seed, hms, packs
         ctx.set_materialize_grads(False)          # an unused `wavg` must not cost a zero-filled (B,L,S) gradient
         return out, wavg
 
@@ -1075,16 +1083,18 @@ class TPStackFn(Function):
             last = l == n - 1
             fin_here = cfg.fin and last
             # second generation (split-bf16, csrc/tplayer2.hip) where it takes the geometry, else the exact-fp32 first generation
-            gen2 = ops.TPLAYER_BWD2 and ops.tplayer2_geom(B, L, S)[0] == 1 and ctx.hms[l] is not None
-            bargs = (xs[l], qpos, Ks[l], Vs[l], lp, lnF if fin_here else None, 1.0 / n, int(n == 2), cfg.p_attn, cfg.p_res, cfg.p_ffn,
-                     ctx.seed, cfg.sites[l], cfg.eps, None if fin_here else up, up if fin_here else None, dwavg if last else None,
-                     dq, want_dq)
+            gen2 = ctx.packs[l] is not None
+            dxo, dfi, dwa = None if fin_here else up, up if fin_here else None, dwavg if last else None
             G2 = 0
             if gen2:
-                dx, dq, kvpart, kvflags, ppart, G2 = ops.tplayer2_bwd(*bargs, hmask=ctx.hms[l])
+                dx, dq, kvpart, kvflags, ppart, G2 = ops.tplayer2_bwd(xs[l], qpos, ctx.packs[l], lp, lnF if fin_here else None, 1.0 / n,
+                                                                      int(n == 2), cfg.p_attn, cfg.p_res, cfg.p_ffn, ctx.seed, cfg.sites[l],
+                                                                      cfg.eps, dxo, dfi, dwa, dq, want_dq, S, hmask=ctx.hms[l])
                 dK, dV = ops.tplayer2_reduce_kv(kvpart, kvflags, B, L, S)
             else:
-                dx, dq, kvpart, ppart = ops.tplayer_bwd(*bargs)
+                dx, dq, kvpart, ppart = ops.tplayer_bwd(xs[l], qpos, Ks[l], Vs[l], lp, lnF if fin_here else None, 1.0 / n, int(n == 2),
+                                                        cfg.p_attn, cfg.p_res, cfg.p_ffn, ctx.seed, cfg.sites[l], cfg.eps, dxo, dfi, dwa,
+                                                        dq, want_dq)
                 dK, dV = ops.tplayer_reduce_kv(kvpart, B, L, S)
             dK2, dV2 = dK.reshape(-1, E), dV.reshape(-1, E)
             in_w = lp[0]

@@ -846,9 +846,8 @@ def _tpl_weights(lp, lnF):
     return [P(t) for t in lp] + [P(lnF[0]) if lnF else None, P(lnF[1]) if lnF else None]
 
 
-def tplayer_fwd(x, qpos, K, V, lp, lnF, fin_scale, fin_both, p_attn, p_res, p_ffn, seed, site0, eps, want_xout, want_wavg, hmask=None):
+def tplayer_fwd(x, qpos, K, V, lp, lnF, fin_scale, fin_both, p_attn, p_res, p_ffn, seed, site0, eps, want_xout, want_wavg):
     """One fused transformer layer (see tatt_tplayer_fwd).  x (B,L,64); qpos (B,L,64) or (L,64); K, V (B,S,64).
-    hmask (int64, B*L words; L % 32 == 0): receives the relu-and-kept bits of the FFN for tplayer2_bwd (tatt_tplayer_fwd_m).
     -> (xout or None, fin or None, wavg or None)"""
     _check_dev(x)
     B, L, E = x.shape
@@ -858,13 +857,8 @@ def tplayer_fwd(x, qpos, K, V, lp, lnF, fin_scale, fin_both, p_attn, p_res, p_ff
     xout = torch.empty_like(x) if want_xout else None
     fin = torch.empty_like(x) if lnF else None
     wavg = new(x, B, L, S) if want_wavg else None
-    if hmask is not None:
-        assert hmask.dtype == torch.int64 and hmask.numel() == B * L and L % 32 == 0
-        call("tatt_tplayer_fwd_m", P(x), P(qpos), qbs, P(K), P(V), *_tpl_weights(lp, lnF), float(fin_scale), int(fin_both), P(xout),
-             P(fin), P(wavg), P(hmask), B, L, S, float(p_attn), float(p_res), float(p_ffn), P(seed), int(site0), float(eps), stream())
-    else:
-        call("tatt_tplayer_fwd", P(x), P(qpos), qbs, P(K), P(V), *_tpl_weights(lp, lnF), float(fin_scale), int(fin_both), P(xout),
-             P(fin), P(wavg), B, L, S, float(p_attn), float(p_res), float(p_ffn), P(seed), int(site0), float(eps), stream())
+    call("tatt_tplayer_fwd", P(x), P(qpos), qbs, P(K), P(V), *_tpl_weights(lp, lnF), float(fin_scale), int(fin_both), P(xout), P(fin),
+         P(wavg), B, L, S, float(p_attn), float(p_res), float(p_ffn), P(seed), int(site0), float(eps), stream())
     return xout, fin, wavg
 
 
@@ -895,31 +889,62 @@ def tplayer_reduce_params(ppart, B, L, dsts, betaF=0.0):
     call("tatt_tplayer_reduce_params", P(ppart), B, L, *[P(t) for t in dsts], float(betaF), stream())
 
 
-# second-generation backward of the fused layer (csrc/tplayer2.hip): split-bf16 on the bf16 matrix cores, a wave owns 16 tokens.
-# False (tatt_amd.set_arithmetic("fp32"), tests) keeps the exact-fp32 first generation for every geometry.
+# second generation of the fused layer in TRAINING (csrc/tplayer2.hip: forward and backward, split-bf16 on the bf16 matrix cores, a wave
+# owns 16 tokens).  False (tatt_amd.set_arithmetic("fp32"), tests) keeps the exact-fp32 first generation for every geometry; evaluation
+# always runs the first generation's forward.
 TPLAYER_BWD2 = True
 
 
 def tplayer2_geom(B, L, S):
-    """-> (taken, work-groups, floats of kvpart, floats of ppart, ints of kvflags, words of wimg, words of kvf)"""
-    out = (ctypes.c_int * 7)()
+    """-> (taken, work-groups, floats of kvpart, floats of ppart, ints of kvflags, words of wimg, words of kvf, floats of wimg32,
+    floats of kvf32)"""
+    out = (ctypes.c_int * 9)()
     call("tatt_tplayer2_geom", int(B), int(L), int(S), out)
-    return tuple(out[i] for i in range(7))
+    return tuple(out[i] for i in range(9))
 
 
-def tplayer2_bwd(x, qpos, K, V, lp, lnF, fin_scale, fin_both, p_attn, p_res, p_ffn, seed, site0, eps, dxout, dfin, dwavg, dqacc,
-                 want_dqpos, hmask=None):
-    """tatt_tplayer2_prep + tatt_tplayer2_bwd -> dx, dqpos (or None), kvpart, kvflags, ppart, work-groups.
-    hmask: the relu bits tplayer_fwd left (None: the recomputation decides the relu itself -- may flip kinks, see csrc/tplayer2.hip)"""
+def tplayer2_prep(lp, K, V):
+    """tatt_tplayer2_prep: the layer's four 64x64 matrices and K, V (B,S,64) as MFMA operand fragments -> (wimg, kvf, wimg32, kvf32):
+    the backward's split-bf16 images (int32 tensors) and the forward's exact-fp32 ones"""
+    B, S = K.shape[0], K.shape[1]
+    g = tplayer2_geom(B, 64, S)
+    wimg = torch.empty(g[5], dtype=torch.int32, device=K.device)
+    kvf = torch.empty(g[6], dtype=torch.int32, device=K.device)
+    wimg32, kvf32 = new(K, g[7]), new(K, g[8])
+    call("tatt_tplayer2_prep", P(lp[0]), P(lp[2]), P(lp[4]), P(lp[6]), P(K), P(V), P(wimg), P(kvf), P(wimg32), P(kvf32), B, S, stream())
+    return wimg, kvf, wimg32, kvf32
+
+
+def tplayer2_fwd(x, qpos, packed, lp, lnF, fin_scale, fin_both, p_attn, p_res, p_ffn, seed, site0, eps, want_xout, want_wavg, S,
+                 want_bits=True):
+    """The layer's forward, second generation (csrc/tplayer2.hip; training mode; exact fp32 products).  packed = tplayer2_prep(...).
+    -> (xout or None, fin or None, wavg or None, hmask or None)"""
+    _check_dev(x)
     B, L, E = x.shape
-    S = K.shape[1]
+    assert E == 64 and x.is_contiguous() and qpos.is_contiguous()
     qbs = L * 64 if qpos.dim() == 3 else 0
-    taken, G, nkv, npp, nfl, nw, nkf = tplayer2_geom(B, L, S)
-    assert taken
-    wimg = torch.empty(nw, dtype=torch.int32, device=x.device)
-    kvf = torch.empty(nkf, dtype=torch.int32, device=x.device)
+    wimg32, kvf32 = packed[2], packed[3]
     in_w, in_b, out_w, out_b, w1, b1, w2, b2, lnA_w, lnA_b, lnB_w, lnB_b = lp
-    call("tatt_tplayer2_prep", P(in_w), P(out_w), P(w1), P(w2), P(K), P(V), P(wimg), P(kvf), B, S, stream())
+    xout = torch.empty_like(x) if want_xout else None
+    fin = torch.empty_like(x) if lnF else None
+    wavg = new(x, B, L, S) if want_wavg else None
+    hmask = torch.empty(B * L, dtype=torch.int64, device=x.device) if want_bits else None
+    call("tatt_tplayer2_fwd", P(x), P(qpos), qbs, P(wimg32), P(kvf32), P(in_b), P(out_b), P(b1), P(b2), P(lnA_w), P(lnA_b), P(lnB_w), P(lnB_b),
+         P(lnF[0]) if lnF else None, P(lnF[1]) if lnF else None, float(fin_scale), int(fin_both), P(xout), P(fin), P(wavg), P(hmask),
+         B, L, S, float(p_attn), float(p_res), float(p_ffn), P(seed), int(site0), float(eps), stream())
+    return xout, fin, wavg, hmask
+
+
+def tplayer2_bwd(x, qpos, packed, lp, lnF, fin_scale, fin_both, p_attn, p_res, p_ffn, seed, site0, eps, dxout, dfin, dwavg, dqacc,
+                 want_dqpos, S, hmask=None):
+    """tatt_tplayer2_bwd -> dx, dqpos (or None), kvpart, kvflags, ppart, work-groups.  packed = tplayer2_prep(...) (the forward's);
+    hmask: the relu bits tplayer2_fwd left (None: the recomputation decides the relu itself -- may flip kinks, see csrc/tplayer2.hip)"""
+    B, L, E = x.shape
+    qbs = L * 64 if qpos.dim() == 3 else 0
+    taken, G, nkv, npp, nfl = tplayer2_geom(B, L, S)[:5]
+    assert taken
+    wimg, kvf = packed[0], packed[1]
+    in_w, in_b, out_w, out_b, w1, b1, w2, b2, lnA_w, lnA_b, lnB_w, lnB_b = lp
     dx = torch.empty_like(x)
     dqpos = torch.empty_like(x) if want_dqpos else None
     kvpart, ppart = new(x, nkv), new(x, npp)

@@ -167,9 +167,11 @@ timeit("tplayer_bwd", lambda: ops.tplayer_bwd(tx, tq, tK, tV, lp, lnF, 0.5, 1, 0
 
 # second generation of the backward (csrc/tplayer2.hip): prep (operand packing) + kernel, the relu bits from the forward launch
 if ops.tplayer2_geom(B, L, 26)[0]:
-    thm = torch.empty(B * L, dtype=torch.int64, device=dev)
-    ops.tplayer_fwd(tx, tq, tK, tV, lp, lnF, 0.5, 1, 0.1, 0.1, 0.1, sd, 10, 1e-5, False, True, hmask=thm)
-    timeit("tplayer2_bwd", lambda: ops.tplayer2_bwd(tx, tq, tK, tV, lp, lnF, 0.5, 1, 0.1, 0.1, 0.1, sd, 10, 1e-5, None, tup, None, None, True, hmask=thm),
+    tpk = ops.tplayer2_prep(lp, tK, tV)
+    t2f = lambda: ops.tplayer2_fwd(tx, tq, tpk, lp, lnF, 0.5, 1, 0.1, 0.1, 0.1, sd, 10, 1e-5, False, True, 26)
+    thm = t2f()[3]
+    timeit("tplayer2_fwd", t2f, B * L * (4 * 2 * 64 * 64 + 2 * 2 * 26 * 64), B * L * (64 * 4 * 3 + 26 * 4))
+    timeit("tplayer2_bwd", lambda: ops.tplayer2_bwd(tx, tq, tpk, lp, lnF, 0.5, 1, 0.1, 0.1, 0.1, sd, 10, 1e-5, None, tup, None, None, True, 26, hmask=thm),
            B * L * (12 * 2 * 64 * 64 + 8 * 2 * 26 * 64), B * L * 64 * 4 * 5)
 
 # ---- TBSRN score-free self-attention (csrc/sattn.hip): P = 1024 tokens, 4 heads x 32 ----

@@ -37,23 +37,27 @@ def layer_case(dev, B, L, S, p, fin):
     bwd = lambda: ops.tplayer_bwd(x, qpos, K, V, lp, lnF, 0.5, int(fin), p, p, p, seed, 10, 1e-5, None if fin else up, up if fin else None,
                                   None, None, True)
     tf, tb = timed(fwd), timed(bwd)
-    tb2 = tprep = float("nan")
+    tb2 = tf2 = tprep = float("nan")
     if ops.tplayer2_geom(B, L, S)[0]:
+        pk = ops.tplayer2_prep(lp, K, V)
+        fargs = (x, qpos, pk, lp, lnF, 0.5, int(fin), p, p, p, seed, 10, 1e-5, not fin, fin, S)
+        tf2 = timed(lambda: ops.tplayer2_fwd(*fargs))
+        hm = ops.tplayer2_fwd(*fargs)[3]
         args = (x, qpos, K, V, lp, lnF, 0.5, int(fin), p, p, p, seed, 10, 1e-5, None if fin else up, up if fin else None, None, None, True)
-        hm = torch.empty(B * L, dtype=torch.int64, device=dev)
-        ops.tplayer_fwd(x, qpos, K, V, lp, lnF, 0.5, int(fin), p, p, p, seed, 10, 1e-5, not fin, fin, hmask=hm)
-        bwd2 = lambda: ops.tplayer2_bwd(*args, hmask=hm)
+        args2 = (x, qpos, pk, lp, lnF, 0.5, int(fin), p, p, p, seed, 10, 1e-5, None if fin else up, up if fin else None, None, None, True, S)
+        bwd2 = lambda: ops.tplayer2_bwd(*args2, hmask=hm)
         tb2 = timed(bwd2)
-        nw, nkf = ops.tplayer2_geom(B, L, S)[5:7]
-        wimg = torch.empty(nw, dtype=torch.int32, device=dev)
-        kvf = torch.empty(nkf, dtype=torch.int32, device=dev)
-        prep = lambda: ops.call("tatt_tplayer2_prep", ops.P(lp[0]), ops.P(lp[2]), ops.P(lp[4]), ops.P(lp[6]), ops.P(K), ops.P(V), ops.P(wimg),
-                                ops.P(kvf), B, S, ops.stream())
-        tprep = timed(prep)
+        tprep = timed(lambda: ops.tplayer2_prep(lp, K, V))
+        # forward parity: second generation (split bf16) against the first (exact fp32)
+        o1 = ops.tplayer_fwd(x, qpos, K, V, lp, lnF, 0.5, int(fin), p, p, p, seed, 10, 1e-5, not fin, fin)
+        o2 = ops.tplayer2_fwd(*fargs)
+        torch.cuda.synchronize()
+        fe = ["%s %.1e" % (n, float((a - b).abs().max()) / (float(b.abs().max()) + 1e-20)) for n, a, b in zip(("xout", "fin", "wavg"), o2, o1) if a is not None]
+        print("   gen2 forward vs gen1 (rel-max err): " + ", ".join(fe))
         # kernel-level parity: second generation (split bf16) against the first (exact fp32), every output after its reducer
         dx1, dq1, kv1, pp1 = ops.tplayer_bwd(*args)
         dK1, dV1 = ops.tplayer_reduce_kv(kv1, B, L, S)
-        dx2, dq2, kv2, fl2, pp2, G2 = ops.tplayer2_bwd(*args, hmask=hm)
+        dx2, dq2, kv2, fl2, pp2, G2 = ops.tplayer2_bwd(*args2, hmask=hm)
         dK2, dV2 = ops.tplayer2_reduce_kv(kv2, fl2, B, L, S)
         names = ["in_w", "in_b", "out_w", "out_b", "w1", "b1", "w2", "b2", "lnA_w", "lnA_b", "lnB_w", "lnB_b", "lnF_w", "lnF_b"]
         shp = [(64, 64), (64,), (64, 64), (64,), (64, 64), (64,), (64, 64), (64,), (64,), (64,), (64,), (64,), (64,), (64,)]
@@ -75,8 +79,8 @@ def layer_case(dev, B, L, S, p, fin):
     f_bwd = tok * (12 * 2 * 64 * 64 + 6 * 2 * S * 64)                # recompute + data gradients + weight gradients
     b_fwd = tok * 64 * 4 * 3 + (tok * S * 4 if fin else 0)           # x, qpos in; one map out (+ weights map)
     b_bwd = tok * 64 * 4 * 5                                         # x, qpos, upstream in; dx, dqpos out
-    print("tplayer B=%d L=%d S=%d p=%.1f fin=%d: fwd %7.1f us %6.1f TFLOP/s %6.0f GB/s | bwd %7.1f us %6.1f TFLOP/s %6.0f GB/s | bwd2 (prep + kernel) %7.1f us, prep alone %5.1f us" % (
-        B, L, S, p, fin, tf, f_fwd / tf / 1e6, b_fwd / tf / 1e3, tb, f_bwd / tb / 1e6, b_bwd / tb / 1e3, tb2, tprep))
+    print("tplayer B=%d L=%d S=%d p=%.1f fin=%d: fwd %7.1f us %6.1f TFLOP/s %6.0f GB/s | bwd %7.1f us %6.1f TFLOP/s %6.0f GB/s | gen2: fwd %7.1f us, bwd %7.1f us, prep %5.1f us" % (
+        B, L, S, p, fin, tf, f_fwd / tf / 1e6, b_fwd / tf / 1e3, tb, f_bwd / tb / 1e6, b_bwd / tb / 1e3, tf2, tb2, tprep))
     return tf, tb
 
 

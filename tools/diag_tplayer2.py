@@ -17,9 +17,10 @@ def case(dev, B, L, S=26, p=0.0, fin=False):
     up = r(B, L, 64)
     args = (x, qpos, K, V, lp, lnF, 0.5, int(fin), p, p, p, seed, 10, 1e-5, None if fin else up, up if fin else None, None, None, True)
     dx1 = ops.tplayer_bwd(*args)[0]
-    hm = torch.empty(B * L, dtype=torch.int64, device=dev)
-    ops.tplayer_fwd(x, qpos, K, V, lp, lnF, 0.5, int(fin), p, p, p, seed, 10, 1e-5, not fin, fin, hmask=hm)
-    outs = [ops.tplayer2_bwd(*args, hmask=hm)[0] for _ in range(3)]
+    pk = ops.tplayer2_prep(lp, K, V)
+    hm = ops.tplayer2_fwd(x, qpos, pk, lp, lnF, 0.5, int(fin), p, p, p, seed, 10, 1e-5, not fin, fin, S)[3]
+    args2 = (x, qpos, pk, lp, lnF, 0.5, int(fin), p, p, p, seed, 10, 1e-5, None if fin else up, up if fin else None, None, None, True, S)
+    outs = [ops.tplayer2_bwd(*args2, hmask=hm)[0] for _ in range(3)]
     torch.cuda.synchronize()
     taken, G = ops.tplayer2_geom(B, L, S)[:2]
     scale = float(dx1.abs().max())
