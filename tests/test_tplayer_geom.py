@@ -14,3 +14,36 @@ def test_fused_layer_raw_abi_geometry():
             b0, b1 = (w * nper) // tps, (min(ntiles, (w + 1) * nper) - 1) // tps
             assert b1 - b0 + 1 <= span, (B, L, w, b0, b1, span)
         assert nkv == G * span * 2 * 32 * 64 and npp == G * (4 * 4096 + 640)
+
+
+def test_second_generation_geometry_and_fallback_rule():
+    """tatt_tplayer2_geom (csrc/tplayer2.hip): the second generation takes whole rounds of four 16-token tiles inside one sample
+    (L % 64 == 0), a work-group's tiles inside two samples at most, at most 32 keys; every tile is covered exactly once by
+    (work-group, round, wave); everything else is left to the first generation."""
+    from tatt_amd import ops
+    for B, L, S, want in [(48, 1024, 26, 1), (16, 4096, 26, 1), (2, 1024, 26, 1), (2, 64, 26, 1), (3, 128, 5, 1), (48, 26, 26, 0),
+                          (3, 80, 26, 0), (1, 32, 26, 0), (2, 1024, 33, 0), (300, 64, 26, 0), (64, 64, 26, 1)]:
+        g = ops.tplayer2_geom(B, L, S)
+        assert g[0] == want, (B, L, S, g)
+        if not want:
+            continue
+        G, nkv, npp, nfl = g[1:5]
+        tps, ntiles = L // 16, B * (L // 16)
+        nper = -(-ntiles // (4 * G))
+        assert 1 <= G <= 256 and 4 * nper <= tps and 4 * nper * G >= ntiles > 4 * nper * (G - 1)
+        assert nkv == G * 5 * 4096 and npp == G * (4 * 4096 + 640) and nfl == 2 * G
+        seen = set()
+        for w in range(G):
+            wg0 = w * 4 * nper
+            nrd = min(nper, (ntiles - wg0) // 4)
+            b0 = wg0 // tps
+            split = min(nrd, ((b0 + 1) * tps - wg0) // 4)
+            assert nrd >= 1 and split >= 1
+            for rd in range(nrd):
+                b = b0 + (0 if rd < split else 1)
+                for wave in range(4):
+                    t = wg0 + 4 * rd + wave
+                    assert t // tps == b, (B, L, w, rd, wave)        # the four tiles of a round lie in ONE sample
+                    seen.add(t)
+        assert seen == set(range(ntiles))
+        assert g[5] == 8 * 4096 and g[6] == B * 8192 and g[7] == 4 * 4096 and g[8] == B * 4096

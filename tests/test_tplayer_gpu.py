@@ -121,3 +121,86 @@ def test_fused_stack_vs_oracle(dev):
             bad.append("%s: %.3e" % (k, e))
     assert not bad, "\n".join(bad)
     assert max_err(got["tp_map"], ref["tp_map"]) < 2e-5 and max_err(got["wts"], ref["wts"]) < 1e-6
+
+
+def _layer_inputs(dev, B, L, S, fin, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: (torch.randn(*s, generator=g) * 0.3).to(dev)
+    x, qpos, K, V, up = r(B, L, 64), r(B, L, 64), r(B, S, 64), r(B, S, 64), r(B, L, 64)
+    lp = (r(192, 64), r(192), r(64, 64), r(64), r(64, 64), r(64), r(64, 64), r(64), r(64) + 1, r(64), r(64) + 1, r(64))
+    lnF = (r(64) + 1, r(64)) if fin else None
+    return x, qpos, K, V, up, lp, lnF
+
+
+@pytest.mark.parametrize("B,L,p,fin", [(48, 1024, 0.1, True), (48, 1024, 0.0, False), (5, 256, 0.1, False), (16, 4096, 0.1, True)])
+def test_second_generation_layer_against_the_first(dev, B, L, p, fin):
+    """csrc/tplayer2.hip against csrc/tplayer.hip on the same inputs, kernel level, at the benchmarked token count (B = 48: three rounds per
+    work-group, work-groups that change sample), the large tile and a small case: the forward (exact fp32, another summation order) to
+    fp32 round-off; the backward (split-bf16 products, relu decisions taken from the forward's bits) to 1e-4 of each output's scale --
+    every token, so a single flipped relu (O(1) on that token) fails."""
+    from tatt_amd import ops, functional as Fh
+    S = 26
+    x, qpos, K, V, up, lp, lnF = _layer_inputs(dev, B, L, S, fin)
+    seed = Fh.seed_tensor(dev)
+    assert ops.tplayer2_geom(B, L, S)[0] == 1
+    pk = ops.tplayer2_prep(lp, K, V)
+    o1 = ops.tplayer_fwd(x, qpos, K, V, lp, lnF, 0.5, int(fin), p, p, p, seed, 10, 1e-5, not fin, fin)
+    o2 = ops.tplayer2_fwd(x, qpos, pk, lp, lnF, 0.5, int(fin), p, p, p, seed, 10, 1e-5, not fin, fin, S)
+    for n, a, b in zip(("xout", "fin", "wavg"), o2[:3], o1):
+        assert (a is None) == (b is None), n
+        if a is not None:
+            assert max_err(a, b) <= 2e-6 * float(b.abs().max()), (n, max_err(a, b))
+    hm = o2[3]
+    bargs = (0.5, int(fin), p, p, p, seed, 10, 1e-5, None if fin else up, up if fin else None, None, None, True)
+    dx1, dq1, kv1, pp1 = ops.tplayer_bwd(x, qpos, K, V, lp, lnF, *bargs)
+    dK1, dV1 = ops.tplayer_reduce_kv(kv1, B, L, S)
+    dx2, dq2, kv2, fl2, pp2, G2 = ops.tplayer2_bwd(x, qpos, pk, lp, lnF, *bargs, S, hmask=hm)
+    dK2, dV2 = ops.tplayer2_reduce_kv(kv2, fl2, B, L, S)
+    shp = [(64, 64), (64,), (64, 64), (64,), (64, 64), (64,), (64, 64), (64,), (64,), (64,), (64,), (64,), (64,), (64,)]
+    g1 = [torch.zeros(*sh, device=dev) for sh in shp]
+    g2 = [torch.zeros(*sh, device=dev) for sh in shp]
+    if not fin:
+        g1[12] = g1[13] = g2[12] = g2[13] = None
+    ops.tplayer_reduce_params(pp1, B, L, g1)
+    ops.tplayer_reduce_params_g(pp2, G2, g2)
+    names = ["dx", "dqpos", "dK", "dV", "in_w", "in_b", "out_w", "out_b", "w1", "b1", "w2", "b2", "lnA_w", "lnA_b", "lnB_w", "lnB_b", "lnF_w", "lnF_b"]
+    bad = []
+    for n, a, b in zip(names, [dx2, dq2, dK2, dV2] + g2, [dx1, dq1, dK1, dV1] + g1):
+        if a is None:
+            continue
+        e = max_err(a, b) / (float(b.abs().max()) + 1e-20)
+        if not e <= 1e-4:
+            bad.append("%s %.2e" % (n, e))
+    assert not bad, bad
+    # deterministic: a second launch reproduces every word
+    dx3, dq3, kv3, fl3, pp3, _ = ops.tplayer2_bwd(x, qpos, pk, lp, lnF, *bargs, S, hmask=hm)
+    assert torch.equal(dx2, dx3) and torch.equal(dq2, dq3) and torch.equal(pp2, pp3)
+    assert torch.equal(ops.tplayer2_reduce_kv(kv3, fl3, B, L, S)[0], dK2)
+
+
+def test_second_generation_is_a_training_path_and_fp32_switch_selects_the_first(dev):
+    """The second generation runs where a backward follows (it exists to leave the relu bits and the packed operands for it); evaluation
+    and tatt_amd.set_arithmetic('fp32') run the first generation.  Checked through what TPStackFn keeps for its backward."""
+    import tatt_amd
+    import tatt_amd.tsrn as T
+    from tatt_amd import functional as Fh, ops
+    ig = _interp(16, 64, 2).to(dev)
+    g = torch.Generator().manual_seed(4)
+    feat = torch.randn(2, 16, 64, 64, generator=g).to(dev).requires_grad_(True)
+    tp = torch.softmax(torch.randn(2, 37, 1, 26, generator=g), 1).to(dev)
+    qpos = (torch.randn(2, 1024, 64, generator=g) * 0.5).to(dev)
+    ig.dropout_on = False
+    Fh.begin_training_forward(dev)
+    tp_map, _ = T._tp_interpreter(feat, tp, ig, True, qpos=qpos)
+    assert tp_map.grad_fn is not None and all(pk is not None for pk in tp_map.grad_fn.packs) and tp_map.grad_fn.hms[0].dtype == torch.int64
+    try:
+        tatt_amd.set_arithmetic("fp32")
+        assert not ops.TPLAYER_BWD2
+        tp_map2, _ = T._tp_interpreter(feat, tp, ig, True, qpos=qpos)
+        assert all(pk is None for pk in tp_map2.grad_fn.packs)
+    finally:
+        tatt_amd.set_arithmetic("split_bf16")
+    assert max_err(tp_map, tp_map2) < 2e-6                  # (both forwards are exact fp32: summation order only)
+    with torch.no_grad():
+        ev, _ = T._tp_interpreter(feat.detach(), tp, ig, False, qpos=qpos)
+    assert max_err(ev, tp_map2.detach()) == 0.0             # evaluation = the first generation's forward, dropout off in both
