@@ -75,10 +75,19 @@ __global__ __launch_bounds__(512, 1) void conv3_c64_wgrad_sb_kernel(Conv3WSP p) 
     cw_bf16x8 ones;
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+    // A group walks a CONTIGUOUS run of segments, ordered (image, column strip, row) with the row fastest: consecutive segments are
+    // consecutive image rows, and two of a segment's three halo rows are already in LDS -- the halo is a ring of three row slots (row hh
+    // of the strip lives in slot (hh + 3) % 3) and only the new bottom row is fetched (round 4 strided the segments over the groups and
+    // fetched every x row three times: 67.8 MB per launch against 44 MB algorithmic, profiles/r04_g_pmc_traffic_conv3_wgrad_64_64.txt).
+    const int per = (p.nseg + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int s_beg = blockIdx.x * per, s_end = min(p.nseg, s_beg + per);
     f32x4 pre[9];
+    auto seg_of = [&](int s, int& n, int& h, int& w0) { h = s % p.H; s /= p.H; w0 = (s % segs) * CW_PX; n = s / segs; };
+    // rows to fetch: all three for the first segment of the run and of a strip (h == 0), else the bottom one
     auto fetch = [&](int s) {
-        const int seg = s % segs; s /= segs;
-        const int h = s % p.H, n = s / p.H, w0 = seg * CW_PX;
+        int n, h, w0;
+        seg_of(s, n, h, w0);
+        const bool fresh = s == s_beg || h == 0;
 #pragma unroll
         for (int r = 0; r < 9; ++r) {
             const int idx = t + 512 * r;
@@ -87,7 +96,7 @@ __global__ __launch_bounds__(512, 1) void conv3_c64_wgrad_sb_kernel(Conv3WSP p) 
                 const int c4 = idx & 15, pp = idx >> 4;
                 const int rr = pp / CW_HW, px = pp - rr * CW_HW;
                 const int hh = h + rr - 1, ww = w0 + px - 1;
-                if (hh >= 0 && hh < p.H && ww >= 0 && ww < p.W)
+                if ((fresh || rr == 2) && hh >= 0 && hh < p.H && ww >= 0 && ww < p.W)
                     u = *reinterpret_cast<const f32x4*>(p.x + (((long)n * p.H + hh) * p.W + ww) * p.Cin + ci0 + 4 * c4);
             } else if (idx < CW_F4) {
                 const int j = idx - 3 * CW_HW * 16, c4 = j & 15, px = j >> 4;
@@ -96,31 +105,38 @@ __global__ __launch_bounds__(512, 1) void conv3_c64_wgrad_sb_kernel(Conv3WSP p) 
             pre[r] = u;
         }
     };
-    auto stash = [&]() {
+    auto stash = [&](int s) {
+        int n, h, w0;
+        seg_of(s, n, h, w0);
+        const bool fresh = s == s_beg || h == 0;
 #pragma unroll
         for (int r = 0; r < 9; ++r) {
             const int idx = t + 512 * r;
             if (idx < CW_F4) {
                 float* d;
-                if (idx < 3 * CW_HW * 16) d = IMG + (idx >> 4) * CW_CP + 4 * (idx & 15);            // halo pixel (row * 66 + px) = idx >> 4
-                else { const int j = idx - 3 * CW_HW * 16; d = IMG + CW_HALO + (j >> 4) * CW_CP + 4 * (j & 15); }
+                if (idx < 3 * CW_HW * 16) {
+                    const int pp = idx >> 4, rr = pp / CW_HW, px = pp - rr * CW_HW;
+                    if (!(fresh || rr == 2)) continue;                                              // rows h - 1, h: already in their slots
+                    d = IMG + (((h + rr + 2) % 3) * CW_HW + px) * CW_CP + 4 * (idx & 15);           // slot of row h + rr - 1
+                } else { const int j = idx - 3 * CW_HW * 16; d = IMG + CW_HALO + (j >> 4) * CW_CP + 4 * (j & 15); }
                 *reinterpret_cast<float2*>(d) = make_float2(pre[r][0], pre[r][1]);                 // pixel rows are 8-byte aligned (66 dwords)
                 *reinterpret_cast<float2*>(d + 2) = make_float2(pre[r][2], pre[r][3]);
             }
         }
     };
-    int s = blockIdx.x;
-    if (s < p.nseg) fetch(s);
-    for (; s < p.nseg; s += gridDim.x) {
-        stash();                                             // IMG: last read by the conversions of the previous segment (before its barriers)
+    int s = s_beg;
+    if (s < s_end) fetch(s);
+    for (; s < s_end; ++s) {
+        stash(s);                                            // IMG: last read by the conversions of the previous segment (before its barriers)
         __syncthreads();                                     // image complete; every wave has left the previous segment's MFMAs (F is free)
-        if (s + (int)gridDim.x < p.nseg) fetch(s + gridDim.x);
+        if (s + 1 < s_end) fetch(s + 1);
+        const int hrow = s % p.H;                            // this segment's image row: halo row ky sits in slot (hrow + ky + 2) % 3
         cw_bf16x8 dh[2][2], dl[2][2];                        // this wave's dy fragments [output-channel tile][pixel half]
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             {   // this wave's share of the transposition: the three shifts of (channel tile (wave >> 1) & 3, pixel half wave & 1) of halo row ky
                 const int xt = (wave >> 1) & 3, ks = wave & 1;
-                const float* col = IMG + ((ky * CW_HW + 32 * ks + 8 * kq) * CW_CP) + 16 * xt + li;
+                const float* col = IMG + ((((hrow + ky + 2) % 3) * CW_HW + 32 * ks + 8 * kq) * CW_CP) + 16 * xt + li;
                 float v[10];
 #pragma unroll
                 for (int e = 0; e < 10; ++e) v[e] = col[e * CW_CP];

@@ -232,9 +232,6 @@ def _default_loss(sr, hr):
     return image_loss_mean(sr, hr, scale=100.0)
 
 
-DP_GROUPS = 3            # data parallel: pass groups (= graphs = collectives) per step, see Trainer.__init__
-
-
 class Trainer:
     """One training step per `step()` call: forward, ImageLoss.mean()*100, backward, [all-reduce], clip, Adam.
 
@@ -337,10 +334,7 @@ class Trainer:
         # interpreter with the query GRU, 19 MB), [pass n-1] -> the last two.  With `use_graph` a group is one hipGraph: four graph
         # launches and three collectives per step instead of ten and ten.
         n = self._npass
-        if DP_GROUPS == 2 and n >= 3:                # (A/B hook: the last two passes as ONE graph, two collectives per step)
-            groups = [list(range(0, n - 2)), [n - 2, n - 1]]
-        else:
-            groups = [list(range(0, n - 2)), [n - 2], [n - 1]] if n >= 3 else [[k] for k in range(n)]
+        groups = [list(range(0, n - 2)), [n - 2], [n - 1]] if n >= 3 else [[k] for k in range(n)]
         self._groups = [g for g in groups if g]
         self.reduce_log = []                         # [(last pass of the group, first bucket, last bucket)] of the latest step
 

@@ -367,11 +367,6 @@ def _tp_fusable(ig: TPInterpreter, L):
     return True
 
 
-# A/B hook: the text side of the TP interpreter (prior -> tokens -> encoder layer: depends on the prior and on parameters only) issued on
-# the forward's forked branch, behind the query embedding, instead of on the main lane between block1 and the decoder layers
-TEXT_ON_FORK = False
-
-
 def _tp_text_side(tp, ig: TPInterpreter, training):
     """The text side of the TP interpreter (model/tsrn.py:194-216, transformer_v2.py:268-276): -> (src, pos, memory); memory is None
     when the encoder layer has to run operator by operator (the caller does that)."""
@@ -594,9 +589,6 @@ class _GeneratorBase(_TrainPathMixin, nn.Module):
         if use_tp and text_emb is None:
             text_emb = torch.zeros(1, 37, 1, 26, device=x.device)         # reference :653-654
         text_side = None
-        if use_tp and TEXT_ON_FORK and training and _tp_fusable(self.infoGen, text_emb.shape[3]):
-            tpf = text_emb.float()
-            text_side = Fh.FWD_FORK.run(tpf, lambda: _tp_text_side(tpf, self.infoGen, training))
         if k > 0 and isinstance(getattr(self, "block2").gru1, GruBlock):
             # the composed 1x1-conv x GRU-input projections of every residual block: parameters only, one launch for all of them
             Fh.gru_precompose([g for i in range(k) for g in (getattr(self, "block%d" % (i + 2)).gru1,
