@@ -515,6 +515,14 @@ int tatt_tplayer2_geom(int B, int L, int S, int* out);
  * backward's split-bf16 operands); wimg32 / kvf32 = the forward's exact-fp32 operands (one float per lane and v_mfma_f32_16x16x4_f32 step) */
 int tatt_tplayer2_prep(const float* in_w, const float* out_w, const float* w1, const float* w2, const float* K, const float* V,
                        unsigned* wimg, unsigned* kvf, float* wimg32, float* kvf32, int B, int S, hipStream_t st);
+/* the same packing with the key / value projections folded in, ONE launch for nl = 1 or 2 layers over one memory: K = (mem + pos) Wk^T + bk and
+ * V = mem Wv^T + bv (Wk / Wv = rows 64..127 / 128..191 of the layer's packed in-projection) are computed per (layer, sample) in fp32 and leave
+ * only as the fragment forms above; kin (B,S,64; nullable) receives mem + pos (the backward's weight gradients read it).  pos: (B,S,64) with
+ * pos_bs = S*64, or (S,64) with pos_bs = 0.  in_w ... kvf32 are HOST arrays of nl device pointers. */
+int tatt_tplayer2_kvprep(const float* mem, const float* pos, long pos_bs, const float* const* in_w, const float* const* in_b,
+                         const float* const* out_w, const float* const* w1, const float* const* w2, unsigned* const* wimg,
+                         unsigned* const* kvf, float* const* wimg32, float* const* kvf32, float* kin, int B, int S, int nl,
+                         hipStream_t st);
 /* the layer's forward in the same organisation (training mode), exact fp32 products (v_mfma_f32_16x16x4_f32): arguments as tatt_tplayer_fwd
  * with the matrices / K / V replaced by wimg32 / kvf32; hmask (B*L 64-bit words, nullable) receives the relu-and-kept bits of the FFN's hidden layer -- word [16-token tile][channel
  * block][r], bit = lane -- which tatt_tplayer2_bwd reads instead of re-deciding the relu (a recomputation that differs from the forward in

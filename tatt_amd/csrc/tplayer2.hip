@@ -1048,6 +1048,129 @@ __global__ __launch_bounds__(256) void tplayer2_prep_kernel(T2Prep p) {
     *dst = hl ? lo : hi;
 }
 
+// ---- the same packing with the key / value projections folded in: ONE launch for all (one or two) decoder layers over a memory --------------
+// Replaces, per training forward: kin = mem + pos (1 launch), K = kin Wk^T + bk and V = mem Wv^T + bv per layer (4 launches), the packing
+// above per layer (2 launches).  A work-group per (layer, sample) computes the sample's 26 x 64 keys and values in fp32 (64 k-ordered FMAs
+// per element: the arithmetic of the GEMM kernel it replaces, another summation order) into LDS and writes the fragment forms from there --
+// K and V themselves never reach memory; 192 more work-groups per layer pack the weight images.
+struct T2KVPrep {
+    const float* mem; const float* pos; long pos_bs;         // (B,S,64); pos (B,S,64) [pos_bs = S*64] or (S,64) [0]
+    const float* in_w[2]; const float* in_b[2]; const float* W[2][4];
+    unsigned* wimg[2]; unsigned* kvf[2]; float* wimg32[2]; float* kvf32[2];
+    float* kin;                                              // (B,S,64) = mem + pos, for the backward's weight gradients (nullable)
+    int B, S, nl;
+};
+#define T2KV_WBLOCKS ((T2_WIMG_WORDS + T2F_WIMG_FLOATS) / 256)
+__global__ __launch_bounds__(256) void tplayer2_kvprep_kernel(T2KVPrep p) {
+    __shared__ float Min[32][64], Kin[32][64], Kc[32][64], Vc[32][64];
+    const int per = p.B + T2KV_WBLOCKS;
+    const int l = blockIdx.x / per, j = blockIdx.x - l * per, tid = threadIdx.x;
+    if (j >= p.B) {                                          // ---- weight images of layer l (as tplayer2_prep_kernel) ----
+        const long idx = (long)(j - p.B) * 256 + tid;
+        if (idx < T2_WIMG_WORDS) {
+            const int e = idx & 3, lane = (idx >> 2) & 63, hl = (idx >> 8) & 1, ks = (idx >> 9) & 1, blk = (idx >> 10) & 3, im = (int)(idx >> 12);
+            const int am = lane & 15, kq = lane >> 4;
+            const float* W = p.W[l][im & 3];
+            const int k0 = t2_kslot(ks, kq, 2 * e), k1 = t2_kslot(ks, kq, 2 * e + 1), n = 16 * blk + am;
+            unsigned hi, lo;
+            if (im < 4) t2_split2(W[n * 64 + k0], W[n * 64 + k1], hi, lo);
+            else t2_split2(W[k0 * 64 + n], W[k1 * 64 + n], hi, lo);
+            p.wimg[l][idx] = hl ? lo : hi;
+        } else {
+            const long q = idx - T2_WIMG_WORDS;
+            const int u = q & 3, lane = (q >> 2) & 63, c4 = (q >> 8) & 3, nb = (q >> 10) & 3, im = (int)(q >> 12);
+            p.wimg32[l][q] = p.W[l][im][(16 * nb + (lane & 15)) * 64 + 16 * c4 + 4 * (lane >> 4) + u];
+        }
+        return;
+    }
+    // ---- keys and values of sample j for layer l ----
+    const int b = j;
+    for (int i = tid; i < 32 * 64; i += 256) {
+        const int s_ = i >> 6, c = i & 63;
+        float m = 0.f, k = 0.f;
+        if (s_ < p.S) {
+            m = p.mem[((long)b * p.S + s_) * 64 + c];
+            k = m + p.pos[(long)b * p.pos_bs + s_ * 64 + c];
+            if (l == 0 && p.kin) p.kin[((long)b * p.S + s_) * 64 + c] = k;
+        }
+        Min[s_][c] = m; Kin[s_][c] = k;
+    }
+    __syncthreads();
+    {
+        const int c = tid & 63, sg = tid >> 6;               // output channel c, rows sg, sg + 4, ...
+        const float* wk = p.in_w[l] + (64 + c) * 64;
+        const float* wv = p.in_w[l] + (128 + c) * 64;
+        const float bk = p.in_b[l][64 + c], bv = p.in_b[l][128 + c];
+        f32x4 w[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) w[q] = t2_ld4(wk + 4 * q);
+        for (int s_ = sg; s_ < 32; s_ += 4) {
+            float a = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(&Kin[s_][4 * q]);
+                a = fmaf(x[0], w[q][0], a); a = fmaf(x[1], w[q][1], a); a = fmaf(x[2], w[q][2], a); a = fmaf(x[3], w[q][3], a);
+            }
+            Kc[s_][c] = s_ < p.S ? a + bk : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) w[q] = t2_ld4(wv + 4 * q);
+        for (int s_ = sg; s_ < 32; s_ += 4) {
+            float a = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(&Min[s_][4 * q]);
+                a = fmaf(x[0], w[q][0], a); a = fmaf(x[1], w[q][1], a); a = fmaf(x[2], w[q][2], a); a = fmaf(x[3], w[q][3], a);
+            }
+            Vc[s_][c] = s_ < p.S ? a + bv : 0.f;
+        }
+    }
+    __syncthreads();
+    unsigned* const kvf = p.kvf[l] + (long)b * T2_KVF_WORDS;
+    for (int w_ = tid; w_ < T2_KVF_WORDS; w_ += 256) {       // the backward's four bf16 forms (layout: tplayer2_prep_kernel)
+        const int form = w_ >> 11, u = w_ & 2047;
+        int s0, s1, c0, c1, hl;
+        if (form < 2) {
+            const int e2 = u & 1, lane = (u >> 1) & 63, sb = (u >> 8) & 1, h = u >> 9;
+            hl = (u >> 7) & 1;
+            s0 = s1 = 16 * sb + (lane & 15);
+            c0 = 16 * h + 4 * (lane >> 4) + 2 * e2; c1 = c0 + 1;
+        } else {
+            const int e = u & 3, lane = (u >> 2) & 63, h = u >> 9;
+            hl = (u >> 8) & 1;
+            c0 = c1 = 16 * h + (lane & 15);
+            s0 = 16 * ((2 * e) >> 2) + 4 * (lane >> 4) + ((2 * e) & 3); s1 = s0 + 1;
+        }
+        const bool useK = form == 0 || form == 3;
+        unsigned hi, lo;
+        t2_split2(useK ? Kc[s0][c0] : Vc[s0][c0], useK ? Kc[s1][c1] : Vc[s1][c1], hi, lo);
+        kvf[w_] = hl ? lo : hi;
+    }
+    float* const kvf32 = p.kvf32[l] + (long)b * T2F_KVF_FLOATS;
+    for (int w_ = tid; w_ < T2F_KVF_FLOATS; w_ += 256) {     // the forward's two fp32 forms
+        const int u = w_ & 3, lane = (w_ >> 2) & 63, i2 = (w_ >> 8) & 1, h = (w_ >> 9) & 3, form = w_ >> 11;
+        const int am = lane & 15, kq = lane >> 4;
+        kvf32[w_] = form == 0 ? Kc[16 * i2 + am][16 * h + 4 * kq + u] : Vc[16 * i2 + 4 * kq + u][16 * h + am];
+    }
+}
+// mem (B,S,64); pos (B,S,64) [pos_bs = S*64] or (S,64) [pos_bs = 0]; per layer l < nl (nl = 1 or 2): in_w (192,64), in_b (192), out_w, w1, w2
+// (64,64) and the four destinations of tatt_tplayer2_prep; kin (B,S,64, nullable) receives mem + pos.  Pointer arrays are HOST arrays.
+TATT_API int tatt_tplayer2_kvprep(const float* mem, const float* pos, long pos_bs, const float* const* in_w, const float* const* in_b,
+                                  const float* const* out_w, const float* const* w1, const float* const* w2, unsigned* const* wimg,
+                                  unsigned* const* kvf, float* const* wimg32, float* const* kvf32, float* kin, int B, int S, int nl,
+                                  hipStream_t st) {
+    if (B < 1 || S < 1 || S > 32 || nl < 1 || nl > 2) return 1;
+    T2KVPrep p = {};
+    p.mem = mem; p.pos = pos; p.pos_bs = pos_bs; p.kin = kin; p.B = B; p.S = S; p.nl = nl;
+    for (int l = 0; l < nl; ++l) {
+        p.in_w[l] = in_w[l]; p.in_b[l] = in_b[l];
+        p.W[l][0] = in_w[l]; p.W[l][1] = out_w[l]; p.W[l][2] = w1[l]; p.W[l][3] = w2[l];
+        p.wimg[l] = wimg[l]; p.kvf[l] = kvf[l]; p.wimg32[l] = wimg32[l]; p.kvf32[l] = kvf32[l];
+    }
+    hipLaunchKernelGGL(tplayer2_kvprep_kernel, dim3(nl * (B + T2KV_WBLOCKS)), dim3(256), 0, st, p);
+    return LAUNCH_CHECK();
+}
+
 // ---- geometry --------------------------------------------------------------------------------------------------------------------------------
 struct T2Geom { int tps, ntiles, G, nper; };
 static inline T2Geom t2_geom(int B, int L) {

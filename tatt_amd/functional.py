@@ -1023,21 +1023,27 @@ class TPStackFn(Function):
         S = mem.shape[1]
         drop = cfg.p_attn > 0.0 or cfg.p_res > 0.0 or cfg.p_ffn > 0.0
         seed = current_seed(x.device) if drop else None
-        kin = ops.axpby(mem, pos, 1.0, 1.0) if pos.dim() == 3 else ops.add_rowbcast(mem, pos, pos.shape[0])
-        kin2, mem2 = kin.reshape(-1, E), mem.reshape(-1, E)
         xs, Ks, Vs, hms, packs = [x], [], [], [], []
         out = wavg = None
         # training (a backward will follow): the second generation of the layer (csrc/tplayer2.hip) where it takes the geometry -- its
         # forward leaves the FFN's relu bits and the packed operands for its backward
         gen2 = any(ctx.needs_input_grad) and ops.TPLAYER_BWD2 and ops.tplayer2_geom(B, L, S)[0] == 1
+        if gen2:
+            # ONE launch: mem + pos, every layer's key / value projection, the operand packing (K and V never reach memory)
+            kin, pks = ops.tplayer2_kvprep(_c(mem), _c(pos), lps)
+        else:
+            kin = ops.axpby(mem, pos, 1.0, 1.0) if pos.dim() == 3 else ops.add_rowbcast(mem, pos, pos.shape[0])
+        kin2, mem2 = kin.reshape(-1, E), mem.reshape(-1, E)
         for l, lp in enumerate(lps):
             in_w, in_b = lp[0], lp[1]
-            K = ops.linear_fwd(kin2, in_w[E:2 * E], in_b[E:2 * E]).reshape(B, S, E)
-            V = ops.linear_fwd(mem2, in_w[2 * E:], in_b[2 * E:]).reshape(B, S, E)
+            K = V = None
+            if not gen2:
+                K = ops.linear_fwd(kin2, in_w[E:2 * E], in_b[E:2 * E]).reshape(B, S, E)
+                V = ops.linear_fwd(mem2, in_w[2 * E:], in_b[2 * E:]).reshape(B, S, E)
             last = l == n - 1
             fin_here = cfg.fin and last
             if gen2:
-                pk = ops.tplayer2_prep(lp, K, V)
+                pk = pks[l]
                 xout, fin, w, hm = ops.tplayer2_fwd(xs[l], qpos, pk, lp, lnF if fin_here else None, 1.0 / n, int(n == 2), cfg.p_attn,
                                                     cfg.p_res, cfg.p_ffn, seed, cfg.sites[l], cfg.eps, not fin_here,
                                                     cfg.need_wavg and last, S)

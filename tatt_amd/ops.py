@@ -915,6 +915,24 @@ def tplayer2_prep(lp, K, V):
     return wimg, kvf, wimg32, kvf32
 
 
+def tplayer2_kvprep(mem, pos, lps):
+    """tatt_tplayer2_kvprep: ONE launch for all layers `lps` over the memory `mem` (B,S,64): mem + pos, the key / value projections of every
+    layer and the packing of tplayer2_prep.  -> (kin (B,S,64), [(wimg, kvf, wimg32, kvf32) per layer])"""
+    _check_dev(mem)
+    B, S, E = mem.shape
+    nl = len(lps)
+    assert E == 64 and 1 <= nl <= 2 and mem.is_contiguous() and pos.is_contiguous()
+    g = tplayer2_geom(B, 64, S)
+    packs = [(torch.empty(g[5], dtype=torch.int32, device=mem.device), torch.empty(g[6], dtype=torch.int32, device=mem.device),
+              new(mem, g[7]), new(mem, g[8])) for _ in range(nl)]
+    kin = torch.empty_like(mem)
+    arr = lambda ts: (ctypes.c_void_p * nl)(*[t.data_ptr() for t in ts])
+    call("tatt_tplayer2_kvprep", P(mem), P(pos), S * 64 if pos.dim() == 3 else 0, arr([lp[0] for lp in lps]), arr([lp[1] for lp in lps]),
+         arr([lp[2] for lp in lps]), arr([lp[4] for lp in lps]), arr([lp[6] for lp in lps]), arr([pk[0] for pk in packs]),
+         arr([pk[1] for pk in packs]), arr([pk[2] for pk in packs]), arr([pk[3] for pk in packs]), P(kin), B, S, nl, stream())
+    return kin, packs
+
+
 def tplayer2_fwd(x, qpos, packed, lp, lnF, fin_scale, fin_both, p_attn, p_res, p_ffn, seed, site0, eps, want_xout, want_wavg, S,
                  want_bits=True):
     """The layer's forward, second generation (csrc/tplayer2.hip; training mode; exact fp32 products).  packed = tplayer2_prep(...).

@@ -191,16 +191,59 @@ def test_second_generation_is_a_training_path_and_fp32_switch_selects_the_first(
     qpos = (torch.randn(2, 1024, 64, generator=g) * 0.5).to(dev)
     ig.dropout_on = False
     Fh.begin_training_forward(dev)
+    def stack_node(t):                                      # the TPStackFn node behind the reshaped output
+        fn = t.grad_fn
+        while fn is not None and not hasattr(fn, "packs"):
+            fn = fn.next_functions[0][0]
+        assert fn is not None
+        return fn
     tp_map, _ = T._tp_interpreter(feat, tp, ig, True, qpos=qpos)
-    assert tp_map.grad_fn is not None and all(pk is not None for pk in tp_map.grad_fn.packs) and tp_map.grad_fn.hms[0].dtype == torch.int64
+    node = stack_node(tp_map)
+    assert all(pk is not None for pk in node.packs) and node.hms[0].dtype == torch.int64
     try:
         tatt_amd.set_arithmetic("fp32")
         assert not ops.TPLAYER_BWD2
         tp_map2, _ = T._tp_interpreter(feat, tp, ig, True, qpos=qpos)
-        assert all(pk is None for pk in tp_map2.grad_fn.packs)
+        assert all(pk is None for pk in stack_node(tp_map2).packs)
     finally:
         tatt_amd.set_arithmetic("split_bf16")
     assert max_err(tp_map, tp_map2) < 2e-6                  # (both forwards are exact fp32: summation order only)
     with torch.no_grad():
         ev, _ = T._tp_interpreter(feat.detach(), tp, ig, False, qpos=qpos)
     assert max_err(ev, tp_map2.detach()) == 0.0             # evaluation = the first generation's forward, dropout off in both
+
+
+def test_fused_kv_projection_and_packing_against_the_separate_launches(dev):
+    """tatt_tplayer2_kvprep (mem + pos, both layers' key / value projections, the operand packing: one launch) against linear_fwd +
+    tatt_tplayer2_prep per layer: weight images bit-identical, mem + pos exact, the fp32 key / value forms to fp32 round-off (another
+    summation order), the bf16 hi + lo forms reconstructed to 2^-16."""
+    from tatt_amd import ops
+    B, S = 5, 26
+    g = torch.Generator().manual_seed(11)
+    r = lambda *s: (torch.randn(*s, generator=g) * 0.4).to(dev)
+    mem = r(B, S, 64)
+    lps = [(r(192, 64), r(192), r(64, 64), r(64), r(64, 64), r(64), r(64, 64), r(64), r(64), r(64), r(64), r(64)) for _ in range(2)]
+
+    def bf16_words(t):                                      # int32 words of two bf16 -> (low, high) as float
+        t = t.view(torch.int32)
+        lo = ((t & 0xFFFF) << 16).view(torch.float32)
+        hi = (t & -65536).view(torch.float32)
+        return lo, hi
+
+    for pos in (r(S, 64), r(B, S, 64)):
+        kin, packs = ops.tplayer2_kvprep(mem, pos, lps)
+        assert torch.equal(kin, mem + pos)
+        for lp, pk in zip(lps, packs):
+            K = ops.linear_fwd(kin.reshape(-1, 64), lp[0][64:128], lp[1][64:128]).reshape(B, S, 64)
+            V = ops.linear_fwd(mem.reshape(-1, 64), lp[0][128:], lp[1][128:]).reshape(B, S, 64)
+            ref = ops.tplayer2_prep(lp, K, V)
+            assert torch.equal(pk[0], ref[0]) and torch.equal(pk[2], ref[2])                      # weight images
+            assert max_err(pk[3], ref[3]) <= 2e-6 * float(ref[3].abs().max())                      # fp32 key / value forms
+            # bf16 forms: [form][...][hl][lane][words]: hi + lo of the two paths agree to the split's own resolution
+            a, b = pk[1].reshape(B, 4, -1), ref[1].reshape(B, 4, -1)
+            for form, nw in ((0, 2), (1, 2), (2, 4), (3, 4)):
+                va = [x.reshape(B, -1, 2, 64 * nw) for x in bf16_words(a[:, form])]
+                vb = [x.reshape(B, -1, 2, 64 * nw) for x in bf16_words(b[:, form])]
+                for xa, xb in zip(va, vb):
+                    ra, rb = xa[:, :, 0] + xa[:, :, 1], xb[:, :, 0] + xb[:, :, 1]                  # hi plane + lo plane
+                    assert max_err(ra, rb) <= 3e-5 * float(rb.abs().max()), form
