@@ -335,12 +335,23 @@ __global__ __launch_bounds__(T2_NT, 1) void tplayer2_bwd_kernel(T2P p) {
             for (int nb = 0; nb < 4; ++nb) acc[nb] = (acc[nb] + vec4(0, nb)) * 0.25f;
             t2_pack16(acc, QP);
             f32x4 ctx[4];
+            // the key / value fragments come from L2: those of head h + 1 are requested before head h is computed
+            t2_u32x2 kfn[2][2];
+            t2_u32x4 vtn[2];
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb) { kfn[sb][0] = kvf2[(sb * 2 + 0) * 64 + lane]; kfn[sb][1] = kvf2[(sb * 2 + 1) * 64 + lane]; }
+            vtn[0] = kvf4[1024 + lane]; vtn[1] = kvf4[1024 + 64 + lane];
 #pragma unroll
             for (int h = 0; h < 4; ++h) {
                 t2_u32x2 kf[2][2];
 #pragma unroll
-                for (int sb = 0; sb < 2; ++sb) { kf[sb][0] = kvf2[((h * 2 + sb) * 2 + 0) * 64 + lane]; kf[sb][1] = kvf2[((h * 2 + sb) * 2 + 1) * 64 + lane]; }
-                const t2_u32x4 vt0 = kvf4[1024 + (h * 2 + 0) * 64 + lane], vt1 = kvf4[1024 + (h * 2 + 1) * 64 + lane];
+                for (int sb = 0; sb < 2; ++sb) { kf[sb][0] = kfn[sb][0]; kf[sb][1] = kfn[sb][1]; }
+                const t2_u32x4 vt0 = vtn[0], vt1 = vtn[1];
+                if (h < 3) {
+#pragma unroll
+                    for (int sb = 0; sb < 2; ++sb) { kfn[sb][0] = kvf2[(((h + 1) * 2 + sb) * 2 + 0) * 64 + lane]; kfn[sb][1] = kvf2[(((h + 1) * 2 + sb) * 2 + 1) * 64 + lane]; }
+                    vtn[0] = kvf4[1024 + ((h + 1) * 2 + 0) * 64 + lane]; vtn[1] = kvf4[1024 + ((h + 1) * 2 + 1) * 64 + lane];
+                }
                 const t2_u32x2 qh = t2_sub4(QP.h, h), ql = t2_sub4(QP.l, h);
                 f32x4 sc[2];
 #pragma unroll

@@ -210,7 +210,9 @@ def test_second_generation_is_a_training_path_and_fp32_switch_selects_the_first(
     assert max_err(tp_map, tp_map2) < 2e-6                  # (both forwards are exact fp32: summation order only)
     with torch.no_grad():
         ev, _ = T._tp_interpreter(feat.detach(), tp, ig, False, qpos=qpos)
-    assert max_err(ev, tp_map2.detach()) == 0.0             # evaluation = the first generation's forward, dropout off in both
+    # evaluation runs the first generation's forward (no backward follows: nothing to leave bits for); fp32 round-off of the small GEMMs
+    # around the layers is all that separates it from the training-mode forward with dropout off
+    assert max_err(ev, tp_map2.detach()) < 5e-6
 
 
 def test_fused_kv_projection_and_packing_against_the_separate_launches(dev):
