@@ -42,6 +42,27 @@ repeat("conv3 ws16 64->256", lambda: ops.conv2d_forward(xl, w4, None), 100)
 repeat("conv3 ws16 dgrad", lambda: ops.conv2d_dgrad(xl, w3), 200)
 repeat("conv3 wgrad (batched reduce off)", lambda: ops.conv_wgrad(xl, xl, 64, 3, 3), 100)
 
+# second-generation TP layer (csrc/tplayer2.hip): the backward's four waves share the weight gradients through their LDS images (16
+# barriers per round), every launch re-reads the forward's relu bits
+r3 = lambda *sh: (torch.randn(*sh, generator=g) * 0.3).to(dev)
+tx, tq, tK, tV, tup = r3(B, 1024, 64), r3(B, 1024, 64), r3(B, 26, 64), r3(B, 26, 64), r3(B, 1024, 64)
+tlp = (r3(192, 64), r3(192), r3(64, 64), r3(64), r3(64, 64), r3(64), r3(64, 64), r3(64), r3(64) + 1, r3(64), r3(64) + 1, r3(64))
+tln = (r3(64) + 1, r3(64))
+tsd = Fh.seed_tensor(dev)
+tpk = ops.tplayer2_prep(tlp, tK, tV)
+t2f = lambda: ops.tplayer2_fwd(tx, tq, tpk, tlp, tln, 0.5, 1, 0.1, 0.1, 0.1, tsd, 10, 1e-5, False, True, 26)
+thm = t2f()[3]
+repeat("tplayer2 fwd (fin, wavg, relu bits)", lambda: torch.cat([t2f()[1].reshape(-1), t2f()[2].reshape(-1), t2f()[3].float()]), 100)
+
+
+def t2b():
+    dx, dq, kv, fl, pp, G2 = ops.tplayer2_bwd(tx, tq, tpk, tlp, tln, 0.5, 1, 0.1, 0.1, 0.1, tsd, 10, 1e-5, None, tup, None, None, True, 26, hmask=thm)
+    dK, dV = ops.tplayer2_reduce_kv(kv, fl, B, 1024, 26)
+    return torch.cat([dx.reshape(-1), dq.reshape(-1), pp.reshape(-1), dK.reshape(-1), dV.reshape(-1)])
+
+
+repeat("tplayer2 bwd (dx, dqpos, records, dK, dV)", t2b, 200)
+
 torch.manual_seed(1234)
 m = tatt_amd.TSRN_TL_TRANS(scale_factor=2, width=128, height=32, STN=True, mask=True, srb_nums=5, hidden_units=32)
 m.load_state_dict(randomize_state_dict(m.state_dict()))
