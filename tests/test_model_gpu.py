@@ -422,6 +422,24 @@ def test_staged_deferred_backward_equals_single_pass(dev, B):
         assert torch.equal(s2[k], s3[k]) and torch.equal(s2[k], s4[k]), k
 
 
+@pytest.mark.parametrize("hook,value", [("OUTCONV_BUCKET", "now"), ("OUTCONV_BUCKET", "trunk"), ("QGRU_BUCKET", "tp")])
+def test_alternative_filings_of_deferred_work_compute_the_same_step(dev, monkeypatch, hook, value):
+    """The measured-and-not-chosen places for the two late-filed pieces of side work (profiles/r05_ab_buckets.txt) stay correct: the 9x9 output
+    convolution's weight gradient issued AT ONCE on the second stream beside the backward from the loss (`SIDE.immediate`: a side lane
+    of the producing pass itself) or with its own stage, the query GRU's backward one pass earlier -- same loss, same gradient norm, same
+    first moments as the default filing after one step, and graph replay == eager over five."""
+    import tatt_amd.tsrn as T
+    l0, s0, _, g0 = _run_steps(dev, 1, 6, True, use_graph=False)
+    monkeypatch.setattr(T, hook, value)
+    l1, s1, _, g1 = _run_steps(dev, 1, 6, True, use_graph=False)
+    assert l1 == l0 and abs(g1 - g0) <= 1e-6 * g0, (l1, l0, g1, g0)
+    l2, s2, _, _ = _run_steps(dev, 5, 6, True, use_graph=False)
+    l3, s3, _, _ = _run_steps(dev, 5, 6, True, use_graph=True)
+    assert l3 == l2
+    for k in s2:
+        assert torch.equal(s2[k], s3[k]), k
+
+
 def test_single_rank_process_group_runs_the_staged_step(dev):
     """The data-parallel step (bucketed flat buffers, backward in stages, asynchronous RCCL all-reduce per bucket between the
     stage graphs, 1/world in Adam) with a world of ONE rank on this GPU equals the plain single-GPU step."""
