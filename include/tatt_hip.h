@@ -369,6 +369,15 @@ int tatt_qgru_bwd_chain(float* dgh0, float* dgh1, const float* whhT0, const floa
                         unsigned* sync, int T, int Wb, int HID, int s0, int s1, int transposed, float* xch0, float* xch1,
                         hipStream_t st);
 
+/* Recurrent weight gradient of the query GRU after the backward recurrence (the gradient nn.GRU's autograd accumulates over the time
+ * steps, model/transformer_v2.py:201-221 backward): for both directions d in one launch dW_d (N x K) = A_d^T B_d and db_d (N) = column
+ * sums of A_d, with A_d = dgh of direction d (M = T*Wb tokens, N = 3*HID) and B_d = h_prev of the same tokens (M, K = HID), contiguous;
+ * split-bf16 products (hi hi + hi lo + lo hi, fp32 accumulation) on the bf16 matrix cores.  M % 32 == 0, N % 128 == 0, K % 128 == 0;
+ * the contraction is split S ways (1 <= S <= M / 32); ws_d >= S*N*K + S*N floats.  Leaves the per-split partials: finish each
+ * direction with tatt_splitk_reduce(ws_d, dW_d, N, K, S, 0, 0, 0, db_d, N).  Returns 1 / 2 for geometries it does not take. */
+int tatt_qgru_wgrad_sb(const float* A0, const float* A1, const float* B0, const float* B1, float* ws0, float* ws1, int M, int N,
+                       int K, int S, hipStream_t st);
+
 /* The forward recurrence (T calls of tatt_qgru_fwd_step) as one persistent launch, time steps s0 .. s1-1 (direction 0 at time s,
  * direction 1 at time T-1-s), same hand-off as tatt_qgru_bwd_chain with h as the exchanged tensor.  hbuf* (T+1, Wb, HID): h of time t
  * at slot t+1 (direction 0; slot 0 zero) / slot t (direction 1; slot T zero), zero slots filled by the caller; gsave* (T, 4, Wb, HID)

@@ -358,3 +358,138 @@ TATT_API int tatt_gru_wgrad_frag(const float* frag, const float* x, const float*
     else hipLaunchKernelGGL(gru_wgrad_frag_kernel<false>, dim3(G), dim3(GF_THREADS), 0, st, p);
     return LAUNCH_CHECK();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Round 5: the recurrent weight gradient of the QUERY GRU (nn.GRU(64 -> 512, bidirectional) over the batch axis, reference
+// model/tsrn.py:248-262 through InfoGen's query embedding): dW_hh (1536 x 512) = dgh^T h_prev, contraction over the B * 64 = 3072
+// (time step, sequence) tokens, and db_hh = column sums of dgh -- per direction 4.8 GFLOP that ran as an fp32-pipe GEMM (gemm_fast,
+// 70 us each, the longest kernels of the last backward pass's side lane).  Same arithmetic as the kernels above (split bf16, three
+// products, fp32 accumulation); a different shape: a LARGE output and a SHORT contraction, so the output is tiled (128 x 128 per
+// work-group, 64 x 64 per wave = 16 accumulator tiles) and the contraction split S ways over grid.y; both directions in one launch
+// (grid.z).  Per chunk of 32 tokens the 128 dgh columns and the 128 h_prev columns of the tile are staged token-major (pitch 130:
+// conflict-free column gathers as above), each wave transposes + splits 4 of the 16 column tiles, then runs 48 MFMAs on them.
+// Partials: [S][N][K] slabs then [S][N] row sums per direction -- the layout tatt_splitk_reduce sums.
+// ------------------------------------------------------------------------------------------------
+#define QW_PITCH 130
+#define QW_IMG (GW_TOK * QW_PITCH)                // floats of one operand's chunk image
+#define QW_LDS ((2 * QW_IMG + 16 * 2 * 64 * 4) * 4)   // 33,280 + 32,768 = 66,048 bytes: two work-groups per CU
+struct QgruWgP {
+    const float* A[2]; const float* Bm[2]; float* part[2];
+    int N, K, nchunks, per, S;
+};
+__global__ __launch_bounds__(256) void qgru_wgrad_sb_kernel(QgruWgP p) {
+    extern __shared__ __attribute__((aligned(16))) float qw_lds[];
+    float* const T = qw_lds;
+    float* const F = qw_lds + 2 * QW_IMG;
+    const int t = threadIdx.x, lane = t & 63, li = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), wr = wave >> 1, wc = wave & 1;
+    const int d = blockIdx.z, s = blockIdx.y, tiles_k = p.K >> 7;
+    const int tn = blockIdx.x / tiles_k, tk = blockIdx.x - tn * tiles_k;
+    const float* __restrict__ A = p.A[d] + 128 * tn;
+    const float* __restrict__ B = p.Bm[d] + 128 * tk;
+    const int c0 = s * p.per, c1 = min(c0 + p.per, p.nchunks);
+    const bool sums = tk == 0 && wc == 0;                          // wave-uniform: these waves also produce the row sums
+    f32x4 pa[4], pb[4];
+    auto fetch = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = t + 256 * i, row = f >> 5, c4 = f & 31;
+            const long tok = (long)c * GW_TOK + row;
+            pa[i] = *reinterpret_cast<const f32x4*>(A + tok * p.N + 4 * c4);
+            pb[i] = *reinterpret_cast<const f32x4*>(B + tok * p.K + 4 * c4);
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = t + 256 * i, row = f >> 5, c4 = f & 31;
+            float* da = T + row * QW_PITCH + 4 * c4;               // rows are 8-byte aligned (130 dwords): two 8-byte stores
+            *reinterpret_cast<float2*>(da) = make_float2(pa[i][0], pa[i][1]);
+            *reinterpret_cast<float2*>(da + 2) = make_float2(pa[i][2], pa[i][3]);
+            *reinterpret_cast<float2*>(da + QW_IMG) = make_float2(pb[i][0], pb[i][1]);
+            *reinterpret_cast<float2*>(da + QW_IMG + 2) = make_float2(pb[i][2], pb[i][3]);
+        }
+    };
+    f32x4 acc[16], accs[4];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) accs[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const gw_bf16x8 ones = gw_ones();
+    if (c0 < c1) fetch(c0);
+    for (int c = c0; c < c1; ++c) {
+        stash();                                                   // T: last read by the conversions of the previous chunk (before barrier 2)
+        __syncthreads();                                           // 1: images complete; every wave has left the previous chunk's MFMAs
+        if (c + 1 < c1) fetch(c + 1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                              // column tiles 0-7: dgh, 8-15: h_prev
+            const int tile = wave + 4 * q;
+            gw_bf16x8 hi, lo;
+            gf_frag<QW_PITCH>(T + (tile >> 3) * QW_IMG + 8 * kq * QW_PITCH + 16 * (tile & 7) + li, hi, lo);
+            *reinterpret_cast<f32x4*>(F + ((tile * 2 + 0) * 64 + lane) * 4) = __builtin_bit_cast(f32x4, hi);
+            *reinterpret_cast<f32x4*>(F + ((tile * 2 + 1) * 64 + lane) * 4) = __builtin_bit_cast(f32x4, lo);
+        }
+        __syncthreads();                                           // 2: fragments complete; T may be overwritten
+        gw_bf16x8 bh[4], bl[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) { bh[n] = gw_ld(F, 8 + 4 * wc + n, 0, lane); bl[n] = gw_ld(F, 8 + 4 * wc + n, 1, lane); }
+#pragma unroll
+        for (int m = 0; m < 4; m += 2) {
+            const gw_bf16x8 a0h = gw_ld(F, 4 * wr + m, 0, lane), a0l = gw_ld(F, 4 * wr + m, 1, lane);
+            const gw_bf16x8 a1h = gw_ld(F, 4 * wr + m + 1, 0, lane), a1l = gw_ld(F, 4 * wr + m + 1, 1, lane);
+            if (sums) {
+                accs[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0h, ones, accs[m], 0, 0, 0);
+                accs[m + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1h, ones, accs[m + 1], 0, 0, 0);
+                accs[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0l, ones, accs[m], 0, 0, 0);
+                accs[m + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1l, ones, accs[m + 1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int n = 0; n < 4; n += 2) {                       // product-major over four accumulators (see the kernel above)
+                f32x4 &c00 = acc[m * 4 + n], &c01 = acc[m * 4 + n + 1], &c10 = acc[(m + 1) * 4 + n], &c11 = acc[(m + 1) * 4 + n + 1];
+                c00 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0h, bh[n], c00, 0, 0, 0);
+                c01 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0h, bh[n + 1], c01, 0, 0, 0);
+                c10 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1h, bh[n], c10, 0, 0, 0);
+                c11 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1h, bh[n + 1], c11, 0, 0, 0);
+                c00 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0h, bl[n], c00, 0, 0, 0);
+                c01 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0h, bl[n + 1], c01, 0, 0, 0);
+                c10 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1h, bl[n], c10, 0, 0, 0);
+                c11 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1h, bl[n + 1], c11, 0, 0, 0);
+                c00 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0l, bh[n], c00, 0, 0, 0);
+                c01 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0l, bh[n + 1], c01, 0, 0, 0);
+                c10 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1l, bh[n], c10, 0, 0, 0);
+                c11 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1l, bh[n + 1], c11, 0, 0, 0);
+            }
+        }
+    }
+    // C layout: row = 4 kq + r, column = li
+    float* __restrict__ slab = p.part[d] + (long)s * p.N * p.K;
+    float* __restrict__ rs = p.part[d] + (long)p.S * p.N * p.K + (long)s * p.N;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 128 * tn + 64 * wr + 16 * m + 4 * kq + r;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) slab[(long)row * p.K + 128 * tk + 64 * wc + 16 * n + li] = acc[m * 4 + n][r];
+            if (sums && li == 0) rs[row] = accs[m][r];
+        }
+}
+
+// dW_d (N x K) = A_d^T B_d and db_d (N) = column sums of A_d for d = 0, 1 in one launch: A_d (M, N), B_d (M, K) contiguous,
+// M % 32 == 0, N % 128 == 0, K % 128 == 0, 1 <= S <= M / 32; ws_d >= S*N*K + S*N floats.  Leaves the per-split partials: finish each
+// direction with tatt_splitk_reduce(ws_d, dW_d, N, K, S, 0, 0, 0, db_d, N) (batched with the stage's other reductions).
+TATT_API int tatt_qgru_wgrad_sb(const float* A0, const float* A1, const float* B0, const float* B1, float* ws0, float* ws1, int M, int N,
+                                int K, int S, hipStream_t st) {
+    if (M <= 0 || M % GW_TOK || N <= 0 || (N & 127) || K <= 0 || (K & 127)) return 1;
+    const int nchunks = M / GW_TOK;
+    if (S < 1 || S > nchunks) return 2;
+    const int per = (nchunks + S - 1) / S;
+    if ((long)(S - 1) * per >= nchunks) return 2;                  // (every split gets at least one chunk)
+    static TattPerDevice attr_once;
+    tatt_per_device(attr_once, [&] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(qgru_wgrad_sb_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, QW_LDS);
+    });
+    QgruWgP p = {{A0, A1}, {B0, B1}, {ws0, ws1}, N, K, nchunks, per, S};
+    hipLaunchKernelGGL(qgru_wgrad_sb_kernel, dim3((N >> 7) * (K >> 7), S, 2), dim3(256), QW_LDS, st, p);
+    return LAUNCH_CHECK();
+}

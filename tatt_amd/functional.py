@@ -77,6 +77,7 @@ class _DeferredParamGrads:
         self.due_of = {}                 # id(parameter) -> index of the stage (= gradient bucket) its gradient belongs to
         self.immediate = frozenset()     # id(parameter): run the closure AT ONCE on `side_stream`, beside the main lane that produced it
         self.side_stream = None          # the Trainer's second stream while a stage's main lane runs with two lanes
+        self.tail_stream = None          # the Trainer's third stream while the LAST stage's main lane runs (train.TAIL_LANE)
         self._pending = []
         self._keep = []
 
@@ -110,14 +111,22 @@ class _DeferredParamGrads:
         convolution's 0.4 ms weight gradient are filed under later buckets, where the main lane beside them has room)."""
         if not self.enabled or any(p is not None and not p.is_leaf for p in params):
             return self._run(fn)
-        if (self.side_stream is not None and lag == 0 and any(p is not None and id(p) in self.immediate for p in params)
-                and all(p is None or self.due_of.get(id(p), 0) <= self.stage for p in params)):
-            # lag 0: a side lane of the producing stage's OWN pass (the 9x9 output convolution's weight gradient is available at the
-            # first kernel of the backward and pass "trunk" has no other side work).  Same stream as every later side lane, so the
-            # gather of the bucket (next pass, that stream) and the per-pass join order it; operands stay referenced until release().
-            main = torch.cuda.current_stream(self.side_stream.device)
-            self.side_stream.wait_stream(main)
-            with torch.cuda.stream(self.side_stream):
+        lane = None
+        if lag == 0 and all(p is None or self.due_of.get(id(p), 0) <= self.stage for p in params):
+            if self.tail_stream is not None:
+                # the LAST stage has no later pass to carry its own parameter gradients: they run on a third stream as its main
+                # lane produces their operands (STN head: six convolution weight gradients, the deepest ones single work-groups)
+                # instead of following it -- 0.16 ms of tail that ran beside nothing but the end of the previous stage's side lane
+                lane = self.tail_stream
+            elif self.side_stream is not None and any(p is not None and id(p) in self.immediate for p in params):
+                # a side lane of the producing stage's OWN pass (the 9x9 output convolution's weight gradient is available at the
+                # first kernel of the backward and pass "trunk" has no other side work).  Same stream as every later side lane, so
+                # the gather of the bucket (next pass, that stream) and the per-pass join order it.
+                lane = self.side_stream
+        if lane is not None:                 # (operands stay referenced until release(): they were allocated on the main stream)
+            main = torch.cuda.current_stream(lane.device)
+            lane.wait_stream(main)
+            with torch.cuda.stream(lane):
                 self._assign(params, self._run(fn))
             self._keep.append(keep)
             return (None,) * len(params)
@@ -1146,6 +1155,7 @@ QGRU_CHAIN_BWD = True
 # their recurrent products on the bf16 matrix cores with split operands (hi hi + hi lo + lo hi, fp32 accumulation) instead of fp32 MFMA:
 # the fp32 form takes a third of the chip's fp32 matrix throughput while the chain runs and slows the lane beside it
 QGRU_CHAIN_SB = True
+QGRU_WGRAD_SB = True            # the recurrent weight gradient (dgh^T h_prev over all steps) in split bf16 too (tatt_qgru_wgrad_sb)
 QGRU_CHAIN_SYNC = []
 
 
@@ -1329,12 +1339,19 @@ class QueryGruFn(Function):
         stamp("qgru bwd: recurrence done", emb)
         grads = []
         dx = ops.new(dev, W, IN)
+        # dW_hh = sum_t dgh_t^T h_{t-1} over ALL steps (h_prev of the first step is the zero slot); db_hh = its row sums
+        g2 = [dgh[d].reshape(B * W, 3 * HID) for d in range(2)]
+        hprev_all = [(hbuf[0, :B] if d == 0 else hbuf[1, 1:]).reshape(B * W, HID) for d in range(2)]
+        hh = None
+        if QGRU_WGRAD_SB and ops.qgru_wgrad_takes(g2[0], hprev_all[0]):
+            # both directions in ONE split-bf16 launch (2 x 4.8 GFLOP: 70 us each on the fp32 pipe, the longest kernels of this lane)
+            hh = ops.qgru_wgrad_sb(g2[0], g2[1], hprev_all[0], hprev_all[1])
         for d, (wih, whh) in enumerate(((wih0, whh0), (wih1, whh1))):
-            g2 = dgh[d].reshape(B * W, 3 * HID)
-            # dW_hh = sum_t dgh_t^T h_{t-1} over ALL steps (h_prev of the first step is the zero slot); db_hh = its row sums
-            hprev_all = (hbuf[0, :B] if d == 0 else hbuf[1, 1:]).reshape(B * W, HID)
-            dbhh = ops.new(dev, 3 * HID)
-            dwhh = ops.linear_bwd_weight(g2, hprev_all, rowsum=dbhh)
+            if hh is not None:
+                dwhh, dbhh = hh[2 * d], hh[2 * d + 1]
+            else:
+                dbhh = ops.new(dev, 3 * HID)
+                dwhh = ops.linear_bwd_weight(g2[d], hprev_all[d], rowsum=dbhh)
             dbih = ops.new(dev, 3 * HID)
             dwih = ops.linear_bwd_weight(dgi_acc[d], x, rowsum=dbih)     # the bias gradient rides along (row sums of dgi_acc^T)
             ops.linear_bwd_input(dgi_acc[d], wih, out=dx, beta=0.0 if d == 0 else 1.0)

@@ -193,6 +193,34 @@ def gru_wgrad_sb(dgi, dgh, x2, xb2, hprev, dWp, dWhh, dbp, dbhh):
     call("tatt_splitk_reduce", P(ws2), P(dWhh), 192, 64, G, 0, 0, 0.0, P(dbhh), 192, stream())
 
 
+QGRU_WGRAD_SPLIT = 6          # contraction splits of tatt_qgru_wgrad_sb (96 output tiles x S work-groups for both directions)
+
+
+def qgru_wgrad_takes(A, B):
+    """tatt_qgru_wgrad_sb's geometry: contiguous (M, N) / (M, K) with M % 32 == 0, N % 128 == 0, K % 128 == 0"""
+    return (A.dim() == 2 and B.dim() == 2 and A.shape[0] == B.shape[0] and A.is_contiguous() and B.is_contiguous()
+            and A.shape[0] % 32 == 0 and A.shape[0] > 0 and A.shape[1] % 128 == 0 and B.shape[1] % 128 == 0)
+
+
+def qgru_wgrad_sb(A0, A1, B0, B1):
+    """-> (dW0, db0, dW1, db1): dW_d (N, K) = A_d^T B_d, db_d = A_d.sum(0) for both directions of the query GRU in one split-bf16
+    launch (tatt_qgru_wgrad_sb) + two (deferrable) split-K reductions."""
+    _check_dev(A0)
+    M, N = A0.shape
+    K = B0.shape[1]
+    S = max(1, min(QGRU_WGRAD_SPLIT, M // 32))
+    while (S - 1) * cdiv(M // 32, S) >= M // 32:          # every split must own at least one 32-token chunk
+        S -= 1
+    ws = [_split_ws(new(A0, S * N * K + S * N)) for _ in range(2)]
+    call("tatt_qgru_wgrad_sb", P(A0), P(A1), P(B0), P(B1), P(ws[0]), P(ws[1]), M, N, K, S, stream())
+    out = []
+    for d in range(2):
+        dW, db = new(A0, N, K), new(A0, N)
+        call("tatt_splitk_reduce", P(ws[d]), P(dW), N, K, S, 0, 0, 0.0, P(db), N, stream())
+        out += [dW, db]
+    return tuple(out)
+
+
 def colsum(x2, *, out=None, scale=1.0, beta=0.0):
     """out[c] = scale * sum_m x2[m, c]  (+ beta*out)."""
     _check_dev(x2)
@@ -321,6 +349,11 @@ def repack_weight(w_oihw, mode, cache=True):
     return out
 
 
+# generic implicit-GEMM convolution: fewer output tiles than CONV_SPLIT_TILES and a deep contraction -> the contraction is split over
+# up to CONV_SPLIT_WGS work-groups (deterministic second-stage sum)
+CONV_SPLIT_TILES, CONV_SPLIT_WGS = 128, 256
+
+
 def conv_fwd(x_bhwc, wpacked, bias, Cout, KH, KW, *, act=ACT_NONE, out=None, beta=0.0):
     """Stride-1 'same' convolution from a mode-0/1 packed filter: 9x9 64k->4 goes to the vector-ALU kernel, everything else to
     the generic implicit-GEMM MFMA kernel (the specialised 3x3 kernels take their own packings: conv2d_forward / conv2d_dgrad)."""
@@ -340,8 +373,8 @@ def conv_fwd(x_bhwc, wpacked, bias, Cout, KH, KW, *, act=ACT_NONE, out=None, bet
     M, K = B * H * W, KH * KW * Cin
     tiles, nchunks = cdiv(M, 64) * cdiv(Cout, 64), cdiv(K, 16)
     splitk, ws = 1, None
-    if tiles < 128 and nchunks >= 32:
-        splitk = max(1, min(256 // tiles, nchunks // 8))
+    if tiles < CONV_SPLIT_TILES and nchunks >= 32:
+        splitk = max(1, min(CONV_SPLIT_WGS // tiles, nchunks // 8))
         if splitk > 1:
             ws = _split_ws(new(x_bhwc, splitk * M * Cout))       # (must outlive a deferred reduction, like every split-K slab)
     call("tatt_conv2d_fwd", P(x_bhwc), sn, sh, sw, sc, P(wpacked), P(bias), P(y), Cout, B, H, W, Cin, Cout, KH, KW,

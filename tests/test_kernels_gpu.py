@@ -435,15 +435,15 @@ def _qgru_run(dev, B, fwd_chain, bwd_chain, seed=5, sb=False):
              "weight_hh_l0_reverse", "bias_ih_l0_reverse", "bias_hh_l0_reverse"]
     leaves = [R(H * W, C).to(dev).requires_grad_()] + [getattr(g, n).detach().to(dev).requires_grad_() for n in names]
     dq = R(B, H, W, C, seed=3).to(dev)
-    old = Fh.QGRU_CHAIN_FWD, Fh.QGRU_CHAIN_BWD, Fh.QGRU_CHAIN_SB
-    Fh.QGRU_CHAIN_FWD, Fh.QGRU_CHAIN_BWD, Fh.QGRU_CHAIN_SB = fwd_chain, bwd_chain, sb
+    old = Fh.QGRU_CHAIN_FWD, Fh.QGRU_CHAIN_BWD, Fh.QGRU_CHAIN_SB, Fh.QGRU_WGRAD_SB
+    Fh.QGRU_CHAIN_FWD, Fh.QGRU_CHAIN_BWD, Fh.QGRU_CHAIN_SB, Fh.QGRU_WGRAD_SB = fwd_chain, bwd_chain, sb, sb
     try:
         q = Fh.QueryGruFn.apply(*leaves, B, H, W)
         grads = torch.autograd.grad(q, leaves, dq)
         torch.cuda.synchronize()
         Fh.qgru_chain_check()
     finally:
-        Fh.QGRU_CHAIN_FWD, Fh.QGRU_CHAIN_BWD, Fh.QGRU_CHAIN_SB = old
+        Fh.QGRU_CHAIN_FWD, Fh.QGRU_CHAIN_BWD, Fh.QGRU_CHAIN_SB, Fh.QGRU_WGRAD_SB = old
     return (q.detach(),) + tuple(grads)
 
 
@@ -1098,6 +1098,34 @@ def test_gru_wgrad_split_bf16_vs_fp64(dev, M, with_xb, groups):
     finally:
         ops.GRU_WGRAD_GROUPS = old
     for name, got, want in zip(("dWp", "dbp", "dWhh", "dbhh"), outs[0], ref):
+        err = float((got.cpu().double() - want).abs().max() / want.abs().max())
+        assert err < 2e-5, (name, err)
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)                                  # deterministic
+
+
+@pytest.mark.parametrize("M,N,K,split", [(3072, 1536, 512, 6), (3072, 1536, 512, 4), (3072, 1536, 512, 96), (128, 384, 128, 6),
+                                         (320, 1536, 512, 6), (32, 128, 256, 6)])
+def test_query_gru_recurrent_weight_gradient_split_bf16_vs_fp64(dev, M, N, K, split):
+    """tatt_qgru_wgrad_sb + tatt_splitk_reduce: dW_hh = dgh^T h_prev and db_hh = sum dgh for both directions of the query GRU in one
+    launch (the gradient nn.GRU accumulates over its time steps, reference model/transformer_v2.py:201-221) against fp64: the
+    published geometry (48 steps x 64 sequences, 3 x 512 gates), ragged split counts (10 chunks over 6 -> 5 splits), one chunk."""
+    from tatt_amd import ops
+    A = [R(M, N, seed=21 + d) for d in range(2)]
+    B = [R(M, K, seed=31 + d) for d in range(2)]
+    ref = []
+    for d in range(2):
+        ref += [A[d].double().t() @ B[d].double(), A[d].double().sum(0)]
+    Ad, Bd = [a.to(dev) for a in A], [b.to(dev) for b in B]
+    assert ops.qgru_wgrad_takes(Ad[0], Bd[0])
+    assert not ops.qgru_wgrad_takes(Ad[0][:, :100].contiguous(), Bd[0])
+    old = ops.QGRU_WGRAD_SPLIT
+    ops.QGRU_WGRAD_SPLIT = split
+    try:
+        outs = [ops.qgru_wgrad_sb(Ad[0], Ad[1], Bd[0], Bd[1]) for _ in range(2)]
+    finally:
+        ops.QGRU_WGRAD_SPLIT = old
+    for name, got, want in zip(("dW0", "db0", "dW1", "db1"), outs[0], ref):
         err = float((got.cpu().double() - want).abs().max() / want.abs().max())
         assert err < 2e-5, (name, err)
     for a, b in zip(outs[0], outs[1]):

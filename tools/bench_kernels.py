@@ -333,3 +333,39 @@ for _sb in (False, True):
     timeit("qgru_bwd_persistent_launch%s" % ("_sb" if _sb else ""), _bwd_chain_only)           # / 47
 print("   persistent launches: error word %d" % int(_sync[1023].item()), flush=True)
 # (the backward chain allocates its split-K workspaces through torch outside a Trainer: not capturable on its own)
+
+# ---- query GRU recurrent weight gradient: two fp32-pipe GEMMs vs one split-bf16 launch for both directions (csrc/gruwgrad.hip) ----
+qA = [R(B * 64, 1536) for _ in range(2)]
+qB = [R(B * 64, 512) for _ in range(2)]
+qf = 2 * 2.0 * B * 64 * 1536 * 512
+
+
+def _qgru_wgrad_gemms():
+    for d in range(2):
+        ops.linear_bwd_weight(qA[d], qB[d], rowsum=torch.empty(1536, device=dev))
+
+
+timeit("qgru_wgrad_gemms", _qgru_wgrad_gemms, qf)
+if ops.qgru_wgrad_takes(qA[0], qB[0]):
+    for sp in (3, 4, 6, 8, 12):
+        def _qgru_wgrad_sb(sp=sp):
+            old = ops.QGRU_WGRAD_SPLIT
+            ops.QGRU_WGRAD_SPLIT = sp
+            try:
+                ops.qgru_wgrad_sb(qA[0], qA[1], qB[0], qB[1])
+            finally:
+                ops.QGRU_WGRAD_SPLIT = old
+        timeit("qgru_wgrad_sb split %d" % sp, _qgru_wgrad_sb, qf)
+
+# ---- STN head: data gradient of its second convolution (64 -> 32 channels at 8 x 32: 192 output tiles of the generic kernel) ----
+sdy = R(B, 8, 32, 64)
+sw = R(64, 32, 3, 3) * 0.05
+for tiles, wgs in ((128, 256), (256, 512), (256, 768), (256, 1024)):
+    def _stn_dgrad(tiles=tiles, wgs=wgs):
+        old = ops.CONV_SPLIT_TILES, ops.CONV_SPLIT_WGS
+        ops.CONV_SPLIT_TILES, ops.CONV_SPLIT_WGS = tiles, wgs
+        try:
+            ops.conv2d_dgrad(sdy, sw)
+        finally:
+            ops.CONV_SPLIT_TILES, ops.CONV_SPLIT_WGS = old
+    timeit("stn_dgrad2 split<%d,%d>" % (tiles, wgs), _stn_dgrad, 2.0 * B * 8 * 32 * 576 * 32)
