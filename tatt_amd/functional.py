@@ -77,7 +77,6 @@ class _DeferredParamGrads:
         self.due_of = {}                 # id(parameter) -> index of the stage (= gradient bucket) its gradient belongs to
         self.immediate = frozenset()     # id(parameter): run the closure AT ONCE on `side_stream`, beside the main lane that produced it
         self.side_stream = None          # the Trainer's second stream while a stage's main lane runs with two lanes
-        self.tail_stream = None          # the Trainer's third stream while the LAST stage's main lane runs (train.TAIL_LANE)
         self._pending = []
         self._keep = []
 
@@ -111,22 +110,16 @@ class _DeferredParamGrads:
         convolution's 0.4 ms weight gradient are filed under later buckets, where the main lane beside them has room)."""
         if not self.enabled or any(p is not None and not p.is_leaf for p in params):
             return self._run(fn)
-        lane = None
-        if lag == 0 and all(p is None or self.due_of.get(id(p), 0) <= self.stage for p in params):
-            if self.tail_stream is not None:
-                # the LAST stage has no later pass to carry its own parameter gradients: they run on a third stream as its main
-                # lane produces their operands (STN head: six convolution weight gradients, the deepest ones single work-groups)
-                # instead of following it -- 0.16 ms of tail that ran beside nothing but the end of the previous stage's side lane
-                lane = self.tail_stream
-            elif self.side_stream is not None and any(p is not None and id(p) in self.immediate for p in params):
-                # a side lane of the producing stage's OWN pass (the 9x9 output convolution's weight gradient is available at the
-                # first kernel of the backward and pass "trunk" has no other side work).  Same stream as every later side lane, so
-                # the gather of the bucket (next pass, that stream) and the per-pass join order it.
-                lane = self.side_stream
-        if lane is not None:                 # (operands stay referenced until release(): they were allocated on the main stream)
-            main = torch.cuda.current_stream(lane.device)
-            lane.wait_stream(main)
-            with torch.cuda.stream(lane):
+        if (self.side_stream is not None and lag == 0 and any(p is not None and id(p) in self.immediate for p in params)
+                and all(p is None or self.due_of.get(id(p), 0) <= self.stage for p in params)):
+            # lag 0: run AT ONCE on the side lane of the producing stage's OWN pass, behind what that lane already holds (the deepest
+            # STN convolutions' weight gradients in the last pass, whose own work otherwise all follows its main lane).  Same stream
+            # as every side lane, so the gather of the bucket and the per-pass join order it; operands stay referenced until release().
+            # (A THIRD stream for this was measured, round 5: the graph executor then queues the main lane's kernels behind the side
+            # lane's -- 0.17 ms slower, profiles/r05_tail_lane_ab.txt.)
+            main = torch.cuda.current_stream(self.side_stream.device)
+            self.side_stream.wait_stream(main)
+            with torch.cuda.stream(self.side_stream):
                 self._assign(params, self._run(fn))
             self._keep.append(keep)
             return (None,) * len(params)

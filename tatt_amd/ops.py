@@ -102,10 +102,10 @@ def gemm(A, sam, sak, B, sbk, sbn, C, scm, scn, M, N, K, *, A2=None, sa2m=0, sa2
     return C
 
 
-def _auto_split(M_out, N_out, Kred):
+def _auto_split(M_out, N_out, Kred, cap=128):
     tiles = cdiv(M_out, 64) * cdiv(N_out, 64)
     nchunks = cdiv(Kred, 16)
-    want = max(1, min(128, 512 // tiles))
+    want = max(1, min(cap, 512 // tiles))
     return max(1, min(want, nchunks // 8 if nchunks >= 16 else 1))
 
 
@@ -521,6 +521,11 @@ def conv_wgrad(x_bhwc, dy_bhwc, Cout, KH, KW, want_db=False):
     return _conv_wgrad_general(x_bhwc, dy_bhwc, dw, Cout, KH, KW, contig)
 
 
+# generic weight gradient: at most this many contraction splits (a one-tile output over 49,152 pixels -- the STN head's first
+# convolution -- is 128 work-groups of 24 K-chunks each with 128)
+CONV_WGRAD_SPLIT_CAP = 128
+
+
 def _conv_wgrad_general(x_bhwc, dy_bhwc, dw, Cout, KH, KW, contig):
     B, H, W, Cin = x_bhwc.shape
     sn, sh, sw, sc = x_bhwc.stride()
@@ -535,7 +540,7 @@ def _conv_wgrad_general(x_bhwc, dy_bhwc, dw, Cout, KH, KW, contig):
         call("tatt_conv9_c4_c64_wgrad", P(x_bhwc), P(dy_bhwc), P(dw), P(part), B, H, W, stream())
         return dw
     Mo, Kred = KH * KW * Cin, B * H * W
-    splitk = max(2, _auto_split(Mo, Cout, Kred))
+    splitk = max(2, _auto_split(Mo, Cout, Kred, cap=CONV_WGRAD_SPLIT_CAP))
     ws = _split_ws(new(x_bhwc, (splitk + 1) * Mo * Cout))
     call("tatt_conv2d_wgrad", P(x_bhwc), sn, sh, sw, sc, P(dy_bhwc), Cout, P(dw), B, H, W, Cin, Cout, KH, KW, 0.0,
          splitk, P(ws), stream())

@@ -25,11 +25,6 @@ from . import functional as Fh
 from . import ops
 from .dp import FlatParams, GradCuts, broadcast_model, rank_dropout_seed
 
-# The last backward stage has no later pass whose side lane could carry its own parameter-gradient kernels.  True: they are issued on
-# a third stream as the stage's main lane produces their operands (and joined before the stage's bucket is gathered); False (A-B
-# hook): they follow the main lane on the main stream, as in rounds 2-4.
-TAIL_LANE = True
-
 
 def image_loss(sr, hr, weights=(1.0, 1e-4)):
     """ImageLoss(gradient=True, loss_weight=[1, 1e-4]).forward (reference loss/image_loss.py:19-34): per-sample loss (B,)."""
@@ -318,8 +313,6 @@ class Trainer:
             if self.dp or dropout_seed is not None:
                 Fh.set_seed(dev, rank_dropout_seed(base, self.rank) if self.dp else base)
         self.side = torch.cuda.Stream(device=dev) if self.two_lanes else None
-        # third stream: the last stage's own parameter gradients, issued as its main lane produces their operands (TAIL_LANE)
-        self.tail = torch.cuda.Stream(device=dev) if self.two_lanes and TAIL_LANE and len(self.stages) > 1 else None
         if self.cuda and isinstance(self.kernels, HipStepKernels):
             Fh.sticky_word(dev)                      # allocated and registered now: never inside the capture of a step
         self._merge_last = len(self.stages) >= 2         # (also without a second stream: one pass structure everywhere)
@@ -354,7 +347,6 @@ class Trainer:
         Fh.SIDE.due_of = self._due
         Fh.SIDE.immediate = self._immediate
         Fh.SIDE.side_stream = self.side if self.two_lanes and len(self.stages) > 1 else None
-        Fh.SIDE.tail_stream = self.tail if self.tail is not None and k == len(self.stages) - 1 else None
         try:
             if k == 0:
                 for p in self.params:
@@ -380,7 +372,6 @@ class Trainer:
         finally:
             Fh.SIDE.enabled = False
             Fh.SIDE.side_stream = None
-            Fh.SIDE.tail_stream = None
             Fh.FWD_FORK.enabled = False
             if k == 0 and self.cuts is not None:
                 self.model.set_grad_cuts(None)
@@ -417,12 +408,15 @@ class Trainer:
         if k < nst:
             self._main_lane(k, x, tp, hr)
             Fh.stamp("pass %s: main lane done" % name)
+        joined = False
         if merge_last and k == nst - 1:
-            if self.tail is not None:
-                main.wait_stream(self.tail)      # (the stage's parameter gradients ran there beside its main lane)
-            self._side_lane(k)
+            Fh.SIDE.flush(None)
+            if k >= 1 and self.two_lanes:
+                main.wait_stream(self.side)      # (gradients of this stage's bucket that ran AT ONCE on the side lane: SIDE.immediate)
+                joined = True
+            self.flat.gather_grads(k)
             Fh.stamp("pass %s: merged side work done" % name)
-        if k >= 1 and self.two_lanes:
+        if k >= 1 and self.two_lanes and not joined:
             main.wait_stream(self.side)          # (without this per-pass join the side lanes form one long branch, which the
                                                  #  hipGraph executor does not overlap with the main lane: 8.98 ms instead of 7.86)
 

@@ -369,3 +369,15 @@ for tiles, wgs in ((128, 256), (256, 512), (256, 768), (256, 1024)):
         finally:
             ops.CONV_SPLIT_TILES, ops.CONV_SPLIT_WGS = old
     timeit("stn_dgrad2 split<%d,%d>" % (tiles, wgs), _stn_dgrad, 2.0 * B * 8 * 32 * 576 * 32)
+
+# ---- STN head: weight gradient of its first convolution (4 -> 32 channels at 16 x 64: ONE output tile, 49,152-pixel contraction) ----
+sx0, sdy0 = R(B, 16, 64, 4), R(B, 16, 64, 32)
+for cap in (128, 256, 512):
+    def _stn_wgrad0(cap=cap):
+        old = ops.CONV_WGRAD_SPLIT_CAP
+        ops.CONV_WGRAD_SPLIT_CAP = cap
+        try:
+            ops.conv_wgrad(sx0, sdy0, 32, 3, 3)
+        finally:
+            ops.CONV_WGRAD_SPLIT_CAP = old
+    timeit("stn_wgrad1 split cap %d" % cap, _stn_wgrad0, 2.0 * B * 1024 * 36 * 32)
