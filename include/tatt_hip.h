@@ -48,6 +48,13 @@ int tatt_conv2d_fwd(const float* x, long xsn, long xsh, long xsw, long xsc, cons
                     const float* bias, float* y, long ldy, int Bn, int H, int W, int Cin, int Cout,
                     int KH, int KW, int act, float beta, int splitk, float* ws, hipStream_t st);
 
+/* tatt_conv2d_fwd without bias / activation / beta that leaves the split contraction UNSUMMED: ws receives *splits partial maps
+ * [s][pixel][Cout] (*splits <= splitk; 1 = the finished map) for a consumer that adds them while it loads them
+ * (tatt_stn_bn_pool_fwd_parts / tatt_stn_bn_pool_bwd_parts: one launch less per link of the STN head's dependent chain,
+ * model/stn_head.py:15).  ws >= max(splitk, 1)*Bn*H*W*Cout floats; `splits` is a HOST pointer, written before the call returns. */
+int tatt_conv2d_fwd_partials(const float* x, long xsn, long xsh, long xsw, long xsc, const float* wpacked, int Bn, int H,
+                             int W, int Cin, int Cout, int KH, int KW, int splitk, float* ws, int* splits, hipStream_t st);
+
 /* dw_oihw[co][ci][kh][kw] = sum_pixels x[pixel+(kh,kw)][ci] * dy[pixel*lddy + co] + beta*dw; ws >= splitk*KH*KW*Cin*Cout floats */
 int tatt_conv2d_wgrad(const float* x, long xsn, long xsh, long xsw, long xsc, const float* dy,
                       long lddy, float* dw_oihw, int Bn, int H, int W, int Cin, int Cout, int KH,
@@ -402,11 +409,23 @@ int tatt_qgru_fwd_chain(const float* gi0, const float* gi1, const float* whh0, c
 int tatt_stn_bn_pool_fwd(const float* X, float* A, const float* gamma, const float* beta, float* mean, float* rstd,
                          float* running_mean, float* running_var, double* part, unsigned* sync, int B, int H, int W, int C,
                          int ph, int pw, float eps, float momentum, hipStream_t st);
+/* the same with the producing convolution's split contraction folded in: Xparts = S partial maps (S,B,H,W,C) as
+ * tatt_conv2d_fwd_partials leaves them; X = their sum in slab order + bias (NULL: none; tatt_splitk_reduce adds the same terms four-way
+ * interleaved: last-bit differences) is written to Xout (the backward reads it) and normalised + pooled into A */
+int tatt_stn_bn_pool_fwd_parts(const float* Xparts, int S, const float* bias, float* Xout, float* A, const float* gamma,
+                               const float* beta, float* mean, float* rstd, float* running_mean, float* running_var,
+                               double* part, unsigned* sync, int B, int H, int W, int C, int ph, int pw, float eps,
+                               float momentum, hipStream_t st);
 /* its backward: dA -> dX (gradient w.r.t. X), dgamma, dbeta, dbias = column sums of dX (the producing convolution's bias gradient;
  * NULL: skipped).  The pooled gradient goes to the first maximum of its window (tatt_maxpool_bwd's rule).  part >= 128*3*C doubles. */
 int tatt_stn_bn_pool_bwd(const float* X, const float* dA, const float* gamma, const float* beta, const float* mean,
                          const float* rstd, float* dX, float* dgamma, float* dbeta, float* dbias, double* part,
                          unsigned* sync, int B, int H, int W, int C, int ph, int pw, hipStream_t st);
+/* tatt_stn_bn_pool_bwd with dA given as S partial maps (S,B,H/ph,W/pw,C) of the data-gradient convolution behind it (summed in
+ * slab order while they are loaded; S = 1: the map itself) */
+int tatt_stn_bn_pool_bwd_parts(const float* X, const float* dAparts, int S, const float* gamma, const float* beta,
+                               const float* mean, const float* rstd, float* dX, float* dgamma, float* dbeta, float* dbias,
+                               double* part, unsigned* sync, int B, int H, int W, int C, int ph, int pw, hipStream_t st);
 /* x.view(B,-1) of the (B,256,1,2) map [given NHWC: A6 (B,2,256)] -> Linear(512,512) -> BatchNorm1d(train) -> ReLU -> x0.1 ->
  * Linear(512,NO): U (B,512) = first Linear's output, S (B,512) = the second Linear's input, ctrl (B,NO); W1 (512,512), W2 (NO,512)
  * row-major [out][in]; part >= 32*B*NO floats.  stn_head.py:51-58,96-106.  B <= 64, NO % 4 == 0, NO <= 64, else 1. */

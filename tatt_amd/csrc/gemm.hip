@@ -857,6 +857,26 @@ TATT_API int tatt_conv2d_fwd(const float* x, long xsn, long xsh, long xsw, long 
     return 0;
 }
 
+// tatt_conv2d_fwd without bias / activation / beta that leaves the split contraction UNSUMMED: ws receives *splits partial maps
+// ([s][pixel][Cout], *splits <= splitk; 1: the finished map) for a consumer that adds them as it loads them
+// (tatt_stn_bn_pool_fwd_parts / _bwd_parts) -- one launch less between two links of the STN head's dependent chain.
+// ws >= max(splitk, 1) * Bn*H*W*Cout floats; `splits` is a HOST pointer, written before the function returns.
+TATT_API int tatt_conv2d_fwd_partials(const float* x, long xsn, long xsh, long xsw, long xsc, const float* wpacked, int Bn, int H,
+                                      int W, int Cin, int Cout, int KH, int KW, int splitk, float* ws, int* splits, hipStream_t st) {
+    if (!ws || !splits) return 1;
+    GemmP p = {};
+    p.A = x; p.B = wpacked; p.bias = nullptr; p.C = ws;
+    p.M = Bn * H * W; p.N = Cout; p.K = KH * KW * Cin;
+    p.sbk = Cout; p.sbn = 1; p.scm = Cout; p.scn = 1;
+    p.alpha = 1.f; p.beta = 0.f; p.act = ACT_NONE;
+    fill_conv(p, H, W, Cin, KH, KW, xsn, xsh, xsw, xsc);
+    set_split(p, splitk, ws);
+    *splits = p.splitk;
+    int rc = try_conv_fast(p, st);
+    if (rc >= 0) return rc;
+    return launch_gemm<3, 16>(p, 1, true, false, st);
+}
+
 // Convolution weight gradient: dW[co][ci][kh][kw] (OIHW, the reference parameter layout)
 //   = sum_pixels x[pixel + (kh,kw), ci] * dy[pixel, co];  dW = result + beta*dW.
 // Split over pixels (splitk) with a deterministic second-stage reduction; ws >= splitk*KH*KW*Cin*Cout floats.

@@ -98,6 +98,10 @@ __device__ __forceinline__ void sn_allsum(double (*red)[4][64], double* v, int c
 struct SnFwdP {
     const float* X; float* A; const float* gamma; const float* beta; float* mean; float* rstd; float* running_mean; float* running_var;
     double* part; unsigned* sync; SnGeom g; float eps, momentum; unsigned* sticky;
+    // X as S partial maps `slab` floats apart (the split contraction of the convolution before it, left unsummed): they are added
+    // here as they are loaded, in slab order, then + bias (tatt_splitk_reduce adds the same terms four-way interleaved: last-bit
+    // differences); Xout receives the finished map
+    int S; long slab; const float* bias; float* Xout;
 };
 template <int PH, int PW>
 __global__ __launch_bounds__(256) void stn_bn_pool_fwd_kernel(SnFwdP p) {
@@ -119,6 +123,24 @@ __global__ __launch_bounds__(256) void stn_bn_pool_fwd_kernel(SnFwdP p) {
 #pragma unroll
         for (int k = 0; k < NW; ++k)
             x[w][k] = *reinterpret_cast<const f32x4*>(p.X + (((b * p.g.H + oh * PH + k / PW) * p.g.W + ow * PW + k % PW) * C + cq * 4));
+    }
+    if (p.S > 1 || p.Xout) {                                              // (uniform) the convolution's split contraction ends here
+        f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (p.bias) b4 = *reinterpret_cast<const f32x4*>(p.bias + cq * 4);
+#pragma unroll
+        for (int w = 0; w < SN_MAXW; ++w) {
+            const long pp = min(p0 + rl + (long)w * RL, P - 1);
+            const int ow = pp % Wo; const long r = pp / Wo; const int oh = r % Ho; const long b = r / Ho;
+#pragma unroll
+            for (int k = 0; k < NW; ++k) {
+                const long idx = ((b * p.g.H + oh * PH + k / PW) * p.g.W + ow * PW + k % PW) * C + cq * 4;
+                f32x4 v = x[w][k];
+                for (int sl = 1; sl < p.S; ++sl) v += *reinterpret_cast<const f32x4*>(p.X + sl * p.slab + idx);
+                v += b4;
+                x[w][k] = v;
+                if (p.Xout && p0 + rl + (long)w * RL < p1) *reinterpret_cast<f32x4*>(p.Xout + idx) = v;
+            }
+        }
     }
     const f32x4 ga = *reinterpret_cast<const f32x4*>(p.gamma + cq * 4), be = *reinterpret_cast<const f32x4*>(p.beta + cq * 4);
     double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -207,16 +229,33 @@ static bool sn_geom_ok(int B, int H, int W, int C, int ph, int pw) {
            H % ph == 0 && W % pw == 0 && sn_groups((long)B * (H / ph) * (W / pw), C) > 0;
 }
 // part >= 128 * 2 * C doubles, sync = the site's 256-word buffer (see the header of this file).  running_* may be NULL.
-TATT_API int tatt_stn_bn_pool_fwd(const float* X, float* A, const float* gamma, const float* beta, float* mean, float* rstd,
-                                  float* running_mean, float* running_var, double* part, unsigned* sync, int B, int H, int W, int C,
-                                  int ph, int pw, float eps, float momentum, hipStream_t st) {
-    if (!sn_geom_ok(B, H, W, C, ph, pw)) return 1;
+static int sn_fwd_launch(const float* X, int S, const float* bias, float* Xout, float* A, const float* gamma, const float* beta,
+                         float* mean, float* rstd, float* running_mean, float* running_var, double* part, unsigned* sync, int B, int H,
+                         int W, int C, int ph, int pw, float eps, float momentum, hipStream_t st) {
+    if (!sn_geom_ok(B, H, W, C, ph, pw) || S < 1) return 1;
     SnGeom g = {B, H, W, C, sn_groups((long)B * (H / ph) * (W / pw), C)};
-    SnFwdP p = {X, A, gamma, beta, mean, rstd, running_mean, running_var, part, sync, g, eps, momentum, tatt_sticky_ptr()};
+    SnFwdP p = {X, A, gamma, beta, mean, rstd, running_mean, running_var, part, sync, g, eps, momentum, tatt_sticky_ptr(),
+                S, (long)B * H * W * C, bias, Xout};
     if (ph == 2) hipLaunchKernelGGL((stn_bn_pool_fwd_kernel<2, 2>), dim3(g.G), dim3(256), 0, st, p);
     else if (pw == 2) hipLaunchKernelGGL((stn_bn_pool_fwd_kernel<1, 2>), dim3(g.G), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((stn_bn_pool_fwd_kernel<1, 1>), dim3(g.G), dim3(256), 0, st, p);
     return LAUNCH_CHECK();
+}
+TATT_API int tatt_stn_bn_pool_fwd(const float* X, float* A, const float* gamma, const float* beta, float* mean, float* rstd,
+                                  float* running_mean, float* running_var, double* part, unsigned* sync, int B, int H, int W, int C,
+                                  int ph, int pw, float eps, float momentum, hipStream_t st) {
+    return sn_fwd_launch(X, 1, nullptr, nullptr, A, gamma, beta, mean, rstd, running_mean, running_var, part, sync, B, H, W, C, ph, pw,
+                         eps, momentum, st);
+}
+// The same with the convolution's split contraction folded in: Xparts = S partial maps (S, B, H, W, C) as tatt_conv2d_fwd_partials
+// leaves them; X = sum of the slabs in order + bias (bias may be NULL) is written to Xout (the backward reads it) and normalised.
+TATT_API int tatt_stn_bn_pool_fwd_parts(const float* Xparts, int S, const float* bias, float* Xout, float* A, const float* gamma,
+                                        const float* beta, float* mean, float* rstd, float* running_mean, float* running_var,
+                                        double* part, unsigned* sync, int B, int H, int W, int C, int ph, int pw, float eps,
+                                        float momentum, hipStream_t st) {
+    if (!Xout) return 1;
+    return sn_fwd_launch(Xparts, S, bias, Xout, A, gamma, beta, mean, rstd, running_mean, running_var, part, sync, B, H, W, C, ph, pw,
+                         eps, momentum, st);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -227,6 +266,7 @@ TATT_API int tatt_stn_bn_pool_fwd(const float* X, float* A, const float* gamma, 
 struct SnBwdP {
     const float* X; const float* dA; const float* gamma; const float* beta; const float* mean; const float* rstd;
     float* dX; float* dgamma; float* dbeta; float* dbias; double* part; unsigned* sync; SnGeom g; unsigned* sticky;
+    int S; long slab;        // dA as S partial maps `slab` floats apart (the data-gradient convolution's split contraction): summed on load
 };
 template <int PH, int PW>
 __global__ __launch_bounds__(256) void stn_bn_pool_bwd_kernel(SnBwdP p) {
@@ -250,6 +290,7 @@ __global__ __launch_bounds__(256) void stn_bn_pool_bwd_kernel(SnBwdP p) {
 #pragma unroll
         for (int k = 0; k < NW; ++k) xh[w][k] = *reinterpret_cast<const f32x4*>(p.X + base[w] + ((k / PW) * p.g.W + k % PW) * C);
         da[w] = *reinterpret_cast<const f32x4*>(p.dA + pp * C + cq * 4);
+        for (int sl = 1; sl < p.S; ++sl) da[w] += *reinterpret_cast<const f32x4*>(p.dA + sl * p.slab + pp * C + cq * 4);
     }
     const f32x4 mu = *reinterpret_cast<const f32x4*>(p.mean + cq * 4), rs = *reinterpret_cast<const f32x4*>(p.rstd + cq * 4);
     const f32x4 ga = *reinterpret_cast<const f32x4*>(p.gamma + cq * 4), be = *reinterpret_cast<const f32x4*>(p.beta + cq * 4);
@@ -359,16 +400,23 @@ __global__ __launch_bounds__(256) void stn_bn_pool_bwd_kernel(SnBwdP p) {
         for (int e = 0; e < 4; ++e) p.dbias[cq * 4 + e] = (float)s[e];
 }
 // part >= 128 * 3 * C doubles; dbias may be NULL.
-TATT_API int tatt_stn_bn_pool_bwd(const float* X, const float* dA, const float* gamma, const float* beta, const float* mean,
-                                  const float* rstd, float* dX, float* dgamma, float* dbeta, float* dbias, double* part,
-                                  unsigned* sync, int B, int H, int W, int C, int ph, int pw, hipStream_t st) {
-    if (!sn_geom_ok(B, H, W, C, ph, pw)) return 1;
+// dA: S partial maps (S, B, H/ph, W/pw, C) summed in slab order as they are loaded (S = 1: the map itself)
+TATT_API int tatt_stn_bn_pool_bwd_parts(const float* X, const float* dAparts, int S, const float* gamma, const float* beta,
+                                        const float* mean, const float* rstd, float* dX, float* dgamma, float* dbeta, float* dbias,
+                                        double* part, unsigned* sync, int B, int H, int W, int C, int ph, int pw, hipStream_t st) {
+    if (!sn_geom_ok(B, H, W, C, ph, pw) || S < 1) return 1;
     SnGeom g = {B, H, W, C, sn_groups((long)B * (H / ph) * (W / pw), C)};
-    SnBwdP p = {X, dA, gamma, beta, mean, rstd, dX, dgamma, dbeta, dbias, part, sync, g, tatt_sticky_ptr()};
+    SnBwdP p = {X, dAparts, gamma, beta, mean, rstd, dX, dgamma, dbeta, dbias, part, sync, g, tatt_sticky_ptr(),
+                S, (long)B * (H / ph) * (W / pw) * C};
     if (ph == 2) hipLaunchKernelGGL((stn_bn_pool_bwd_kernel<2, 2>), dim3(g.G), dim3(256), 0, st, p);
     else if (pw == 2) hipLaunchKernelGGL((stn_bn_pool_bwd_kernel<1, 2>), dim3(g.G), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((stn_bn_pool_bwd_kernel<1, 1>), dim3(g.G), dim3(256), 0, st, p);
     return LAUNCH_CHECK();
+}
+TATT_API int tatt_stn_bn_pool_bwd(const float* X, const float* dA, const float* gamma, const float* beta, const float* mean,
+                                  const float* rstd, float* dX, float* dgamma, float* dbeta, float* dbias, double* part,
+                                  unsigned* sync, int B, int H, int W, int C, int ph, int pw, hipStream_t st) {
+    return tatt_stn_bn_pool_bwd_parts(X, dA, 1, gamma, beta, mean, rstd, dX, dgamma, dbeta, dbias, part, sync, B, H, W, C, ph, pw, st);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------

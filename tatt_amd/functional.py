@@ -1387,6 +1387,7 @@ def stamp(name, ref=None):
 # through the ordinary entry points; everything between them is one launch per layer and direction, and the fully connected end is one
 # launch each way.  53 -> 17 launches forward, 62 -> 23 backward, at both exposed ends of the training step.
 # --------------------------------------------------------------------------------------------------
+STN_FOLD_SPLITS = True   # test / A-B hook: False -> every split convolution of the head is followed by its own tatt_splitk_reduce launch
 STN_SYNC = []            # every sync buffer handed to those launches (sync_check reads their error words)
 
 
@@ -1451,15 +1452,28 @@ class StnHeadFn(Function):
         for L in range(6):
             w, b, ga, be = pr[4 * L:4 * L + 4]
             bn = stn.stn_convnet[2 * L][1]
-            xc = ops.conv2d_forward(a, w, b, ACT_NONE)
+            C = w.shape[0]
+            fold = STN_FOLD_SPLITS and a.is_contiguous() and ops.conv_split(a, C, 3, 3) > 1
+            if fold:
+                # the deep layers' convolutions split their contraction over the CUs: the partial maps are summed (+ bias) by the
+                # BatchNorm launch as it loads them -- one launch less per link of this dependent chain
+                xparts, S = ops.conv_partials(a, ops.repack_weight(w, 0), C, 3, 3)
+                xc = ops.new(a, B, a.shape[1], a.shape[2], C)
+            else:
+                xc = ops.conv2d_forward(a, w, b, ACT_NONE)
             _, H, W, C = xc.shape
             ph, pw = StnHeadFn.POOLS[L]
             A = ops.new(xc, B, H // ph, W // pw, C)
             mean, rstd = ops.new(xc, C), ops.new(xc, C)
             part = ops.new(xc, 128 * 3 * C, dtype=torch.float64)
-            ops.call("tatt_stn_bn_pool_fwd", ops.P(xc), ops.P(A), ops.P(ga), ops.P(be), ops.P(mean), ops.P(rstd),
-                     ops.P(bn.running_mean), ops.P(bn.running_var), ops.P(part), ops.P(_stn_sync(stn, "f%d" % L, xc)), B, H, W, C,
-                     ph, pw, float(bn.eps), float(bn.momentum), ops.stream())
+            if fold:
+                ops.call("tatt_stn_bn_pool_fwd_parts", ops.P(xparts), S, ops.P(b), ops.P(xc), ops.P(A), ops.P(ga), ops.P(be),
+                         ops.P(mean), ops.P(rstd), ops.P(bn.running_mean), ops.P(bn.running_var), ops.P(part),
+                         ops.P(_stn_sync(stn, "f%d" % L, xc)), B, H, W, C, ph, pw, float(bn.eps), float(bn.momentum), ops.stream())
+            else:
+                ops.call("tatt_stn_bn_pool_fwd", ops.P(xc), ops.P(A), ops.P(ga), ops.P(be), ops.P(mean), ops.P(rstd),
+                         ops.P(bn.running_mean), ops.P(bn.running_var), ops.P(part), ops.P(_stn_sync(stn, "f%d" % L, xc)), B, H, W,
+                         C, ph, pw, float(bn.eps), float(bn.momentum), ops.stream())
             saved += [a, xc, mean, rstd]
             geoms.append((H, W, C, ph, pw))
             a = A
@@ -1494,6 +1508,7 @@ class StnHeadFn(Function):
                  ops.P(_stn_sync(stn, "bfc", a6)), B, NO, ops.stream())
         grads = [None] * 24
         stamp("stn bwd: fc done", dctrl)
+        S = 1                                        # dA: S partial maps (a data-gradient convolution's split contraction, unsummed)
         for L in range(5, -1, -1):
             a_in, xc, mean, rstd = saved[4 * L:4 * L + 4]
             w, b, ga, be = pr[4 * L:4 * L + 4]
@@ -1501,12 +1516,15 @@ class StnHeadFn(Function):
             dX = torch.empty_like(xc)
             dga, dbe, dbias = torch.empty_like(ga), torch.empty_like(be), torch.empty_like(b)
             part = ops.new(xc, 128 * 3 * C, dtype=torch.float64)
-            ops.call("tatt_stn_bn_pool_bwd", ops.P(xc), ops.P(dA), ops.P(ga), ops.P(be), ops.P(mean), ops.P(rstd), ops.P(dX),
+            ops.call("tatt_stn_bn_pool_bwd_parts", ops.P(xc), ops.P(dA), S, ops.P(ga), ops.P(be), ops.P(mean), ops.P(rstd), ops.P(dX),
                      ops.P(dga), ops.P(dbe), ops.P(dbias), ops.P(part), ops.P(_stn_sync(stn, "b%d" % L, xc)), B, H, W, C, ph, pw,
                      ops.stream())
             stamp("stn bwd: layer %d BatchNorm done" % (L + 1), dctrl)
             if L > 0:
-                dA = ops.conv2d_dgrad(dX, w)
+                if STN_FOLD_SPLITS and ops.conv_split(dX, w.shape[1], 3, 3) > 1:
+                    dA, S = ops.conv_partials(dX, ops.repack_weight(w, 1), w.shape[1], 3, 3)     # summed by the next layer's launch
+                else:
+                    dA, S = ops.conv2d_dgrad(dX, w), 1
                 stamp("stn bwd: layer %d data gradient done" % (L + 1), dctrl)
             Cout = w.shape[0]
             (dw,) = SIDE.submit((w,), (lambda a_in=a_in, dX=dX, Cout=Cout: (ops.conv_wgrad(a_in, dX, Cout, 3, 3),)), a_in, dX)

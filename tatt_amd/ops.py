@@ -350,8 +350,9 @@ def repack_weight(w_oihw, mode, cache=True):
 
 
 # generic implicit-GEMM convolution: fewer output tiles than CONV_SPLIT_TILES and a deep contraction -> the contraction is split over
-# up to CONV_SPLIT_WGS work-groups (deterministic second-stage sum)
-CONV_SPLIT_TILES, CONV_SPLIT_WGS = 128, 256
+# up to CONV_SPLIT_WGS work-groups (deterministic second-stage sum).  Round 5: 128 / 256 -> 256 / 768 (the data gradient of the STN
+# head's second convolution, 192 tiles x 36 K-chunks on the main lane of the last pass: 45 -> 30 us)
+CONV_SPLIT_TILES, CONV_SPLIT_WGS = 256, 768
 
 
 def conv_fwd(x_bhwc, wpacked, bias, Cout, KH, KW, *, act=ACT_NONE, out=None, beta=0.0):
@@ -370,16 +371,36 @@ def conv_fwd(x_bhwc, wpacked, bias, Cout, KH, KW, *, act=ACT_NONE, out=None, bet
             and y.is_contiguous():
         call("tatt_conv9_c4_to_c64", P(x_bhwc), P(wpacked), P(bias), P(y), B, H, W, act, stream())
         return y
-    M, K = B * H * W, KH * KW * Cin
-    tiles, nchunks = cdiv(M, 64) * cdiv(Cout, 64), cdiv(K, 16)
-    splitk, ws = 1, None
-    if tiles < CONV_SPLIT_TILES and nchunks >= 32:
-        splitk = max(1, min(CONV_SPLIT_WGS // tiles, nchunks // 8))
-        if splitk > 1:
-            ws = _split_ws(new(x_bhwc, splitk * M * Cout))       # (must outlive a deferred reduction, like every split-K slab)
+    M = B * H * W
+    splitk, ws = conv_split(x_bhwc, Cout, KH, KW), None
+    if splitk > 1:
+        ws = _split_ws(new(x_bhwc, splitk * M * Cout))           # (must outlive a deferred reduction, like every split-K slab)
     call("tatt_conv2d_fwd", P(x_bhwc), sn, sh, sw, sc, P(wpacked), P(bias), P(y), Cout, B, H, W, Cin, Cout, KH, KW,
          act, beta, splitk, P(ws), stream())
     return y
+
+
+def conv_split(x_bhwc, Cout, KH, KW):
+    """contraction splits the generic convolution kernel runs this shape with (1: none)"""
+    B, H, W, Cin = x_bhwc.shape
+    tiles, nchunks = cdiv(B * H * W, 64) * cdiv(Cout, 64), cdiv(KH * KW * Cin, 16)
+    if tiles < CONV_SPLIT_TILES and nchunks >= 32:
+        return max(1, min(CONV_SPLIT_WGS // tiles, nchunks // 8))
+    return 1
+
+
+def conv_partials(x_bhwc, wpacked, Cout, KH, KW):
+    """conv_fwd's generic kernel without bias / activation, its split contraction left UNSUMMED -> (parts, S): S partial maps
+    (S, B, H, W, Cout) for a consumer that adds them as it loads them (the STN head's BatchNorm launches).  S = 1: the finished map."""
+    _check_dev(x_bhwc)
+    B, H, W, Cin = x_bhwc.shape
+    sn, sh, sw, sc = x_bhwc.stride()
+    splitk = conv_split(x_bhwc, Cout, KH, KW)
+    ws = new(x_bhwc, splitk, B, H, W, Cout)
+    got = ctypes.c_int(0)
+    call("tatt_conv2d_fwd_partials", P(x_bhwc), sn, sh, sw, sc, P(wpacked), B, H, W, Cin, Cout, KH, KW, splitk, P(ws),
+         ctypes.byref(got), stream())
+    return ws, int(got.value)
 
 
 def _conv3_fast_ok(x_bhwc, Cin, Cout, KH, KW):
@@ -522,8 +543,8 @@ def conv_wgrad(x_bhwc, dy_bhwc, Cout, KH, KW, want_db=False):
 
 
 # generic weight gradient: at most this many contraction splits (a one-tile output over 49,152 pixels -- the STN head's first
-# convolution -- is 128 work-groups of 24 K-chunks each with 128)
-CONV_WGRAD_SPLIT_CAP = 128
+# convolution -- is 128 work-groups of 24 K-chunks each with 128: 37 us; 256: 26 us, profiles/r05_kernel_microbench.txt)
+CONV_WGRAD_SPLIT_CAP = 256
 
 
 def _conv_wgrad_general(x_bhwc, dy_bhwc, dw, Cout, KH, KW, contig):

@@ -349,9 +349,6 @@ OUTCONV_BUCKET = "srb0"
 # their work-groups to leave the CUs (156 us in the step, 15 alone) on a side lane that is the longer one of that pass; filed with its
 # own stage it runs in a pass whose side lane has room
 OUTCONV_BIAS_BUCKET = "trunk"
-# how many of the STN head's six convolutions (deepest first) have their weight gradient issued AT ONCE on the side lane of the last
-# pass, behind the query GRU's backward, instead of after the pass's main lane with the rest (0: all follow the main lane, rounds 2-4)
-STN_WGRAD_SIDE = 4
 TP_FUSED = True          # test hook: False walks the operator-by-operator path for every geometry (tests compare the two)
 
 
@@ -505,19 +502,14 @@ class _TrainPathMixin:
         return [(n, groups[n]) for n in order if groups[n]]
 
     def immediate_grad_params(self):
-        """Parameters whose gradient kernels run AT ONCE on the side lane of the very pass that produces them:
-          * the weights of the STN_WGRAD_SIDE deepest STN convolutions -- "stn" is the LAST pass, so its own parameter gradients
-            otherwise all follow its main lane while the side lane (the query GRU's backward) has already finished;
-          * OUTCONV_BUCKET = "now": the 9x9 output convolution's weight -- its operands exist at the first kernel of the backward,
-            and that pass has no side work."""
-        ps = []
-        if getattr(self, "stn", False) and hasattr(self, "stn_head"):
-            convs = [self.stn_head.stn_convnet[2 * L][0] for L in range(6)]
-            ps += [c.weight for c in convs[6 - min(max(int(STN_WGRAD_SIDE), 0), 6):]]
-        if OUTCONV_BUCKET == "now" and hasattr(self, "infoGen") and self.srb_nums > 0:
-            b8 = getattr(self, "block%d" % (self.srb_nums + 3))
-            ps.append(b8[len(b8) - 1].weight)
-        return ps
+        """Parameters whose gradient kernels run AT ONCE on the side lane of the very pass that produces them (OUTCONV_BUCKET = "now": the
+        9x9 output convolution's weight -- its operands exist at the first kernel of the backward, and that pass has no side work).
+        (Round 5 tried the same for the STN head's deepest weight gradients in the LAST pass: a dependency from the middle of a main
+        lane to the side lane costs the two lanes their overlap, +0.23 ms -- profiles/r05_tail_lane_ab.txt.)"""
+        if OUTCONV_BUCKET != "now" or not hasattr(self, "infoGen") or self.srb_nums == 0:
+            return []
+        b8 = getattr(self, "block%d" % (self.srb_nums + 3))
+        return [b8[len(b8) - 1].weight]
 
     def _bn_on_path(self):
         skip = () if getattr(self, "stn", False) else ("stn_head",)

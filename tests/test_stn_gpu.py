@@ -98,6 +98,31 @@ def test_stn_head_fused_vs_operator_chain_and_fp64(dev, B):
     print("B = %d: worst fused-vs-fp64 %.2e (%s)" % (B, worst[0], worst[1]))
 
 
+@pytest.mark.parametrize("B", [5, 48])
+def test_stn_head_split_sums_folded_into_the_batchnorm_launches(dev, B):
+    """The head's deep convolutions (forward and data gradient) split their contraction over the CUs; by default the partial maps are
+    summed by the BatchNorm launch that consumes them (tatt_conv2d_fwd_partials -> tatt_stn_bn_pool_{fwd,bwd}_parts) instead of a
+    tatt_splitk_reduce launch of their own.  Same terms, different order of addition: both forms sit at the same distance from fp64."""
+    from tatt_amd import functional as Fh
+    stn0 = _head()
+    x, dctrl = _inputs(B)
+    ref = _run_fp64(stn0, x, dctrl)
+    assert Fh.STN_FOLD_SPLITS
+    folded = _run_hip(stn0, x, dctrl, True, dev)
+    Fh.STN_FOLD_SPLITS = False
+    try:
+        separate = _run_hip(stn0, x, dctrl, True, dev)
+    finally:
+        Fh.STN_FOLD_SPLITS = True
+    for k in sorted(ref):
+        if k.endswith("num_batches_tracked") or (k.startswith("d.stn_convnet") and k.endswith(".0.bias")) or k == "d.stn_fc1.0.bias":
+            continue
+        scale = float(ref[k].abs().max()) + 1e-30
+        e_f = float((folded[k].double() - ref[k]).abs().max()) / scale
+        e_s = float((separate[k].double() - ref[k]).abs().max()) / scale
+        assert e_f <= 4.0 * e_s + 2e-5 and e_s <= 4.0 * e_f + 2e-5, (k, e_f, e_s)
+
+
 def test_stn_head_fused_is_deterministic_under_load(dev):
     stn0 = _head()
     x, dctrl = _inputs(48)
