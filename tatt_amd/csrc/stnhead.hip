@@ -125,22 +125,35 @@ __global__ __launch_bounds__(256) void stn_bn_pool_fwd_kernel(SnFwdP p) {
             x[w][k] = *reinterpret_cast<const f32x4*>(p.X + (((b * p.g.H + oh * PH + k / PW) * p.g.W + ow * PW + k % PW) * C + cq * 4));
     }
     if (p.S > 1 || p.Xout) {                                              // (uniform) the convolution's split contraction ends here
-        f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (p.bias) b4 = *reinterpret_cast<const f32x4*>(p.bias + cq * 4);
+        long idx[SN_MAXW];
 #pragma unroll
         for (int w = 0; w < SN_MAXW; ++w) {
             const long pp = min(p0 + rl + (long)w * RL, P - 1);
             const int ow = pp % Wo; const long r = pp / Wo; const int oh = r % Ho; const long b = r / Ho;
+            idx[w] = ((b * p.g.H + oh * PH) * p.g.W + ow * PW) * C + cq * 4;
+        }
+        for (int sl = 1; sl < p.S; ++sl) {                                  // slab-major: the loads of one slab are independent
+            const float* Xs = p.X + sl * p.slab;
+            f32x4 tv[SN_MAXW][NW];
+#pragma unroll
+            for (int w = 0; w < SN_MAXW; ++w)
+#pragma unroll
+                for (int k = 0; k < NW; ++k) tv[w][k] = *reinterpret_cast<const f32x4*>(Xs + idx[w] + ((k / PW) * p.g.W + k % PW) * C);
+#pragma unroll
+            for (int w = 0; w < SN_MAXW; ++w)
+#pragma unroll
+                for (int k = 0; k < NW; ++k) x[w][k] += tv[w][k];
+        }
+        f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (p.bias) b4 = *reinterpret_cast<const f32x4*>(p.bias + cq * 4);
+#pragma unroll
+        for (int w = 0; w < SN_MAXW; ++w)
 #pragma unroll
             for (int k = 0; k < NW; ++k) {
-                const long idx = ((b * p.g.H + oh * PH + k / PW) * p.g.W + ow * PW + k % PW) * C + cq * 4;
-                f32x4 v = x[w][k];
-                for (int sl = 1; sl < p.S; ++sl) v += *reinterpret_cast<const f32x4*>(p.X + sl * p.slab + idx);
-                v += b4;
-                x[w][k] = v;
-                if (p.Xout && p0 + rl + (long)w * RL < p1) *reinterpret_cast<f32x4*>(p.Xout + idx) = v;
+                x[w][k] += b4;
+                if (p.Xout && p0 + rl + (long)w * RL < p1)
+                    *reinterpret_cast<f32x4*>(p.Xout + idx[w] + ((k / PW) * p.g.W + k % PW) * C) = x[w][k];
             }
-        }
     }
     const f32x4 ga = *reinterpret_cast<const f32x4*>(p.gamma + cq * 4), be = *reinterpret_cast<const f32x4*>(p.beta + cq * 4);
     double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -290,7 +303,18 @@ __global__ __launch_bounds__(256) void stn_bn_pool_bwd_kernel(SnBwdP p) {
 #pragma unroll
         for (int k = 0; k < NW; ++k) xh[w][k] = *reinterpret_cast<const f32x4*>(p.X + base[w] + ((k / PW) * p.g.W + k % PW) * C);
         da[w] = *reinterpret_cast<const f32x4*>(p.dA + pp * C + cq * 4);
-        for (int sl = 1; sl < p.S; ++sl) da[w] += *reinterpret_cast<const f32x4*>(p.dA + sl * p.slab + pp * C + cq * 4);
+    }
+    for (int sl = 1; sl < p.S; sl += 2) {                                   // slab-major, two slabs in flight; added in slab order
+        const bool two = sl + 1 < p.S;
+        f32x4 t0[SN_MAXW], t1[SN_MAXW];
+#pragma unroll
+        for (int w = 0; w < SN_MAXW; ++w) {
+            const long pp = min(p0 + rl + (long)w * RL, P - 1);
+            t0[w] = *reinterpret_cast<const f32x4*>(p.dA + sl * p.slab + pp * C + cq * 4);
+            t1[w] = two ? *reinterpret_cast<const f32x4*>(p.dA + (sl + 1) * p.slab + pp * C + cq * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int w = 0; w < SN_MAXW; ++w) { da[w] += t0[w]; if (two) da[w] += t1[w]; }
     }
     const f32x4 mu = *reinterpret_cast<const f32x4*>(p.mean + cq * 4), rs = *reinterpret_cast<const f32x4*>(p.rstd + cq * 4);
     const f32x4 ga = *reinterpret_cast<const f32x4*>(p.gamma + cq * 4), be = *reinterpret_cast<const f32x4*>(p.beta + cq * 4);

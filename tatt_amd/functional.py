@@ -1388,6 +1388,7 @@ def stamp(name, ref=None):
 # launch each way.  53 -> 17 launches forward, 62 -> 23 backward, at both exposed ends of the training step.
 # --------------------------------------------------------------------------------------------------
 STN_FOLD_SPLITS = True   # test / A-B hook: False -> every split convolution of the head is followed by its own tatt_splitk_reduce launch
+STN_FOLD_MAX = 9         # ... only up to this many partial maps: the consumer's few work-groups add them one dependent load after the other
 STN_SYNC = []            # every sync buffer handed to those launches (sync_check reads their error words)
 
 
@@ -1453,7 +1454,7 @@ class StnHeadFn(Function):
             w, b, ga, be = pr[4 * L:4 * L + 4]
             bn = stn.stn_convnet[2 * L][1]
             C = w.shape[0]
-            fold = STN_FOLD_SPLITS and a.is_contiguous() and ops.conv_split(a, C, 3, 3) > 1
+            fold = STN_FOLD_SPLITS and a.is_contiguous() and 1 < ops.conv_split(a, C, 3, 3) <= STN_FOLD_MAX
             if fold:
                 # the deep layers' convolutions split their contraction over the CUs: the partial maps are summed (+ bias) by the
                 # BatchNorm launch as it loads them -- one launch less per link of this dependent chain
@@ -1521,7 +1522,7 @@ class StnHeadFn(Function):
                      ops.stream())
             stamp("stn bwd: layer %d BatchNorm done" % (L + 1), dctrl)
             if L > 0:
-                if STN_FOLD_SPLITS and ops.conv_split(dX, w.shape[1], 3, 3) > 1:
+                if STN_FOLD_SPLITS and 1 < ops.conv_split(dX, w.shape[1], 3, 3) <= STN_FOLD_MAX:
                     dA, S = ops.conv_partials(dX, ops.repack_weight(w, 1), w.shape[1], 3, 3)     # summed by the next layer's launch
                 else:
                     dA, S = ops.conv2d_dgrad(dX, w), 1
