@@ -193,7 +193,7 @@ def gru_wgrad_sb(dgi, dgh, x2, xb2, hprev, dWp, dWhh, dbp, dbhh):
     call("tatt_splitk_reduce", P(ws2), P(dWhh), 192, 64, G, 0, 0, 0.0, P(dbhh), 192, stream())
 
 
-QGRU_WGRAD_SPLIT = 6          # contraction splits of tatt_qgru_wgrad_sb (96 output tiles x S work-groups for both directions)
+QGRU_WGRAD_SPLIT = 8          # contraction splits of tatt_qgru_wgrad_sb (96 output tiles x S work-groups for both directions; 4: 81 us, 6: 85, 8: 77, 12: 82)
 
 
 def qgru_wgrad_takes(A, B):
