@@ -66,7 +66,8 @@ int tatt_conv2d_wgrad(const float* x, long xsn, long xsh, long xsw, long xsc, co
  * per-lane register order of tatt_conv3_c64_fwd_ws16 (4 / 5: retired);
  * modes 8 / 9: the Toeplitz-expanded 9x9 filter of tatt_conv9_c64_to_c4_mfma in its MFMA fragment order (out needs 110,592 floats);
  * modes 10 / 11: the split-bf16 (hi / lo) forward / data-gradient operand of tatt_conv3_c64_fwd_sb (3x3, channel counts multiples
- * of 64; Cout*Cin*9 32-bit words of two bf16, one chunk per 64 contraction channels) */
+ * of 64; Cout*Cin*9 32-bit words of two bf16, one chunk per 64 contraction channels);
+ * modes 12 / 13: the Toeplitz filter of modes 8 / 9 as split-bf16 hi / lo operand fragments of tatt_conv9_c64_to_c4_sb (110,592 words) */
 int tatt_repack_conv_weight(const float* w_oihw, float* out, int Cout, int Cin, int KH, int KW,
                             int mode, hipStream_t st);
 /* number of 32-bit words the packed layout `mode` of a (Cout, Cin, KH, KW) filter occupies = the size of `out` above; -1 for an
@@ -159,6 +160,11 @@ int tatt_conv9_c64_to_c4(const float* x, const float* wpacked, const float* bias
  * block1's 4->64 convolution, :597); x (B,H,W,64) NHWC contiguous, H % 4 == 0, W % 64 == 0; y (B,H,W,4) */
 int tatt_conv9_c64_to_c4_mfma(const float* x, const float* wt, const float* bias, float* y, int B, int H, int W,
                               hipStream_t st);
+/* the same Toeplitz convolution on v_mfma_f32_16x16x32_bf16 with every fp32 operand split a = hi + lo (hi hi + hi lo + lo hi, fp32
+ * accumulation: 2^-16 relative per product, the arithmetic of tatt_conv3_c64_fwd_sb); wt from tatt_repack_conv_weight mode 12
+ * (forward, model/tsrn.py:623) / mode 13 (data gradient of block1's 4->64 convolution, :597); geometry as the _mfma entry */
+int tatt_conv9_c64_to_c4_sb(const float* x, const float* wt, const float* bias, float* y, int B, int H, int W,
+                            hipStream_t st);
 /* 9x9 convolution from 4 channels to 64 (weight-stationary MFMA kernel, k = the 4 input channels): y = act(conv(in, wp) + bias),
  * wp [81][4][64] = tatt_repack_conv_weight mode 0 of block1's filter (reference model/tsrn.py:597) or mode 1 of the 64->4
  * reconstruction filter (its data gradient, :623); in (B,H,W,4), out (B,H,W,64) NHWC contiguous, H % 4 == 0, W % 64 == 0 */

@@ -222,6 +222,155 @@ TATT_API int tatt_conv9_c64_to_c4_mfma(const float* x, const float* wt, const fl
     return LAUNCH_CHECK();
 }
 
+// ---- the same Toeplitz convolution on the bf16 matrix cores with split operands (round 5) ------------------------------------------
+// The fp32 form above runs at 65 % of the fp32 MFMA peak: 107 us for the 64 -> 4 output convolution at HR resolution, the longest
+// kernel of the training step.  Here every fp32 operand is a = hi + lo (hi = bf16(a), lo = bf16(a - hi)) and a b = hi hi + hi lo +
+// lo hi with fp32 accumulation (2^-16 relative per product -- the arithmetic of tatt_conv3_c64_fwd_sb), on v_mfma_f32_16x16x32_bf16:
+// 16x the fp32 rate for three products.  Same tile and wave roles (4 rows x 64 pixels, wave = (row, kh), 16-channel chunks, phases
+// = (chunk, filter row), filter fragments from global memory three phases ahead, halo of the next chunk prefetched to registers).
+//   rows i = pixel group g = i (4 pixels), columns n = (j, o), one MFMA contracts k = 32 = 2 pixel offsets x 16 channels:
+//   lane (i, kq): dx = 2 pair + (kq >> 1), channels 8 (kq & 1) .. + 7 of the chunk -- 8 consecutive bf16 of ONE halo pixel, one ds_read_b128.
+//   A wave owns the dx pairs 3 kh .. 3 kh + 2: 9 MFMAs per phase (three accumulator chains x hi hi, hi lo, lo hi), 324 per tile.
+//   Halo: a hi and a lo bf16 image, pixel-major with the four pixel PHASES (px & 3) of a row apart: [row 12][px & 3][px >> 2 (18)][16 ch]
+//   = 32 B per pixel.  A lane group of a ds_read_b128 then holds 8 lanes of one channel half and 8 of the other over consecutive pixel
+//   groups: 16 distinct 16-byte slots of the 256-byte bank row (MI355X_MICROARCH.md, LDS) -- conflict-free without padding.  The
+//   operands are split ONCE, when the halo is stored.
+#define S9_ROWB (4 * 18 * 32)                    // bytes of one halo row of one image: 2304
+#define S9_IMG (M9_ROWS * S9_ROWB)               // bytes of one image (hi or lo): 27,648
+typedef __bf16 s9_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 s9_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float s9_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned s9_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void s9_split(f32x4 v, unsigned& h0, unsigned& h1, unsigned& l0, unsigned& l1) {
+    const s9_f32x2 a = (s9_f32x2){v[0], v[1]}, b = (s9_f32x2){v[2], v[3]};
+    const s9_bf16x2 ha = __builtin_convertvector(a, s9_bf16x2), hb = __builtin_convertvector(b, s9_bf16x2);
+    const s9_bf16x2 la = __builtin_convertvector(a - __builtin_convertvector(ha, s9_f32x2), s9_bf16x2);
+    const s9_bf16x2 lb = __builtin_convertvector(b - __builtin_convertvector(hb, s9_f32x2), s9_bf16x2);
+    h0 = __builtin_bit_cast(unsigned, ha); h1 = __builtin_bit_cast(unsigned, hb);
+    l0 = __builtin_bit_cast(unsigned, la); l1 = __builtin_bit_cast(unsigned, lb);
+}
+__global__ __launch_bounds__(512) void conv9_c64_to_c4_sb_kernel(const float* __restrict__ x, const float* __restrict__ wt,
+                                                                 const float* __restrict__ bias, float* __restrict__ y,
+                                                                 int B, int H, int W, int ntiles) {
+    __shared__ __attribute__((aligned(16))) unsigned char Xs[2 * S9_IMG];        // hi image, lo image: 55,296 B
+    __shared__ __attribute__((aligned(16))) float Red[4 * 64 * 4];               // the kh = 1 accumulators of the four rows
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int row = wave & 3, kh = wave >> 2;
+    const int tiles_w = W / M9_TW, tiles_h = H / M9_TH;
+    const int i = lane & 15, kq = lane >> 4;
+    // A fragment of (ky, pair): lane base + the pair's (pixel phase, group) offset + ky rows
+    const int lane_base = ((row * 4 + (kq >> 1)) * 18 + i) * 32 + (kq & 1) * 16;
+    int xa[3];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+        const int pair = 3 * kh + pl;
+        xa[pl] = lane_base + (((2 * pair) & 3) * 18 + (pair >> 1)) * 32;
+    }
+    const int wl = (kh * 6 * 64 + lane) * 16;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wt), 0, 9 * 4 * 2 * 6 * 64 * 4 * 4, 0x00020000);
+    f32x4 wpre[M9_D + 1][6];                                           // [pair-in-wave * 2 + {hi, lo}] of phase p in set p % (M9_D + 1)
+    f32x4 hpre[M9_HQ][4];
+    auto filt_load = [&](int p) {
+#pragma unroll
+        for (int f = 0; f < 6; ++f)
+            wpre[p % (M9_D + 1)][f] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                wrs, wl, (((p % 9) * 4 + p / 9) * 12 + f) * 1024, 0));
+    };
+    auto halo_load = [&](int tile, int c0, int q) {
+        const int tw = tile % tiles_w, th = (tile / tiles_w) % tiles_h, n = tile / (tiles_w * tiles_h);
+        const int pp = t + 512 * q;
+        const int r = pp / 72, px = pp - r * 72;
+        const int hh = th * M9_TH + r - 4, ww = tw * M9_TW + px - 4;
+        const bool ok = tile < ntiles && pp < M9_HPX && hh >= 0 && hh < H && ww >= 0 && ww < W;
+        const f32x4* src = reinterpret_cast<const f32x4*>(x + (((long)n * H + hh) * W + ww) * 64 + c0);
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) hpre[q][c4] = ok ? src[c4] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+    auto halo_store = [&](int q) {
+        const int pp = t + 512 * q;
+        if (pp < M9_HPX) {
+            const int r = pp / 72, px = pp - r * 72;
+            unsigned char* d = Xs + ((r * 4 + (px & 3)) * 18 + (px >> 2)) * 32;
+            unsigned h[8], l[8];
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) s9_split(hpre[q][c4], h[2 * c4], h[2 * c4 + 1], l[2 * c4], l[2 * c4 + 1]);
+            *reinterpret_cast<s9_u32x4*>(d) = (s9_u32x4){h[0], h[1], h[2], h[3]};
+            *reinterpret_cast<s9_u32x4*>(d + 16) = (s9_u32x4){h[4], h[5], h[6], h[7]};
+            *reinterpret_cast<s9_u32x4*>(d + S9_IMG) = (s9_u32x4){l[0], l[1], l[2], l[3]};
+            *reinterpret_cast<s9_u32x4*>(d + S9_IMG + 16) = (s9_u32x4){l[4], l[5], l[6], l[7]};
+        }
+    };
+#pragma unroll
+    for (int q = 0; q < M9_D; ++q) filt_load(q);
+#pragma unroll
+    for (int q = 0; q < M9_HQ; ++q) halo_load(blockIdx.x, 0, q);
+#pragma unroll
+    for (int q = 0; q < M9_HQ; ++q) halo_store(q);
+    __syncthreads();
+    const float bo = bias ? bias[i & 3] : 0.f;
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        f32x4 acc3[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) acc3[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int ky = 0; ky < 9; ++ky) {
+                const int p = 9 * c + ky;
+                filt_load((p + M9_D) % 36);                   // beyond phase 35: the next tile's first phases (same filter)
+                if (ky < M9_HQ) {                             // the next chunk's halo: of this tile, or chunk 0 of the next one
+                    if (c < 3) halo_load(tile, 16 * (c + 1), ky);
+                    else halo_load(tile + gridDim.x, 0, ky);
+                }
+                s9_bf16x8 ah[3], al[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    ah[pl] = *reinterpret_cast<const s9_bf16x8*>(Xs + xa[pl] + ky * S9_ROWB);
+                    al[pl] = *reinterpret_cast<const s9_bf16x8*>(Xs + xa[pl] + ky * S9_ROWB + S9_IMG);
+                }
+                // product-major over the three accumulator chains: consecutive MFMAs never depend on each other
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    acc3[pl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[pl], __builtin_bit_cast(s9_bf16x8, wpre[p % (M9_D + 1)][2 * pl]), acc3[pl], 0, 0, 0);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    acc3[pl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[pl], __builtin_bit_cast(s9_bf16x8, wpre[p % (M9_D + 1)][2 * pl + 1]), acc3[pl], 0, 0, 0);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    acc3[pl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[pl], __builtin_bit_cast(s9_bf16x8, wpre[p % (M9_D + 1)][2 * pl]), acc3[pl], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (ky == 8) {                                // chunk boundary: every wave must have left the halo first
+                    f32x4 acc = (acc3[0] + acc3[1]) + acc3[2];
+                    __syncthreads();
+#pragma unroll
+                    for (int q = 0; q < M9_HQ; ++q) halo_store(q);
+                    if (c == 3 && kh == 1) *reinterpret_cast<f32x4*>(&Red[(row * 64 + lane) * 4]) = acc;
+                    __syncthreads();
+                    if (c == 3 && kh == 0) {                  // the two dx halves of a row meet
+                        acc += *reinterpret_cast<const f32x4*>(&Red[(row * 64 + lane) * 4]);
+                        // C layout: column n = lane & 15 = (j, o); row 4 (lane >> 4) + reg = pixel group: 16 consecutive floats of y
+                        const int tw = tile % tiles_w, th = (tile / tiles_w) % tiles_h, n = tile / (tiles_w * tiles_h);
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg)
+                            y[(((long)n * H + th * M9_TH + row) * W + tw * M9_TW + 4 * (4 * kq + reg)) * 4 + i] = acc[reg] + bo;
+                    }
+                }
+            }
+        }
+    }
+}
+// as tatt_conv9_c64_to_c4_mfma; wt = the split-bf16 Toeplitz filter from tatt_repack_conv_weight mode 12 (forward filter of a
+// 64 -> 4 convolution) / mode 13 (data gradient of a 4 -> 64 one)
+TATT_API int tatt_conv9_c64_to_c4_sb(const float* x, const float* wt, const float* bias, float* y, int B, int H, int W,
+                                     hipStream_t st) {
+    if (H % M9_TH || W % M9_TW) return 1;
+    const int ntiles = B * (H / M9_TH) * (W / M9_TW);
+    hipLaunchKernelGGL(conv9_c64_to_c4_sb_kernel, dim3(ntiles < 256 ? ntiles : 256), dim3(512), 0, st, x, wt, bias, y, B, H, W,
+                       ntiles);
+    return LAUNCH_CHECK();
+}
+
 // ---- 9x9 convolution FROM 4 channels TO 64 on the matrix cores -----------------------------------------------------------------
 // y[px][n] = act(sum_{tap, k} in[px + tap - 4][k] * wp[tap][k][n] + bias[n]),  wp = [81][4][64] (repack mode 0: block1's forward
 // convolution, reference model/tsrn.py:597; mode 1: the data gradient of the 64->4 reconstruction convolution, :623).

@@ -922,7 +922,7 @@ __device__ __forceinline__ float toeplitz9(const float* __restrict__ w, int idx,
     return mode == 8 ? w[(((long)o * 64 + ci) * 9 + ky) * 9 + kx] : w[(((long)ci * 4 + o) * 9 + (8 - ky)) * 9 + (8 - kx)];
 }
 static inline long repack_total(int Cout, int Cin, int KH, int KW, int mode) {
-    return (mode == 8 || mode == 9) ? (long)TOEPLITZ9_WORDS : (long)Cout * Cin * KH * KW;
+    return (mode == 8 || mode == 9 || mode == 12 || mode == 13) ? (long)TOEPLITZ9_WORDS : (long)Cout * Cin * KH * KW;
 }
 // modes 10 / 11: the split-bf16 B operand of tatt_conv3_c64_fwd_sb (3x3; conv input channels a multiple of 64, output channels of 16):
 // 32-bit words of two bf16 with consecutive input channels,
@@ -946,9 +946,35 @@ __device__ __forceinline__ float repack_sb(const float* __restrict__ w, long idx
     const rp_bf16x2 lo = __builtin_convertvector(v - __builtin_convertvector(hi, rp_f32x2), rp_bf16x2);
     return __builtin_bit_cast(float, hl ? lo : hi);
 }
+// modes 12 / 13: the Toeplitz-expanded 9x9 filter of modes 8 / 9 as the split-bf16 B operand of tatt_conv9_c64_to_c4_sb
+// (v_mfma_f32_16x16x32_bf16: a lane supplies 8 consecutive k = two pixel offsets x 16 channels spread over the four k-quarters):
+//   word[((((ky * 4 + c) * 6 + pair) * 2 + hl) * 64 + lane) * 4 + e2]  = two bf16 of input channels ci, ci + 1,
+//   n = lane & 15 = 4 j + o, kq = lane >> 4, dx = 2 pair + (kq >> 1), ci = 16 c + 8 (kq & 1) + 2 e2,
+//   value = f[o][ci][ky][dx - j] if 0 <= dx - j < 9 else 0 (f as for modes 8 / 9), hl = 0: hi = bf16(v), 1: lo = bf16(v - hi).
+__device__ __forceinline__ float toeplitz9_sb(const float* __restrict__ w, int idx, int mode) {
+    const int e2 = idx & 3, lane = (idx >> 2) & 63, hl = (idx >> 8) & 1;
+    int r = idx >> 9;
+    const int pair = r % 6; r /= 6;
+    const int c = r & 3, ky = r >> 2;
+    const int nn = lane & 15, kq = lane >> 4;
+    const int j = nn >> 2, o = nn & 3, kx = 2 * pair + (kq >> 1) - j, ci = 16 * c + 8 * (kq & 1) + 2 * e2;
+    rp_f32x2 v = (rp_f32x2){0.f, 0.f};
+    if (kx >= 0 && kx < 9) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            v[u] = mode == 12 ? w[(((long)o * 64 + ci + u) * 9 + ky) * 9 + kx] : w[(((long)(ci + u) * 4 + o) * 9 + (8 - ky)) * 9 + (8 - kx)];
+    }
+    const rp_bf16x2 hi = __builtin_convertvector(v, rp_bf16x2);
+    const rp_bf16x2 lo = __builtin_convertvector(v - __builtin_convertvector(hi, rp_f32x2), rp_bf16x2);
+    return __builtin_bit_cast(float, hl ? lo : hi);
+}
 __global__ void repack_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin,
                                      int KH, int KW, int mode) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (mode >= 12) {
+        if (idx < TOEPLITZ9_WORDS) out[idx] = toeplitz9_sb(w, idx, mode);
+        return;
+    }
     if (mode >= 10) {
         if (idx < Cout * Cin * 9) out[idx] = repack_sb(w, idx, Cout, Cin, mode);
         return;
@@ -987,14 +1013,15 @@ __global__ void repack_weight_kernel(const float* __restrict__ w, float* __restr
 }
 // 32-bit words a packed layout occupies (what `out` of tatt_repack_conv_weight must hold); -1 for an unknown mode.  Host-only.
 TATT_API int tatt_repack_words(int Cout, int Cin, int KH, int KW, int mode) {
-    if (mode == 4 || mode == 5 || mode < 0 || mode > 11) return -1;
+    if (mode == 4 || mode == 5 || mode < 0 || mode > 13) return -1;
     return (int)repack_total(Cout, Cin, KH, KW, mode);
 }
 TATT_API int tatt_repack_conv_weight(const float* w_oihw, float* out, int Cout, int Cin, int KH, int KW,
                                      int mode, hipStream_t st) {
-    if ((mode == 8 || mode == 9) && !(KH == 9 && KW == 9 && ((mode == 8 && Cout == 4 && Cin == 64) || (mode == 9 && Cout == 64 && Cin == 4)))) return 1;
-    if (mode >= 10 && !(mode <= 11 && KH == 3 && KW == 3 && Cout % 64 == 0 && Cin % 64 == 0)) return 1;
-    if (mode == 4 || mode == 5 || mode < 0 || mode > 11) return 1;     // (4 / 5: the retired 32x32 weight-stationary kernel)
+    const bool fwd9 = mode == 8 || mode == 12, dgrad9 = mode == 9 || mode == 13;
+    if ((fwd9 || dgrad9) && !(KH == 9 && KW == 9 && ((fwd9 && Cout == 4 && Cin == 64) || (dgrad9 && Cout == 64 && Cin == 4)))) return 1;
+    if ((mode == 10 || mode == 11) && !(KH == 3 && KW == 3 && Cout % 64 == 0 && Cin % 64 == 0)) return 1;
+    if (mode == 4 || mode == 5 || mode < 0 || mode > 13) return 1;     // (4 / 5: the retired 32x32 weight-stationary kernel)
     long total = repack_total(Cout, Cin, KH, KW, mode);
     hipLaunchKernelGGL(repack_weight_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w_oihw, out, Cout, Cin,
                        KH, KW, mode);
@@ -1011,6 +1038,10 @@ __global__ void repack_batch_kernel(RepackTable t) {
     while (k + 1 < t.n && (int)blockIdx.x >= t.e[k + 1].block0) ++k;          // wave-uniform walk over <= 96 entries
     const RepackEntry& e = t.e[k];
     const int idx = ((int)blockIdx.x - e.block0) * blockDim.x + threadIdx.x;
+    if (e.mode >= 12) {
+        if (idx < TOEPLITZ9_WORDS) e.out[idx] = toeplitz9_sb(e.w, idx, e.mode);
+        return;
+    }
     if (e.mode >= 10) {
         if (idx < e.Cout * e.Cin * 9) e.out[idx] = repack_sb(e.w, idx, e.Cout, e.Cin, e.mode);
         return;

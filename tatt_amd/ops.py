@@ -434,6 +434,11 @@ def _conv3_sb(x_bhwc, w_oihw, mode, bias, act=ACT_NONE, in_scale=None, in_shift=
     return y
 
 
+# The 9x9 convolutions 64 -> 4 (output convolution forward, block1's data gradient) on the bf16 matrix cores with split operands
+# (tatt_conv9_c64_to_c4_sb).  Test / A-B hook: False -> the exact-fp32 Toeplitz kernel.
+CONV9_SB = True
+
+
 def _conv9_mfma_ok(x_bhwc):
     return x_bhwc.is_contiguous() and x_bhwc.shape[1] % 4 == 0 and x_bhwc.shape[2] % 64 == 0 and x_bhwc.shape[3] == 64
 
@@ -444,7 +449,10 @@ def conv2d_forward(x_bhwc, weight_oihw, bias, act=ACT_NONE):
     if KH == 9 and KW == 9 and Cout == 4 and Cin == 64 and act == ACT_NONE and _conv9_mfma_ok(x_bhwc):
         B, H, W, _ = x_bhwc.shape
         y = new(x_bhwc, B, H, W, 4)
-        call("tatt_conv9_c64_to_c4_mfma", P(x_bhwc), P(repack_weight(weight_oihw, 8)), P(bias), P(y), B, H, W, stream())
+        if CONV9_SB:
+            call("tatt_conv9_c64_to_c4_sb", P(x_bhwc), P(repack_weight(weight_oihw, 12)), P(bias), P(y), B, H, W, stream())
+        else:
+            call("tatt_conv9_c64_to_c4_mfma", P(x_bhwc), P(repack_weight(weight_oihw, 8)), P(bias), P(y), B, H, W, stream())
         return y
     if _conv3_fast_ok(x_bhwc, Cin, Cout, KH, KW):
         B, H, W, _ = x_bhwc.shape
@@ -503,7 +511,10 @@ def conv2d_dgrad(dy_bhwc, weight_oihw):
     if KH == 9 and KW == 9 and Cout == 64 and Cin == 4 and _conv9_mfma_ok(dy_bhwc):
         B, H, W, _ = dy_bhwc.shape
         dx = new(dy_bhwc, B, H, W, 4)
-        call("tatt_conv9_c64_to_c4_mfma", P(dy_bhwc), P(repack_weight(weight_oihw, 9)), None, P(dx), B, H, W, stream())
+        if CONV9_SB:
+            call("tatt_conv9_c64_to_c4_sb", P(dy_bhwc), P(repack_weight(weight_oihw, 13)), None, P(dx), B, H, W, stream())
+        else:
+            call("tatt_conv9_c64_to_c4_mfma", P(dy_bhwc), P(repack_weight(weight_oihw, 9)), None, P(dx), B, H, W, stream())
         return dx
     if _conv3_fast_ok(dy_bhwc, Cout, Cin, KH, KW):
         B, H, W, _ = dy_bhwc.shape

@@ -754,11 +754,14 @@ def test_semantic_loss_and_psnr_kernels(dev):
     assert float(calculate_psnr(a, a)) == float("inf")
 
 
+@pytest.mark.parametrize("sb", [True, False])
 @pytest.mark.parametrize("B,H,W", [(2, 32, 128), (3, 16, 64), (1, 8, 64), (1, 4, 64), (5, 64, 256)])
-def test_conv9_mfma_toeplitz(dev, B, H, W):
-    """tatt_conv9_c64_to_c4_mfma (4 pixels x 4 channels per MFMA column block, Toeplitz-expanded filter): the 64->4 reconstruction
-    convolution (repack mode 8) and the data gradient of a 4->64 convolution (mode 9) against F.conv2d in fp64."""
+def test_conv9_mfma_toeplitz(dev, B, H, W, sb, monkeypatch):
+    """tatt_conv9_c64_to_c4_sb / _mfma (4 pixels x 4 channels per MFMA column block, Toeplitz-expanded filter; split-bf16 products on
+    the bf16 matrix cores -- the default -- and exact fp32 ones): the 64->4 reconstruction convolution (repack mode 12 / 8) and the
+    data gradient of a 4->64 convolution (mode 13 / 9) against F.conv2d in fp64."""
     from tatt_amd import ops
+    monkeypatch.setattr(ops, "CONV9_SB", sb)
     g = torch.Generator().manual_seed(31)
     x = torch.randn(B, H, W, 64, generator=g)
     w = torch.randn(4, 64, 9, 9, generator=g) * 0.02
@@ -767,6 +770,10 @@ def test_conv9_mfma_toeplitz(dev, B, H, W):
     xd, wd, bd = x.to(dev), w.to(dev), b.to(dev)
     y = ops.conv2d_forward(xd, wd, bd)
     check_close("conv9_mfma_fwd", y, ref.float(), 2e-4, 2e-4)
+    # against the scale of the result: the split-bf16 form keeps 16 mantissa bits per operand (2^-16 relative per product)
+    err = float((y.cpu().double() - ref).abs().max() / ref.abs().max())
+    assert err < (2e-5 if sb else 3e-6), err
+    assert torch.equal(y, ops.conv2d_forward(xd, wd, bd))
     # data gradient of block1 (4 -> 64): dx = conv_transpose(dy, w1)
     w1 = (torch.randn(64, 4, 9, 9, generator=g) * 0.02)
     xin = torch.randn(B, 4, H, W, generator=g, dtype=torch.float64).requires_grad_(True)
@@ -775,6 +782,9 @@ def test_conv9_mfma_toeplitz(dev, B, H, W):
     dyd, w1d = dy.to(dev), w1.to(dev)
     dx = ops.conv2d_dgrad(dyd, w1d)
     check_close("conv9_mfma_dgrad", dx, xin.grad.permute(0, 2, 3, 1).float(), 2e-4, 2e-4)
+    gref = xin.grad.permute(0, 2, 3, 1)
+    err = float((dx.cpu().double() - gref).abs().max() / gref.abs().max())
+    assert err < (2e-5 if sb else 3e-6), err
     # the packed-filter cache follows an in-place update of the weights
     wd.mul_(2.0)
     check_close("conv9_mfma_fwd_after_update", ops.conv2d_forward(xd, wd, bd), (2 * (ref - b.double()) + b.double()).float(), 4e-4, 4e-4)

@@ -381,3 +381,28 @@ for cap in (128, 256, 512):
         finally:
             ops.CONV_WGRAD_SPLIT_CAP = old
     timeit("stn_wgrad1 split cap %d" % cap, _stn_wgrad0, 2.0 * B * 1024 * 36 * 32)
+
+# ---- 9x9 output convolution 64 -> 4 at HR resolution (B x 32 x 128) and block1's data gradient at LR: fp32 Toeplitz MFMA vs split bf16 ----
+ox = R(B, 32, 128, 64)
+ow = (R(4, 64, 9, 9) * 0.02).requires_grad_(False)
+ob = R(4)
+dy1 = R(B, 16, 64, 64)
+w1 = R(64, 4, 9, 9) * 0.02
+f9 = 2.0 * B * 32 * 128 * 64 * 4 * 81
+for sbm in (False, True):
+    def _c9(sbm=sbm):
+        old = ops.CONV9_SB
+        ops.CONV9_SB = sbm
+        try:
+            ops.conv2d_forward(ox, ow, ob)
+        finally:
+            ops.CONV9_SB = old
+    def _c9d(sbm=sbm):
+        old = ops.CONV9_SB
+        ops.CONV9_SB = sbm
+        try:
+            ops.conv2d_dgrad(dy1, w1)
+        finally:
+            ops.CONV9_SB = old
+    timeit("conv9_out_fwd %s" % ("sb" if sbm else "fp32"), _c9, f9)
+    timeit("conv9_block1_dgrad %s" % ("sb" if sbm else "fp32"), _c9d, f9 / 4)
