@@ -226,17 +226,28 @@ TATT_API int tatt_conv9_c64_to_c4_mfma(const float* x, const float* wt, const fl
 // The fp32 form above runs at 65 % of the fp32 MFMA peak: 107 us for the 64 -> 4 output convolution at HR resolution, the longest
 // kernel of the training step.  Here every fp32 operand is a = hi + lo (hi = bf16(a), lo = bf16(a - hi)) and a b = hi hi + hi lo +
 // lo hi with fp32 accumulation (2^-16 relative per product -- the arithmetic of tatt_conv3_c64_fwd_sb), on v_mfma_f32_16x16x32_bf16:
-// 16x the fp32 rate for three products.  Same tile and wave roles (4 rows x 64 pixels, wave = (row, kh), 16-channel chunks, phases
-// = (chunk, filter row), filter fragments from global memory three phases ahead, halo of the next chunk prefetched to registers).
+// 16x the fp32 rate for three products.  Same tile (4 rows x 64 pixels), 16-channel chunks, phases = (chunk, filter row), filter
+// fragments from global memory some phases ahead, halo of the next chunk prefetched to registers.
 //   rows i = pixel group g = i (4 pixels), columns n = (j, o), one MFMA contracts k = 32 = 2 pixel offsets x 16 channels:
 //   lane (i, kq): dx = 2 pair + (kq >> 1), channels 8 (kq & 1) .. + 7 of the chunk -- 8 consecutive bf16 of ONE halo pixel, one ds_read_b128.
-//   A wave owns the dx pairs 3 kh .. 3 kh + 2: 9 MFMAs per phase (three accumulator chains x hi hi, hi lo, lo hi), 324 per tile.
+//   12 waves: wave = (dx pair 0..5, row half): ONE pair of filter fragments (hi, lo) per phase serves its two rows -- the first version
+//   (wave = (row, three pairs), 6 fragments per wave and phase, each fragment fetched by four waves) was bound by the filter's way
+//   through the vector memory path and by fetching only three now much shorter phases ahead: 75 us; with two fragments per phase
+//   the same registers hold five phases: 67 us.  Six accumulator chains per wave ((row, product)): no MFMA waits for its predecessor.
+//   With the images dealt to the XCDs (below) HBM traffic fell from 221 to 53 MB: 58 us (fp32 form: 115).  What is left (PMC,
+//   profiles/r05_pmc_conv9_sb.txt): the MFMA pipe is busy 27 % of the time; a wave spends 36 % of its cycles at s_waitcnt -- vector
+//   loads return in order, so the filter fragments (L2 hits, needed 5 phases later) queue behind the next chunk's halo loads (first
+//   touch of the lines), and a chunk's nine phases (1.1 us) are shorter than that latency.
 //   Halo: a hi and a lo bf16 image, pixel-major with the four pixel PHASES (px & 3) of a row apart: [row 12][px & 3][px >> 2 (18)][16 ch]
 //   = 32 B per pixel.  A lane group of a ds_read_b128 then holds 8 lanes of one channel half and 8 of the other over consecutive pixel
 //   groups: 16 distinct 16-byte slots of the 256-byte bank row (MI355X_MICROARCH.md, LDS) -- conflict-free without padding.  The
-//   operands are split ONCE, when the halo is stored.
+//   operands are split ONCE, when the halo is stored.  The six pairs' partial sums of a row meet through LDS at the end of a tile.
 #define S9_ROWB (4 * 18 * 32)                    // bytes of one halo row of one image: 2304
 #define S9_IMG (M9_ROWS * S9_ROWB)               // bytes of one image (hi or lo): 27,648
+#define S9_THREADS 768
+#define S9_D 5                                   // filter fragments are fetched S9_D phases ahead (S9_D + 1 divides 36)
+#define S9_RED (12 * 2 * 64 * 16)                // bytes: every wave's two row accumulators
+#define S9_LDS (2 * S9_IMG + S9_RED)             // 79,872 B
 typedef __bf16 s9_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 s9_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float s9_f32x2 __attribute__((ext_vector_type(2)));
@@ -249,36 +260,36 @@ __device__ __forceinline__ void s9_split(f32x4 v, unsigned& h0, unsigned& h1, un
     h0 = __builtin_bit_cast(unsigned, ha); h1 = __builtin_bit_cast(unsigned, hb);
     l0 = __builtin_bit_cast(unsigned, la); l1 = __builtin_bit_cast(unsigned, lb);
 }
-__global__ __launch_bounds__(512) void conv9_c64_to_c4_sb_kernel(const float* __restrict__ x, const float* __restrict__ wt,
-                                                                 const float* __restrict__ bias, float* __restrict__ y,
-                                                                 int B, int H, int W, int ntiles) {
-    __shared__ __attribute__((aligned(16))) unsigned char Xs[2 * S9_IMG];        // hi image, lo image: 55,296 B
-    __shared__ __attribute__((aligned(16))) float Red[4 * 64 * 4];               // the kh = 1 accumulators of the four rows
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int row = wave & 3, kh = wave >> 2;
+__global__ __launch_bounds__(S9_THREADS) void conv9_c64_to_c4_sb_kernel(const float* __restrict__ x, const float* __restrict__ wt,
+                                                                        const float* __restrict__ bias, float* __restrict__ y,
+                                                                        int B, int H, int W, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s9_lds[];
+    unsigned char* const Xs = s9_lds;                                       // hi image, lo image
+    float* const Red = reinterpret_cast<float*>(s9_lds + 2 * S9_IMG);
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int pair = wave % 6, rh = wave / 6;
     const int tiles_w = W / M9_TW, tiles_h = H / M9_TH;
     const int i = lane & 15, kq = lane >> 4;
-    // A fragment of (ky, pair): lane base + the pair's (pixel phase, group) offset + ky rows
-    const int lane_base = ((row * 4 + (kq >> 1)) * 18 + i) * 32 + (kq & 1) * 16;
-    int xa[3];
+    // A fragment of (row, ky): lane base + the pair's (pixel phase, group) offset + ky rows
+    const int pair_off = (((2 * pair) & 3) * 18 + (pair >> 1)) * 32;
+    int xa[2];
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
-        const int pair = 3 * kh + pl;
-        xa[pl] = lane_base + (((2 * pair) & 3) * 18 + (pair >> 1)) * 32;
-    }
-    const int wl = (kh * 6 * 64 + lane) * 16;
+    for (int r = 0; r < 2; ++r) xa[r] = (((2 * rh + r) * 4 + (kq >> 1)) * 18 + i) * 32 + (kq & 1) * 16 + pair_off;
+    const int wl = (pair * 2 * 64 + lane) * 16;
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wt), 0, 9 * 4 * 2 * 6 * 64 * 4 * 4, 0x00020000);
-    f32x4 wpre[M9_D + 1][6];                                           // [pair-in-wave * 2 + {hi, lo}] of phase p in set p % (M9_D + 1)
+    f32x4 wpre[S9_D + 1][2];                                           // {hi, lo} of phase p in set p % (S9_D + 1)
     f32x4 hpre[M9_HQ][4];
     auto filt_load = [&](int p) {
 #pragma unroll
-        for (int f = 0; f < 6; ++f)
-            wpre[p % (M9_D + 1)][f] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+        for (int f = 0; f < 2; ++f)
+            wpre[p % (S9_D + 1)][f] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                 wrs, wl, (((p % 9) * 4 + p / 9) * 12 + f) * 1024, 0));
     };
+    // halo rows h0-4 .. h0+7, pixels w0-4 .. w0+67, channels c0 .. c0+15 of tile `tile`: thread t owns halo pixels t and t+768 (< 864)
     auto halo_load = [&](int tile, int c0, int q) {
         const int tw = tile % tiles_w, th = (tile / tiles_w) % tiles_h, n = tile / (tiles_w * tiles_h);
-        const int pp = t + 512 * q;
+        const int pp = t + S9_THREADS * q;
         const int r = pp / 72, px = pp - r * 72;
         const int hh = th * M9_TH + r - 4, ww = tw * M9_TW + px - 4;
         const bool ok = tile < ntiles && pp < M9_HPX && hh >= 0 && hh < H && ww >= 0 && ww < W;
@@ -287,7 +298,7 @@ __global__ __launch_bounds__(512) void conv9_c64_to_c4_sb_kernel(const float* __
         for (int c4 = 0; c4 < 4; ++c4) hpre[q][c4] = ok ? src[c4] : (f32x4){0.f, 0.f, 0.f, 0.f};
     };
     auto halo_store = [&](int q) {
-        const int pp = t + 512 * q;
+        const int pp = t + S9_THREADS * q;
         if (pp < M9_HPX) {
             const int r = pp / 72, px = pp - r * 72;
             unsigned char* d = Xs + ((r * 4 + (px & 3)) * 18 + (px >> 2)) * 32;
@@ -300,60 +311,79 @@ __global__ __launch_bounds__(512) void conv9_c64_to_c4_sb_kernel(const float* __
             *reinterpret_cast<s9_u32x4*>(d + S9_IMG + 16) = (s9_u32x4){l[4], l[5], l[6], l[7]};
         }
     };
+    // Tile order.  A tile's halo is 12 rows for 4 rows of output: neighbouring tiles read each other's rows, and in launch order they
+    // run on different XCDs -- the fp32 kernel's order fetches 221 MB from HBM for a 50 MB input (PMC, B = 48), which binds this
+    // 5x shorter kernel.  Here an XCD (= blockIdx.x & 7) owns whole images (x, x + 8, ...) and its work-groups walk their tiles in
+    // image order, so that vertical neighbours are in flight on the same L2 together.
+    const int per_img = tiles_w * tiles_h;
+    const bool by_xcd = (gridDim.x & 7) == 0 && (B & 7) == 0;       // (whole images per XCD: other batch sizes keep the launch order)
+    const int xcd = blockIdx.x & 7, wg_m = blockIdx.x >> 3, wg_M = gridDim.x >> 3;
+    auto tile_of = [&](int s) -> int {                        // s-th tile of this work-group; ntiles: none
+        if (!by_xcd) { const long tl = (long)blockIdx.x + (long)s * gridDim.x; return tl < ntiles ? (int)tl : ntiles; }
+        const int sq = wg_m + s * wg_M, img = xcd + 8 * (sq / per_img);
+        return img < B ? img * per_img + sq % per_img : ntiles;
+    };
 #pragma unroll
-    for (int q = 0; q < M9_D; ++q) filt_load(q);
+    for (int q = 0; q < S9_D; ++q) filt_load(q);
 #pragma unroll
-    for (int q = 0; q < M9_HQ; ++q) halo_load(blockIdx.x, 0, q);
+    for (int q = 0; q < M9_HQ; ++q) halo_load(tile_of(0), 0, q);
 #pragma unroll
     for (int q = 0; q < M9_HQ; ++q) halo_store(q);
     __syncthreads();
     const float bo = bias ? bias[i & 3] : 0.f;
 #pragma unroll 1
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        f32x4 acc3[3];
+    for (int ts = 0;; ++ts) {
+        const int tile = tile_of(ts);
+        if (tile >= ntiles) break;
+        const int tile_next = tile_of(ts + 1);
+        f32x4 acc6[2][3];                                     // [row][product]: six independent chains
 #pragma unroll
-        for (int q = 0; q < 3; ++q) acc3[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < 6; ++q) acc6[q / 3][q % 3] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
 #pragma unroll
             for (int ky = 0; ky < 9; ++ky) {
                 const int p = 9 * c + ky;
-                filt_load((p + M9_D) % 36);                   // beyond phase 35: the next tile's first phases (same filter)
+                filt_load((p + S9_D) % 36);                   // beyond phase 35: the next tile's first phases (same filter)
                 if (ky < M9_HQ) {                             // the next chunk's halo: of this tile, or chunk 0 of the next one
                     if (c < 3) halo_load(tile, 16 * (c + 1), ky);
-                    else halo_load(tile + gridDim.x, 0, ky);
+                    else halo_load(tile_next, 0, ky);
                 }
-                s9_bf16x8 ah[3], al[3];
+                const s9_bf16x8 bh = __builtin_bit_cast(s9_bf16x8, wpre[p % (S9_D + 1)][0]);
+                const s9_bf16x8 bl = __builtin_bit_cast(s9_bf16x8, wpre[p % (S9_D + 1)][1]);
+                s9_bf16x8 ah[2], al[2];
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
-                    ah[pl] = *reinterpret_cast<const s9_bf16x8*>(Xs + xa[pl] + ky * S9_ROWB);
-                    al[pl] = *reinterpret_cast<const s9_bf16x8*>(Xs + xa[pl] + ky * S9_ROWB + S9_IMG);
+                for (int r = 0; r < 2; ++r) {
+                    ah[r] = *reinterpret_cast<const s9_bf16x8*>(Xs + xa[r] + ky * S9_ROWB);
+                    al[r] = *reinterpret_cast<const s9_bf16x8*>(Xs + xa[r] + ky * S9_ROWB + S9_IMG);
                 }
-                // product-major over the three accumulator chains: consecutive MFMAs never depend on each other
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    acc3[pl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[pl], __builtin_bit_cast(s9_bf16x8, wpre[p % (M9_D + 1)][2 * pl]), acc3[pl], 0, 0, 0);
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    acc3[pl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[pl], __builtin_bit_cast(s9_bf16x8, wpre[p % (M9_D + 1)][2 * pl + 1]), acc3[pl], 0, 0, 0);
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    acc3[pl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[pl], __builtin_bit_cast(s9_bf16x8, wpre[p % (M9_D + 1)][2 * pl]), acc3[pl], 0, 0, 0);
+                for (int r = 0; r < 2; ++r) {
+                    acc6[r][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[r], bh, acc6[r][0], 0, 0, 0);
+                    acc6[r][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[r], bl, acc6[r][1], 0, 0, 0);
+                    acc6[r][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[r], bh, acc6[r][2], 0, 0, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 if (ky == 8) {                                // chunk boundary: every wave must have left the halo first
-                    f32x4 acc = (acc3[0] + acc3[1]) + acc3[2];
                     __syncthreads();
 #pragma unroll
                     for (int q = 0; q < M9_HQ; ++q) halo_store(q);
-                    if (c == 3 && kh == 1) *reinterpret_cast<f32x4*>(&Red[(row * 64 + lane) * 4]) = acc;
+                    if (c == 3) {
+#pragma unroll
+                        for (int r = 0; r < 2; ++r)
+                            *reinterpret_cast<f32x4*>(&Red[((wave * 2 + r) * 64 + lane) * 4]) = (acc6[r][0] + acc6[r][1]) + acc6[r][2];
+                    }
                     __syncthreads();
-                    if (c == 3 && kh == 0) {                  // the two dx halves of a row meet
-                        acc += *reinterpret_cast<const f32x4*>(&Red[(row * 64 + lane) * 4]);
+                    if (c == 3 && pair < 2) {                 // the six dx pairs of a row meet: wave (pair 0 / 1, rh) finishes row 2 rh + pair
+                        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int pw = 0; pw < 6; ++pw)
+                            acc += *reinterpret_cast<const f32x4*>(&Red[(((rh * 6 + pw) * 2 + pair) * 64 + lane) * 4]);
                         // C layout: column n = lane & 15 = (j, o); row 4 (lane >> 4) + reg = pixel group: 16 consecutive floats of y
                         const int tw = tile % tiles_w, th = (tile / tiles_w) % tiles_h, n = tile / (tiles_w * tiles_h);
 #pragma unroll
                         for (int reg = 0; reg < 4; ++reg)
-                            y[(((long)n * H + th * M9_TH + row) * W + tw * M9_TW + 4 * (4 * kq + reg)) * 4 + i] = acc[reg] + bo;
+                            y[(((long)n * H + th * M9_TH + 2 * rh + pair) * W + tw * M9_TW + 4 * (4 * kq + reg)) * 4 + i] = acc[reg] + bo;
                     }
                 }
             }
@@ -366,8 +396,12 @@ TATT_API int tatt_conv9_c64_to_c4_sb(const float* x, const float* wt, const floa
                                      hipStream_t st) {
     if (H % M9_TH || W % M9_TW) return 1;
     const int ntiles = B * (H / M9_TH) * (W / M9_TW);
-    hipLaunchKernelGGL(conv9_c64_to_c4_sb_kernel, dim3(ntiles < 256 ? ntiles : 256), dim3(512), 0, st, x, wt, bias, y, B, H, W,
-                       ntiles);
+    static TattPerDevice attr_once;
+    tatt_per_device(attr_once, [&] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv9_c64_to_c4_sb_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, S9_LDS);
+    });
+    hipLaunchKernelGGL(conv9_c64_to_c4_sb_kernel, dim3(ntiles < 256 ? ntiles : 256), dim3(S9_THREADS), S9_LDS, st, x, wt, bias, y, B,
+                       H, W, ntiles);
     return LAUNCH_CHECK();
 }
 

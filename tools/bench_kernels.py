@@ -404,5 +404,5 @@ for sbm in (False, True):
             ops.conv2d_dgrad(dy1, w1)
         finally:
             ops.CONV9_SB = old
-    timeit("conv9_out_fwd %s" % ("sb" if sbm else "fp32"), _c9, f9)
-    timeit("conv9_block1_dgrad %s" % ("sb" if sbm else "fp32"), _c9d, f9 / 4)
+    timeit("conv9_out_fwd_%s" % ("sb" if sbm else "fp32"), _c9, f9)
+    timeit("conv9_block1_dgrad_%s" % ("sb" if sbm else "fp32"), _c9d, f9 / 4)
