@@ -170,6 +170,10 @@ int tatt_conv9_c64_to_c4_sb(const float* x, const float* wt, const float* bias, 
  * reconstruction filter (its data gradient, :623); in (B,H,W,4), out (B,H,W,64) NHWC contiguous, H % 4 == 0, W % 64 == 0 */
 int tatt_conv9_c4_to_c64(const float* in, const float* wp, const float* bias, float* out, int B, int H, int W, int act,
                          hipStream_t st);
+/* the same convolution on v_mfma_f32_16x16x32_bf16 with split operands (k = 8 taps x 4 input channels; hi hi + hi lo + lo hi, fp32
+ * accumulation: 2^-16 relative per product); same arguments and the same fp32 packed filter (the kernel splits it itself) */
+int tatt_conv9_c4_to_c64_sb(const float* in, const float* wp, const float* bias, float* out, int B, int H, int W, int act,
+                            hipStream_t st);
 /* dw (4,64,9,9) = sum_px x[px+tap][ci] * dy[px][co] on v_mfma_f32_16x16x4_f32 (rows = input channels, columns = (tap, output
  * channel) read Toeplitz-fashion from the dy tile; weight gradient of reference model/tsrn.py:623); H % 4 == 0, W % 64 == 0;
  * part >= min(B*(H/4)*(W/64), 256) * 64 * 336 floats */

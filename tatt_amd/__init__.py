@@ -24,7 +24,7 @@ def set_arithmetic(mode: str) -> None:
           GruBlock weight gradients, the backward of the TP-interpreter layers and the recurrent products and recurrent weight gradient of the query GRU run on the bf16 matrix cores with every fp32 operand split a = hi + lo and
           a b ~ hi hi + hi lo + lo hi: 2^-16 relative per product, ~16-17 mantissa bits instead of 24
           (profiles/r03_split_bf16_probe.txt: eval SR moves 1.1e-6, gradients ~1e-5 relative);
-      "fp32" -- the same operators on v_mfma_f32_* (exact fp32 products), about 0.7 ms per training step slower at B = 48.
+      "fp32" -- the same operators on v_mfma_f32_* (exact fp32 products), about 2 ms per training step slower at B = 48 (`exact_fp32` in the bench line).
 
     Call it before building a Trainer / capturing a hipGraph: captured graphs keep the kernels they were captured with."""
     from . import functional as _F, ops as _ops

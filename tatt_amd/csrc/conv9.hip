@@ -491,6 +491,128 @@ TATT_API int tatt_conv9_c4_to_c64(const float* in, const float* wp, const float*
     return LAUNCH_CHECK();
 }
 
+// ---- the same 4 -> 64 convolution on the bf16 matrix cores with split operands (round 5) ------------------------------------------
+// k = 32 per v_mfma_f32_16x16x32_bf16 = 8 taps x 4 input channels: the 81 x 4 = 324-long contraction is 11 MFMAs (92 % useful) x 3
+// products (hi hi, hi lo, lo hi; a = hi + lo, 2^-16 relative per product) instead of 81 fp32 ones at a sixteenth of the rate.
+//   k-slot (m, kq, e): tap = 8 m + 2 kq + (e >> 2), channel e & 3.  A (weights, rows = 16 output channels) is stationary: 11 x (hi, lo)
+//   fragments = 88 registers, split once per work-group from the fp32 filter [81][4][64].  B (columns = 16 pixels): a lane's 8 bf16
+//   are the 4 channels of TWO taps' pixels = two 8-byte LDS reads from a pixel-major bf16 halo image (12 rows x 72 pixels x 4 channels,
+//   a hi and a lo one: 13.8 KB); their addresses differ per lane quarter (a tap pair may wrap to the next filter row), so each lane
+//   keeps its 22 tap addresses in registers and (row, pixel group) go into the instructions' immediate offsets.
+// Same tile, wave roles and epilogue as the fp32 kernel: 4 rows x 64 pixels, wave (nt, half) = 16 output channels of 2 rows, the next
+// tile's halo prefetched to registers.
+#define G9_IMG (F9_ROWS * F9_DW * 8)              // bytes of one halo image (hi or lo): 6912
+typedef __bf16 g9_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned g9_u32x2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(512) void conv9_c4_to_c64_sb_kernel(F9P p) {
+    __shared__ __attribute__((aligned(16))) unsigned char Ds[2 * G9_IMG];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int nt = wave & 3, half = wave >> 2, li = lane & 15, lk = lane >> 4;
+    const int tiles_w = p.W / F9_TW, tiles_h = p.H / F9_TH;
+    // stationary A fragments: output channel 16 nt + li, k-slots (tap 8 m + 2 lk + (e >> 2), channel e & 3); taps >= 81 are zero
+    g9_bf16x8 wh[11], wl[11];
+    int ta[11][2];                                         // byte address of the lane's two taps' pixels for (row 2 half, group 0)
+#pragma unroll
+    for (int m = 0; m < 11; ++m) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int tap = 8 * m + 2 * lk + (e >> 2);
+            v[e] = tap < 81 ? p.wp[(tap * 4 + (e & 3)) * 64 + 16 * nt + li] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            const s9_f32x2 a = (s9_f32x2){v[e], v[e + 1]};
+            const s9_bf16x2 h = __builtin_convertvector(a, s9_bf16x2);
+            const s9_bf16x2 l = __builtin_convertvector(a - __builtin_convertvector(h, s9_f32x2), s9_bf16x2);
+            wh[m][e] = h[0]; wh[m][e + 1] = h[1];
+            wl[m][e] = l[0]; wl[m][e + 1] = l[1];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int tap = min(8 * m + 2 * lk + u, 80), ky = tap / 9, kx = tap - 9 * ky;
+            ta[m][u] = (((2 * half + ky) * F9_DW) + li + kx) * 8;
+        }
+    }
+    f32x4 bo = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bo = *reinterpret_cast<const f32x4*>(p.bias + 16 * nt + 4 * lk);
+    f32x4 dr0, dr1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto decode = [&](int tile, int& b, int& h0, int& w0) {
+        const int tw = tile % tiles_w; tile /= tiles_w;
+        h0 = (tile % tiles_h) * F9_TH; b = tile / tiles_h; w0 = tw * F9_TW;
+    };
+    auto load1 = [&](int e, int b, int h0, int w0) -> f32x4 {
+        const int d = e / F9_DW, q = e - d * F9_DW, row = h0 - 4 + d, px = w0 - 4 + q;
+        if (row < 0 || row >= p.H || px < 0 || px >= p.W) return (f32x4){0.f, 0.f, 0.f, 0.f};
+        return *reinterpret_cast<const f32x4*>(p.in + (((long)b * p.H + row) * p.W + px) * 4);
+    };
+    auto load_halo = [&](int tile) {
+        int b, h0, w0; decode(tile, b, h0, w0);
+        dr0 = load1(t, b, h0, w0);
+        if (t < F9_ROWS * F9_DW - 512) dr1 = load1(t + 512, b, h0, w0);
+    };
+    auto store1 = [&](int e, f32x4 v) {                    // split once: 4 channels -> 8 bytes of hi, 8 bytes of lo
+        unsigned h0, h1, l0, l1;
+        s9_split(v, h0, h1, l0, l1);
+        *reinterpret_cast<g9_u32x2*>(Ds + e * 8) = (g9_u32x2){h0, h1};
+        *reinterpret_cast<g9_u32x2*>(Ds + G9_IMG + e * 8) = (g9_u32x2){l0, l1};
+    };
+    if ((int)blockIdx.x < p.ntiles) load_halo(blockIdx.x);
+    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        __syncthreads();                                   // the previous tile has been consumed
+        store1(t, dr0);
+        if (t < F9_ROWS * F9_DW - 512) store1(t + 512, dr1);
+        if (tile + (int)gridDim.x < p.ntiles) load_halo(tile + gridDim.x);
+        __syncthreads();
+        int b, h0, w0; decode(tile, b, h0, w0);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            f32x4 acc[4];
+#pragma unroll
+            for (int mg = 0; mg < 4; ++mg) acc[mg] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int m = 0; m < 11; ++m) {
+                g9_bf16x8 bh[4], bl[4];
+#pragma unroll
+                for (int mg = 0; mg < 4; ++mg) {
+                    const int off = (r * F9_DW + 16 * mg) * 8;
+                    g9_u32x2 q0 = *reinterpret_cast<const g9_u32x2*>(Ds + ta[m][0] + off), q1 = *reinterpret_cast<const g9_u32x2*>(Ds + ta[m][1] + off);
+                    g9_u32x2 q2 = *reinterpret_cast<const g9_u32x2*>(Ds + ta[m][0] + off + G9_IMG), q3 = *reinterpret_cast<const g9_u32x2*>(Ds + ta[m][1] + off + G9_IMG);
+                    bh[mg] = __builtin_bit_cast(g9_bf16x8, (s9_u32x4){q0[0], q0[1], q1[0], q1[1]});
+                    bl[mg] = __builtin_bit_cast(g9_bf16x8, (s9_u32x4){q2[0], q2[1], q3[0], q3[1]});
+                }
+                // product-major over the four pixel groups: consecutive MFMAs never depend on each other
+#pragma unroll
+                for (int mg = 0; mg < 4; ++mg) acc[mg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[m], bh[mg], acc[mg], 0, 0, 0);
+#pragma unroll
+                for (int mg = 0; mg < 4; ++mg) acc[mg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[m], bl[mg], acc[mg], 0, 0, 0);
+#pragma unroll
+                for (int mg = 0; mg < 4; ++mg) acc[mg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[m], bh[mg], acc[mg], 0, 0, 0);
+            }
+            const int row = 2 * half + r;
+            float* o = p.out + (((long)b * p.H + h0 + row) * p.W + w0 + li) * 64 + 16 * nt + 4 * lk;
+#pragma unroll
+            for (int mg = 0; mg < 4; ++mg) {
+                f32x4 v = acc[mg] + bo;
+                if (p.act != ACT_NONE) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+                }
+                *reinterpret_cast<f32x4*>(o + (long)16 * mg * 64) = v;
+            }
+        }
+    }
+}
+// as tatt_conv9_c4_to_c64 (same packed fp32 filter wp [81][4][64]: the kernel splits it itself), products in split bf16
+TATT_API int tatt_conv9_c4_to_c64_sb(const float* in, const float* wp, const float* bias, float* out, int B, int H, int W, int act,
+                                     hipStream_t st) {
+    if (H % F9_TH || W % F9_TW) return 1;
+    F9P p = {in, wp, bias, out, B, H, W, B * (H / F9_TH) * (W / F9_TW), act};
+    const int G = p.ntiles < 256 ? p.ntiles : 256;
+    hipLaunchKernelGGL(conv9_c4_to_c64_sb_kernel, dim3(G), dim3(512), 0, st, p);
+    return LAUNCH_CHECK();
+}
+
 // ---- weight gradient on the matrix cores -------------------------------------------------------------------------
 // dW[ky][kx][ci][co] = sum_{b,r,p} X[b][r][p][ci] * dY[b][r-ky+4][p-kx+4][co]  (r, p = position of the INPUT pixel).
 // As a GEMM per input row: A[m = ci][k = p] = X[r][p][ci] (64 rows), B[k = p][n = tap*4 + co] = dY[r-ky+4][p-kx+4][co]: the

@@ -369,7 +369,7 @@ def conv_fwd(x_bhwc, wpacked, bias, Cout, KH, KW, *, act=ACT_NONE, out=None, bet
         return y
     if contig and KH == 9 and KW == 9 and Cout == 64 and Cin == 4 and H % 4 == 0 and W % 64 == 0 and beta == 0.0 \
             and y.is_contiguous():
-        call("tatt_conv9_c4_to_c64", P(x_bhwc), P(wpacked), P(bias), P(y), B, H, W, act, stream())
+        call("tatt_conv9_c4_to_c64_sb" if CONV9_SB else "tatt_conv9_c4_to_c64", P(x_bhwc), P(wpacked), P(bias), P(y), B, H, W, act, stream())
         return y
     M = B * H * W
     splitk, ws = conv_split(x_bhwc, Cout, KH, KW), None
@@ -434,8 +434,9 @@ def _conv3_sb(x_bhwc, w_oihw, mode, bias, act=ACT_NONE, in_scale=None, in_shift=
     return y
 
 
-# The 9x9 convolutions 64 -> 4 (output convolution forward, block1's data gradient) on the bf16 matrix cores with split operands
-# (tatt_conv9_c64_to_c4_sb).  Test / A-B hook: False -> the exact-fp32 Toeplitz kernel.
+# The 9x9 convolutions 64 -> 4 (output convolution forward, block1's data gradient: tatt_conv9_c64_to_c4_sb) and 4 -> 64 (block1
+# forward, the output convolution's data gradient: tatt_conv9_c4_to_c64_sb) on the bf16 matrix cores with split operands.
+# Test / A-B hook: False -> the exact-fp32 MFMA kernels.
 CONV9_SB = True
 
 

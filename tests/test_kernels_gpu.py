@@ -790,12 +790,15 @@ def test_conv9_mfma_toeplitz(dev, B, H, W, sb, monkeypatch):
     check_close("conv9_mfma_fwd_after_update", ops.conv2d_forward(xd, wd, bd), (2 * (ref - b.double()) + b.double()).float(), 4e-4, 4e-4)
 
 
+@pytest.mark.parametrize("sb", [True, False])
 @pytest.mark.parametrize("B,H,W", [(2, 16, 64), (3, 4, 64), (1, 8, 192), (67, 8, 64), (2, 32, 128)])
-def test_conv9_c4_to_c64_weight_stationary(dev, B, H, W):
-    """tatt_conv9_c4_to_c64 (k = the 4 input channels, 81 filter registers per lane): block1's 4->64 convolution with bias
+def test_conv9_c4_to_c64_weight_stationary(dev, B, H, W, sb, monkeypatch):
+    """tatt_conv9_c4_to_c64_sb (k = 8 taps x 4 input channels on the bf16 matrix cores, split operands; the default) and
+    tatt_conv9_c4_to_c64 (k = the 4 input channels, 81 filter registers per lane, exact fp32): block1's 4->64 convolution with bias
     (reference model/tsrn.py:597) and the data gradient of the 64->4 reconstruction convolution (:623) against F.conv2d in fp64.
     (67, 8, 64): more tiles than persistent groups' first round can take evenly."""
     from tatt_amd import ops
+    monkeypatch.setattr(ops, "CONV9_SB", sb)
     g = torch.Generator().manual_seed(53)
     x = torch.randn(B, H, W, 4, generator=g)
     w = torch.randn(64, 4, 9, 9, generator=g) * 0.05
@@ -803,6 +806,8 @@ def test_conv9_c4_to_c64_weight_stationary(dev, B, H, W):
     ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), padding=4).permute(0, 2, 3, 1)
     y = ops.conv2d_forward(x.to(dev), w.to(dev), b.to(dev))
     check_close("conv9_4_64_fwd", y, ref.float(), 1e-4, 1e-4)
+    err = float((y.cpu().double() - ref).abs().max() / ref.abs().max())
+    assert err < (2e-5 if sb else 3e-6), err
     y = ops.conv2d_forward(x.to(dev), w.to(dev), b.to(dev), act=ops.ACT_RELU)
     check_close("conv9_4_64_fwd_relu", y, ref.clamp_min(0).float(), 1e-4, 1e-4)
     w2 = torch.randn(4, 64, 9, 9, generator=g) * 0.02
@@ -811,6 +816,9 @@ def test_conv9_c4_to_c64_weight_stationary(dev, B, H, W):
     torch.nn.functional.conv2d(xin, w2.double(), None, padding=4).backward(dy.permute(0, 3, 1, 2).double())
     dx = ops.conv2d_dgrad(dy.to(dev), w2.to(dev))
     check_close("conv9_64_4_dgrad", dx, xin.grad.permute(0, 2, 3, 1).float(), 1e-4, 1e-4)
+    gref = xin.grad.permute(0, 2, 3, 1)
+    err = float((dx.cpu().double() - gref).abs().max() / gref.abs().max())
+    assert err < (2e-5 if sb else 3e-6), err
 
 
 @pytest.mark.parametrize("B,H,W", [(2, 32, 128), (3, 4, 64), (1, 8, 192), (67, 8, 64), (2, 64, 256)])

@@ -406,3 +406,26 @@ for sbm in (False, True):
             ops.CONV9_SB = old
     timeit("conv9_out_fwd_%s" % ("sb" if sbm else "fp32"), _c9, f9)
     timeit("conv9_block1_dgrad_%s" % ("sb" if sbm else "fp32"), _c9d, f9 / 4)
+
+# ---- 9x9 convolutions 4 -> 64: block1 forward (LR) and the output convolution's data gradient (HR): fp32 weight-stationary MFMA vs split bf16 ----
+bx = R(B, 16, 64, 4)
+bw = R(64, 4, 9, 9) * 0.05
+bb = R(64)
+ody = R(B, 32, 128, 4)
+for sbm in (False, True):
+    def _b1(sbm=sbm):
+        old = ops.CONV9_SB
+        ops.CONV9_SB = sbm
+        try:
+            ops.conv2d_forward(bx, bw, bb)
+        finally:
+            ops.CONV9_SB = old
+    def _od(sbm=sbm):
+        old = ops.CONV9_SB
+        ops.CONV9_SB = sbm
+        try:
+            ops.conv2d_dgrad(ody, ow)
+        finally:
+            ops.CONV9_SB = old
+    timeit("conv9_block1_fwd_%s" % ("sb" if sbm else "fp32"), _b1, f9 / 4)
+    timeit("conv9_out_dgrad_%s" % ("sb" if sbm else "fp32"), _od, f9)
