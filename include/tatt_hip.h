@@ -183,6 +183,13 @@ int tatt_conv9_c64_c4_wgrad(const float* x, const float* dy, float* dw, float* p
  * 4->64 convolution, reference model/tsrn.py:597); same constraints and workspace */
 int tatt_conv9_c4_c64_wgrad(const float* x, const float* dy, float* dw, float* part, int B, int H, int W,
                             hipStream_t st);
+/* the two 9x9 weight gradients above on v_mfma_f32_16x16x32_bf16 with split operands (the contraction runs over pixels: both operands
+ * are gathered 8 pixels per lane from the fp32 images and split hi + lo in registers; hi hi + hi lo + lo hi, fp32 accumulation);
+ * same arguments, constraints and workspace */
+int tatt_conv9_c64_c4_wgrad_sb(const float* x, const float* dy, float* dw, float* part, int B, int H, int W,
+                               hipStream_t st);
+int tatt_conv9_c4_c64_wgrad_sb(const float* x, const float* dy, float* dw, float* part, int B, int H, int W,
+                               hipStream_t st);
 
 /* ---- reductions / normalisation ------------------------------------------------------------------- */
 

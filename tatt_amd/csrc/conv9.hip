@@ -712,6 +712,114 @@ __global__ __launch_bounds__(768) void conv9_c64_c4_wgrad_mfma_kernel(W9P p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) P[(long)(16 * mt + 4 * lk + e) * W9_N + 16 * (7 * ng + j) + li] = acc[j][e];
 }
+// ---- the same weight gradient on the bf16 matrix cores with split operands (round 5) --------------------------------------------
+// The contraction runs over PIXELS, so an operand of v_mfma_f32_16x16x32_bf16 needs 8 consecutive pixels of one channel per lane: both
+// operands are gathered from the token-major fp32 images with 8 ds_read_b32 down a column and split in registers (a = hi + lo,
+// hi hi + hi lo + lo hi, fp32 accumulation: 2^-16 relative per product) -- 1 A + 7 B fragments per 32 pixels for 21 MFMAs, where the
+// fp32 form issues 56 MFMAs of twice the cycles each.  Same tile walk, staging and partial layout as the kernel above; the X image's
+// pitch is 82 dwords (the two pixel octets of a 32-lane read group fall in different bank halves; rows are 8-byte aligned: two
+// 8-byte stores per vector).
+#define W9S_XP 82
+__device__ __forceinline__ void w9s_frag(const float* __restrict__ col, int stride, g9_bf16x8& hi, g9_bf16x8& lo) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = col[e * stride];
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+        const s9_f32x2 a = (s9_f32x2){v[e], v[e + 1]};
+        const s9_bf16x2 h = __builtin_convertvector(a, s9_bf16x2);
+        const s9_bf16x2 l = __builtin_convertvector(a - __builtin_convertvector(h, s9_f32x2), s9_bf16x2);
+        hi[e] = h[0]; hi[e + 1] = h[1];
+        lo[e] = l[0]; lo[e + 1] = l[1];
+    }
+}
+__global__ __launch_bounds__(768) void conv9_c64_c4_wgrad_sb_kernel(W9P p) {
+    __shared__ __attribute__((aligned(16))) float Xs[2][W9_P * W9S_XP];
+    __shared__ __attribute__((aligned(16))) float Ds[(W9_DROWS + 1) * W9_DW * 4];     // + one row of zeros for the 12 unused columns
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int mt = wave & 3, ng = wave >> 2, li = lane & 15, lk = lane >> 4;
+    const int tiles_w = p.W / W9_P, tiles_h = p.H / W9_R;
+    int bbase[7], bstep[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        const int n = 16 * (7 * ng + j) + li, tap = n >> 2, co = n & 3;
+        if (tap < 81) {
+            const int ky = tap / 9, kx = tap - 9 * ky;
+            bbase[j] = p.flip ? (ky * W9_DW + 8 * lk + kx) * 4 + co : ((8 - ky) * W9_DW + 8 * lk + 8 - kx) * 4 + co;
+            bstep[j] = W9_DW * 4;
+        } else { bbase[j] = W9_DROWS * W9_DW * 4; bstep[j] = 0; }
+    }
+    for (int e = t; e < W9_DW * 4; e += 768) Ds[W9_DROWS * W9_DW * 4 + e] = 0.f;
+    f32x4 acc[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int my_tiles = p.ntiles > (int)blockIdx.x ? (p.ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int nsteps = my_tiles * W9_R;
+    f32x4 xr0, xr1 = (f32x4){0.f, 0.f, 0.f, 0.f}, dr0, dr1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto tile_of = [&](int s, int& b, int& r0, int& p0) {
+        int tile = blockIdx.x + (s / W9_R) * gridDim.x;
+        const int tw = tile % tiles_w; tile /= tiles_w;
+        r0 = (tile % tiles_h) * W9_R; b = tile / tiles_h; p0 = tw * W9_P;
+    };
+    auto load_x = [&](int s) {
+        int b, r0, p0; tile_of(s, b, r0, p0);
+        const float* src = p.x + (((long)b * p.H + r0 + s % W9_R) * p.W + p0) * 64;
+        xr0 = *reinterpret_cast<const f32x4*>(src + 4 * t);
+        if (t < 256) xr1 = *reinterpret_cast<const f32x4*>(src + 4 * (t + 768));
+    };
+    auto store_x = [&](int buf) {
+        float* d0 = &Xs[buf][(t >> 4) * W9S_XP + 4 * (t & 15)];
+        *reinterpret_cast<float2*>(d0) = make_float2(xr0[0], xr0[1]);
+        *reinterpret_cast<float2*>(d0 + 2) = make_float2(xr0[2], xr0[3]);
+        if (t < 256) {
+            float* d1 = &Xs[buf][((t + 768) >> 4) * W9S_XP + 4 * (t & 15)];
+            *reinterpret_cast<float2*>(d1) = make_float2(xr1[0], xr1[1]);
+            *reinterpret_cast<float2*>(d1 + 2) = make_float2(xr1[2], xr1[3]);
+        }
+    };
+    auto load_d1 = [&](int e, int b, int r0, int p0) -> f32x4 {
+        const int d = e / W9_DW, q = e - d * W9_DW, row = r0 - 4 + d, px = p0 - 4 + q;
+        if (row < 0 || row >= p.H || px < 0 || px >= p.W) return (f32x4){0.f, 0.f, 0.f, 0.f};
+        return *reinterpret_cast<const f32x4*>(p.dy + (((long)b * p.H + row) * p.W + px) * 4);
+    };
+    auto load_d = [&](int s) {
+        int b, r0, p0; tile_of(s, b, r0, p0);
+        dr0 = load_d1(t, b, r0, p0);
+        if (t < W9_DROWS * W9_DW - 768) dr1 = load_d1(t + 768, b, r0, p0);
+    };
+    auto store_d = [&]() {
+        *reinterpret_cast<f32x4*>(&Ds[4 * t]) = dr0;
+        if (t < W9_DROWS * W9_DW - 768) *reinterpret_cast<f32x4*>(&Ds[4 * (t + 768)]) = dr1;
+    };
+    if (nsteps > 0) { load_x(0); load_d(0); }
+    for (int s = 0; s < nsteps; ++s) {
+        const int rr = s % W9_R, buf = s & 1;
+        if (rr == 0) __syncthreads();            // the previous tile's last row has been consumed: Ds may change
+        store_x(buf);
+        if (rr == 0) store_d();
+        if (s + 1 < nsteps) { load_x(s + 1); if (rr == W9_R - 1) load_d(s + 1); }
+        __syncthreads();
+        const float* xa = &Xs[buf][8 * lk * W9S_XP + 16 * mt + li];
+#pragma unroll
+        for (int ks = 0; ks < W9_P / 32; ++ks) {
+            g9_bf16x8 ah, al, bh[7], bl[7];
+            w9s_frag(xa + ks * 32 * W9S_XP, W9S_XP, ah, al);
+#pragma unroll
+            for (int j = 0; j < 7; ++j) w9s_frag(&Ds[bbase[j] + rr * bstep[j] + ks * 32 * 4], 4, bh[j], bl[j]);
+#pragma unroll
+            for (int j = 0; j < 7; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 7; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 7; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[j], 0, 0, 0);
+        }
+    }
+    float* P = p.part + (long)blockIdx.x * 64 * W9_N;
+#pragma unroll
+    for (int j = 0; j < 7; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) P[(long)(16 * mt + 4 * lk + e) * W9_N + 16 * (7 * ng + j) + li] = acc[j][e];
+}
 // dw[co][ci][tap] (OIHW, Cout = 4, Cin = 64) = sum_g part[g][ci][tap*4 + co]; block = 64 outputs x 16 lanes over g
 // (swap: dw[ci][co][tap], the OIHW gradient of the 4->64 convolution whose 64 OUTPUT channels are the matrix rows)
 __global__ __launch_bounds__(1024) void conv9_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int G,
@@ -740,11 +848,12 @@ __global__ __launch_bounds__(1024) void conv9_wgrad_reduce_kernel(const float* _
 // x (B,H,W,64), dy (B,H,W,4) -> dw (4,64,9,9); H % 4 == 0, W % 64 == 0; part >= min(#tiles, 256) * 64 * 336 floats,
 // #tiles = B * (H/4) * (W/64)
 static int conv9_wgrad_launch(const float* x64, const float* t4, float* dw, float* part, int B, int H, int W, int flip,
-                              hipStream_t st) {
+                              hipStream_t st, bool sb = false) {
     if (H % W9_R || W % W9_P) return 1;
     W9P p = {x64, t4, part, B, H, W, B * (H / W9_R) * (W / W9_P), flip};
     const int G = p.ntiles < 256 ? p.ntiles : 256;
-    hipLaunchKernelGGL(conv9_c64_c4_wgrad_mfma_kernel, dim3(G), dim3(768), 0, st, p);
+    if (sb) hipLaunchKernelGGL(conv9_c64_c4_wgrad_sb_kernel, dim3(G), dim3(768), 0, st, p);
+    else hipLaunchKernelGGL(conv9_c64_c4_wgrad_mfma_kernel, dim3(G), dim3(768), 0, st, p);
     hipLaunchKernelGGL(conv9_wgrad_reduce_kernel, dim3(64 * 324 / 64), dim3(1024), 0, st, part, dw, G, flip);
     return LAUNCH_CHECK();
 }
@@ -757,4 +866,13 @@ TATT_API int tatt_conv9_c64_c4_wgrad(const float* x, const float* dy, float* dw,
 TATT_API int tatt_conv9_c4_c64_wgrad(const float* x, const float* dy, float* dw, float* part, int B, int H, int W,
                                      hipStream_t st) {
     return conv9_wgrad_launch(dy, x, dw, part, B, H, W, 1, st);
+}
+// the two weight gradients with split-bf16 products on the bf16 matrix cores (same arguments, same workspace)
+TATT_API int tatt_conv9_c64_c4_wgrad_sb(const float* x, const float* dy, float* dw, float* part, int B, int H, int W,
+                                        hipStream_t st) {
+    return conv9_wgrad_launch(x, dy, dw, part, B, H, W, 0, st, true);
+}
+TATT_API int tatt_conv9_c4_c64_wgrad_sb(const float* x, const float* dy, float* dw, float* part, int B, int H, int W,
+                                        hipStream_t st) {
+    return conv9_wgrad_launch(dy, x, dw, part, B, H, W, 1, st, true);
 }

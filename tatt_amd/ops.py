@@ -435,7 +435,8 @@ def _conv3_sb(x_bhwc, w_oihw, mode, bias, act=ACT_NONE, in_scale=None, in_shift=
 
 
 # The 9x9 convolutions 64 -> 4 (output convolution forward, block1's data gradient: tatt_conv9_c64_to_c4_sb) and 4 -> 64 (block1
-# forward, the output convolution's data gradient: tatt_conv9_c4_to_c64_sb) on the bf16 matrix cores with split operands.
+# forward, the output convolution's data gradient: tatt_conv9_c4_to_c64_sb) and their weight gradients (tatt_conv9_*_wgrad_sb) on the
+# bf16 matrix cores with split operands.
 # Test / A-B hook: False -> the exact-fp32 MFMA kernels.
 CONV9_SB = True
 
@@ -565,12 +566,12 @@ def _conv_wgrad_general(x_bhwc, dy_bhwc, dw, Cout, KH, KW, contig):
     if contig and KH == 9 and KW == 9 and Cout == 4 and Cin == 64 and H % 4 == 0 and W % 64 == 0:
         G = min(B * (H // 4) * (W // 64), 256)
         part = new(x_bhwc, G * 64 * 336)
-        call("tatt_conv9_c64_c4_wgrad", P(x_bhwc), P(dy_bhwc), P(dw), P(part), B, H, W, stream())
+        call("tatt_conv9_c64_c4_wgrad_sb" if CONV9_SB else "tatt_conv9_c64_c4_wgrad", P(x_bhwc), P(dy_bhwc), P(dw), P(part), B, H, W, stream())
         return dw
     if contig and KH == 9 and KW == 9 and Cout == 64 and Cin == 4 and H % 4 == 0 and W % 64 == 0:
         G = min(B * (H // 4) * (W // 64), 256)
         part = new(x_bhwc, G * 64 * 336)
-        call("tatt_conv9_c4_c64_wgrad", P(x_bhwc), P(dy_bhwc), P(dw), P(part), B, H, W, stream())
+        call("tatt_conv9_c4_c64_wgrad_sb" if CONV9_SB else "tatt_conv9_c4_c64_wgrad", P(x_bhwc), P(dy_bhwc), P(dw), P(part), B, H, W, stream())
         return dw
     Mo, Kred = KH * KW * Cin, B * H * W
     splitk = max(2, _auto_split(Mo, Cout, Kred, cap=CONV_WGRAD_SPLIT_CAP))

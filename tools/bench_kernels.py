@@ -429,3 +429,26 @@ for sbm in (False, True):
             ops.CONV9_SB = old
     timeit("conv9_block1_fwd_%s" % ("sb" if sbm else "fp32"), _b1, f9 / 4)
     timeit("conv9_out_dgrad_%s" % ("sb" if sbm else "fp32"), _od, f9)
+
+# ---- 9x9 weight gradients: output convolution (HR, 64 x 4) and block1 (LR, 4 x 64) ----
+gx = R(B, 32, 128, 64)
+gdy = R(B, 32, 128, 4)
+gx1 = R(B, 16, 64, 4)
+gdy1 = R(B, 16, 64, 64)
+for sbm in (False, True):
+    def _wo(sbm=sbm):
+        old = ops.CONV9_SB
+        ops.CONV9_SB = sbm
+        try:
+            ops.conv_wgrad(gx, gdy, 4, 9, 9)
+        finally:
+            ops.CONV9_SB = old
+    def _wb(sbm=sbm):
+        old = ops.CONV9_SB
+        ops.CONV9_SB = sbm
+        try:
+            ops.conv_wgrad(gx1, gdy1, 64, 9, 9)
+        finally:
+            ops.CONV9_SB = old
+    timeit("conv9_out_wgrad_%s" % ("sb" if sbm else "fp32"), _wo, f9)
+    timeit("conv9_block1_wgrad_%s" % ("sb" if sbm else "fp32"), _wb, f9 / 4)
