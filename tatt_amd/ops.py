@@ -369,7 +369,7 @@ def conv_fwd(x_bhwc, wpacked, bias, Cout, KH, KW, *, act=ACT_NONE, out=None, bet
         return y
     if contig and KH == 9 and KW == 9 and Cout == 64 and Cin == 4 and H % 4 == 0 and W % 64 == 0 and beta == 0.0 \
             and y.is_contiguous():
-        call("tatt_conv9_c4_to_c64_sb" if CONV9_SB else "tatt_conv9_c4_to_c64", P(x_bhwc), P(wpacked), P(bias), P(y), B, H, W, act, stream())
+        call("tatt_conv9_c4_to_c64_sb" if CONV9_SB and CONV9_SB_C4 else "tatt_conv9_c4_to_c64", P(x_bhwc), P(wpacked), P(bias), P(y), B, H, W, act, stream())
         return y
     M = B * H * W
     splitk, ws = conv_split(x_bhwc, Cout, KH, KW), None
@@ -439,6 +439,8 @@ def _conv3_sb(x_bhwc, w_oihw, mode, bias, act=ACT_NONE, in_scale=None, in_shift=
 # bf16 matrix cores with split operands.
 # Test / A-B hook: False -> the exact-fp32 MFMA kernels.
 CONV9_SB = True
+CONV9_SB_C4 = True             # (finer hooks under CONV9_SB: the 4 -> 64 direction; the two weight gradients)
+CONV9_SB_WGRAD = True
 
 
 def _conv9_mfma_ok(x_bhwc):
@@ -566,12 +568,12 @@ def _conv_wgrad_general(x_bhwc, dy_bhwc, dw, Cout, KH, KW, contig):
     if contig and KH == 9 and KW == 9 and Cout == 4 and Cin == 64 and H % 4 == 0 and W % 64 == 0:
         G = min(B * (H // 4) * (W // 64), 256)
         part = new(x_bhwc, G * 64 * 336)
-        call("tatt_conv9_c64_c4_wgrad_sb" if CONV9_SB else "tatt_conv9_c64_c4_wgrad", P(x_bhwc), P(dy_bhwc), P(dw), P(part), B, H, W, stream())
+        call("tatt_conv9_c64_c4_wgrad_sb" if CONV9_SB and CONV9_SB_WGRAD else "tatt_conv9_c64_c4_wgrad", P(x_bhwc), P(dy_bhwc), P(dw), P(part), B, H, W, stream())
         return dw
     if contig and KH == 9 and KW == 9 and Cout == 64 and Cin == 4 and H % 4 == 0 and W % 64 == 0:
         G = min(B * (H // 4) * (W // 64), 256)
         part = new(x_bhwc, G * 64 * 336)
-        call("tatt_conv9_c4_c64_wgrad_sb" if CONV9_SB else "tatt_conv9_c4_c64_wgrad", P(x_bhwc), P(dy_bhwc), P(dw), P(part), B, H, W, stream())
+        call("tatt_conv9_c4_c64_wgrad_sb" if CONV9_SB and CONV9_SB_WGRAD else "tatt_conv9_c4_c64_wgrad", P(x_bhwc), P(dy_bhwc), P(dw), P(part), B, H, W, stream())
         return dw
     Mo, Kred = KH * KW * Cin, B * H * W
     splitk = max(2, _auto_split(Mo, Cout, Kred, cap=CONV_WGRAD_SPLIT_CAP))

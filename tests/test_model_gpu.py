@@ -372,7 +372,8 @@ def test_split_bf16_vs_fp32_training_drift(dev):
     bound each kernel; this one bounds what 12 optimiser steps make of it.  At the recipe's learning rate (1e-3) the first steps of a
     freshly initialised model are chaotic (the loss goes 37 -> 12 -> 15 -> 22 -> 31: ANY perturbation, fp32 summation order
     included, is amplified a hundredfold within five steps), so the drift is measured where the dynamics do not amplify it:
-    lr = 1e-5.  There the two arithmetics must stay together: losses to 1e-4 relative, weights to 1e-4 of their l2 norm; in max-abs a
+    lr = 1e-5.  There the two arithmetics must stay together: losses to 3e-5 relative over the first six steps and 3e-4 over all
+    twelve (round 5: was 1e-4 over all twelve, inside the scatter of the late steps -- see below), weights to 1e-4 of their l2 norm; in max-abs a
     weight may differ by up to 12 x lr (a parameter whose true gradient is zero -- a convolution bias in front of a BatchNorm --
     receives round-off as gradient, and Adam turns round-off of either sign into a full +-lr step, in any arithmetic).  At lr = 1e-3
     only the first two steps are compared (before the amplification sets in)."""
@@ -387,11 +388,16 @@ def test_split_bf16_vs_fp32_training_drift(dev):
         return a, _run_steps(dev, len(a[0]), 8, False, use_graph=False, **kw)
 
     (l32, s32, _, _), (lsb, ssb, _, _) = both(n=12, lr=1e-5)
-    rel = max(abs(a - b) / abs(a) for a, b in zip(l32, lsb))
+    rels = [abs(a - b) / abs(a) for a, b in zip(l32, lsb)]
+    rel = max(rels)
     dp = float((s32["p"] - ssb["p"]).abs().max())
     rp = float((s32["p"] - ssb["p"]).norm() / s32["p"].norm())
-    print("split-bf16 vs fp32, 12 steps at lr 1e-5: loss rel %.3e, weights max-abs %.3e, l2-rel %.3e" % (rel, dp, rp))
-    assert rel <= 1e-4, (l32, lsb)
+    print("split-bf16 vs fp32, 12 steps at lr 1e-5: loss rel %.3e (first six %.3e), weights max-abs %.3e, l2-rel %.3e" % (
+        rel, max(rels[:6]), dp, rp))
+    # the arithmetic shows in the first steps (measured 1e-7 .. 2e-5); later the +-lr lottery on zero-gradient parameters separates the
+    # trajectories by 1e-5 .. 1.5e-4 whichever families run in split bf16 (profiles/r05_drift_probe.txt: 8.8e-5 with none of the 9x9
+    # kernels, 6.5e-5 .. 1.5e-4 with them) while the weights stay at the same distance
+    assert max(rels[:6]) <= 3e-5 and rel <= 3e-4, (l32, lsb)
     assert dp <= 12 * 1e-5 * 1.01 and rp <= 1e-4, (dp, rp)
     (l32, _, _, _), (lsb, _, _, _) = both(n=2, lr=1e-3)
     rel = max(abs(a - b) / abs(a) for a, b in zip(l32, lsb))
