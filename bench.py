@@ -580,7 +580,7 @@ def main():
             "ms_per_step": round(ms, 4), "sustained_ms_per_step": None if sustained is None else round(sustained, 4),
             "sustained_steps": a.sustain if sustained is not None else 0, "exact_fp32": exact,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "fp32" + (" (split-bf16 MFMA operands in conv3 / conv3-wgrad / conv9 64->4 / tokgemm / gru-wgrad%s)"
+            "dtype": "fp32" + (" (split-bf16 MFMA operands in conv3 / conv3-wgrad / conv9 / tokgemm / gru-wgrad%s)"
                                % (" / query-GRU recurrence and dW_hh / TP-layer backward" if _Fh.QGRU_CHAIN_SB and a.arch in ("tatt", "tatt_tpg") and a.tile == "std" else "")
                                if _ops.CONV3_SB else ""),
             "data": "synthetic",
@@ -593,7 +593,7 @@ def main():
                        "launch": ("hipGraph replay" if graph_ok else "eager") + ("" if a.no_defer else ", staged backward" + ("" if a.no_side_stream else " on 2 streams")), "final_loss": round(loss_v, 5),
                        "host_issue_ms_per_step": round(t_issue / a.steps * 1e3, 3), "known_answer": kat,
                        "arithmetic": "fp32 storage, accumulation and results throughout (the reference's arithmetic)"
-                                     + ("; the 3x3 convolutions, the 9x9 convolutions from 64 to 4 channels, the GruBlock input projections, the GruBlock "
+                                     + ("; the 3x3 convolutions, the 9x9 convolutions at the image end, the GruBlock input projections, the GruBlock "
                                         "weight gradients, the backward of the TP-interpreter layers and the recurrent products and recurrent "
                                         "weight gradient of the query GRU evaluate "
                                         "every fp32 product as three bf16 matrix-core products of hi/lo operand halves (2^-16 relative, "

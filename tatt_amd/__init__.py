@@ -20,7 +20,7 @@ def set_arithmetic(mode: str) -> None:
     """Process-wide choice of the arithmetic inside the GEMM-shaped kernels of the path (storage, accumulation and results are fp32
     either way; INTEGRATION.md "Arithmetic"):
 
-      "split_bf16" (default) -- the 64-channel 3x3 convolutions (forward, data and weight gradients), the 9x9 convolutions from 64 to 4 channels, the GruBlock projections, the
+      "split_bf16" (default) -- the 64-channel 3x3 convolutions (forward, data and weight gradients), the 9x9 convolutions at the image end (forward, data and weight gradients), the GruBlock projections, the
           GruBlock weight gradients, the backward of the TP-interpreter layers and the recurrent products and recurrent weight gradient of the query GRU run on the bf16 matrix cores with every fp32 operand split a = hi + lo and
           a b ~ hi hi + hi lo + lo hi: 2^-16 relative per product, ~16-17 mantissa bits instead of 24
           (profiles/r03_split_bf16_probe.txt: eval SR moves 1.1e-6, gradients ~1e-5 relative);
