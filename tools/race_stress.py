@@ -34,6 +34,16 @@ repeat("conv9 64->4 mfma, HR", lambda: ops.conv2d_forward(x, w, b), 300)
 xl = torch.randn(B, 16, 64, 64, generator=g).to(dev)
 w1 = (torch.randn(64, 4, 9, 9, generator=g) * 0.02).to(dev)
 repeat("conv9 dgrad mfma, LR", lambda: ops.conv2d_dgrad(xl, w1), 300)
+x4 = torch.randn(B, 16, 64, 4, generator=g).to(dev)
+b64 = torch.randn(64, generator=g).to(dev)
+repeat("conv9 4->64 (block1 forward), LR", lambda: ops.conv2d_forward(x4, w1, b64), 300)
+dy4 = torch.randn(B, 32, 128, 4, generator=g).to(dev)
+repeat("conv9 4->64 (output conv data gradient), HR", lambda: ops.conv2d_dgrad(dy4, w), 200)
+repeat("conv9 weight gradient 64 x 4, HR", lambda: ops.conv_wgrad(x, dy4, 4, 9, 9), 100)
+repeat("conv9 weight gradient 4 x 64, LR", lambda: ops.conv_wgrad(x4, xl, 64, 9, 9), 100)
+qa = [torch.randn(B * 64, 1536, generator=g).to(dev) for _ in range(2)]
+qb = [torch.randn(B * 64, 512, generator=g).to(dev) for _ in range(2)]
+repeat("query GRU dW_hh, both directions", lambda: torch.cat([t.reshape(-1) for t in ops.qgru_wgrad_sb(qa[0], qa[1], qb[0], qb[1])]), 100)
 w3 = (torch.randn(64, 64, 3, 3, generator=g) * 0.05).to(dev)
 b3 = torch.randn(64, generator=g).to(dev)
 repeat("conv3 ws16 64->64", lambda: ops.conv2d_forward(xl, w3, b3), 300)
