@@ -713,13 +713,20 @@ __global__ __launch_bounds__(768) void conv9_c64_c4_wgrad_mfma_kernel(W9P p) {
         for (int e = 0; e < 4; ++e) P[(long)(16 * mt + 4 * lk + e) * W9_N + 16 * (7 * ng + j) + li] = acc[j][e];
 }
 // ---- the same weight gradient on the bf16 matrix cores with split operands (round 5) --------------------------------------------
-// The contraction runs over PIXELS, so an operand of v_mfma_f32_16x16x32_bf16 needs 8 consecutive pixels of one channel per lane: both
+// The contraction runs over PIXELS, so an operand of v_mfma_f32_16x16x32_bf16 needs 8 consecutive pixels of one channel per lane: the
 // operands are gathered from the token-major fp32 images with 8 ds_read_b32 down a column and split in registers (a = hi + lo,
-// hi hi + hi lo + lo hi, fp32 accumulation: 2^-16 relative per product) -- 1 A + 7 B fragments per 32 pixels for 21 MFMAs, where the
-// fp32 form issues 56 MFMAs of twice the cycles each.  Same tile walk, staging and partial layout as the kernel above; the X image's
-// pitch is 82 dwords (the two pixel octets of a 32-lane read group fall in different bank halves; rows are 8-byte aligned: two
-// 8-byte stores per vector).
+// hi hi + hi lo + lo hi, fp32 accumulation: 2^-16 relative per product).  Per input row there are 8 A fragments (4 channel tiles x 2
+// halves of the 64 pixels) and 42 B fragments (21 column tiles x 2); every A fragment is needed by three waves and every B fragment
+// by four.  The first version gathered each in every wave that needs it (192 gathers per row, LDS-bound: 52 us at HR against 83 for
+// the fp32 form); here the 12 waves share the 50 gathers of a row, leave the hi / lo fragments in LDS in MFMA order (as
+// gru_wgrad_sb_kernel does) and every wave then reads its 1 + 7 fragments per half with ds_read_b128: two barriers per row.
+// Same tile walk, staging and partial layout as the fp32 kernel; the X image's pitch is 82 dwords (the two pixel octets of a 32-lane
+// read group fall in different bank halves; rows are 8-byte aligned: two 8-byte stores per vector).
 #define W9S_XP 82
+#define W9S_NFRAG 50
+#define W9S_XS (2 * W9_P * W9S_XP)                          // floats
+#define W9S_DS ((W9_DROWS + 1) * W9_DW * 4)                  // floats (+ one row of zeros for the 12 unused columns)
+#define W9S_LDS ((W9S_XS + W9S_DS) * 4 + W9S_NFRAG * 2 * 64 * 16)      // 41,984 + 14,976 + 102,400 = 159,360 bytes
 __device__ __forceinline__ void w9s_frag(const float* __restrict__ col, int stride, g9_bf16x8& hi, g9_bf16x8& lo) {
     float v[8];
 #pragma unroll
@@ -734,20 +741,33 @@ __device__ __forceinline__ void w9s_frag(const float* __restrict__ col, int stri
     }
 }
 __global__ __launch_bounds__(768) void conv9_c64_c4_wgrad_sb_kernel(W9P p) {
-    __shared__ __attribute__((aligned(16))) float Xs[2][W9_P * W9S_XP];
-    __shared__ __attribute__((aligned(16))) float Ds[(W9_DROWS + 1) * W9_DW * 4];     // + one row of zeros for the 12 unused columns
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    extern __shared__ __attribute__((aligned(16))) float w9s_lds[];
+    float* const Xs = w9s_lds;                                             // [2][64 pixels][82]
+    float* const Ds = w9s_lds + W9S_XS;
+    f32x4* const Fr = reinterpret_cast<f32x4*>(w9s_lds + W9S_XS + W9S_DS); // [fragment][hi, lo][lane]
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int mt = wave & 3, ng = wave >> 2, li = lane & 15, lk = lane >> 4;
     const int tiles_w = p.W / W9_P, tiles_h = p.H / W9_R;
-    int bbase[7], bstep[7];
+    // this wave's share of a row's 50 gathers: fragments wave, wave + 12, ... ; < 8: A (channel tile f >> 1, half f & 1), else B
+    // (column tile (f - 8) >> 1, half (f - 8) & 1).  gb: the lane's gather base (dwords), gs: stride between the 8 pixels, gr: per-row step
+    int gb[5], gs[5], gr[5];
 #pragma unroll
-    for (int j = 0; j < 7; ++j) {
-        const int n = 16 * (7 * ng + j) + li, tap = n >> 2, co = n & 3;
-        if (tap < 81) {
-            const int ky = tap / 9, kx = tap - 9 * ky;
-            bbase[j] = p.flip ? (ky * W9_DW + 8 * lk + kx) * 4 + co : ((8 - ky) * W9_DW + 8 * lk + 8 - kx) * 4 + co;
-            bstep[j] = W9_DW * 4;
-        } else { bbase[j] = W9_DROWS * W9_DW * 4; bstep[j] = 0; }
+    for (int q = 0; q < 5; ++q) {
+        const int f = wave + 12 * q;
+        if (f < 8) {
+            gb[q] = ((f & 1) * 32 + 8 * lk) * W9S_XP + 16 * (f >> 1) + li; gs[q] = W9S_XP; gr[q] = 0;
+        } else {
+            const int ntile = (f - 8) >> 1, ks = (f - 8) & 1;
+            const int n = 16 * ntile + li, tap = n >> 2, co = n & 3;
+            if (tap < 81 && f < W9S_NFRAG) {
+                const int ky = tap / 9, kx = tap - 9 * ky;
+                // flip: the 4-channel tensor is the convolution's INPUT (weight gradient of a 4->64 convolution): rows r+ky-4, pixels p+kx-4
+                gb[q] = W9S_XS + (p.flip ? (ky * W9_DW + 8 * lk + kx) * 4 + co : ((8 - ky) * W9_DW + 8 * lk + 8 - kx) * 4 + co) + ks * 128;
+                gr[q] = W9_DW * 4;
+            } else { gb[q] = W9S_XS + W9_DROWS * W9_DW * 4; gr[q] = 0; }
+            gs[q] = 4;
+        }
     }
     for (int e = t; e < W9_DW * 4; e += 768) Ds[W9_DROWS * W9_DW * 4 + e] = 0.f;
     f32x4 acc[7];
@@ -768,11 +788,11 @@ __global__ __launch_bounds__(768) void conv9_c64_c4_wgrad_sb_kernel(W9P p) {
         if (t < 256) xr1 = *reinterpret_cast<const f32x4*>(src + 4 * (t + 768));
     };
     auto store_x = [&](int buf) {
-        float* d0 = &Xs[buf][(t >> 4) * W9S_XP + 4 * (t & 15)];
+        float* d0 = Xs + buf * W9_P * W9S_XP + (t >> 4) * W9S_XP + 4 * (t & 15);
         *reinterpret_cast<float2*>(d0) = make_float2(xr0[0], xr0[1]);
         *reinterpret_cast<float2*>(d0 + 2) = make_float2(xr0[2], xr0[3]);
         if (t < 256) {
-            float* d1 = &Xs[buf][((t + 768) >> 4) * W9S_XP + 4 * (t & 15)];
+            float* d1 = Xs + buf * W9_P * W9S_XP + ((t + 768) >> 4) * W9S_XP + 4 * (t & 15);
             *reinterpret_cast<float2*>(d1) = make_float2(xr1[0], xr1[1]);
             *reinterpret_cast<float2*>(d1 + 2) = make_float2(xr1[2], xr1[3]);
         }
@@ -794,18 +814,32 @@ __global__ __launch_bounds__(768) void conv9_c64_c4_wgrad_sb_kernel(W9P p) {
     if (nsteps > 0) { load_x(0); load_d(0); }
     for (int s = 0; s < nsteps; ++s) {
         const int rr = s % W9_R, buf = s & 1;
-        if (rr == 0) __syncthreads();            // the previous tile's last row has been consumed: Ds may change
-        store_x(buf);
-        if (rr == 0) store_d();
+        store_x(buf);                            // (the other X buffer than the one the previous row's gathers read)
+        if (rr == 0) store_d();                  // Ds: last read by the previous row's gathers, which every wave left at ITS barrier 2
         if (s + 1 < nsteps) { load_x(s + 1); if (rr == W9_R - 1) load_d(s + 1); }
-        __syncthreads();
-        const float* xa = &Xs[buf][8 * lk * W9S_XP + 16 * mt + li];
+        __syncthreads();                         // 1: images complete; every wave has left the previous row's MFMAs (the fragments are free)
 #pragma unroll
-        for (int ks = 0; ks < W9_P / 32; ++ks) {
-            g9_bf16x8 ah, al, bh[7], bl[7];
-            w9s_frag(xa + ks * 32 * W9S_XP, W9S_XP, ah, al);
+        for (int q = 0; q < 5; ++q) {
+            const int f = wave + 12 * q;
+            if (f < W9S_NFRAG) {
+                g9_bf16x8 hi, lo;
+                w9s_frag(w9s_lds + gb[q] + (f < 8 ? buf * W9_P * W9S_XP : rr * gr[q]), gs[q], hi, lo);
+                Fr[(f * 2 + 0) * 64 + lane] = __builtin_bit_cast(f32x4, hi);
+                Fr[(f * 2 + 1) * 64 + lane] = __builtin_bit_cast(f32x4, lo);
+            }
+        }
+        __syncthreads();                         // 2: fragments complete
 #pragma unroll
-            for (int j = 0; j < 7; ++j) w9s_frag(&Ds[bbase[j] + rr * bstep[j] + ks * 32 * 4], 4, bh[j], bl[j]);
+        for (int ks = 0; ks < 2; ++ks) {
+            const g9_bf16x8 ah = __builtin_bit_cast(g9_bf16x8, Fr[((2 * mt + ks) * 2 + 0) * 64 + lane]);
+            const g9_bf16x8 al = __builtin_bit_cast(g9_bf16x8, Fr[((2 * mt + ks) * 2 + 1) * 64 + lane]);
+            g9_bf16x8 bh[7], bl[7];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const int f = 8 + 2 * (7 * ng + j) + ks;
+                bh[j] = __builtin_bit_cast(g9_bf16x8, Fr[(f * 2 + 0) * 64 + lane]);
+                bl[j] = __builtin_bit_cast(g9_bf16x8, Fr[(f * 2 + 1) * 64 + lane]);
+            }
 #pragma unroll
             for (int j = 0; j < 7; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[j], 0, 0, 0);
 #pragma unroll
@@ -852,7 +886,13 @@ static int conv9_wgrad_launch(const float* x64, const float* t4, float* dw, floa
     if (H % W9_R || W % W9_P) return 1;
     W9P p = {x64, t4, part, B, H, W, B * (H / W9_R) * (W / W9_P), flip};
     const int G = p.ntiles < 256 ? p.ntiles : 256;
-    if (sb) hipLaunchKernelGGL(conv9_c64_c4_wgrad_sb_kernel, dim3(G), dim3(768), 0, st, p);
+    if (sb) {
+        static TattPerDevice attr_once;
+        tatt_per_device(attr_once, [&] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv9_c64_c4_wgrad_sb_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W9S_LDS);
+        });
+        hipLaunchKernelGGL(conv9_c64_c4_wgrad_sb_kernel, dim3(G), dim3(768), W9S_LDS, st, p);
+    }
     else hipLaunchKernelGGL(conv9_c64_c4_wgrad_mfma_kernel, dim3(G), dim3(768), 0, st, p);
     hipLaunchKernelGGL(conv9_wgrad_reduce_kernel, dim3(64 * 324 / 64), dim3(1024), 0, st, part, dw, G, flip);
     return LAUNCH_CHECK();
