@@ -202,15 +202,22 @@ def qgru_wgrad_takes(A, B):
             and A.shape[0] % 32 == 0 and A.shape[0] > 0 and A.shape[1] % 128 == 0 and B.shape[1] % 128 == 0)
 
 
+def qgru_wgrad_splits(M):
+    """contraction splits tatt_qgru_wgrad_sb runs M tokens with: at most QGRU_WGRAD_SPLIT, every split owning at least one 32-token chunk"""
+    chunks = M // 32
+    S = max(1, min(QGRU_WGRAD_SPLIT, chunks))
+    while (S - 1) * cdiv(chunks, S) >= chunks:
+        S -= 1
+    return S
+
+
 def qgru_wgrad_sb(A0, A1, B0, B1):
     """-> (dW0, db0, dW1, db1): dW_d (N, K) = A_d^T B_d, db_d = A_d.sum(0) for both directions of the query GRU in one split-bf16
     launch (tatt_qgru_wgrad_sb) + two (deferrable) split-K reductions."""
     _check_dev(A0)
     M, N = A0.shape
     K = B0.shape[1]
-    S = max(1, min(QGRU_WGRAD_SPLIT, M // 32))
-    while (S - 1) * cdiv(M // 32, S) >= M // 32:          # every split must own at least one 32-token chunk
-        S -= 1
+    S = qgru_wgrad_splits(M)
     ws = [_split_ws(new(A0, S * N * K + S * N)) for _ in range(2)]
     call("tatt_qgru_wgrad_sb", P(A0), P(A1), P(B0), P(B1), P(ws[0]), P(ws[1]), M, N, K, S, stream())
     out = []

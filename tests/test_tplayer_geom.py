@@ -47,3 +47,24 @@ def test_second_generation_geometry_and_fallback_rule():
                     seen.add(t)
         assert seen == set(range(ntiles))
         assert g[5] == 8 * 4096 and g[6] == B * 8192 and g[7] == 4 * 4096 and g[8] == B * 4096
+
+
+def test_contraction_split_rules_of_the_round5_kernels():
+    """Host-side split selection (no GPU): tatt_qgru_wgrad_sb must give every split at least one 32-token chunk for any token count;
+    the generic convolution kernel's split rule gives the STN head's deep layers the partial-map counts the folded BatchNorm launches
+    were measured with (functional.STN_FOLD_MAX: up to 9 are folded, the 18-map ones keep their own reduction launch)."""
+    import torch
+    from tatt_amd import ops
+    for chunks in list(range(1, 40)) + [96, 192, 97, 1000]:
+        S = ops.qgru_wgrad_splits(32 * chunks)
+        per = -(-chunks // S)
+        assert 1 <= S <= ops.QGRU_WGRAD_SPLIT and (S - 1) * per < chunks <= S * per, (chunks, S)
+    B = 48
+
+    def split(H, W, Cin, Cout):
+        return ops.conv_split(torch.empty(B, H, W, Cin), Cout, 3, 3)
+    # forward convolutions of the head at B = 48 (model/stn_head.py:33-49): 4->32 @16x64, 32->64 @8x32, 64->128 @4x16, 128->256 @2x8, 256->256 @1x4, @1x2
+    assert [split(16, 64, 4, 32), split(8, 32, 32, 64), split(4, 16, 64, 128), split(2, 8, 128, 256), split(1, 4, 256, 256),
+            split(1, 2, 256, 256)] == [1, 1, 4, 9, 18, 18]
+    # their data gradients, last layer first: 256->256 @1x2, @1x4, 256->128 @2x8, 128->64 @4x16, 64->32 @8x32
+    assert [split(1, 2, 256, 256), split(1, 4, 256, 256), split(2, 8, 256, 128), split(4, 16, 128, 64), split(8, 32, 64, 32)] == [18, 18, 18, 9, 4]
