@@ -127,7 +127,7 @@ def _k_conv3_sb(dev, B, H, W):
     b = torch.zeros(64, device=dev)
     px = B * H * W
     nbytes = 2 * px * 64 * 4 + 9 * 64 * 64 * 4
-    wl = ops.repack_weight(w, 10 if ops.CONV3_SB else ops._WS_FWD_MODE)
+    wl = ops.repack_weight(w, ops.LIB.tatt_conv3_sb_packing(B, H, W, 64, 64, 0, 0) if ops.CONV3_SB else ops._WS_FWD_MODE)
     runs = []
     for _ in range(_nsets(nbytes)):
         x, y = torch.randn(B, H, W, 64, device=dev), torch.empty(B, H, W, 64, device=dev)

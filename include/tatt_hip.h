@@ -124,7 +124,7 @@ int tatt_conv3_c64_fwd_ws16_bn(const float* x, const float* wl, const float* bia
 /* The same 3x3 convolution on the bf16 matrix cores by operand splitting: a = hi + lo (hi = bf16(a), lo = bf16(a - hi)),
  * a*b ~ hi hi + hi lo + lo hi accumulated in fp32 (the dropped lo*lo term is 2^-16 relative; measured effect on the network:
  * profiles/r03_split_bf16_probe.txt).  x holds cin_total >= 64 channels per pixel; the 64-channel slice starting at ci0 is
- * contracted with the matching chunk of a mode-10 / mode-11 packed filter (chunk c starts c*Cout*576 words in); wider inputs are
+ * contracted with the matching chunk of a mode-10 / mode-11 (or 14 / 15: tatt_conv3_sb_packing) packed filter (chunk c starts c*Cout*576 words in); wider inputs are
  * chunked by the caller with beta = 1.  BatchNorm folding arguments as tatt_conv3_c64_fwd_ws16_bn. */
 int tatt_conv3_c64_fwd_sb(const float* x, int cin_total, int ci0, const float* wl, const float* bias, float* y, int B, int H,
                           int W, int Cout, int act, float beta, const float* in_scale, const float* in_shift, int in_act,
@@ -140,6 +140,14 @@ int tatt_conv3_c64_dgrad_bn_sb(const float* x, const float* x2, const float* in_
                                const float* in_shift, const float* wl, float* y, int B, int H, int W, const float* ep_x,
                                const float* ep_mean, const float* ep_rstd, const float* ep_gamma, const float* ep_beta,
                                int ep_act, double* stats, hipStream_t st);
+/* Which kernel the two entries above launch, and the filter packing it wants.  tatt_conv3_sb_generation (test / A-B hook; returns the
+ * previous setting, other values only query): 3 (default) = 4 x 16-pixel tiles, one wave per SIMD owning 32 output channels over half the
+ * contraction, v_mfma_f32_32x32x16_bf16 (round 6); 2 = the same tiles with 16-channel waves and v_mfma_f32_16x16x32_bf16; 1 = the
+ * 64-pixel row tiles of rounds 3-5.  Generations 2 / 3 take H % 4 == 0, W % 16 == 0, no output activation, no tanh: everything else
+ * runs generation 1 (W % 64 == 0).  tatt_conv3_sb_packing: the tatt_repack_conv_weight mode of the FORWARD filter for a call with these
+ * arguments -- 10 (generations 1 / 2) or 14 (generation 3); the data-gradient packing is that + 1. */
+int tatt_conv3_sb_generation(int gen);
+int tatt_conv3_sb_packing(int B, int H, int W, int cin_total, int Cout, int act, int ep_act);
 /* weight-gradient partials part[G][9*Cin][Cout] (G persistent work-groups, G <= B*H*W/64) and, if pdb != NULL, bias-gradient
  * partials pdb[G][Cout] (the column sums of dy the kernel streams anyway; nn.Conv2d's bias gradient); finish with
  * tatt_splitk_reduce(part, dw_oihw, 9*Cin, Cout, G, Cin, 9, beta, db, Cout) where pdb = part + G*9*Cin*Cout */

@@ -40,10 +40,11 @@ __device__ __forceinline__ void tatt_raise_sticky(unsigned* sticky, unsigned cod
 // tanh(softplus(x)) = ((1+e^x)^2 - 1) / ((1+e^x)^2 + 1) = n / (n + 2) with n = e^x (e^x + 2): one v_exp + one v_rcp, and no
 // cancellation for x << 0 (n -> e^x * 2).  Matches x*tanh(log1p(exp(x))) to fp32 round-off (|err| < 2e-7 on the value).
 __device__ __forceinline__ float tanh_softplus_f(float x) {
-    if (x > 20.f) return tanhf(x);           // reference: softplus(x) = x beyond the threshold; tanh(x>20) == 1.f in fp32
-    const float e = __expf(x);
+    // reference: softplus(x) = x beyond the threshold, and tanh(x > 20) == 1.f in fp32 -- a select, not a branch (the exponent is
+    // clamped so the unselected lane stays finite)
+    const float e = __expf(fminf(x, 20.f));
     const float n = e * (e + 2.f);
-    return n * __builtin_amdgcn_rcpf(n + 2.f);
+    return x > 20.f ? 1.f : n * __builtin_amdgcn_rcpf(n + 2.f);
 }
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(__expf(x)); }
 __device__ __forceinline__ float mish_f(float x) { return x * tanh_softplus_f(x); }

@@ -946,6 +946,26 @@ __device__ __forceinline__ float repack_sb(const float* __restrict__ w, long idx
     const rp_bf16x2 lo = __builtin_convertvector(v - __builtin_convertvector(hi, rp_f32x2), rp_bf16x2);
     return __builtin_bit_cast(float, hl ? lo : hi);
 }
+// modes 14 / 15: the same values for tatt_conv3_c64_fwd_sb's 32x32x16 kernel (round 6: 32 output channels per wave, A operand of
+// v_mfma_f32_32x32x16_bf16: lane (i = lane & 31, kb = lane >> 5) supplies 8 consecutive k of row i):
+//   word[((((chunk * nblk + blk) * 9 + tap) * 2 + kh) * 4 + s * 2 + hl) * 64 + lane) * 4 + e2],  nblk = conv output channels / 32,
+//   conv output channel o = 32 blk + (lane & 31), conv input channel i = 64 chunk + 32 kh + 16 s + 8 (lane >> 5) + 2 e2 + {0, 1};
+//   mode 14: v = filter[o][i][tap] (forward);  mode 15: v = filter[i][o][8 - tap] (data gradient)
+__device__ __forceinline__ float repack_sb32(const float* __restrict__ w, long idx, int Cout, int Cin, int mode) {
+    const int e2 = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
+    long r = idx >> 8;
+    const int F = (int)(r % 72); r /= 72;
+    const int nblk = (mode == 14 ? Cout : Cin) / 32;
+    const int blk = (int)(r % nblk), chunk = (int)(r / nblk);
+    const int hl = F & 1, sstep = (F >> 1) & 1, kh = (F >> 2) & 1, tap = F >> 3;
+    const int o = 32 * blk + (lane & 31), i = 64 * chunk + 32 * kh + 16 * sstep + 8 * (lane >> 5) + 2 * e2;
+    rp_f32x2 v;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) v[u] = mode == 14 ? w[((long)o * Cin + (i + u)) * 9 + tap] : w[((long)(i + u) * Cin + o) * 9 + (8 - tap)];
+    const rp_bf16x2 hi = __builtin_convertvector(v, rp_bf16x2);
+    const rp_bf16x2 lo = __builtin_convertvector(v - __builtin_convertvector(hi, rp_f32x2), rp_bf16x2);
+    return __builtin_bit_cast(float, hl ? lo : hi);
+}
 // modes 12 / 13: the Toeplitz-expanded 9x9 filter of modes 8 / 9 as the split-bf16 B operand of tatt_conv9_c64_to_c4_sb
 // (v_mfma_f32_16x16x32_bf16: a lane supplies 8 consecutive k = two pixel offsets x 16 channels spread over the four k-quarters):
 //   word[((((ky * 4 + c) * 6 + pair) * 2 + hl) * 64 + lane) * 4 + e2]  = two bf16 of input channels ci, ci + 1,
@@ -971,6 +991,10 @@ __device__ __forceinline__ float toeplitz9_sb(const float* __restrict__ w, int i
 __global__ void repack_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin,
                                      int KH, int KW, int mode) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (mode >= 14) {
+        if (idx < Cout * Cin * 9) out[idx] = repack_sb32(w, idx, Cout, Cin, mode);
+        return;
+    }
     if (mode >= 12) {
         if (idx < TOEPLITZ9_WORDS) out[idx] = toeplitz9_sb(w, idx, mode);
         return;
@@ -1013,15 +1037,15 @@ __global__ void repack_weight_kernel(const float* __restrict__ w, float* __restr
 }
 // 32-bit words a packed layout occupies (what `out` of tatt_repack_conv_weight must hold); -1 for an unknown mode.  Host-only.
 TATT_API int tatt_repack_words(int Cout, int Cin, int KH, int KW, int mode) {
-    if (mode == 4 || mode == 5 || mode < 0 || mode > 13) return -1;
+    if (mode == 4 || mode == 5 || mode < 0 || mode > 15) return -1;
     return (int)repack_total(Cout, Cin, KH, KW, mode);
 }
 TATT_API int tatt_repack_conv_weight(const float* w_oihw, float* out, int Cout, int Cin, int KH, int KW,
                                      int mode, hipStream_t st) {
     const bool fwd9 = mode == 8 || mode == 12, dgrad9 = mode == 9 || mode == 13;
     if ((fwd9 || dgrad9) && !(KH == 9 && KW == 9 && ((fwd9 && Cout == 4 && Cin == 64) || (dgrad9 && Cout == 64 && Cin == 4)))) return 1;
-    if ((mode == 10 || mode == 11) && !(KH == 3 && KW == 3 && Cout % 64 == 0 && Cin % 64 == 0)) return 1;
-    if (mode == 4 || mode == 5 || mode < 0 || mode > 13) return 1;     // (4 / 5: the retired 32x32 weight-stationary kernel)
+    if ((mode == 10 || mode == 11 || mode == 14 || mode == 15) && !(KH == 3 && KW == 3 && Cout % 64 == 0 && Cin % 64 == 0)) return 1;
+    if (mode == 4 || mode == 5 || mode < 0 || mode > 15) return 1;     // (4 / 5: the retired 32x32 weight-stationary kernel)
     long total = repack_total(Cout, Cin, KH, KW, mode);
     hipLaunchKernelGGL(repack_weight_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w_oihw, out, Cout, Cin,
                        KH, KW, mode);
@@ -1038,6 +1062,10 @@ __global__ void repack_batch_kernel(RepackTable t) {
     while (k + 1 < t.n && (int)blockIdx.x >= t.e[k + 1].block0) ++k;          // wave-uniform walk over <= 96 entries
     const RepackEntry& e = t.e[k];
     const int idx = ((int)blockIdx.x - e.block0) * blockDim.x + threadIdx.x;
+    if (e.mode >= 14) {
+        if (idx < e.Cout * e.Cin * 9) e.out[idx] = repack_sb32(e.w, idx, e.Cout, e.Cin, e.mode);
+        return;
+    }
     if (e.mode >= 12) {
         if (idx < TOEPLITZ9_WORDS) e.out[idx] = toeplitz9_sb(e.w, idx, e.mode);
         return;

@@ -410,9 +410,15 @@ def conv_partials(x_bhwc, wpacked, Cout, KH, KW):
     return ws, int(got.value)
 
 
+def _conv3_geom_ok(x_bhwc):
+    """map sizes the 3x3 64-channel kernels tile: 64-pixel row segments, or (split-bf16 kernel, round 6) 4 x 16-pixel tiles"""
+    H, W = x_bhwc.shape[1], x_bhwc.shape[2]
+    return W % 64 == 0 or (CONV3_SB and H % 4 == 0 and W % 16 == 0)
+
+
 def _conv3_fast_ok(x_bhwc, Cin, Cout, KH, KW):
     return (x_bhwc.is_contiguous() and KH == 3 and KW == 3 and Cin % 64 == 0 and Cout % 64 == 0
-            and x_bhwc.shape[2] % 64 == 0)
+            and _conv3_geom_ok(x_bhwc))
 
 
 # exact-fp32 3x3 kernels (used when CONV3_SB is off): weight-stationary ws16 kernel for 64 input channels, filter packings 6 / 7
@@ -431,7 +437,7 @@ def _conv3_sb(x_bhwc, w_oihw, mode, bias, act=ACT_NONE, in_scale=None, in_shift=
     B, H, W, cin = x_bhwc.shape
     cout = w_oihw.shape[0] if mode == 10 else w_oihw.shape[1]
     assert cin == (w_oihw.shape[1] if mode == 10 else w_oihw.shape[0])
-    wl = repack_weight(w_oihw, mode)
+    wl = repack_weight(w_oihw, LIB.tatt_conv3_sb_packing(B, H, W, cin, cout, int(act), ACT_NONE) + (mode - 10))
     y = new(x_bhwc, B, H, W, cout)
     nchunk = cin // 64
     assert nchunk == 1 or (act == ACT_NONE and stats is None)
@@ -467,16 +473,17 @@ def conv2d_forward(x_bhwc, weight_oihw, bias, act=ACT_NONE):
         return y
     if _conv3_fast_ok(x_bhwc, Cin, Cout, KH, KW):
         B, H, W, _ = x_bhwc.shape
-        if CONV3_SB and (Cin == 64 or act == ACT_NONE):
+        if CONV3_SB and (Cin == 64 or act == ACT_NONE) and (W % 64 == 0 or act == ACT_NONE):
             return _conv3_sb(x_bhwc, weight_oihw, 10, bias, act)
-        y = new(x_bhwc, B, H, W, Cout)
-        if Cin == 64:                                            # weight-stationary kernel: the filter lives in registers
-            wl = repack_weight(weight_oihw, _WS_FWD_MODE)
-            call(_WS_ENTRY, P(x_bhwc), P(wl), P(bias), P(y), B, H, W, Cout, act, 0.0, stream())
+        if W % 64 == 0:                                          # (the exact-fp32 kernels walk 64-pixel row segments)
+            y = new(x_bhwc, B, H, W, Cout)
+            if Cin == 64:                                        # weight-stationary kernel: the filter lives in registers
+                wl = repack_weight(weight_oihw, _WS_FWD_MODE)
+                call(_WS_ENTRY, P(x_bhwc), P(wl), P(bias), P(y), B, H, W, Cout, act, 0.0, stream())
+                return y
+            wt = repack_weight(weight_oihw, 2)                   # [9][Cout][Cin]
+            call("tatt_conv3_c64_fwd_t", P(x_bhwc), P(wt), P(bias), P(y), B, H, W, Cin, Cout, act, 0.0, stream())
             return y
-        wt = repack_weight(weight_oihw, 2)                       # [9][Cout][Cin]
-        call("tatt_conv3_c64_fwd_t", P(x_bhwc), P(wt), P(bias), P(y), B, H, W, Cin, Cout, act, 0.0, stream())
-        return y
     return conv_fwd(x_bhwc, repack_weight(weight_oihw, 0), bias, Cout, KH, KW, act=act)
 
 
@@ -489,7 +496,7 @@ def conv3_bn_fusable(x_bhwc, weight_oihw, bn=None):
     if bn is not None and (bn.momentum is None or not bn.affine or not bn.track_running_stats or bn.running_mean is None):
         return False
     return (tuple(weight_oihw.shape) == (64, 64, 3, 3) and x_bhwc.is_contiguous()
-            and x_bhwc.shape[3] == 64 and x_bhwc.shape[2] % 64 == 0)
+            and x_bhwc.shape[3] == 64 and _conv3_geom_ok(x_bhwc))
 
 
 def conv3_bn_forward(x_bhwc, weight_oihw, bias, in_scale=None, in_shift=None, in_act=ACT_NONE, want_stats=True):
@@ -497,7 +504,7 @@ def conv3_bn_forward(x_bhwc, weight_oihw, bias, in_scale=None, in_shift=None, in
     partials of y's per-channel batch statistics ([G][2][64] doubles) -> (y, part, G)."""
     _check_dev(x_bhwc)
     B, H, W, _ = x_bhwc.shape
-    G = min(256, B * H * (W // 64))
+    G = min(256, B * H * W // 64)
     part = new(x_bhwc, G * 128, dtype=torch.float64) if want_stats else None
     if CONV3_SB:
         return _conv3_sb(x_bhwc, weight_oihw, 10, bias, ACT_NONE, in_scale, in_shift, in_act, part), part, G
@@ -656,9 +663,9 @@ def conv3_dgrad_bn(du_bhwc, weight_oihw, x2_bhwc=None, coef=None, ep=None):
     multiplied by act'(bn(y_below)) and the stage-1 partials of that BatchNorm's backward come back -> (out, part or None, G)."""
     _check_dev(du_bhwc)
     B, H, W, _ = du_bhwc.shape
-    wl = repack_weight(weight_oihw, 11)
+    wl = repack_weight(weight_oihw, LIB.tatt_conv3_sb_packing(B, H, W, 64, 64, ACT_NONE, int(ep[5]) if ep is not None else ACT_NONE) + 1)
     out = new(du_bhwc, B, H, W, 64)
-    G = min(256, B * H * (W // 64))
+    G = min(256, B * H * W // 64)
     part = new(du_bhwc, G * 128, dtype=torch.float64) if ep is not None else None
     a = b = c = None
     if x2_bhwc is not None:

@@ -1033,6 +1033,76 @@ def test_conv3_split_bf16_bn_folding(dev):
         check_close("stats.sq", st[1].float(), (y.double() ** 2).reshape(-1, 64).sum(0).float(), rtol=1e-5, atol=1e-3)
 
 
+@pytest.mark.parametrize("B,H,W", [(3, 16, 64), (2, 32, 128), (1, 4, 16), (5, 8, 48), (2, 4, 64)])
+def test_conv3_split_bf16_square_tiles_vs_fp64_and_row_tiles(dev, B, H, W):
+    """Round 6's 4 x 16-pixel-tile kernels (tatt_conv3_sb_generation 3: 32-channel waves on v_mfma_f32_32x32x16_bf16, filter packing 14 / 15;
+    2: 16-channel waves; both: contraction split over wave pairs, LDS exchange, swapped MFMA operands, buffer-descriptor padding,
+    epilogue re-threaded over pixels) against fp64 AND against the row-tile kernel of rounds 3-5 on every variant the model runs:
+    plain / bias + activation epilogue, Cout = 256, a 64-channel slice of a 256-channel input with beta = 1, BatchNorm + mish folded
+    into the staging with output statistics, and the data gradient with the BatchNorm backward folded in on both sides.  Geometries:
+    the benchmark's, the large tile, a single tile (every halo side is padding), a ragged tile count, one tile row."""
+    from tatt_amd import ops
+    from tatt_amd._lib import LIB
+    x, w, b = R(B, H, W, 64, seed=1), R(64, 64, 3, 3, seed=2) / 24, R(64, seed=3)
+    w256, x256 = R(256, 64, 3, 3, seed=4) / 24, R(B, H, W, 256, seed=5)
+    sc, sh = 1.0 + 0.3 * R(64, seed=6), 0.2 * R(64, seed=7)
+    coef = torch.stack([1.0 + 0.2 * R(64, seed=8), 0.1 * R(64, seed=9), 0.1 * R(64, seed=10)])
+    mean, rstd = 0.1 * R(64, seed=11), 1.0 + 0.2 * R(64, seed=12).abs()
+    x2, below = R(B, H, W, 64, seed=13), R(B, H, W, 64, seed=14)
+    d = lambda t: t.to(dev)                                               # noqa: E731
+    conv = lambda xx, ww, bb=None: F.conv2d(xx.double().permute(0, 3, 1, 2), ww.double(), None if bb is None else bb.double(), padding=1).permute(0, 2, 3, 1)  # noqa: E731
+    dconv = lambda g, ww: torch.nn.grad.conv2d_input((B, ww.shape[1], H, W), ww.double(), g.double().permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)  # noqa: E731
+    xh = (below.double() - mean.double()) * rstd.double()
+    gin = coef[0].double() * x.double() + coef[1].double() * x2.double() + coef[2].double()
+    ref = {
+        "plain": conv(x, w, b),
+        "mish_epilogue": O.mish(conv(x, w, b).float()).double(),
+        "cout256": conv(x, w256),
+        "dgrad256": dconv(x256, w256),                                   # four 64-channel slices, beta = 1 after the first
+        "bn_mish": conv(F.mish(x.double() * sc.double() + sh.double()), w, b),
+        "dgrad_in2_epbn": dconv(gin, w) * _mish_grad64(sc.double() * xh + sh.double()),
+        "dgrad_in2": dconv(gin, w),
+    }
+    got = {}
+    gens = (3, 2, 1) if W % 64 == 0 else (3, 2)                         # (the row-tile kernel walks 64-pixel segments)
+    for gen in gens:
+        assert LIB.tatt_conv3_sb_generation(gen) in (1, 2, 3)
+        try:
+            o = {}
+            o["plain"] = ops.conv2d_forward(d(x), d(w), d(b))
+            o["mish_epilogue"] = ops.conv2d_forward(d(x), d(w), d(b), act=ops.ACT_MISH)
+            o["cout256"] = ops.conv2d_forward(d(x), d(w256), None)
+            o["dgrad256"] = ops.conv2d_dgrad(d(x256), d(w256))
+            y, part, G = ops.conv3_bn_forward(d(x), d(w), d(b), d(sc), d(sh), ops.ACT_MISH, True)
+            o["bn_mish"], o["bn_mish.stats"] = y, part.reshape(G, 2, 64).sum(0)
+            y, part, G = ops.conv3_dgrad_bn(d(x), d(w), d(x2), d(coef), (d(below), d(mean), d(rstd), d(sc), d(sh), ops.ACT_MISH))
+            o["dgrad_in2_epbn"], o["dgrad_in2_epbn.stats"] = y, part.reshape(G, 2, 64).sum(0)
+            o["dgrad_in2"] = ops.conv3_dgrad_bn(d(x), d(w), d(x2), d(coef), None)[0]
+            got[gen] = {k: v.cpu().double() for k, v in o.items()}
+        finally:
+            LIB.tatt_conv3_sb_generation(3)
+    for k, r in ref.items():
+        for gen in gens:
+            err = float((got[gen][k] - r).abs().max() / r.abs().max())
+            assert err < 2e-5, (k, gen, err)
+        # the kernels evaluate the same products and differ in summation order only
+        for gen in gens[1:]:
+            assert float((got[gens[0]][k] - got[gen][k]).abs().max() / r.abs().max()) < 2e-6, (k, gen)
+    for gen in gens[:2]:
+        y = got[gen]["bn_mish"]
+        check_close("stats.sum", got[gen]["bn_mish.stats"][0].float(), y.reshape(-1, 64).sum(0).float(), rtol=1e-5, atol=1e-3)
+        check_close("stats.sq", got[gen]["bn_mish.stats"][1].float(), (y ** 2).reshape(-1, 64).sum(0).float(), rtol=1e-5, atol=1e-3)
+        y = got[gen]["dgrad_in2_epbn"]
+        check_close("bwd stats.sum", got[gen]["dgrad_in2_epbn.stats"][0].float(), y.reshape(-1, 64).sum(0).float(), rtol=1e-5, atol=1e-3)
+        check_close("bwd stats.xhat", got[gen]["dgrad_in2_epbn.stats"][1].float(), (y * xh).reshape(-1, 64).sum(0).float(), rtol=1e-5, atol=1e-3)
+
+
+def _mish_grad64(u):
+    u = u.clone().requires_grad_(True)
+    F.mish(u).sum().backward()
+    return u.grad
+
+
 # ------------------------------------------------------------------------------------------- score-free self-attention (TBSRN)
 @pytest.mark.parametrize("B,Pn", [(2, 256), (1, 1024), (3, 64), (2, 4096)])
 def test_flash_self_attention_vs_reference(dev, B, Pn):

@@ -66,8 +66,32 @@ timeit("conv3_fwd_ws16_64_64", lambda: ops.call("tatt_conv3_c64_fwd_ws16", ops.P
 wsb = ops.repack_weight(w33, 10)
 xs_ = R(B, a.H, a.W, 64)
 ys_ = torch.empty_like(xs_)
-timeit("conv3_fwd_sb_64_64", lambda: ops.call("tatt_conv3_c64_fwd_sb", ops.P(xs_), 64, 0, ops.P(wsb), ops.P(b64), ops.P(ys_), B, a.H, a.W, 64, 0, 0.0,
+_wsb_cur = ops.repack_weight(w33, ops.LIB.tatt_conv3_sb_packing(B, a.H, a.W, 64, 64, 0, 0))
+timeit("conv3_fwd_sb_64_64", lambda: ops.call("tatt_conv3_c64_fwd_sb", ops.P(xs_), 64, 0, ops.P(_wsb_cur), ops.P(b64), ops.P(ys_), B, a.H, a.W, 64, 0, 0.0,
                                                None, None, 0, None, ops.stream()), 2.0 * B * a.H * a.W * 576 * 64, 2.0 * B * a.H * a.W * 64 * 4)
+# round 6: both generations of the split-bf16 kernel (tatt_conv3_sb_generation) and its folded variants as the residual blocks run them
+from tatt_amd._lib import LIB as _LIB  # noqa: E402
+_f3, _b3 = 2.0 * B * a.H * a.W * 576 * 64, 2.0 * B * a.H * a.W * 64 * 4
+_sc, _sh = 1.0 + 0.1 * R(64), 0.1 * R(64)
+_coef = torch.stack([1.0 + 0.1 * R(64), 0.01 * R(64), 0.01 * R(64)])
+_mean, _rstd = 0.1 * R(64), 1.0 + 0.1 * R(64).abs()
+_w64 = w33.clone()
+_wsb_gen = {1: wsb, 2: wsb, 3: ops.repack_weight(w33, 14)}
+for _gen in (1, 2, 3):
+    def _g(fn, _gen=_gen):
+        def run():
+            _LIB.tatt_conv3_sb_generation(_gen)
+            try:
+                fn()
+            finally:
+                _LIB.tatt_conv3_sb_generation(3)
+        return run
+    timeit("conv3_sb_g%d_plain" % _gen, _g(lambda _gen=_gen: ops.call("tatt_conv3_c64_fwd_sb", ops.P(xs_), 64, 0, ops.P(_wsb_gen[_gen]), ops.P(b64), ops.P(ys_), B, a.H, a.W, 64, 0, 0.0,
+                                                                None, None, 0, None, ops.stream())), _f3, _b3)
+    timeit("conv3_sb_g%d_bn_mish_stats" % _gen, _g(lambda: ops.conv3_bn_forward(xs_, _w64, b64, _sc, _sh, 2, True)), _f3, _b3)
+    timeit("conv3_sb_g%d_stats" % _gen, _g(lambda: ops.conv3_bn_forward(xs_, _w64, b64, None, None, 0, True)), _f3, _b3)
+    timeit("conv3_sb_g%d_dgrad_in2_epbn" % _gen, _g(lambda: ops.conv3_dgrad_bn(xs_, _w64, ys_, _coef, (xs_, _mean, _rstd, _sc, _sh, 2))), _f3, 2 * _b3)
+    timeit("conv3_sb_g%d_dgrad_in2" % _gen, _g(lambda: ops.conv3_dgrad_bn(xs_, _w64, ys_, _coef, None)), _f3, 1.5 * _b3)
 timeit("conv3_wgrad_64_64", lambda: ops.conv_wgrad(x64, y64, 64, 3, 3), f33)
 ops.CONV3_WGRAD_SB = False
 timeit("conv3_wgrad_64_64_fp32", lambda: ops.conv_wgrad(x64, y64, 64, 3, 3), f33)
