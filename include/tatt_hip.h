@@ -157,6 +157,9 @@ int tatt_conv3_c64_wgrad_partial(const float* x, const float* dy, float* part, f
  * arguments, same outputs up to 2^-16 relative per product */
 int tatt_conv3_c64_wgrad_partial_sb(const float* x, const float* dy, float* part, float* pdb, int B, int H, int W,
                                     int Cin, int Cout, int G, hipStream_t st);
+/* Test / A-B hook: 2 (default) = 4 x 16-pixel tiles, transposing LDS reads, staging waves beside MFMA waves (round 6; H % 4 == 0,
+ * W % 16 == 0), 1 = the 64-pixel row segments of rounds 3-5 (also what H % 4 != 0 runs; W % 64 == 0).  Returns the previous setting. */
+int tatt_conv3_wgrad_sb_generation(int gen);
 
 /* 9x9 convolution 64 -> 4 channels (fp32 vector ALU; filter through the scalar cache): the final reconstruction conv
  * (model/tsrn.py:623) and, with the mode-1 packed filter, the data gradient of block1 (model/tsrn.py:597).

@@ -196,10 +196,207 @@ __global__ __launch_bounds__(512, 1) void conv3_c64_wgrad_sb_kernel(Conv3WSP p) 
     }
 }
 
+// ---- round 6: square tiles, hardware-transposed operand reads, staging waves beside MFMA waves ------------------------------------------
+// The kernel above (46.9 us per launch in the step, 0.035 of the bf16 pipe) transposes every operand with scalar LDS reads behind seven
+// work-group barriers per 64-pixel segment, and all of its 8 waves do everything in lock step.  What the forward kernel's rebuild
+// measured (profiles/r06_conv3_sb2_stamps.txt) applies here as well: one wave per SIMD cannot issue staging arithmetic AND feed the MFMA
+// pipe; the CU's memory pipe takes ~37 cycles per 1 KB request; v_mfma_f32_32x32x16_bf16 is the faster form.  Here:
+//   * tile = 4 rows x 16 pixels (as the forward kernel: x halo 6 x 18); one tile row = the 16 pixels of ONE MFMA's contraction;
+//   * both maps are staged as they lie in memory -- pixel-major, channel-contiguous -- as a hi and a lo bf16 image (pitch 192 B per
+//     pixel), and the MFMA operands (8 consecutive PIXELS of one channel per lane) come out of ds_read_b64_tr_b16, gfx950's transposing
+//     LDS read: lane a of a 16-lane group points at the piece (pixel a / 4, channel quad a % 4) of a [4 pixels][16 channels] block and
+//     receives channel a of the four pixels (tools/ubench/tr_probe.hip); with the 192-byte pitch the four pixel rows of a read fall into
+//     disjoint bank quarters;
+//   * waves 0-3 only read operands and issue MFMAs: wave (cih, coh) owns the (32 ci x 32 co) quadrant of all nine taps (9 accumulators,
+//     144 registers) for the whole launch; waves 4-7 only stage: global -> registers (requested a tile ahead) -> split -> LDS, and sum
+//     the bias gradient in fp32 from the dy values passing through; the two kinds meet at one barrier per tile (double-buffered images);
+//   * the partial slab leaves as whole 128-byte lines (each accumulator transposed through a wave-private LDS tile).
+// Same contract and outputs as the kernel above.  Geometries with H % 4 != 0 keep it.
+typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 cw_bf16x4_t;
+typedef __attribute__((address_space(3))) cw_bf16x4_t* cw_lds_b64;
+typedef float cw_f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned cw_u32x4 __attribute__((ext_vector_type(4)));
+#define W2_PB 192                                   // bytes per pixel of an image (64 bf16 + 64 B: the bank spread of the transposing reads)
+#define W2_XIMG (108 * W2_PB)                       // x halo image (hi or lo): 20,736 B
+#define W2_DIMG (64 * W2_PB)                        // dy tile image: 12,288 B
+#define W2_BUF (2 * W2_XIMG + 2 * W2_DIMG)          // one buffer: x hi, x lo, dy hi, dy lo = 66,048 B
+#define W2_LDS (2 * W2_BUF)                         // 132,096 B
+#define W2_OOB 0x80000000u
+__device__ __forceinline__ cw_bf16x8 w2_tr(const char* p0, int off) {        // 8 consecutive pixels of this lane's channel: two transposing reads
+    const cw_bf16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((cw_lds_b64)(p0 + off));
+    const cw_bf16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((cw_lds_b64)(p0 + off + 4 * W2_PB));
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ void w2_split_put(char* dst_hi, int lo_off, f32x4 v) {
+    const cw_bf16x2 h0 = __builtin_convertvector((cw_f32x2){v[0], v[1]}, cw_bf16x2), h1 = __builtin_convertvector((cw_f32x2){v[2], v[3]}, cw_bf16x2);
+    const cw_f32x2 r0 = (cw_f32x2){v[0], v[1]} - __builtin_convertvector(h0, cw_f32x2), r1 = (cw_f32x2){v[2], v[3]} - __builtin_convertvector(h1, cw_f32x2);
+    const cw_bf16x2 l0 = __builtin_convertvector(r0, cw_bf16x2), l1 = __builtin_convertvector(r1, cw_bf16x2);
+    *reinterpret_cast<uint2*>(dst_hi) = make_uint2(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1));
+    *reinterpret_cast<uint2*>(dst_hi + lo_off) = make_uint2(__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1));
+}
+__global__ __launch_bounds__(512, 2) void conv3_c64_wgrad_sb2_kernel(Conv3WSP p) {
+    extern __shared__ __attribute__((aligned(16))) char w2_smem[];
+    __shared__ float dbred[16][64];
+    const unsigned t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const unsigned cib = blockIdx.y % (p.Cin / 64), cob = blockIdx.y / (p.Cin / 64);
+    const unsigned ci0 = cib * 64, co0 = cob * 64;
+    const unsigned W = p.W, H = p.H, tws = W / 16, ths = H / 4;
+    const unsigned per = (p.nseg + gridDim.x - 1) / gridDim.x;
+    const unsigned s_beg = blockIdx.x * per, s_end = min((unsigned)p.nseg, s_beg + per);
+    const bool want_db = p.pdb != nullptr && cib == 0;
+    auto decode = [&](unsigned tile, unsigned& org, unsigned& te) {           // -> origin pixel index, edge mask (bit 0 top, 1 bottom, 2 left, 3 right)
+        const unsigned tw = tile % tws; tile /= tws;
+        const unsigned th = tile % ths, n = tile / ths;
+        org = (n * H + th * 4) * W + tw * 16;
+        te = (th == 0 ? 1u : 0u) | (th == ths - 1 ? 2u : 0u) | (tw == 0 ? 4u : 0u) | (tw == tws - 1 ? 8u : 0u) | 16u;
+    };
+    if (wave >= 4) {
+        // ---------------- staging waves: 256 threads; x halo = 1728 16-byte items (7 per thread), dy tile = 1024 (4 per thread) ----------------
+        const unsigned h = t - 256, c4 = h & 15;
+        const unsigned npix = p.B * H * W;
+        const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, npix * p.Cin * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, npix * p.Cout * 4, 0x00020000);
+        const unsigned xps = p.Cin * 4, dps = p.Cout * 4;
+        unsigned xoff[7], xput[7], edge[2] = {0, 0}, doff[4], dput[4];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const unsigned pix = (h >> 4) + 16 * k, r = pix / 18, c = pix - r * 18;
+            xoff[k] = (unsigned)(((int)r - 1) * (int)W + (int)c - 1) * xps + (ci0 + 4 * c4) * 4;
+            xput[k] = pix * W2_PB + 8 * c4;
+            edge[k >> 2] |= ((r == 0 ? 1u : 0u) | (r == 5 ? 2u : 0u) | (c == 0 ? 4u : 0u) | (c == 17 ? 8u : 0u) | (pix >= 108 ? 16u : 0u)) << (8 * (k & 3));
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned pix = (h >> 4) + 16 * k;                           // tile pixel: row k, column h >> 4
+            doff[k] = (k * W + (h >> 4)) * dps + (co0 + 4 * c4) * 4;
+            dput[k] = 2 * W2_XIMG + pix * W2_PB + 8 * c4;
+        }
+        f32x4 hx[7], hd[4], dbacc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        auto issue = [&](unsigned tile, bool valid) {
+            unsigned org, te;
+            decode(tile, org, te);
+            const unsigned inv = valid ? 0u : W2_OOB;
+#pragma unroll
+            for (int k = 0; k < 7; ++k)
+                hx[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (org * xps + xoff[k]) | ((((edge[k >> 2] >> (8 * (k & 3))) & te) != 0) ? W2_OOB : inv), 0, 0));
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                hd[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_d, (org * dps + doff[k]) | inv, 0, 0));
+        };
+        auto put = [&](char* buf) {
+#pragma unroll
+            for (int k = 0; k < 7; ++k)
+                if (k < 6 || h < 1728 - 6 * 256) w2_split_put(buf + xput[k], W2_XIMG, hx[k]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { w2_split_put(buf + dput[k], W2_DIMG, hd[k]); dbacc += hd[k]; }
+        };
+        if (s_beg < s_end) {
+            issue(s_beg, true);
+            put(w2_smem);
+            issue(s_beg + 1, s_beg + 1 < s_end);
+        }
+        __syncthreads();                                                      // tile s_beg staged
+        for (unsigned s = s_beg; s < s_end; ++s) {
+            // while the MFMA waves work on tile s: stage tile s + 1 (requested a tile ago) into the other buffer, request tile s + 2
+            if (s + 1 < s_end) {
+                put(w2_smem + ((s + 1 - s_beg) & 1) * W2_BUF);
+                issue(s + 2, s + 2 < s_end);
+            }
+            __syncthreads();
+        }
+        if (want_db) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dbred[h >> 4][4 * c4 + e] = dbacc[e];
+        }
+        __syncthreads();                                                      // (the MFMA waves' last barrier too)
+        if (want_db && h < 64) {
+            float a = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) a += dbred[g][h];
+            p.pdb[(long)blockIdx.x * p.Cout + co0 + h] = a;
+        }
+        return;
+    }
+    // ---------------- MFMA waves: (cih, coh) quadrant of all nine taps ----------------
+    const unsigned cih = wave & 1, coh = wave >> 1, a16 = lane & 15, g16 = (lane >> 4) & 1, kb = lane >> 5;
+    cw_f32x16 acc[9];
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[tp][i] = 0.f;
+    // this lane's piece of the [4 pixels][16 channels] blocks: pixel 8 kb + a16 / 4 (+ 4 for the second read), channel quad a16 % 4 of
+    // channels 32 half + 16 g16 ..
+    const unsigned la = (8 * kb + (a16 >> 2)) * W2_PB + (32 * cih + 16 * g16) * 2 + (a16 & 3) * 8;
+    const unsigned lb = 2 * W2_XIMG + (8 * kb + (a16 >> 2)) * W2_PB + (32 * coh + 16 * g16) * 2 + (a16 & 3) * 8;
+    __syncthreads();                                                          // tile s_beg staged
+    for (unsigned s = s_beg; s < s_end; ++s) {
+        const char* buf = w2_smem + ((s - s_beg) & 1) * W2_BUF;
+        const char* pa = buf + la;
+        const char* pb = buf + lb;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                                         // tile row r = 16 pixels of contraction
+            const cw_bf16x8 bh = w2_tr(pb, r * 16 * W2_PB), bl = w2_tr(pb, r * 16 * W2_PB + W2_DIMG);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                cw_bf16x8 ah[3], al[3];
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    ah[kx] = w2_tr(pa, ((r + ky) * 18 + kx) * W2_PB);
+                    al[kx] = w2_tr(pa, ((r + ky) * 18 + kx) * W2_PB + W2_XIMG);
+                }
+                // D[ci][co] += x^T[ci][pixel] dy[pixel][co]; the three MFMAs of an accumulator are three issues apart
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kx], bh, acc[ky * 3 + kx], 0, 0, 0);
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kx], bl, acc[ky * 3 + kx], 0, 0, 0);
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[kx], bh, acc[ky * 3 + kx], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                                      // next tile staged; everyone has left this tile's images
+    }
+    __syncthreads();                                                          // (the staging waves' bias-gradient hand-over)
+    // ---- partial[blockIdx.x][tap * Cin + ci][Cout]: accumulator register 4 q + e of lane (j = lane & 31, kb) = row ci = 8 q + 4 kb + e, column
+    // co = j of the quadrant; transposed through a wave-private LDS tile [32 ci][36] and stored as 128-byte rows, 8 rows per instruction ----
+    float* P = p.part + (long)blockIdx.x * 9 * p.Cin * p.Cout;
+    float* T = reinterpret_cast<float*>(w2_smem) + wave * (32 * 36);
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) T[((v & 3) + 8 * (v >> 2) + 4 * kb) * 36 + (lane & 31)] = acc[tp][v];
+        wave_lds_sync();
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            const int row = (lane >> 3) + 8 * qd, cq4 = lane & 7;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(T + row * 36 + 4 * cq4);
+            *reinterpret_cast<f32x4*>(P + ((long)tp * p.Cin + ci0 + 32 * cih + row) * p.Cout + co0 + 32 * coh + 4 * cq4) = v;
+        }
+        wave_lds_sync();
+    }
+}
+static int conv3_wgrad_sb_generation = 2;                 // A/B hook (tatt_conv3_wgrad_sb_generation): 1 = the row-segment kernel of rounds 3-5
+TATT_API int tatt_conv3_wgrad_sb_generation(int gen) {
+    const int old = conv3_wgrad_sb_generation;
+    if (gen == 1 || gen == 2) conv3_wgrad_sb_generation = gen;
+    return old;
+}
+
 // same contract as tatt_conv3_c64_wgrad_partial (conv3.hip): partials part[G][9*Cin][Cout] (+ pdb[G][Cout]) for the split-K reducer
 TATT_API int tatt_conv3_c64_wgrad_partial_sb(const float* x, const float* dy, float* part, float* pdb, int B, int H, int W,
                                              int Cin, int Cout, int G, hipStream_t st) {
-    if (Cin % 64 || Cout % 64 || W % CW_PX) return 1;
+    if (Cin % 64 || Cout % 64 || W % 16) return 1;
+    const long maxb = (long)B * H * W * (Cin > Cout ? Cin : Cout) * 4;       // (32-bit buffer offsets)
+    if (conv3_wgrad_sb_generation == 2 && H % 4 == 0 && maxb < 0x7fffffffL) {
+        const int ntile = B * (H / 4) * (W / 16);
+        Conv3WSP p2 = {x, dy, part, B, H, W, Cin, Cout, ntile, pdb};
+        static TattPerDevice attr2_once;
+        tatt_per_device(attr2_once, [&] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_wgrad_sb2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W2_LDS);
+        });
+        hipLaunchKernelGGL(conv3_c64_wgrad_sb2_kernel, dim3(G, (Cin / 64) * (Cout / 64)), dim3(512), W2_LDS, st, p2);
+        return LAUNCH_CHECK();
+    }
+    if (W % CW_PX) return 1;
     const int nseg = B * H * (W / CW_PX);
     Conv3WSP p = {x, dy, part, B, H, W, Cin, Cout, nseg, pdb};
     static TattPerDevice attr_once;

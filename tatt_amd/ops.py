@@ -556,9 +556,10 @@ def conv_wgrad(x_bhwc, dy_bhwc, Cout, KH, KW, want_db=False):
     sn, sh, sw, sc = x_bhwc.stride()
     dw = new(x_bhwc, Cout, Cin, KH, KW)
     contig = x_bhwc.is_contiguous() and dy_bhwc.is_contiguous()
-    if contig and KH == 3 and KW == 3 and Cin % 64 == 0 and Cout % 64 == 0 and W % 64 == 0:
-        nseg = B * H * (W // 64)
-        G = min(nseg, max(1, CONV3_WGRAD_GROUPS // ((Cin // 64) * (Cout // 64))))
+    if contig and KH == 3 and KW == 3 and Cin % 64 == 0 and Cout % 64 == 0 and (W % 64 == 0 or (CONV3_WGRAD_SB and H % 4 == 0 and W % 16 == 0)):
+        nseg = B * H * W // 64
+        nblk = (Cin // 64) * (Cout // 64)
+        G = min(nseg, max(1, (CONV3_WGRAD_GROUPS if nblk == 1 else 256) // nblk))     # (several channel blocks: one group per CU together)
         n = G * 9 * Cin * Cout
         part = _split_ws(new(x_bhwc, n + (G * Cout if want_db else 0)))
         db = new(x_bhwc, Cout) if want_db else None

@@ -93,6 +93,18 @@ for _gen in (1, 2, 3):
     timeit("conv3_sb_g%d_dgrad_in2_epbn" % _gen, _g(lambda: ops.conv3_dgrad_bn(xs_, _w64, ys_, _coef, (xs_, _mean, _rstd, _sc, _sh, 2))), _f3, 2 * _b3)
     timeit("conv3_sb_g%d_dgrad_in2" % _gen, _g(lambda: ops.conv3_dgrad_bn(xs_, _w64, ys_, _coef, None)), _f3, 1.5 * _b3)
 timeit("conv3_wgrad_64_64", lambda: ops.conv_wgrad(x64, y64, 64, 3, 3), f33)
+for _gen in (1, 2):
+    for _G in (64, 128, 256):
+        def _wg(_gen=_gen, _G=_G):
+            _LIB.tatt_conv3_wgrad_sb_generation(_gen)
+            old = ops.CONV3_WGRAD_GROUPS
+            ops.CONV3_WGRAD_GROUPS = _G
+            try:
+                ops.conv_wgrad(x64, y64, 64, 3, 3, want_db=True)
+            finally:
+                _LIB.tatt_conv3_wgrad_sb_generation(2)
+                ops.CONV3_WGRAD_GROUPS = old
+        timeit("conv3_wgrad_g%d_G%d" % (_gen, _G), _wg, f33)
 ops.CONV3_WGRAD_SB = False
 timeit("conv3_wgrad_64_64_fp32", lambda: ops.conv_wgrad(x64, y64, 64, 3, 3), f33)
 ops.CONV3_WGRAD_SB = True
