@@ -141,11 +141,12 @@ int tatt_conv3_c64_dgrad_bn_sb(const float* x, const float* x2, const float* in_
                                const float* ep_mean, const float* ep_rstd, const float* ep_gamma, const float* ep_beta,
                                int ep_act, double* stats, hipStream_t st);
 /* Which kernel the two entries above launch, and the filter packing it wants.  tatt_conv3_sb_generation (test / A-B hook; returns the
- * previous setting, other values only query): 3 (default) = 4 x 16-pixel tiles, one wave per SIMD owning 32 output channels over half the
- * contraction, v_mfma_f32_32x32x16_bf16 (round 6); 2 = the same tiles with 16-channel waves and v_mfma_f32_16x16x32_bf16; 1 = the
- * 64-pixel row tiles of rounds 3-5.  Generations 2 / 3 take H % 4 == 0, W % 16 == 0, no output activation, no tanh: everything else
- * runs generation 1 (W % 64 == 0).  tatt_conv3_sb_packing: the tatt_repack_conv_weight mode of the FORWARD filter for a call with these
- * arguments -- 10 (generations 1 / 2) or 14 (generation 3); the data-gradient packing is that + 1. */
+ * previous setting, other values only query): 4 (default) = 4 x 16-pixel tiles, four MFMA waves (one per SIMD, each owning 32 output
+ * channels over half the contraction, v_mfma_f32_32x32x16_bf16) with four staging waves beside them (round 6); 3 = the same without
+ * staging waves (one 512-register wave per SIMD does everything); 1 = the 64-pixel row tiles of rounds 3-5.  Generations 3 / 4 take
+ * H % 4 == 0, W % 16 == 0, no output activation, no tanh: everything else runs generation 1 (W % 64 == 0).  tatt_conv3_sb_packing:
+ * the tatt_repack_conv_weight mode of the FORWARD filter for a call with these arguments -- 10 (generation 1) or 14 (generations
+ * 3 / 4); the data-gradient packing is that + 1. */
 int tatt_conv3_sb_generation(int gen);
 int tatt_conv3_sb_packing(int B, int H, int W, int cin_total, int Cout, int act, int ep_act);
 /* weight-gradient partials part[G][9*Cin][Cout] (G persistent work-groups, G <= B*H*W/64) and, if pdb != NULL, bias-gradient

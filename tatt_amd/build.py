@@ -15,10 +15,13 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libtatt_hip.so")
 SOURCES = ["gemm.hip", "conv3.hip", "conv3w.hip", "conv9.hip", "norm.hip", "elementwise.hip", "gru.hip", "attn.hip", "sattn.hip", "tplayer.hip", "tplayer2.hip", "tokgemm.hip", "gruwgrad.hip", "tps.hip", "loss.hip", "lstm.hip", "ssim.hip", "stnhead.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-ffp-contract=fast"]
+# per-source additions.  conv3.hip: the staging waves of the 3x3 kernels run beside MFMA waves on the same SIMD, and packed fp32 VALU forms
+# (what SLP vectorisation makes of adjacent scalar adds / fmas) take issue time from the matrix pipe (profiles/r06_conv3_sb4_roles.txt)
+EXTRA_FLAGS = {"conv3.hip": ["-fno-slp-vectorize"], "conv3w.hip": ["-fno-slp-vectorize"]}
 
 
-def _digest(paths) -> str:
-    h = hashlib.sha256(" ".join(FLAGS).encode())
+def _digest(paths, extra=()) -> str:
+    h = hashlib.sha256(" ".join(FLAGS + list(extra)).encode())
     for p in paths:
         with open(p, "rb") as f:
             h.update(f.read())
@@ -50,13 +53,13 @@ def build(force: bool = False, verbose: bool = True) -> str:
             for s in SOURCES:
                 src = os.path.join(CSRC, s)
                 obj = os.path.join(objdir, s.replace(".hip", ".o"))
-                digests[s] = _digest([src, common])
+                digests[s] = _digest([src, common], EXTRA_FLAGS.get(s, ()))
                 if force or not os.path.exists(obj) or manifest.get(s) != digests[s]:
                     jobs.append((src, obj))
 
             def cc(job):
                 src, obj = job
-                cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+                cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
                 r = subprocess.run(cmd, capture_output=True, text=True)
                 if r.returncode != 0:
                     raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr))

@@ -426,10 +426,14 @@ struct Conv3SB {
     const float* ep_x; const float* ep_mean; const float* ep_rstd; const float* ep_gamma; const float* ep_beta; int ep_act;   // EPBN
 };
 __device__ __forceinline__ void sb_split(f32x4 v, uint2& hi, uint2& lo) {
+    // scalar arithmetic on purpose (and the file is built with -fno-slp-vectorize): packed fp32 VALU forms (v_pk_add_f32 ...) cost the
+    // MFMA waves beside them issue time (MI355X_MICROARCH.md, "price of one filler beside MFMAs")
     const bf16x2 h0 = __builtin_convertvector((f32x2){v[0], v[1]}, bf16x2), h1 = __builtin_convertvector((f32x2){v[2], v[3]}, bf16x2);
-    const f32x2 r0 = (f32x2){v[0], v[1]} - __builtin_convertvector(h0, f32x2), r1 = (f32x2){v[2], v[3]} - __builtin_convertvector(h1, f32x2);
-    const bf16x2 l0 = __builtin_convertvector(r0, bf16x2), l1 = __builtin_convertvector(r1, bf16x2);
-    hi = make_uint2(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1));
+    const unsigned u0 = __builtin_bit_cast(unsigned, h0), u1 = __builtin_bit_cast(unsigned, h1);
+    const float r0 = v[0] - __builtin_bit_cast(float, u0 << 16), r1 = v[1] - __builtin_bit_cast(float, u0 & 0xffff0000u);
+    const float r2 = v[2] - __builtin_bit_cast(float, u1 << 16), r3 = v[3] - __builtin_bit_cast(float, u1 & 0xffff0000u);
+    const bf16x2 l0 = __builtin_convertvector((f32x2){r0, r1}, bf16x2), l1 = __builtin_convertvector((f32x2){r2, r3}, bf16x2);
+    hi = make_uint2(u0, u1);
     lo = make_uint2(__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1));
 }
 template <bool IN2, bool EPBN>
@@ -586,30 +590,26 @@ __global__ __launch_bounds__(512, 1) void conv3_c64_sb_kernel(Conv3SB q) {
         if (t < 128) p.stats[(long)blockIdx.x * 128 + t] = (double)st_red[0][t >> 6][t & 63] + (double)st_red[1][t >> 6][t & 63];
     }
 }
-// ---- round 6: the same arithmetic on square tiles with the contraction split over the wave pairs --------------------------------------
-// What bound the kernel above (profiles/r06_pmc_conv3_sb_old.txt): every tile's next halo was fetched as SEVEN dependent global-load ->
-// LDS-store round trips spread over its k-steps (one load, waited for one k-step later), the 144-register filter copy was loaded twice
+// ---- round 6: the same arithmetic on square tiles -------------------------------------------------------------------------------------------
+// What bound the kernel above (profiles/r06_pmc_conv3_sb_old_and_g2.txt): every tile's next halo was fetched as SEVEN dependent global-load
+// -> LDS-store round trips spread over its k-steps (one load, waited for one k-step later), the 144-register filter copy was loaded twice
 // per work-group (pixel halves), a one-row tile fetched and transformed (BatchNorm + mish + split) every input pixel three times, and
-// the epilogue left as 4-byte stores.  Here:
+// the epilogue left as 4-byte stores.  Common to the kernels below:
 //   * tile = 4 rows x 16 pixels (halo 6 x 18 = 108 pixels: 1.69 pixels staged per output pixel instead of 3.09);
-//   * wave (kh, cq) owns ALL 64 pixels x 16 output channels over HALF the contraction (input channels 32 kh .. 32 kh + 31 of the nine
-//     taps: 72 filter registers instead of 144, no duplicate filter loads); the two halves of a pair meet through a 32 KB LDS exchange
-//     in front of the tile's only barrier and each finishes two of the four pixel rows -- in the middle of the NEXT tile's k-loop;
-//   * the next tile's halo (and the epilogue's own inputs) are ALL requested at the top of the tile and land in registers under the
-//     MFMAs; they are transformed, split and stored to the other LDS buffer during the last half-steps.  Requests are buffer loads
-//     with 32-bit offsets: the zero padding is the descriptor's out-of-range answer (no divergent branches, no 64-bit address math);
-//   * the MFMA operands are swapped (A = filter, B = activations), so a lane ends up with 4 consecutive output channels of ONE pixel,
-//     and since the half sums travel through LDS anyway the epilogue is re-threaded over them: 16 lanes finish the 256 bytes of one
-//     pixel, a wave stores 1 KB of one map row per instruction (whole cache lines; the same for the BatchNorm-backward map it reads).
-// Same filter packing (modes 10 / 11), same statistics layout, same entry points; geometries with H % 4 != 0 keep the row-tile kernel.
+//   * the contraction is split over wave pairs (kh = input-channel half): half the filter registers per wave, no duplicate filter loads;
+//     the halves meet through an LDS exchange image [kh][pixel][channel] in front of the tile's only barrier;
+//   * the next tile's halo and the epilogue's own inputs are requested a tile ahead with buffer loads (32-bit offsets; the zero padding is
+//     the descriptor's out-of-range answer: no divergent branches, no 64-bit address math) and staged into the other LDS buffer;
+//   * the MFMA operands are swapped (A = filter, B = activations): a lane ends up with consecutive output channels of ONE pixel, and the
+//     epilogue is re-threaded over the exchange image: 16 lanes finish the 256 bytes of one pixel, a wave stores 1 KB of one map row per
+//     instruction (whole cache lines; the same for the BatchNorm-backward map it reads).
+// Same statistics layout, same entry points; geometries with H % 4 != 0 keep the row-tile kernel.
 #define S2_HW 18                                             // halo width (pixels)
 #define S2_NPX (6 * S2_HW)                                   // 108 halo pixels
-#define S2_IMG (S2_NPX * SB_PW)                              // words of one image (hi or lo) of one halo buffer: 4320
 #define S2_XP 68                                             // words per pixel of an exchange image (64 channels + 4: conflict-free 16-byte writes)
 #define S2_XCH (2 * 64 * S2_XP)                              // words of one exchange buffer: [kh 2][pixel 64][S2_XP]: 34,816 B
-#define S2_LDS ((4 * S2_IMG + 2 * S2_XCH) * 4)               // 138,752 B
-#define S2_DEPTH 1                                           // LDS operand reads run this many half-steps ahead of their MFMAs
-#define S2_NIT 4                                             // 16-byte items of the halo per thread (108 x 16 = 1728 <= 4 x 512)
+// instrumentation, off in the product build: S2_STAMP 1 = s_memtime stamps of the generation-3 kernel (tools/conv3_stamps.py),
+// S2_DEBUG 1 = the role switches of the generation-4 kernel (tools/conv3_sweep.py <gens> <mode>; profiles/r06_conv3_sb4_roles.txt)
 #define S2_STAMP 0
 #define S2_DEBUG 0
 #if S2_DEBUG
@@ -629,315 +629,11 @@ __device__ __forceinline__ f32x4 s2_ld(__amdgpu_buffer_rsrc_t rs, unsigned off) 
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
 }
 // INMODE 0: the input as it is; 1: mish(x * in_scale + in_shift); 2: x * in_scale + x2 * in_scale2 + in_shift; 3: x * in_scale + in_shift,
-// through ReLU if in_act says so.  The body between two barriers is ONE basic block (selects, never branches: uniform conditions
-// included), so the side work can be interleaved with the MFMAs; what that cannot express (an output activation, a tanh) runs the
-// row-tile kernel.
-template <int INMODE, bool EPBN>
-__global__ __launch_bounds__(512, 2) void conv3_c64_sb2_kernel(Conv3SB q) {
-    const Conv3P& p = q.c;
-    extern __shared__ __attribute__((aligned(16))) unsigned smem_u[];
-    unsigned* const XCH = smem_u + 4 * S2_IMG;
-    const unsigned t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const unsigned cq = wave & 3, kh = wave >> 2, li = lane & 15, kq = lane >> 4;
-    const unsigned W = p.W, H = p.H, tws = W / 16, ths = H / 4, cob = p.Cout / 64;
-    const unsigned npt = p.B * ths * tws;
-    const unsigned stride = gridDim.x / cob;
-    unsigned cb = blockIdx.x % cob, pt = blockIdx.x / cob;
-    if (gridDim.x % 8 == 0 && 8 % cob == 0 && stride % (8 / cob) == 0) {      // XCD-aware tile order (see conv3_c64_ws_kernel)
-        const unsigned x = blockIdx.x & 7, m = blockIdx.x >> 3, xg = 8 / cob;
-        cb = x % cob;
-        pt = (x / cob) * (stride / xg) + m;
-    }
-    __shared__ float st_red[8][2][64];
-    if (pt >= npt) {
-        if (p.stats && t < 128) p.stats[(long)blockIdx.x * 128 + t] = 0.0;
-        return;
-    }
-#if S2_STAMP
-    unsigned long long* const sbuf = s2_stamp_buf;
-    unsigned long long ts[32];
-#pragma unroll
-    for (int i = 0; i < 32; ++i) ts[i] = 0;
-#endif
-    S2_STAMP_AT(0)
-#if S2_DEBUG
-    if (s2_wrep & 16) return;
-#endif
-#if S2_STAMP
-    ts[30] = wall_clock64();
-#endif
-    const unsigned co0 = cb * 64 + cq * 16 + 4 * kq;         // this lane's 4 consecutive output channels
-    const unsigned npix = p.B * H * W;
-    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, npix * q.cin_total * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_x2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(INMODE == 2 ? q.x2 : p.x), 0, npix * 256, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, npix * p.Cout * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_e = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(EPBN ? q.ep_x : p.y), 0, npix * (EPBN ? 64 : p.Cout) * 4, 0x00020000);
-    // per-channel constants live in LDS (read back 16 bytes at a time where they are used: registers are the scarce resource here)
-    __shared__ __attribute__((aligned(16))) float cst[7][64];   // in_scale, in_shift, in_scale2, ep_mean, ep_rstd, ep_gamma, ep_beta
-    __shared__ __attribute__((aligned(16))) float cbias[64];    // this work-group's 64 output channels
-    const bool in_relu = p.in_act == ACT_RELU;
-    f32x4 st_s = (f32x4){0.f, 0.f, 0.f, 0.f}, st_q = st_s;
-    // halo item k of this thread: 16-byte channel group t & 15 of halo pixel (t >> 4) + 32 k (row-major 6 x 18).  Its byte offset from
-    // the tile's origin pixel and the tile edges at which it falls outside the map (bit 0: top, 1: bottom, 2: left, 3: right; 4: no item)
-    const unsigned xps = q.cin_total * 4, yps = p.Cout * 4, eps_ = EPBN ? 256u : yps;     // bytes per pixel of the maps
-    unsigned boff[S2_NIT];                                   // (the same in x2: IN2 maps hold 64 channels)
-    unsigned edge = 0;
-#pragma unroll
-    for (int k = 0; k < S2_NIT; ++k) {
-        const unsigned pix = (t >> 4) + 32 * k, r = pix / S2_HW, c = pix - r * S2_HW;
-        boff[k] = (unsigned)(((int)r - 1) * (int)W + (int)c - 1) * xps + (q.ci0 + 4 * (t & 15)) * 4;
-        edge |= ((r == 0 ? 1u : 0u) | (r == 5 ? 2u : 0u) | (c == 0 ? 4u : 0u) | (c == S2_HW - 1 ? 8u : 0u) | (pix >= S2_NPX ? 16u : 0u)) << (8 * k);
-    }
-    unsigned* const put0 = smem_u + (t >> 4) * SB_PW + 2 * (t & 15);                    // item k: + 32 k pixels
-    auto decode = [&](unsigned tile, unsigned& org, unsigned& te) {                     // -> origin pixel index, edge mask of the tile
-        const unsigned tw = tile % tws; tile /= tws;
-        const unsigned th = tile % ths, n = tile / ths;
-        org = (n * H + th * 4) * W + tw * 16;
-        te = (th == 0 ? 1u : 0u) | (th == ths - 1 ? 2u : 0u) | (tw == 0 ? 4u : 0u) | (tw == tws - 1 ? 8u : 0u) | 16u;
-    };
-    f32x4 hp[S2_NIT], hp2[S2_NIT];
-#if S2_DEBUG
-    const int dbg = s2_wrep;
-#endif
-    auto halo_issue1 = [&](unsigned org, unsigned te, bool valid, int k) {   // !valid: the request is out of range (no memory traffic)
-#if S2_DEBUG
-        if (dbg & 2) valid = false;
-#endif
-        const unsigned a = (org * xps + boff[k]) | ((((edge >> (8 * k)) & te) != 0) ? S2_OOB : (valid ? 0u : S2_OOB));
-        hp[k] = s2_ld(rs_x, a);
-        if (INMODE == 2) hp2[k] = s2_ld(rs_x2, a);
-    };
-    auto halo_issue = [&](unsigned org, unsigned te, bool valid) {
-#pragma unroll
-        for (int k = 0; k < S2_NIT; ++k) halo_issue1(org, te, valid, k);
-    };
-    auto halo_put = [&](unsigned* dst, unsigned te, int k) {       // transform, split, store item k
-        const bool ok = ((edge >> (8 * k)) & te) == 0;
-        f32x4 v = hp[k];
-        f32x4 isc, ish;
-        if (INMODE != 0) { isc = *reinterpret_cast<const f32x4*>(&cst[0][4 * (t & 15)]); ish = *reinterpret_cast<const f32x4*>(&cst[1][4 * (t & 15)]); }
-        if (INMODE == 2) {
-            const f32x4 isc2 = *reinterpret_cast<const f32x4*>(&cst[2][4 * (t & 15)]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], isc[e], fmaf(hp2[k][e], isc2[e], ish[e]));
-        } else if (INMODE == 1) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = mish_f(fmaf(v[e], isc[e], ish[e]));
-        } else if (INMODE == 3) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float u = fmaf(v[e], isc[e], ish[e]);
-                v[e] = in_relu ? fmaxf(u, 0.f) : u;
-            }
-        }
-        if (INMODE != 0) {                                   // (the zero padding is a padding of the TRANSFORMED map)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
-        }
-        if (k < S2_NIT - 1 || t < S2_NPX * 16 - 512 * (S2_NIT - 1)) {
-            uint2 hi, lo;
-            sb_split(v, hi, lo);
-            unsigned* d = dst + 32 * k * SB_PW;
-            *reinterpret_cast<uint2*>(d) = hi;
-            *reinterpret_cast<uint2*>(d + S2_IMG) = lo;
-        }
-    };
-    // first tile: its halo is requested before anything else (the first HBM round trip is the longest wait of the kernel)
-    unsigned org, te;
-    decode(pt, org, te);
-    halo_issue(org, te, true);
-    if (t < 64) {
-        cbias[t] = p.bias ? p.bias[cb * 64 + t] : 0.f;
-        if (INMODE != 0) { cst[0][t] = p.in_scale[t]; cst[1][t] = p.in_shift[t]; }
-        if (INMODE == 2) cst[2][t] = q.in_scale2[t];
-        if (EPBN) { cst[3][t] = q.ep_mean[t]; cst[4][t] = q.ep_rstd[t]; cst[5][t] = q.ep_gamma[t]; cst[6][t] = q.ep_beta[t]; }
-    }
-    __syncthreads();                                         // constants in place (the staging below reads them)
-#pragma unroll
-    for (int k = 0; k < S2_NIT; ++k) halo_put(put0, te, k);
-    unsigned norg, nte;
-    bool has_next = pt + stride < npt;
-    decode(pt + stride, norg, nte);
-    halo_issue(norg, nte, has_next);
-    __syncthreads();
-    S2_STAMP_AT(1)
-#if S2_DEBUG
-    if (dbg & 32) return;
-#endif
-    // The filter: [tap * 2 + {hi, lo}] = 8 bf16 = input channels 32 kh + 8 kq .. of output channel 16 cq + li.  147 KB per work-group
-    // through a memory pipe that takes ~37 cycles per 1 KB request (measured, profiles/r06_conv3_sb2_stamps.txt): longer than a tile's
-    // MFMAs -- so the first tile's k-loop is peeled and requests each tap's registers two taps ahead of its MFMAs.
-    f32x4 wq[18];
-    const f32x4* const wsrc = reinterpret_cast<const f32x4*>(p.w) + (cb * 4 + cq) * 36 * 64 + lane;
-    auto w_issue = [&](int tap) {
-#if S2_DEBUG
-        if (dbg & 4) { wq[2 * tap] = (f32x4){0.f, 0.f, 0.f, 0.f}; wq[2 * tap + 1] = wq[2 * tap]; return; }
-#endif
-        wq[2 * tap] = wsrc[((tap * 2 + kh) * 2 + 0) * 64];
-        wq[2 * tap + 1] = wsrc[((tap * 2 + kh) * 2 + 1) * 64];
-    };
-    const unsigned bbase = li * SB_PW + 16 * kh + 4 * kq;
-    const bool use_beta = p.beta != 0.f;
-    const bool ep_mish = q.ep_act == ACT_MISH, ep_relu = q.ep_act == ACT_RELU;
-    // One tile's epilogue runs inside the NEXT tile's k-loop (half-step S2_EPI_HS), off the barrier-to-first-MFMA path: the wave's own
-    // half sums (pixel rows 2 kh + {0, 1}) wait in keep[], the partner's in the exchange buffer, the epilogue's inputs are requested at
-    // the end of the tile's own k-loop.
-    f32x4 epx[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // (the first tile's idle epilogue pass multiplies by what is in here)
-    unsigned eorg = 0, ebuf = 0;
-    bool epi_pending = false;
-    // epilogue item e of this thread: channels 4 (t & 15) .. + 3 of tile pixel (t >> 4) + 32 e (row (t >> 8) + 2 e, column (t >> 4) & 15)
-    const unsigned ecol = (t >> 4) & 15, erow = t >> 8, ec4 = 4 * (t & 15);
-    auto epi_request = [&](unsigned org_, int e) {           // (neither an EPBN map nor a beta: out of range, the answer is 0)
-        epx[e] = s2_ld(rs_e, ((org_ + (erow + 2 * e) * W + ecol) * eps_ + (cb * 64 + ec4) * 4) | ((EPBN || use_beta) ? 0u : S2_OOB));
-    };
-    auto epilogue = [&](bool live, int e) {                  // !live (no tile is waiting): nothing is stored, nothing is counted
-#if S2_DEBUG
-        if (dbg & 8) live = false;
-#endif
-        const unsigned* X = XCH + ebuf * S2_XCH + ((t >> 4) + 32 * e) * S2_XP + ec4;
-        const f32x4 bj = *reinterpret_cast<const f32x4*>(&cbias[ec4]);
-        f32x4 ep_mu, ep_rs, ep_g, ep_b;
-        if (EPBN) {                                          // (Cout == 64)
-            ep_mu = *reinterpret_cast<const f32x4*>(&cst[3][ec4]); ep_rs = *reinterpret_cast<const f32x4*>(&cst[4][ec4]);
-            ep_g = *reinterpret_cast<const f32x4*>(&cst[5][ec4]); ep_b = *reinterpret_cast<const f32x4*>(&cst[6][ec4]);
-        }
-        f32x4 v = *reinterpret_cast<const f32x4*>(X) + *reinterpret_cast<const f32x4*>(X + 64 * S2_XP);      // the two halves of the contraction
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            v[r] += bj[r];                                   // (no output activation in this kernel)
-            if (EPBN) {                                      // v = gradient w.r.t. act(bn(ep_x)); Cout == 64
-                const float xh = (epx[e][r] - ep_mu[r]) * ep_rs[r], u = fmaf(ep_g[r], xh, ep_b[r]);
-                const float g = ep_mish ? mish_grad_f(u) : 1.f;
-                v[r] *= ep_relu ? (u > 0.f ? 1.f : 0.f) : g;
-                v[r] = live ? v[r] : 0.f;
-                st_s[r] += v[r]; st_q[r] += v[r] * xh;
-            } else {
-                v[r] = fmaf(p.beta, epx[e][r], v[r]);
-                v[r] = live ? v[r] : 0.f;
-                st_s[r] += v[r]; st_q[r] += v[r] * v[r];
-            }
-        }
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_s2, v), rs_y,
-                                               ((eorg + (erow + 2 * e) * W + ecol) * yps + (cb * 64 + ec4) * 4) | (live ? 0u : S2_OOB), 0, 0);
-    };
-    unsigned xbuf = 0;
-#if S2_STAMP
-    int tix = 0;
-#endif
-    bool had_next = false;
-    auto tile_body = [&](auto first_tag) {
-        constexpr bool FIRST = decltype(first_tag)::value;
-        const unsigned* Xs = smem_u + xbuf * 2 * S2_IMG + bbase;
-        unsigned* putN = put0 + (xbuf ^ 1) * 2 * S2_IMG;
-        f32x4 accM[4], accC[4];                              // hi*hi products; cross products (hi*lo + lo*hi), summed separately
-#pragma unroll
-        for (int m = 0; m < 4; ++m) { accM[m] = (f32x4){0.f, 0.f, 0.f, 0.f}; accC[m] = accM[m]; }
-        f32x4 vb[S2_DEPTH + 1][4];                           // ring: [.][2 (m & 1) + {hi, lo}]; reads of half-step hs + S2_DEPTH are issued before the MFMAs of hs
-        // half-step hs = tap * 2 + mh: pixel rows 2 mh, 2 mh + 1 of the tile against tap (dy, dx) = (tap / 3, tap % 3)
-#define S2_BOFF(hs, m1) (((2 * ((hs) & 1) + (m1) + ((hs) >> 1) / 3) * S2_HW + ((hs) >> 1) % 3) * SB_PW)
-#define S2_LD(hs) vb[(hs) % (S2_DEPTH + 1)][0] = *reinterpret_cast<const f32x4*>(Xs + S2_BOFF(hs, 0)); \
-                  vb[(hs) % (S2_DEPTH + 1)][1] = *reinterpret_cast<const f32x4*>(Xs + S2_BOFF(hs, 0) + S2_IMG); \
-                  vb[(hs) % (S2_DEPTH + 1)][2] = *reinterpret_cast<const f32x4*>(Xs + S2_BOFF(hs, 1)); \
-                  vb[(hs) % (S2_DEPTH + 1)][3] = *reinterpret_cast<const f32x4*>(Xs + S2_BOFF(hs, 1) + S2_IMG);
-        // a half-step that carries side work (the previous tile's epilogue, an item of the next halo): one MFMA, then a slice of it
-#define S2_INTERLEAVE(nvalu) _Pragma("unroll") for (int g_ = 0; g_ < 6; ++g_) { \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, nvalu, 0); }
-#if S2_STAMP
-        { const unsigned long long now = __builtin_amdgcn_s_memtime();
-          if (tix == 0) ts[2] = now; else if (tix == 1) ts[5] = now; else if (tix == 2) ts[8] = now; }
-#endif
-        if (FIRST) { w_issue(0); w_issue(1); w_issue(2); }
-        S2_LD(0)
-        if (S2_DEPTH > 1) { S2_LD(1) }
-        had_next = has_next;
-        unsigned nnorg, nnte;
-        decode(pt + 2 * stride, nnorg, nnte);                // (past the last tile: unused)
-#pragma unroll
-        for (int hs = 0; hs < 18; ++hs) {
-            if (hs + S2_DEPTH < 18) { S2_LD(hs + S2_DEPTH) }
-            if (FIRST && hs % 2 == 0 && hs / 2 + 3 < 9) w_issue(hs / 2 + 3);
-            __builtin_amdgcn_sched_barrier(0);
-            const bf16x8 wh = __builtin_bit_cast(bf16x8, wq[2 * (hs >> 1)]), wl = __builtin_bit_cast(bf16x8, wq[2 * (hs >> 1) + 1]);
-            const int m0 = 2 * (hs & 1), rb = hs % (S2_DEPTH + 1);
-            const bf16x8 b0h = __builtin_bit_cast(bf16x8, vb[rb][0]), b0l = __builtin_bit_cast(bf16x8, vb[rb][1]);
-            const bf16x8 b1h = __builtin_bit_cast(bf16x8, vb[rb][2]), b1l = __builtin_bit_cast(bf16x8, vb[rb][3]);
-#if S2_DEBUG
-            if (!(dbg & 1)) {
-#endif
-            accM[m0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, b0h, accM[m0], 0, 0, 0);
-            accM[m0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, b1h, accM[m0 + 1], 0, 0, 0);
-            accC[m0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, b0h, accC[m0], 0, 0, 0);
-            accC[m0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, b1h, accC[m0 + 1], 0, 0, 0);
-            accC[m0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, b0l, accC[m0], 0, 0, 0);
-            accC[m0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, b1l, accC[m0 + 1], 0, 0, 0);
-#if S2_DEBUG
-            } else { accM[m0][0] += vb[rb][0][0] + vb[rb][1][0]; accM[m0 + 1][0] += vb[rb][2][0] + vb[rb][3][0]; }
-#endif
-            // Side work, one memory instruction per wave every other half-step (the CU's memory pipe takes ~37 cycles per 1 KB request and
-            // a wave that cannot issue stops its MFMAs too -- bunched requests cost 1,900 cycles per tile, profiles/r06_conv3_sb2_ablation.txt):
-            //   hs 1, 5, 9, 13: stage item k of the next tile's halo (requested a tile ago), request that register again for the tile after;
-            //   hs 3, 11: the previous tile's epilogue, one pixel row each (one store);  hs 7, 15: this tile's epilogue inputs.
-            if (hs % 4 == 1) {
-                halo_put(putN, nte, hs / 4);                 // (without a next tile the item is zeros and nobody reads the other buffer)
-                halo_issue1(nnorg, nnte, had_next && pt + 2 * stride < npt, hs / 4);
-                S2_INTERLEAVE(INMODE == 1 ? 14 : 8)
-            }
-            if (hs == 3 || hs == 11) { epilogue(epi_pending, hs == 11); S2_INTERLEAVE(8) }
-            if (hs == 7 || hs == 15) epi_request(org, hs == 15);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#if S2_STAMP
-        { const unsigned long long now = __builtin_amdgcn_s_memtime();
-          if (tix == 0) ts[3] = now; else if (tix == 1) ts[6] = now; else if (tix == 2) ts[9] = now; }
-#endif
-        has_next = had_next && pt + 2 * stride < npt;
-        // the exchange: every wave leaves its half sums as an image [kh][pixel][channel] (epilogue: re-threaded over pixels)
-        {
-            unsigned* xw = XCH + xbuf * S2_XCH + (kh * 64 + li) * S2_XP + cq * 16 + 4 * kq;
-#pragma unroll
-            for (int m = 0; m < 4; ++m) *reinterpret_cast<f32x4*>(xw + 16 * m * S2_XP) = accM[m] + accC[m];
-        }
-        eorg = org; ebuf = xbuf; epi_pending = true;
-#if S2_STAMP
-        { const unsigned long long now = __builtin_amdgcn_s_memtime();
-          if (tix == 0) ts[4] = now; else if (tix == 1) ts[7] = now; else if (tix == 2) ts[10] = now; }
-        ++tix;
-#endif
-        __syncthreads();                                     // exchange + next halo published; everyone has left this tile's k-loop
-        if (had_next) { pt += stride; org = norg; te = nte; norg = nnorg; nte = nnte; xbuf ^= 1; }
-    };
-    tile_body(std::true_type{});
-    while (had_next) tile_body(std::false_type{});
-    S2_STAMP_AT(11)
-    epilogue(true, 0);
-    epilogue(true, 1);
-    S2_STAMP_AT(12)
-#if S2_STAMP
-    ts[31] = wall_clock64();
-    if (lane == 0 && sbuf) {
-#pragma unroll
-        for (int i = 0; i < 32; ++i) sbuf[(blockIdx.x * 8 + wave) * 32 + i] = ts[i];
-    }
-#endif
-    if (p.stats) {                                           // lanes li = 0..15 of a row hold 16 pixels of the same 4 channels
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {                        // lanes l, l + 16, l + 32, l + 48 hold four pixels of the same channels
-            st_s[r] += __shfl_xor(st_s[r], 16, 64); st_s[r] += __shfl_xor(st_s[r], 32, 64);
-            st_q[r] += __shfl_xor(st_q[r], 16, 64); st_q[r] += __shfl_xor(st_q[r], 32, 64);
-        }
-        if (lane < 16) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { st_red[wave][0][ec4 + r] = st_s[r]; st_red[wave][1][ec4 + r] = st_q[r]; }
-        }
-        __syncthreads();
-        if (t < 128) {
-            double a = 0.0;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) a += (double)st_red[w][t >> 6][t & 63];
-            p.stats[(long)blockIdx.x * 128 + t] = a;
-        }
-    }
-}
+// through ReLU if in_act says so.  The staging code is written with selects, never branches (uniform conditions included); what that
+// cannot express (an output activation, a tanh) runs the row-tile kernel.
+// (The first cut of this rebuild -- eight waves of 16 output channels on v_mfma_f32_16x16x32_bf16, everything in every wave -- is in the
+// history of this file (commit "3x3 split-bf16 convolution rebuilt"); its counters, stamps and ablation are profiles/r06_pmc_conv3_sb_old_and_g2.txt,
+// r06_conv3_sb2_stamps.txt, r06_conv3_sb2_ablation.txt.  The kernels below keep its tiles, exchange image and request schedule.)
 // ---- round 6, second cut: one wave per SIMD, 32 output channels per wave, v_mfma_f32_32x32x16_bf16 ----------------------------------------
 // What the ablation of the kernel above showed (profiles/r06_conv3_sb2_ablation.txt, B = 48, graph-captured launches): with every
 // MFMA, global load and store removed the launch still took 10.2 of 15.2 us -- 2.4 us per tile of LDS operand reads (576 16-byte
@@ -1231,11 +927,278 @@ __global__ __launch_bounds__(256, 1) void conv3_c64_sb3_kernel(Conv3SB q) {
         }
     }
 }
-static int conv3_sb_generation = 3;                          // A/B hook (tatt_conv3_sb_generation): 1 = the row-tile kernel of rounds 3-5
+// ---- round 6, third cut: the 32-channel MFMA waves of the kernel above with STAGING WAVES beside them -------------------------------------
+// profiles/r06_conv3_sb2_stamps.txt: the one-wave-per-SIMD kernel above issues 740 instructions per tile per wave (108 MFMA, 304 VALU,
+// 152 SALU, 106 LDS, 15 memory, 56 waits) and needs 5,200 cycles for 3,456 cycles of MFMAs: ONE in-order wave cannot issue the staging
+// arithmetic and feed the matrix pipe.  The weight-gradient kernel (conv3w.hip) showed the way out: a second wave per SIMD that does
+// everything except MFMAs.  Here waves 0-3 are the (coh, kh) MFMA waves -- operand reads and MFMAs only, one accumulator pair (the
+// cross products join the hi*hi sum in the same register, freeing 32 registers: the 256-register budget of two waves per SIMD) -- and
+// waves 4-7 stage the next tile's halo, request the tile after, run the previous tile's epilogue out of the exchange image and count the
+// BatchNorm statistics.  One barrier per tile.  Same images, exchange, filter packing (modes 14 / 15) and results as generation 3 up to
+// the order of fp32 summation.
+template <int INMODE, bool EPBN>
+__global__ __launch_bounds__(512, 2) void conv3_c64_sb4_kernel(Conv3SB q) {
+    const Conv3P& p = q.c;
+    extern __shared__ __attribute__((aligned(16))) unsigned smem_u[];
+    unsigned* const XCH = smem_u + 4 * S3_IMG;
+    const unsigned t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const unsigned W = p.W, H = p.H, tws = W / 16, ths = H / 4, cob = p.Cout / 64;
+    const unsigned npt = p.B * ths * tws;
+    const unsigned stride = gridDim.x / cob;
+    unsigned cb = blockIdx.x % cob, pt = blockIdx.x / cob;
+    if (gridDim.x % 8 == 0 && 8 % cob == 0 && stride % (8 / cob) == 0) {      // XCD-aware tile order (see conv3_c64_ws_kernel)
+        const unsigned x = blockIdx.x & 7, m = blockIdx.x >> 3, xg = 8 / cob;
+        cb = x % cob;
+        pt = (x / cob) * (stride / xg) + m;
+    }
+    __shared__ float st_red[4][2][64];
+    __shared__ __attribute__((aligned(16))) float cst[7][64];   // in_scale, in_shift, in_scale2, ep_mean, ep_rstd, ep_gamma, ep_beta
+    __shared__ __attribute__((aligned(16))) float cbias[64];    // this work-group's 64 output channels
+    if (pt >= npt) {
+        if (p.stats && t < 128) p.stats[(long)blockIdx.x * 128 + t] = 0.0;
+        return;
+    }
+    const unsigned ntile = (npt - pt + stride - 1) / stride;    // tiles of this work-group: pt, pt + stride, ...
+    auto decode = [&](unsigned tile, unsigned& org, unsigned& te) {                     // -> origin pixel index, edge mask of the tile
+        const unsigned tw = tile % tws; tile /= tws;
+        const unsigned th = tile % ths, n = tile / ths;
+        org = (n * H + th * 4) * W + tw * 16;
+        te = (th == 0 ? 1u : 0u) | (th == ths - 1 ? 2u : 0u) | (tw == 0 ? 4u : 0u) | (tw == tws - 1 ? 8u : 0u) | 16u;
+    };
+    if (wave >= 4) {
+        // ------------------------------------------------ staging waves (256 threads) ------------------------------------------------
+        const unsigned h = t - 256;
+        const unsigned npix = p.B * H * W;
+        const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, npix * q.cin_total * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_x2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(INMODE == 2 ? q.x2 : p.x), 0, npix * 256, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, npix * p.Cout * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_e = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(EPBN ? q.ep_x : p.y), 0, npix * (EPBN ? 64 : p.Cout) * 4, 0x00020000);
+        const bool in_relu = p.in_act == ACT_RELU;
+        const unsigned xps = q.cin_total * 4, yps = p.Cout * 4, eps_ = EPBN ? 256u : yps;     // bytes per pixel of the maps
+        unsigned boff[S3_NIT], poff[S3_NIT], edge[2] = {0, 0};
+#pragma unroll
+        for (int k = 0; k < S3_NIT; ++k) {                   // halo item k: 16-byte channel group h & 15 of halo pixel (h >> 4) + 16 k (row-major 6 x 18)
+            const unsigned pix = (h >> 4) + 16 * k, r = pix / S2_HW, c = pix - r * S2_HW;
+            boff[k] = (unsigned)(((int)r - 1) * (int)W + (int)c - 1) * xps + (q.ci0 + 4 * (h & 15)) * 4;
+            poff[k] = r * S3_RP + c * SB_PW + 2 * (h & 15);
+            edge[k >> 2] |= ((r == 0 ? 1u : 0u) | (r == 5 ? 2u : 0u) | (c == 0 ? 4u : 0u) | (c == S2_HW - 1 ? 8u : 0u) | (pix >= S2_NPX ? 16u : 0u)) << (8 * (k & 3));
+        }
+        f32x4 hp[S3_NIT], hp2[S3_NIT];
+        auto halo_issue = [&](unsigned tile, bool valid) {   // !valid: every request is out of range (no memory traffic)
+            unsigned org, te;
+            decode(tile, org, te);
+#if S2_DEBUG
+            if (s2_wrep & 4) valid = false;
+#endif
+#pragma unroll
+            for (int k = 0; k < S3_NIT; ++k) {
+                const unsigned a = (org * xps + boff[k]) | ((((edge[k >> 2] >> (8 * (k & 3))) & te) != 0) ? S2_OOB : (valid ? 0u : S2_OOB));
+                hp[k] = s2_ld(rs_x, a);
+                if (INMODE == 2) hp2[k] = s2_ld(rs_x2, a);
+            }
+        };
+        auto halo_put = [&](unsigned* img, unsigned tile) {  // transform, split, store the seven items of `tile` into the image at `img`
+            unsigned org, te;
+            decode(tile, org, te);
+            f32x4 isc, ish, isc2;
+            if (INMODE != 0) { isc = *reinterpret_cast<const f32x4*>(&cst[0][4 * (h & 15)]); ish = *reinterpret_cast<const f32x4*>(&cst[1][4 * (h & 15)]); }
+            if (INMODE == 2) isc2 = *reinterpret_cast<const f32x4*>(&cst[2][4 * (h & 15)]);
+#pragma unroll
+            for (int k = 0; k < S3_NIT; ++k) {
+                const bool ok = ((edge[k >> 2] >> (8 * (k & 3))) & te) == 0;
+                f32x4 v = hp[k];
+                if (INMODE == 2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], isc[e], fmaf(hp2[k][e], isc2[e], ish[e]));
+                } else if (INMODE == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = mish_f(fmaf(v[e], isc[e], ish[e]));
+                } else if (INMODE == 3) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float u = fmaf(v[e], isc[e], ish[e]);
+                        v[e] = in_relu ? fmaxf(u, 0.f) : u;
+                    }
+                }
+                if (INMODE != 0) {                           // (the zero padding is a padding of the TRANSFORMED map)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
+                }
+                if (k < S3_NIT - 1 || h < S2_NPX * 16 - 256 * (S3_NIT - 1)) {
+                    uint2 hi, lo;
+                    sb_split(v, hi, lo);
+                    unsigned* d = img + poff[k];
+                    *reinterpret_cast<uint2*>(d) = hi;
+                    *reinterpret_cast<uint2*>(d + S3_IMG) = lo;
+                }
+            }
+        };
+        halo_issue(pt, true);                                // (the first HBM round trip is the longest wait of the kernel: requested before anything else)
+        if (h < 64) {
+            cbias[h] = p.bias ? p.bias[cb * 64 + h] : 0.f;
+            if (INMODE != 0) { cst[0][h] = p.in_scale[h]; cst[1][h] = p.in_shift[h]; }
+            if (INMODE == 2) cst[2][h] = q.in_scale2[h];
+            if (EPBN) { cst[3][h] = q.ep_mean[h]; cst[4][h] = q.ep_rstd[h]; cst[5][h] = q.ep_gamma[h]; cst[6][h] = q.ep_beta[h]; }
+        }
+        __syncthreads();                                     // #1: constants in place
+        halo_put(smem_u, pt);
+        halo_issue(pt + stride, ntile > 1);
+        __syncthreads();                                     // #2: tile 0 staged
+        // epilogue item e of this thread: channels 4 (h & 15) .. + 3 of tile pixel (h >> 4) + 16 e (row e, column h >> 4)
+        const bool use_beta = p.beta != 0.f;
+        const bool ep_mish = q.ep_act == ACT_MISH, ep_relu = q.ep_act == ACT_RELU;
+        const unsigned ecol = h >> 4, ec4 = 4 * (h & 15);
+        f32x4 epx[S3_NEP], st_s = (f32x4){0.f, 0.f, 0.f, 0.f}, st_q = st_s;
+        auto epi_request = [&](unsigned tile) {              // (neither an EPBN map nor a beta: out of range, the answer is 0)
+            unsigned org, te;
+            decode(tile, org, te);
+#pragma unroll
+            for (int e = 0; e < S3_NEP; ++e)
+                epx[e] = s2_ld(rs_e, ((org + e * W + ecol) * eps_ + (cb * 64 + ec4) * 4) | ((EPBN || use_beta) ? 0u : S2_OOB));
+        };
+        auto epilogue = [&](unsigned tile, unsigned xb) {
+            unsigned org, te;
+            decode(tile, org, te);
+            const f32x4 bj = *reinterpret_cast<const f32x4*>(&cbias[ec4]);
+            f32x4 ep_mu, ep_rs, ep_g, ep_b;
+            if (EPBN) {                                      // (Cout == 64)
+                ep_mu = *reinterpret_cast<const f32x4*>(&cst[3][ec4]); ep_rs = *reinterpret_cast<const f32x4*>(&cst[4][ec4]);
+                ep_g = *reinterpret_cast<const f32x4*>(&cst[5][ec4]); ep_b = *reinterpret_cast<const f32x4*>(&cst[6][ec4]);
+            }
+#pragma unroll
+            for (int e = 0; e < S3_NEP; ++e) {
+                const unsigned* X = XCH + xb * S2_XCH + ((h >> 4) + 16 * e) * S2_XP + ec4;
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(X), v1 = *reinterpret_cast<const f32x4*>(X + 64 * S2_XP);   // the two halves of the contraction
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = (v0[r] + v1[r]) + bj[r];          // (no output activation in this kernel)
+                    if (EPBN) {                              // v = gradient w.r.t. act(bn(ep_x)); Cout == 64
+                        const float xh = (epx[e][r] - ep_mu[r]) * ep_rs[r], u = fmaf(ep_g[r], xh, ep_b[r]);
+                        const float g = ep_mish ? mish_grad_f(u) : 1.f;
+                        v[r] *= ep_relu ? (u > 0.f ? 1.f : 0.f) : g;
+                        st_s[r] += v[r]; st_q[r] += v[r] * xh;
+                    } else {
+                        v[r] = fmaf(p.beta, epx[e][r], v[r]);
+                        st_s[r] += v[r]; st_q[r] += v[r] * v[r];
+                    }
+                }
+#if S2_DEBUG
+                if (s2_wrep & 8) continue;
+#endif
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_s2, v), rs_y, (org + e * W + ecol) * yps + (cb * 64 + ec4) * 4, 0, 0);
+            }
+        };
+        for (unsigned i = 0; i < ntile; ++i) {
+            // beside the MFMAs of tile i: finish tile i - 1, stage tile i + 1 (requested a tile ago), request tile i + 2 and tile i's epilogue inputs
+            const unsigned tile = pt + i * stride;
+#if S2_DEBUG
+            if (s2_wrep & 1) { __syncthreads(); continue; }
+#endif
+#if S2_DEBUG
+            if (!(s2_wrep & 32))
+#endif
+            if (i > 0) epilogue(tile - stride, (i - 1) & 1);
+#if S2_DEBUG
+            if (!(s2_wrep & 16))
+#endif
+            if (i + 1 < ntile) halo_put(smem_u + ((i + 1) & 1) * 2 * S3_IMG, tile + stride);
+            halo_issue(tile + 2 * stride, i + 2 < ntile);
+            epi_request(tile);
+            __syncthreads();                                 // tile i's exchange image written; tile i + 1 staged
+        }
+        epilogue(pt + (ntile - 1) * stride, (ntile - 1) & 1);
+        if (p.stats) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {                    // lanes l, l + 16, l + 32, l + 48 hold four pixels of the same channels
+                st_s[r] += __shfl_xor(st_s[r], 16, 64); st_s[r] += __shfl_xor(st_s[r], 32, 64);
+                st_q[r] += __shfl_xor(st_q[r], 16, 64); st_q[r] += __shfl_xor(st_q[r], 32, 64);
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { st_red[wave - 4][0][ec4 + r] = st_s[r]; st_red[wave - 4][1][ec4 + r] = st_q[r]; }
+            }
+        }
+        __syncthreads();                                     // (last: the statistics of the four staging waves)
+        if (p.stats && h < 128) {
+            double a = 0.0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) a += (double)st_red[w][h >> 6][h & 63];
+            p.stats[(long)blockIdx.x * 128 + h] = a;
+        }
+        return;
+    }
+    // ------------------------------------------------------ MFMA waves (coh, kh) ------------------------------------------------------
+    const unsigned coh = wave & 1, kh = wave >> 1, lj = lane & 31, kb = lane >> 5;
+    // The filter: [(tap * 2 + s) * 2 + {hi, lo}] = 8 bf16 = input channels 32 kh + 16 s + 8 kb .. of output channel 32 coh + lj (mode 14 / 15
+    // packing); requested at once, consumed tap by tap as it arrives (the first tile is paced by it: 147 KB per work-group at ~27 B/clk)
+    f32x4 wq[36];
+    {
+        const f32x4* const wsrc = reinterpret_cast<const f32x4*>(p.w) + (cb * 2 + coh) * 72 * 64 + lane;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int f = 0; f < 4; ++f) wq[4 * tap + f] = wsrc[((tap * 2 + kh) * 4 + f) * 64];
+    }
+    const unsigned bbase = (lj >> 4) * S3_RP + (lj & 15) * SB_PW + 16 * kh + 4 * kb;
+    __syncthreads();                                         // #1
+    __syncthreads();                                         // #2: tile 0 staged
+    for (unsigned i = 0; i < ntile; ++i) {
+#if S2_DEBUG
+        if (s2_wrep & 2) { __syncthreads(); continue; }
+#endif
+        const unsigned* Xs = smem_u + (i & 1) * 2 * S3_IMG + bbase;
+        f32x16_s3 acc[2];                                    // [pixel rows 2 p, 2 p + 1]: hi*hi and the cross products in one sum
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[pp][v] = 0.f;
+        f32x4 vb[2][4];                                      // ring: [.][2 p + {hi, lo}]; reads of step st + 1 are issued before the MFMAs of st
+        S3_LD(0)                                             // (two steps ahead measured the same: profiles/r06_conv3_sb4_roles.txt)
+#pragma unroll
+        for (int st = 0; st < 18; ++st) {
+            if (st + 1 < 18) { S3_LD(st + 1) }
+            __builtin_amdgcn_sched_barrier(0);
+            const bf16x8 wh = __builtin_bit_cast(bf16x8, wq[2 * st]), wl = __builtin_bit_cast(bf16x8, wq[2 * st + 1]);
+            const bf16x8 b0h = __builtin_bit_cast(bf16x8, vb[st % 2][0]), b0l = __builtin_bit_cast(bf16x8, vb[st % 2][1]);
+            const bf16x8 b1h = __builtin_bit_cast(bf16x8, vb[st % 2][2]), b1l = __builtin_bit_cast(bf16x8, vb[st % 2][3]);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, b0h, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, b1h, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, b0h, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, b1h, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, b0l, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, b1l, acc[1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // the exchange: every MFMA wave leaves its half sums as an image [kh][pixel][channel] for the staging waves' epilogue.
+        // 32x32 accumulator: register 4 g + r of lane (lj, kb) = output channel 32 coh + 8 g + 4 kb + r of pixel 32 p + lj
+        unsigned* xw = XCH + (i & 1) * S2_XCH + (kh * 64 + lj) * S2_XP + 32 * coh + 4 * kb;
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = acc[pp][4 * g + r];
+                *reinterpret_cast<f32x4*>(xw + 32 * pp * S2_XP + 8 * g) = v;
+            }
+        __syncthreads();
+    }
+    __syncthreads();                                         // (last: the staging waves' statistics hand-over)
+}
+static int conv3_sb_generation = 4;                          // A/B hook (tatt_conv3_sb_generation): 1 = the row-tile kernel of rounds 3-5
 TATT_API int tatt_conv3_sb_generation(int gen) {
     const int old = conv3_sb_generation;
-    if (gen >= 1 && gen <= 3) conv3_sb_generation = gen;
+    if (gen == 1 || gen == 3 || gen == 4) conv3_sb_generation = gen;
     return old;
+}
+template <int INMODE, bool EPBN>
+static void conv3_sb4_go(const Conv3SB& q, dim3 grid, hipStream_t st) {
+    static TattPerDevice attr_once;
+    tatt_per_device(attr_once, [&] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_sb4_kernel<INMODE, EPBN>), hipFuncAttributeMaxDynamicSharedMemorySize, S3_LDS);
+    });
+    hipLaunchKernelGGL((conv3_c64_sb4_kernel<INMODE, EPBN>), grid, dim3(512), S3_LDS, st, q);
 }
 template <int INMODE, bool EPBN>
 static void conv3_sb3_go(const Conv3SB& q, dim3 grid, hipStream_t st) {
@@ -1245,37 +1208,33 @@ static void conv3_sb3_go(const Conv3SB& q, dim3 grid, hipStream_t st) {
     });
     hipLaunchKernelGGL((conv3_c64_sb3_kernel<INMODE, EPBN>), grid, dim3(256), S3_LDS, st, q);
 }
-template <int INMODE, bool EPBN>
-static void conv3_sb2_go(const Conv3SB& q, dim3 grid, hipStream_t st) {
-    static TattPerDevice attr_once;
-    tatt_per_device(attr_once, [&] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_sb2_kernel<INMODE, EPBN>), hipFuncAttributeMaxDynamicSharedMemorySize, S2_LDS);
-    });
-    hipLaunchKernelGGL((conv3_c64_sb2_kernel<INMODE, EPBN>), grid, dim3(512), S2_LDS, st, q);
-}
-// Split-bf16 3x3 convolution (see the kernels): x holds cin_total >= 64 channels per pixel, the 64-channel slice starting at ci0 is
-// contracted; wl = the matching 64-input-channel chunk of the filter from tatt_repack_conv_weight mode 10 (forward) / mode 11 (data
-// gradient): chunk c of a mode-10/11 buffer starts c * Cout * 576 words in.  BatchNorm folding arguments as tatt_conv3_c64_fwd_ws16_bn.
-// which kernel a geometry runs: 1 = row tiles (filter packing modes 10 / 11), 2 = square tiles, 16-channel waves (10 / 11), 3 = square
-// tiles, 32-channel waves (14 / 15)
+// which kernel a geometry runs: 1 = row tiles (filter packing modes 10 / 11), 3 = square tiles, 32-channel waves (14 / 15), 4 = 3 with
+// staging waves beside the MFMA waves (14 / 15)
 static int conv3_sb_pick(int B, int H, int W, int cin_total, int Cout, int act, int ep_act) {
     const long maxb = (long)B * H * W * (cin_total > Cout ? cin_total : Cout) * 4;       // 32-bit buffer offsets
     const bool acts_ok = act == ACT_NONE && ep_act != ACT_TANH;              // (what the square-tile kernels evaluate without branches)
-    return (conv3_sb_generation >= 2 && H % 4 == 0 && W % 16 == 0 && maxb < 0x7fffffffL && acts_ok) ? conv3_sb_generation : 1;
+    return (conv3_sb_generation >= 3 && H % 4 == 0 && W % 16 == 0 && maxb < 0x7fffffffL && acts_ok) ? conv3_sb_generation : 1;
 }
 TATT_API int tatt_conv3_sb_packing(int B, int H, int W, int cin_total, int Cout, int act, int ep_act) {
-    return conv3_sb_pick(B, H, W, cin_total, Cout, act, ep_act) == 3 ? 14 : 10;
+    return conv3_sb_pick(B, H, W, cin_total, Cout, act, ep_act) >= 3 ? 14 : 10;
 }
 static int conv3_sb_launch(const Conv3SB& q, hipStream_t st) {
     const Conv3P& p = q.c;
     const int pick = conv3_sb_pick(p.B, p.H, p.W, q.cin_total, p.Cout, p.act, q.ep_act);
-    if (pick >= 2) {
+    if (pick >= 3) {
         const int cob = p.Cout / 64, npt = p.B * (p.H / 4) * (p.W / 16);
         int per = 256 / cob;
         if (per > npt) per = npt;
         const dim3 grid(per * cob);
         const bool ep = q.ep_x != nullptr;
         const int inmode = q.x2 ? 2 : (p.in_scale ? (p.in_act == ACT_MISH ? 1 : 3) : 0);
+        if (pick == 4) {                                     // (filter packing: modes 14 / 15)
+            if (inmode == 2) { if (ep) conv3_sb4_go<2, true>(q, grid, st); else conv3_sb4_go<2, false>(q, grid, st); }
+            else if (inmode == 1) { if (ep) conv3_sb4_go<1, true>(q, grid, st); else conv3_sb4_go<1, false>(q, grid, st); }
+            else if (inmode == 3) { if (ep) conv3_sb4_go<3, true>(q, grid, st); else conv3_sb4_go<3, false>(q, grid, st); }
+            else { if (ep) conv3_sb4_go<0, true>(q, grid, st); else conv3_sb4_go<0, false>(q, grid, st); }
+            return LAUNCH_CHECK();
+        }
         if (pick == 3) {                                     // (filter packing: modes 14 / 15)
             if (inmode == 2) { if (ep) conv3_sb3_go<2, true>(q, grid, st); else conv3_sb3_go<2, false>(q, grid, st); }
             else if (inmode == 1) { if (ep) conv3_sb3_go<1, true>(q, grid, st); else conv3_sb3_go<1, false>(q, grid, st); }
@@ -1283,10 +1242,6 @@ static int conv3_sb_launch(const Conv3SB& q, hipStream_t st) {
             else { if (ep) conv3_sb3_go<0, true>(q, grid, st); else conv3_sb3_go<0, false>(q, grid, st); }
             return LAUNCH_CHECK();
         }
-        if (inmode == 2) { if (ep) conv3_sb2_go<2, true>(q, grid, st); else conv3_sb2_go<2, false>(q, grid, st); }
-        else if (inmode == 1) { if (ep) conv3_sb2_go<1, true>(q, grid, st); else conv3_sb2_go<1, false>(q, grid, st); }
-        else if (inmode == 3) { if (ep) conv3_sb2_go<3, true>(q, grid, st); else conv3_sb2_go<3, false>(q, grid, st); }
-        else { if (ep) conv3_sb2_go<0, true>(q, grid, st); else conv3_sb2_go<0, false>(q, grid, st); }
         return LAUNCH_CHECK();
     }
     if (p.W % C3_PX) return 1;                               // the row-tile kernel walks 64-pixel row segments

@@ -429,6 +429,7 @@ _WS_ENTRY, _WS_FWD_MODE, _WS_DGRAD_MODE = "tatt_conv3_c64_fwd_ws16", 6, 7
 # bf16 products per fp32 product, fp32 accumulation; measured effect on SR 1e-6, profiles/r03_split_bf16_probe.txt).  Test / A-B hook:
 # False -> the exact-fp32 MFMA kernels.
 CONV3_SB = True
+CONV3_SB_GENERATION = 4        # test / A-B hook: which split-bf16 3x3 forward / data-gradient kernel runs (tatt_conv3_sb_generation)
 
 
 def _conv3_sb(x_bhwc, w_oihw, mode, bias, act=ACT_NONE, in_scale=None, in_shift=None, in_act=ACT_NONE, stats=None):
@@ -437,6 +438,8 @@ def _conv3_sb(x_bhwc, w_oihw, mode, bias, act=ACT_NONE, in_scale=None, in_shift=
     B, H, W, cin = x_bhwc.shape
     cout = w_oihw.shape[0] if mode == 10 else w_oihw.shape[1]
     assert cin == (w_oihw.shape[1] if mode == 10 else w_oihw.shape[0])
+    if LIB.tatt_conv3_sb_generation(0) != CONV3_SB_GENERATION:
+        LIB.tatt_conv3_sb_generation(int(CONV3_SB_GENERATION))
     wl = repack_weight(w_oihw, LIB.tatt_conv3_sb_packing(B, H, W, cin, cout, int(act), ACT_NONE) + (mode - 10))
     y = new(x_bhwc, B, H, W, cout)
     nchunk = cin // 64
@@ -664,6 +667,8 @@ def conv3_dgrad_bn(du_bhwc, weight_oihw, x2_bhwc=None, coef=None, ep=None):
     multiplied by act'(bn(y_below)) and the stage-1 partials of that BatchNorm's backward come back -> (out, part or None, G)."""
     _check_dev(du_bhwc)
     B, H, W, _ = du_bhwc.shape
+    if LIB.tatt_conv3_sb_generation(0) != CONV3_SB_GENERATION:
+        LIB.tatt_conv3_sb_generation(int(CONV3_SB_GENERATION))
     wl = repack_weight(weight_oihw, LIB.tatt_conv3_sb_packing(B, H, W, 64, 64, ACT_NONE, int(ep[5]) if ep is not None else ACT_NONE) + 1)
     out = new(du_bhwc, B, H, W, 64)
     G = min(256, B * H * W // 64)

@@ -1035,9 +1035,10 @@ def test_conv3_split_bf16_bn_folding(dev):
 
 @pytest.mark.parametrize("B,H,W", [(3, 16, 64), (2, 32, 128), (1, 4, 16), (5, 8, 48), (2, 4, 64)])
 def test_conv3_split_bf16_square_tiles_vs_fp64_and_row_tiles(dev, B, H, W):
-    """Round 6's 4 x 16-pixel-tile kernels (tatt_conv3_sb_generation 3: 32-channel waves on v_mfma_f32_32x32x16_bf16, filter packing 14 / 15;
-    2: 16-channel waves; both: contraction split over wave pairs, LDS exchange, swapped MFMA operands, buffer-descriptor padding,
-    epilogue re-threaded over pixels) against fp64 AND against the row-tile kernel of rounds 3-5 on every variant the model runs:
+    """Round 6's 4 x 16-pixel-tile kernels (tatt_conv3_sb_generation 4: 32-channel MFMA waves on v_mfma_f32_32x32x16_bf16 with staging
+    waves beside them, filter packing 14 / 15; 3: the same without staging waves; both: contraction split over wave pairs, LDS
+    exchange, swapped MFMA operands, buffer-descriptor padding, epilogue re-threaded over pixels) against fp64 AND against the
+    row-tile kernel of rounds 3-5 on every variant the model runs:
     plain / bias + activation epilogue, Cout = 256, a 64-channel slice of a 256-channel input with beta = 1, BatchNorm + mish folded
     into the staging with output statistics, and the data gradient with the BatchNorm backward folded in on both sides.  Geometries:
     the benchmark's, the large tile, a single tile (every halo side is padding), a ragged tile count, one tile row."""
@@ -1064,9 +1065,9 @@ def test_conv3_split_bf16_square_tiles_vs_fp64_and_row_tiles(dev, B, H, W):
         "dgrad_in2": dconv(gin, w),
     }
     got = {}
-    gens = (3, 2, 1) if W % 64 == 0 else (3, 2)                         # (the row-tile kernel walks 64-pixel segments)
+    gens = (4, 3, 1) if W % 64 == 0 else (4, 3)                         # (the row-tile kernel walks 64-pixel segments)
     for gen in gens:
-        assert LIB.tatt_conv3_sb_generation(gen) in (1, 2, 3)
+        assert LIB.tatt_conv3_sb_generation(gen) in (1, 3, 4)
         try:
             o = {}
             o["plain"] = ops.conv2d_forward(d(x), d(w), d(b))
@@ -1080,7 +1081,7 @@ def test_conv3_split_bf16_square_tiles_vs_fp64_and_row_tiles(dev, B, H, W):
             o["dgrad_in2"] = ops.conv3_dgrad_bn(d(x), d(w), d(x2), d(coef), None)[0]
             got[gen] = {k: v.cpu().double() for k, v in o.items()}
         finally:
-            LIB.tatt_conv3_sb_generation(3)
+            LIB.tatt_conv3_sb_generation(4)
     for k, r in ref.items():
         for gen in gens:
             err = float((got[gen][k] - r).abs().max() / r.abs().max())

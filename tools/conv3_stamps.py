@@ -1,9 +1,13 @@
+"""s_memtime stamps of conv3_c64_sb3_kernel (B = 48, 16x64, 64 -> 64 channels): build csrc/conv3.hip with S2_STAMP 1 first.
+Output of the round-6 session: profiles/r06_conv3_sb2_stamps.txt."""
 import sys, os, ctypes
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
 from tatt_amd import ops
 from tatt_amd._lib import LIB
 dev = torch.device("cuda:0")
+LIB.load()
+LIB.tatt_conv3_sb_generation(3)        # the stamps live in the one-wave-per-SIMD kernel (build with S2_STAMP 1 in csrc/conv3.hip)
 B = 48
 x = torch.randn(B, 16, 64, 64, device=dev); w = torch.randn(64, 64, 3, 3, device=dev) * 0.05; b = torch.randn(64, device=dev)
 y = torch.empty_like(x)
