@@ -410,10 +410,14 @@ def conv_partials(x_bhwc, wpacked, Cout, KH, KW):
     return ws, int(got.value)
 
 
+CONV3_SB_NARROW_MAPS = False    # True: maps with H % 4 == 0, W % 16 == 0 (not only W % 64 == 0) take the split-bf16 3x3 kernels too.  Off: the
+                                # only such maps of the models are the STN head's, whose operator-chain path stays on exact-fp32 products
+
+
 def _conv3_geom_ok(x_bhwc):
-    """map sizes the 3x3 64-channel kernels tile: 64-pixel row segments, or (split-bf16 kernel, round 6) 4 x 16-pixel tiles"""
+    """map sizes the 3x3 64-channel kernels tile: 64-pixel row segments, or (split-bf16 kernels of round 6, on request) 4 x 16-pixel tiles"""
     H, W = x_bhwc.shape[1], x_bhwc.shape[2]
-    return W % 64 == 0 or (CONV3_SB and H % 4 == 0 and W % 16 == 0)
+    return W % 64 == 0 or (CONV3_SB and CONV3_SB_NARROW_MAPS and H % 4 == 0 and W % 16 == 0)
 
 
 def _conv3_fast_ok(x_bhwc, Cin, Cout, KH, KW):
@@ -559,7 +563,7 @@ def conv_wgrad(x_bhwc, dy_bhwc, Cout, KH, KW, want_db=False):
     sn, sh, sw, sc = x_bhwc.stride()
     dw = new(x_bhwc, Cout, Cin, KH, KW)
     contig = x_bhwc.is_contiguous() and dy_bhwc.is_contiguous()
-    if contig and KH == 3 and KW == 3 and Cin % 64 == 0 and Cout % 64 == 0 and (W % 64 == 0 or (CONV3_WGRAD_SB and H % 4 == 0 and W % 16 == 0)):
+    if contig and KH == 3 and KW == 3 and Cin % 64 == 0 and Cout % 64 == 0 and (W % 64 == 0 or (CONV3_WGRAD_SB and CONV3_SB_NARROW_MAPS and H % 4 == 0 and W % 16 == 0)):
         nseg = B * H * W // 64
         nblk = (Cin // 64) * (Cout // 64)
         G = min(nseg, max(1, (CONV3_WGRAD_GROUPS if nblk == 1 else 256) // nblk))     # (several channel blocks: one group per CU together)

@@ -1066,8 +1066,9 @@ def test_conv3_split_bf16_square_tiles_vs_fp64_and_row_tiles(dev, B, H, W):
     }
     got = {}
     gens = (4, 3, 1) if W % 64 == 0 else (4, 3)                         # (the row-tile kernel walks 64-pixel segments)
+    ops.CONV3_SB_NARROW_MAPS = True                                     # (the W = 16 / 48 cases; off in the product: ops.py)
     for gen in gens:
-        assert LIB.tatt_conv3_sb_generation(gen) in (1, 3, 4)
+        ops.CONV3_SB_GENERATION = gen
         try:
             o = {}
             o["plain"] = ops.conv2d_forward(d(x), d(w), d(b))
@@ -1081,7 +1082,9 @@ def test_conv3_split_bf16_square_tiles_vs_fp64_and_row_tiles(dev, B, H, W):
             o["dgrad_in2"] = ops.conv3_dgrad_bn(d(x), d(w), d(x2), d(coef), None)[0]
             got[gen] = {k: v.cpu().double() for k, v in o.items()}
         finally:
-            LIB.tatt_conv3_sb_generation(4)
+            ops.CONV3_SB_GENERATION = 4
+            if gen == gens[-1]:
+                ops.CONV3_SB_NARROW_MAPS = False
     for k, r in ref.items():
         for gen in gens:
             err = float((got[gen][k] - r).abs().max() / r.abs().max())
@@ -1240,10 +1243,12 @@ def test_conv3_wgrad_split_bf16_vs_fp64(dev, B, H, W, Cin, Cout, gen):
     if gen == 1 and W % 64:
         pytest.skip("the row-segment kernel walks 64-pixel segments")
     LIB.tatt_conv3_wgrad_sb_generation(gen)
+    ops.CONV3_SB_NARROW_MAPS = True
     try:
         _conv3_wgrad_case(dev, B, H, W, Cin, Cout)
     finally:
         LIB.tatt_conv3_wgrad_sb_generation(2)
+        ops.CONV3_SB_NARROW_MAPS = False
 
 
 def _conv3_wgrad_case(dev, B, H, W, Cin, Cout):

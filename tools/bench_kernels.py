@@ -81,10 +81,12 @@ for _gen in (1, 3, 4):
     def _g(fn, _gen=_gen):
         def run():
             _LIB.tatt_conv3_sb_generation(_gen)
+            ops.CONV3_SB_GENERATION = _gen
             try:
                 fn()
             finally:
                 _LIB.tatt_conv3_sb_generation(4)
+                ops.CONV3_SB_GENERATION = 4
         return run
     timeit("conv3_sb_g%d_plain" % _gen, _g(lambda _gen=_gen: ops.call("tatt_conv3_c64_fwd_sb", ops.P(xs_), 64, 0, ops.P(_wsb_gen[_gen]), ops.P(b64), ops.P(ys_), B, a.H, a.W, 64, 0, 0.0,
                                                                 None, None, 0, None, ops.stream())), _f3, _b3)
