@@ -22,9 +22,9 @@ SR_TOL = 1e-3
 SR_TRAIN_TOL = 5e-5
 
 
-def build(cls, dev, randomize=True, **kw):
+def build(cls, dev, randomize=True, seed=1234, **kw):
     import tatt_amd
-    torch.manual_seed(1234)
+    torch.manual_seed(seed)
     m = getattr(tatt_amd, cls)(**kw)
     if randomize:
         m.load_state_dict(randomize_state_dict(m.state_dict()))
@@ -330,16 +330,16 @@ def _flat_state(m, tr):
             "nbt": torch.stack([v.reshape(()) for k, v in sd.items() if k.endswith("num_batches_tracked")])}
 
 
-def _run_steps(dev, nsteps, B, dropout, stn=True, **trainer_kw):
+def _run_steps(dev, nsteps, B, dropout, stn=True, model_seed=1234, **trainer_kw):
     from tatt_amd import functional as Fh
     from tatt_amd.train import Trainer
-    m = build("TSRN_TL_TRANS", dev, **dict(STD, STN=stn)).train()
+    m = build("TSRN_TL_TRANS", dev, seed=model_seed, **dict(STD, STN=stn)).train()
     m.infoGen.dropout_on = dropout
     Fh.set_seed(dev, 99)
     tr = Trainer(m, **trainer_kw)
     losses = []
     for i in range(nsteps):
-        x, tp, hr = make_inputs(B, seed=40 + i)
+        x, tp, hr = make_inputs(B, seed=40 + i + (0 if model_seed == 1234 else model_seed))    # (tools/gen_golden_drift.py: data_seed)
         losses.append(tr.step(x.to(dev), tp.to(dev), hr.to(dev)))
     torch.cuda.synchronize()
     return [float(l) for l in losses], _flat_state(m, tr), int(Fh.seed_tensor(dev)), float(tr.last_grad_norm)
@@ -366,43 +366,55 @@ def test_graph_replay_equals_eager(dev, dropout, B, stn):
     assert abs(gn_e - gn_g) <= 1e-6 * gn_e
 
 
-def test_split_bf16_vs_fp32_training_drift(dev):
-    """Multi-step drift of the default arithmetic: 12 training steps (B = 8, STN on, dropout off, fresh data every step) with the
-    split-bf16 kernel families against the same steps with exact fp32 products (`tatt_amd.set_arithmetic`).  The single-step tests
-    bound each kernel; this one bounds what 12 optimiser steps make of it.  At the recipe's learning rate (1e-3) the first steps of a
-    freshly initialised model are chaotic (the loss goes 37 -> 12 -> 15 -> 22 -> 31: ANY perturbation, fp32 summation order
-    included, is amplified a hundredfold within five steps), so the drift is measured where the dynamics do not amplify it:
-    lr = 1e-5.  There the two arithmetics must stay together: losses to 3e-5 relative over the first six steps and 3e-4 over all
-    twelve (round 5: was 1e-4 over all twelve, inside the scatter of the late steps -- see below), weights to 1e-4 of their l2 norm; in max-abs a
-    weight may differ by up to 12 x lr (a parameter whose true gradient is zero -- a convolution bias in front of a BatchNorm --
-    receives round-off as gradient, and Adam turns round-off of either sign into a full +-lr step, in any arithmetic).  At lr = 1e-3
-    only the first two steps are compared (before the amplification sets in)."""
+@pytest.mark.parametrize("si", [0, 1, 2])
+def test_split_bf16_training_drift_against_the_fp64_yardstick(dev, si):
+    """Multi-step drift of the default arithmetic, measured against float64: 12 training steps (B = 8, STN on, dropout off, fresh data
+    every step, lr 1e-5) on the GPU with the split-bf16 kernel families AND with exact fp32 products (`tatt_amd.set_arithmetic`), both
+    against the same 12 steps evaluated by the CPU oracle in float64 (tests/golden/drift_fp64.npz, tools/gen_golden_drift.py), three
+    model / data seeds.  Rounds 4-5 compared the two GPU arithmetics with EACH OTHER and had to widen the bound when new kernels moved the
+    late steps (a self-comparison inside the scatter of Adam's +-lr steps on zero-gradient parameters); against float64 each arithmetic
+    has a distance of its own and the assertion is the one that matters: per step, the split-bf16 run is no further from float64 than
+    K = 4 x the worst fp32 step so far is (plus a floor of 2e-6 relative for steps where fp32 happens to land on the yardstick).  Measured:
+    the fp32 run itself is 5e-8 .. 2.4e-4 from float64 over the twelve steps and the split-bf16 run 1.5e-7 .. 2.3e-4 -- the late-step
+    separation that rounds 4-5 attributed to the split kernels is the conditioning of the trajectory in ANY fp32 arithmetic.  lr = 1e-5 because at the recipe's 1e-3 the first steps of a fresh model amplify ANY perturbation a hundredfold within
+    five steps (loss 37 -> 12 -> 15 -> 22 -> 31); there only the first two steps are compared (seed 0)."""
     import tatt_amd
-
-    def both(**kw):
-        try:
-            tatt_amd.set_arithmetic("fp32")
-            a = _run_steps(dev, kw.pop("n"), 8, False, use_graph=False, **kw)
-        finally:
-            tatt_amd.set_arithmetic("split_bf16")
-        return a, _run_steps(dev, len(a[0]), 8, False, use_graph=False, **kw)
-
-    (l32, s32, _, _), (lsb, ssb, _, _) = both(n=12, lr=1e-5)
-    rels = [abs(a - b) / abs(a) for a, b in zip(l32, lsb)]
-    rel = max(rels)
+    gold = np.load("tests/golden/drift_fp64.npz")
+    seed = int(gold["seeds"][si])
+    l64 = gold["losses"][si]
+    n = int(gold["nstep"])
+    assert int(gold["batch"]) == 8 and abs(float(gold["lr"]) - 1e-5) < 1e-12
+    try:
+        tatt_amd.set_arithmetic("fp32")
+        l32, s32, _, _ = _run_steps(dev, n, 8, False, use_graph=False, lr=1e-5, model_seed=seed)
+    finally:
+        tatt_amd.set_arithmetic("split_bf16")
+    lsb, ssb, _, _ = _run_steps(dev, n, 8, False, use_graph=False, lr=1e-5, model_seed=seed)
+    e32 = np.abs(np.array(l32) - l64) / np.abs(l64)
+    esb = np.abs(np.array(lsb) - l64) / np.abs(l64)
+    print("seed %d, 12 steps at lr 1e-5, |loss - fp64| / |fp64| per step:\n  fp32       %s\n  split bf16 %s" % (
+        seed, " ".join("%.1e" % v for v in e32), " ".join("%.1e" % v for v in esb)))
+    K = 4.0
+    run32 = np.maximum.accumulate(e32)                      # (the worst fp32 step so far: a single lucky fp32 step is not the yardstick)
+    assert (esb <= K * run32 + 2e-6).all(), (e32, esb)
+    assert esb.max() <= 1e-3 and e32.max() <= 1e-3, (e32, esb)     # (sanity only: measured <= 2.4e-4 for BOTH arithmetics, profiles/r06_drift_fp64.txt)
+    # the weights: both arithmetics end at the same distance from each other as in rounds 4-5 (max-abs <= 12 lr: a parameter whose true
+    # gradient is zero receives round-off as gradient and Adam turns either sign into a full lr step, in any arithmetic)
     dp = float((s32["p"] - ssb["p"]).abs().max())
     rp = float((s32["p"] - ssb["p"]).norm() / s32["p"].norm())
-    print("split-bf16 vs fp32, 12 steps at lr 1e-5: loss rel %.3e (first six %.3e), weights max-abs %.3e, l2-rel %.3e" % (
-        rel, max(rels[:6]), dp, rp))
-    # the arithmetic shows in the first steps (measured 1e-7 .. 2e-5); later the +-lr lottery on zero-gradient parameters separates the
-    # trajectories by 1e-5 .. 1.5e-4 whichever families run in split bf16 (profiles/r05_drift_probe.txt: 8.8e-5 with none of the 9x9
-    # kernels, 6.5e-5 .. 1.5e-4 with them) while the weights stay at the same distance
-    assert max(rels[:6]) <= 3e-5 and rel <= 3e-4, (l32, lsb)
     assert dp <= 12 * 1e-5 * 1.01 and rp <= 1e-4, (dp, rp)
-    (l32, _, _, _), (lsb, _, _, _) = both(n=2, lr=1e-3)
-    rel = max(abs(a - b) / abs(a) for a, b in zip(l32, lsb))
-    print("split-bf16 vs fp32, first 2 steps at lr 1e-3: loss rel %.3e" % rel)
-    assert rel <= 1e-4, (l32, lsb)
+    wn = float(s32["p"].double().norm())
+    assert abs(wn - float(gold["weight_norm"][si])) <= 1e-5 * wn, (wn, float(gold["weight_norm"][si]))
+    if si == 0:
+        try:
+            tatt_amd.set_arithmetic("fp32")
+            a, _, _, _ = _run_steps(dev, 2, 8, False, use_graph=False, lr=1e-3)
+        finally:
+            tatt_amd.set_arithmetic("split_bf16")
+        b, _, _, _ = _run_steps(dev, 2, 8, False, use_graph=False, lr=1e-3)
+        rel = max(abs(u - v) / abs(u) for u, v in zip(a, b))
+        print("split-bf16 vs fp32, first 2 steps at lr 1e-3: loss rel %.3e" % rel)
+        assert rel <= 1e-4, (a, b)
 
 
 @pytest.mark.parametrize("B", [6, 48])
