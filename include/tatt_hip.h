@@ -143,8 +143,9 @@ int tatt_conv3_c64_dgrad_bn_sb(const float* x, const float* x2, const float* in_
 /* Which kernel the two entries above launch, and the filter packing it wants.  tatt_conv3_sb_generation (test / A-B hook; returns the
  * previous setting, other values only query): 4 (default) = 4 x 16-pixel tiles, four MFMA waves (one per SIMD, each owning 32 output
  * channels over half the contraction, v_mfma_f32_32x32x16_bf16) with four staging waves beside them (round 6); 3 = the same without
- * staging waves (one 512-register wave per SIMD does everything); 1 = the 64-pixel row tiles of rounds 3-5.  Generations 3 / 4 take
- * H % 4 == 0, W % 16 == 0, no output activation, no tanh: everything else runs generation 1 (W % 64 == 0).  tatt_conv3_sb_packing:
+ * staging waves (one 512-register wave per SIMD does everything); 1 = the 64-pixel row tiles of rounds 3-5.  Generation 4 takes
+ * H % 4 == 0, any W (the last tile column of a ragged map is cut), act none / ReLU, no tanh; generation 3 H % 4 == 0, W % 16 == 0, no
+ * output activation; everything else runs generation 1 (W % 64 == 0).  tatt_conv3_sb_packing:
  * the tatt_repack_conv_weight mode of the FORWARD filter for a call with these arguments -- 10 (generation 1) or 14 (generations
  * 3 / 4); the data-gradient packing is that + 1. */
 int tatt_conv3_sb_generation(int gen);
@@ -159,7 +160,8 @@ int tatt_conv3_c64_wgrad_partial(const float* x, const float* dy, float* part, f
 int tatt_conv3_c64_wgrad_partial_sb(const float* x, const float* dy, float* part, float* pdb, int B, int H, int W,
                                     int Cin, int Cout, int G, hipStream_t st);
 /* Test / A-B hook: 2 (default) = 4 x 16-pixel tiles, transposing LDS reads, staging waves beside MFMA waves (round 6; H % 4 == 0,
- * W % 16 == 0), 1 = the 64-pixel row segments of rounds 3-5 (also what H % 4 != 0 runs; W % 64 == 0).  Returns the previous setting. */
+ * any W: the last tile column of a ragged map is cut; G <= B * (H / 4) * ceil(W / 16)), 1 = the 64-pixel row segments of rounds 3-5
+ * (also what H % 4 != 0 runs; W % 64 == 0).  Returns the previous setting. */
 int tatt_conv3_wgrad_sb_generation(int gen);
 
 /* 9x9 convolution 64 -> 4 channels (fp32 vector ALU; filter through the scalar cache): the final reconstruction conv

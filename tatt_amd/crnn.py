@@ -74,7 +74,7 @@ class CRNN(nn.Module):
             conv = getattr(self.cnn, "conv%d" % i)
             bn = getattr(self.cnn, "batchnorm%d" % i, None)
             if conv.kernel_size == (3, 3):
-                h = Fh.conv2d(h, conv.weight, conv.bias, ACT_NONE if bn is not None else ACT_RELU)
+                h = Fh.conv2d(h, conv.weight, conv.bias, ACT_NONE if bn is not None else ACT_RELU, any_width=True)   # (split-bf16 3x3 kernels on the 50 / 25 / 26-pixel maps)
             else:
                 h = Fh.Conv2x2ValidFn.apply(Fh._c(h), conv.weight, conv.bias)
                 if bn is None:

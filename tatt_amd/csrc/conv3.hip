@@ -942,7 +942,7 @@ __global__ __launch_bounds__(512, 2) void conv3_c64_sb4_kernel(Conv3SB q) {
     extern __shared__ __attribute__((aligned(16))) unsigned smem_u[];
     unsigned* const XCH = smem_u + 4 * S3_IMG;
     const unsigned t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const unsigned W = p.W, H = p.H, tws = W / 16, ths = H / 4, cob = p.Cout / 64;
+    const unsigned W = p.W, H = p.H, tws = (W + 15) / 16, ths = H / 4, cob = p.Cout / 64;     // (W may be ragged: the last tile column is cut by the map)
     const unsigned npt = p.B * ths * tws;
     const unsigned stride = gridDim.x / cob;
     unsigned cb = blockIdx.x % cob, pt = blockIdx.x / cob;
@@ -959,11 +959,14 @@ __global__ __launch_bounds__(512, 2) void conv3_c64_sb4_kernel(Conv3SB q) {
         return;
     }
     const unsigned ntile = (npt - pt + stride - 1) / stride;    // tiles of this work-group: pt, pt + stride, ...
-    auto decode = [&](unsigned tile, unsigned& org, unsigned& te) {                     // -> origin pixel index, edge mask of the tile
+    // -> origin pixel index; te: bit 0 / 1 / 2 = the tile touches the top / bottom / left edge of the map, bits 8-15 = the number of its
+    // 18 halo columns that lie inside the map on the right (17 + 1 for an inner tile; fewer in the last column of a ragged map)
+    auto decode = [&](unsigned tile, unsigned& org, unsigned& te) {
         const unsigned tw = tile % tws; tile /= tws;
         const unsigned th = tile % ths, n = tile / ths;
         org = (n * H + th * 4) * W + tw * 16;
-        te = (th == 0 ? 1u : 0u) | (th == ths - 1 ? 2u : 0u) | (tw == 0 ? 4u : 0u) | (tw == tws - 1 ? 8u : 0u) | 16u;
+        const unsigned cin = min(18u, W - tw * 16 + 1);      // halo column c holds map column 16 tw + c - 1: inside while c <= W - 16 tw
+        te = (th == 0 ? 1u : 0u) | (th == ths - 1 ? 2u : 0u) | (tw == 0 ? 4u : 0u) | (cin << 8);
     };
     if (wave >= 4) {
         // ------------------------------------------------ staging waves (256 threads) ------------------------------------------------
@@ -975,14 +978,19 @@ __global__ __launch_bounds__(512, 2) void conv3_c64_sb4_kernel(Conv3SB q) {
         const __amdgpu_buffer_rsrc_t rs_e = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(EPBN ? q.ep_x : p.y), 0, npix * (EPBN ? 64 : p.Cout) * 4, 0x00020000);
         const bool in_relu = p.in_act == ACT_RELU;
         const unsigned xps = q.cin_total * 4, yps = p.Cout * 4, eps_ = EPBN ? 256u : yps;     // bytes per pixel of the maps
-        unsigned boff[S3_NIT], poff[S3_NIT], edge[2] = {0, 0};
+        unsigned boff[S3_NIT], poff[S3_NIT], edge[2] = {0, 0}, colk[2] = {0, 0};
 #pragma unroll
         for (int k = 0; k < S3_NIT; ++k) {                   // halo item k: 16-byte channel group h & 15 of halo pixel (h >> 4) + 16 k (row-major 6 x 18)
             const unsigned pix = (h >> 4) + 16 * k, r = pix / S2_HW, c = pix - r * S2_HW;
             boff[k] = (unsigned)(((int)r - 1) * (int)W + (int)c - 1) * xps + (q.ci0 + 4 * (h & 15)) * 4;
             poff[k] = r * S3_RP + c * SB_PW + 2 * (h & 15);
-            edge[k >> 2] |= ((r == 0 ? 1u : 0u) | (r == 5 ? 2u : 0u) | (c == 0 ? 4u : 0u) | (c == S2_HW - 1 ? 8u : 0u) | (pix >= S2_NPX ? 16u : 0u)) << (8 * (k & 3));
+            edge[k >> 2] |= ((r == 0 ? 1u : 0u) | (r == 5 ? 2u : 0u) | (c == 0 ? 4u : 0u) | (pix >= S2_NPX ? 8u : 0u)) << (8 * (k & 3));
+            colk[k >> 2] |= c << (8 * (k & 3));
         }
+        // item k lies outside the map: a top / bottom / left edge it sits on, no item at all, or its column beyond the map's last
+        auto outside = [&](int k, unsigned te) -> bool {
+            return (((edge[k >> 2] >> (8 * (k & 3))) & (te | 8u) & 15u) != 0) || (((colk[k >> 2] >> (8 * (k & 3))) & 255u) >= (te >> 8));
+        };
         f32x4 hp[S3_NIT], hp2[S3_NIT];
         auto halo_issue = [&](unsigned tile, bool valid) {   // !valid: every request is out of range (no memory traffic)
             unsigned org, te;
@@ -992,7 +1000,7 @@ __global__ __launch_bounds__(512, 2) void conv3_c64_sb4_kernel(Conv3SB q) {
 #endif
 #pragma unroll
             for (int k = 0; k < S3_NIT; ++k) {
-                const unsigned a = (org * xps + boff[k]) | ((((edge[k >> 2] >> (8 * (k & 3))) & te) != 0) ? S2_OOB : (valid ? 0u : S2_OOB));
+                const unsigned a = (org * xps + boff[k]) | (outside(k, te) ? S2_OOB : (valid ? 0u : S2_OOB));
                 hp[k] = s2_ld(rs_x, a);
                 if (INMODE == 2) hp2[k] = s2_ld(rs_x2, a);
             }
@@ -1005,7 +1013,7 @@ __global__ __launch_bounds__(512, 2) void conv3_c64_sb4_kernel(Conv3SB q) {
             if (INMODE == 2) isc2 = *reinterpret_cast<const f32x4*>(&cst[2][4 * (h & 15)]);
 #pragma unroll
             for (int k = 0; k < S3_NIT; ++k) {
-                const bool ok = ((edge[k >> 2] >> (8 * (k & 3))) & te) == 0;
+                const bool ok = !outside(k, te);
                 f32x4 v = hp[k];
                 if (INMODE == 2) {
 #pragma unroll
@@ -1045,21 +1053,23 @@ __global__ __launch_bounds__(512, 2) void conv3_c64_sb4_kernel(Conv3SB q) {
         halo_issue(pt + stride, ntile > 1);
         __syncthreads();                                     // #2: tile 0 staged
         // epilogue item e of this thread: channels 4 (h & 15) .. + 3 of tile pixel (h >> 4) + 16 e (row e, column h >> 4)
-        const bool use_beta = p.beta != 0.f;
+        const bool use_beta = p.beta != 0.f, out_relu = p.act == ACT_RELU;
         const bool ep_mish = q.ep_act == ACT_MISH, ep_relu = q.ep_act == ACT_RELU;
         const unsigned ecol = h >> 4, ec4 = 4 * (h & 15);
         f32x4 epx[S3_NEP], st_s = (f32x4){0.f, 0.f, 0.f, 0.f}, st_q = st_s;
         auto epi_request = [&](unsigned tile) {              // (neither an EPBN map nor a beta: out of range, the answer is 0)
             unsigned org, te;
             decode(tile, org, te);
+            const bool in_map = ecol + 1 < (te >> 8);        // (tile column ecol = halo column ecol + 1)
 #pragma unroll
             for (int e = 0; e < S3_NEP; ++e)
-                epx[e] = s2_ld(rs_e, ((org + e * W + ecol) * eps_ + (cb * 64 + ec4) * 4) | ((EPBN || use_beta) ? 0u : S2_OOB));
+                epx[e] = s2_ld(rs_e, ((org + e * W + ecol) * eps_ + (cb * 64 + ec4) * 4) | (((EPBN || use_beta) && in_map) ? 0u : S2_OOB));
         };
         auto epilogue = [&](unsigned tile, unsigned xb) {
             unsigned org, te;
             decode(tile, org, te);
             const f32x4 bj = *reinterpret_cast<const f32x4*>(&cbias[ec4]);
+            const bool in_map = ecol + 1 < (te >> 8);        // pixels of a ragged map's last tile column beyond the map: not stored, not counted
             f32x4 ep_mu, ep_rs, ep_g, ep_b;
             if (EPBN) {                                      // (Cout == 64)
                 ep_mu = *reinterpret_cast<const f32x4*>(&cst[3][ec4]); ep_rs = *reinterpret_cast<const f32x4*>(&cst[4][ec4]);
@@ -1072,21 +1082,24 @@ __global__ __launch_bounds__(512, 2) void conv3_c64_sb4_kernel(Conv3SB q) {
                 f32x4 v;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    v[r] = (v0[r] + v1[r]) + bj[r];          // (no output activation in this kernel)
+                    v[r] = (v0[r] + v1[r]) + bj[r];
                     if (EPBN) {                              // v = gradient w.r.t. act(bn(ep_x)); Cout == 64
                         const float xh = (epx[e][r] - ep_mu[r]) * ep_rs[r], u = fmaf(ep_g[r], xh, ep_b[r]);
                         const float g = ep_mish ? mish_grad_f(u) : 1.f;
                         v[r] *= ep_relu ? (u > 0.f ? 1.f : 0.f) : g;
+                        v[r] = in_map ? v[r] : 0.f;
                         st_s[r] += v[r]; st_q[r] += v[r] * xh;
                     } else {
                         v[r] = fmaf(p.beta, epx[e][r], v[r]);
+                        v[r] = out_relu ? fmaxf(v[r], 0.f) : v[r];   // (the only output activation of this kernel; mish / tanh: row-tile kernel)
+                        v[r] = in_map ? v[r] : 0.f;
                         st_s[r] += v[r]; st_q[r] += v[r] * v[r];
                     }
                 }
 #if S2_DEBUG
                 if (s2_wrep & 8) continue;
 #endif
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_s2, v), rs_y, (org + e * W + ecol) * yps + (cb * 64 + ec4) * 4, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_s2, v), rs_y, ((org + e * W + ecol) * yps + (cb * 64 + ec4) * 4) | (in_map ? 0u : S2_OOB), 0, 0);
             }
         };
         for (unsigned i = 0; i < ntile; ++i) {
@@ -1212,8 +1225,11 @@ static void conv3_sb3_go(const Conv3SB& q, dim3 grid, hipStream_t st) {
 // staging waves beside the MFMA waves (14 / 15)
 static int conv3_sb_pick(int B, int H, int W, int cin_total, int Cout, int act, int ep_act) {
     const long maxb = (long)B * H * W * (cin_total > Cout ? cin_total : Cout) * 4;       // 32-bit buffer offsets
-    const bool acts_ok = act == ACT_NONE && ep_act != ACT_TANH;              // (what the square-tile kernels evaluate without branches)
-    return (conv3_sb_generation >= 3 && H % 4 == 0 && W % 16 == 0 && maxb < 0x7fffffffL && acts_ok) ? conv3_sb_generation : 1;
+    if (conv3_sb_generation < 3 || H % 4 || maxb >= 0x7fffffffL || ep_act == ACT_TANH) return 1;
+    // what the square-tile kernels evaluate without branches: generation 4 also a ReLU on its output and map widths that are not a
+    // multiple of 16 (the CRNN's 50-, 25-, 26-pixel maps: the last tile column is cut by the map)
+    if (conv3_sb_generation == 4 && (act == ACT_NONE || (act == ACT_RELU && ep_act == ACT_NONE))) return 4;
+    return (conv3_sb_generation == 3 && W % 16 == 0 && act == ACT_NONE) ? 3 : 1;
 }
 TATT_API int tatt_conv3_sb_packing(int B, int H, int W, int cin_total, int Cout, int act, int ep_act) {
     return conv3_sb_pick(B, H, W, cin_total, Cout, act, ep_act) >= 3 ? 14 : 10;
@@ -1222,7 +1238,7 @@ static int conv3_sb_launch(const Conv3SB& q, hipStream_t st) {
     const Conv3P& p = q.c;
     const int pick = conv3_sb_pick(p.B, p.H, p.W, q.cin_total, p.Cout, p.act, q.ep_act);
     if (pick >= 3) {
-        const int cob = p.Cout / 64, npt = p.B * (p.H / 4) * (p.W / 16);
+        const int cob = p.Cout / 64, npt = p.B * (p.H / 4) * ((p.W + 15) / 16);
         int per = 256 / cob;
         if (per > npt) per = npt;
         const dim3 grid(per * cob);
@@ -1266,7 +1282,7 @@ static int conv3_sb_launch(const Conv3SB& q, hipStream_t st) {
 TATT_API int tatt_conv3_c64_fwd_sb(const float* x, int cin_total, int ci0, const float* wl, const float* bias, float* y, int B, int H,
                                    int W, int Cout, int act, float beta, const float* in_scale, const float* in_shift, int in_act,
                                    double* stats, hipStream_t st) {
-    if (Cout % 64 || W % 16 || cin_total % 4 || ci0 % 4 || ci0 + 64 > cin_total) return 1;
+    if (Cout % 64 || cin_total % 4 || ci0 % 4 || ci0 + 64 > cin_total) return 1;
     if (stats && (Cout != 64 || act != ACT_NONE || beta != 0.f)) return 2;
     if (in_scale && (!in_shift || in_act == ACT_TANH)) return 3;
     Conv3SB q = {{x, wl, bias, y, B, H, W, 64, Cout, act, beta, in_scale, in_shift, in_act, stats}, cin_total, ci0,
@@ -1283,7 +1299,6 @@ TATT_API int tatt_conv3_c64_dgrad_bn_sb(const float* x, const float* x2, const f
                                         const float* in_shift, const float* wl, float* y, int B, int H, int W, const float* ep_x,
                                         const float* ep_mean, const float* ep_rstd, const float* ep_gamma, const float* ep_beta,
                                         int ep_act, double* stats, hipStream_t st) {
-    if (W % 16) return 1;
     if (x2 && (!in_scale || !in_scale2 || !in_shift)) return 2;
     if (ep_x && (!ep_mean || !ep_rstd || !ep_gamma || !ep_beta || !stats)) return 3;
     if (!ep_x && stats) return 4;

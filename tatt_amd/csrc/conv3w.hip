@@ -240,15 +240,16 @@ __global__ __launch_bounds__(512, 2) void conv3_c64_wgrad_sb2_kernel(Conv3WSP p)
     const unsigned t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const unsigned cib = blockIdx.y % (p.Cin / 64), cob = blockIdx.y / (p.Cin / 64);
     const unsigned ci0 = cib * 64, co0 = cob * 64;
-    const unsigned W = p.W, H = p.H, tws = W / 16, ths = H / 4;
+    const unsigned W = p.W, H = p.H, tws = (W + 15) / 16, ths = H / 4;        // (W may be ragged: the last tile column is cut by the map)
     const unsigned per = (p.nseg + gridDim.x - 1) / gridDim.x;
     const unsigned s_beg = blockIdx.x * per, s_end = min((unsigned)p.nseg, s_beg + per);
     const bool want_db = p.pdb != nullptr && cib == 0;
-    auto decode = [&](unsigned tile, unsigned& org, unsigned& te) {           // -> origin pixel index, edge mask (bit 0 top, 1 bottom, 2 left, 3 right)
+    // -> origin pixel index; te: bit 0 / 1 / 2 = the tile touches the top / bottom / left edge, bits 8-15 = its halo columns inside the map
+    auto decode = [&](unsigned tile, unsigned& org, unsigned& te) {
         const unsigned tw = tile % tws; tile /= tws;
         const unsigned th = tile % ths, n = tile / ths;
         org = (n * H + th * 4) * W + tw * 16;
-        te = (th == 0 ? 1u : 0u) | (th == ths - 1 ? 2u : 0u) | (tw == 0 ? 4u : 0u) | (tw == tws - 1 ? 8u : 0u) | 16u;
+        te = (th == 0 ? 1u : 0u) | (th == ths - 1 ? 2u : 0u) | (tw == 0 ? 4u : 0u) | (min(18u, W - tw * 16 + 1) << 8);
     };
     if (wave >= 4) {
         // ---------------- staging waves: 256 threads; x halo = 1728 16-byte items (7 per thread), dy tile = 1024 (4 per thread) ----------------
@@ -257,13 +258,14 @@ __global__ __launch_bounds__(512, 2) void conv3_c64_wgrad_sb2_kernel(Conv3WSP p)
         const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, npix * p.Cin * 4, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, npix * p.Cout * 4, 0x00020000);
         const unsigned xps = p.Cin * 4, dps = p.Cout * 4;
-        unsigned xoff[7], xput[7], edge[2] = {0, 0}, doff[4], dput[4];
+        unsigned xoff[7], xput[7], edge[2] = {0, 0}, colk[2] = {0, 0}, doff[4], dput[4];
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
             const unsigned pix = (h >> 4) + 16 * k, r = pix / 18, c = pix - r * 18;
             xoff[k] = (unsigned)(((int)r - 1) * (int)W + (int)c - 1) * xps + (ci0 + 4 * c4) * 4;
             xput[k] = pix * W2_PB + 8 * c4;
-            edge[k >> 2] |= ((r == 0 ? 1u : 0u) | (r == 5 ? 2u : 0u) | (c == 0 ? 4u : 0u) | (c == 17 ? 8u : 0u) | (pix >= 108 ? 16u : 0u)) << (8 * (k & 3));
+            edge[k >> 2] |= ((r == 0 ? 1u : 0u) | (r == 5 ? 2u : 0u) | (c == 0 ? 4u : 0u) | (pix >= 108 ? 8u : 0u)) << (8 * (k & 3));
+            colk[k >> 2] |= c << (8 * (k & 3));
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -277,11 +279,14 @@ __global__ __launch_bounds__(512, 2) void conv3_c64_wgrad_sb2_kernel(Conv3WSP p)
             decode(tile, org, te);
             const unsigned inv = valid ? 0u : W2_OOB;
 #pragma unroll
-            for (int k = 0; k < 7; ++k)
-                hx[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (org * xps + xoff[k]) | ((((edge[k >> 2] >> (8 * (k & 3))) & te) != 0) ? W2_OOB : inv), 0, 0));
+            for (int k = 0; k < 7; ++k) {                    // outside the map: an edge the item sits on, no item, or a column beyond the map's last
+                const bool out = (((edge[k >> 2] >> (8 * (k & 3))) & (te | 8u) & 15u) != 0) || (((colk[k >> 2] >> (8 * (k & 3))) & 255u) >= (te >> 8));
+                hx[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (org * xps + xoff[k]) | (out ? W2_OOB : inv), 0, 0));
+            }
+            const unsigned dinv = ((h >> 4) + 1 < (te >> 8)) ? inv : W2_OOB;     // (tile column h >> 4 = halo column + 1)
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                hd[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_d, (org * dps + doff[k]) | inv, 0, 0));
+                hd[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_d, (org * dps + doff[k]) | dinv, 0, 0));
         };
         auto put = [&](char* buf) {
 #pragma unroll
@@ -384,10 +389,10 @@ TATT_API int tatt_conv3_wgrad_sb_generation(int gen) {
 // same contract as tatt_conv3_c64_wgrad_partial (conv3.hip): partials part[G][9*Cin][Cout] (+ pdb[G][Cout]) for the split-K reducer
 TATT_API int tatt_conv3_c64_wgrad_partial_sb(const float* x, const float* dy, float* part, float* pdb, int B, int H, int W,
                                              int Cin, int Cout, int G, hipStream_t st) {
-    if (Cin % 64 || Cout % 64 || W % 16) return 1;
+    if (Cin % 64 || Cout % 64) return 1;
     const long maxb = (long)B * H * W * (Cin > Cout ? Cin : Cout) * 4;       // (32-bit buffer offsets)
     if (conv3_wgrad_sb_generation == 2 && H % 4 == 0 && maxb < 0x7fffffffL) {
-        const int ntile = B * (H / 4) * (W / 16);
+        const int ntile = B * (H / 4) * ((W + 15) / 16);
         Conv3WSP p2 = {x, dy, part, B, H, W, Cin, Cout, ntile, pdb};
         static TattPerDevice attr2_once;
         tatt_per_device(attr2_once, [&] {

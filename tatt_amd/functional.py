@@ -216,11 +216,12 @@ class Conv2dFn(Function):
     optional fused output activation (none / tanh)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, act):
+    def forward(ctx, x, weight, bias, act, any_width=False):
         Cout, Cin, KH, KW = weight.shape
-        y = ops.conv2d_forward(x, weight, bias, act)
+        y = ops.conv2d_forward(x, weight, bias, act, any_width)
         ctx.save_for_backward(x, weight, y if act != ACT_NONE else None)
         ctx.act = act
+        ctx.any_width = any_width
         ctx.has_bias = bias is not None
         ctx.leaves = (weight, bias)
         return y
@@ -234,28 +235,30 @@ class Conv2dFn(Function):
             dy = ops.act_bwd(y, dy, ctx.act, True)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = ops.conv2d_dgrad(dy, weight)
+            dx = ops.conv2d_dgrad(dy, weight, ctx.any_width)
         want_dw, want_db = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        aw = ctx.any_width
 
         def param_grads():
             if want_dw and want_db:
-                return ops.conv_wgrad(x, dy, Cout, KH, KW, want_db=True)
-            dw = ops.conv_wgrad(x, dy, Cout, KH, KW) if want_dw else None
+                return ops.conv_wgrad(x, dy, Cout, KH, KW, want_db=True, any_width=aw)
+            dw = ops.conv_wgrad(x, dy, Cout, KH, KW, any_width=aw) if want_dw else None
             db = ops.colsum(dy.reshape(-1, Cout)) if want_db else None
             return dw, db
         wleaf, bleaf = ctx.leaves
         if want_dw and want_db and SIDE.enabled and (SIDE.due_of.get(id(wleaf)) != SIDE.due_of.get(id(bleaf))
                                                      or (id(wleaf) in SIDE.immediate) != (id(bleaf) in SIDE.immediate)):
             # weight and bias filed under different stages (tsrn.OUTCONV_*): two closures, each with its own stage's side lane
-            (dw,) = SIDE.submit((wleaf,), lambda: (ops.conv_wgrad(x, dy, Cout, KH, KW),), x, dy)
+            (dw,) = SIDE.submit((wleaf,), lambda: (ops.conv_wgrad(x, dy, Cout, KH, KW, any_width=aw),), x, dy)
             (db,) = SIDE.submit((bleaf,), lambda: (ops.colsum(dy.reshape(-1, Cout)),), dy)
-            return dx, dw, db, None
+            return dx, dw, db, None, None
         dw, db = SIDE.submit(ctx.leaves, param_grads, x, dy)
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
-def conv2d(x, weight, bias, act=ACT_NONE):
-    return Conv2dFn.apply(x, weight, bias, act)
+def conv2d(x, weight, bias, act=ACT_NONE, any_width=False):
+    """any_width: see ops.conv2d_forward (the CRNN's maps)"""
+    return Conv2dFn.apply(x, weight, bias, act, any_width)
 
 
 # --------------------------------------------------------------------------------------------------

@@ -414,15 +414,16 @@ CONV3_SB_NARROW_MAPS = False    # True: maps with H % 4 == 0, W % 16 == 0 (not o
                                 # only such maps of the models are the STN head's, whose operator-chain path stays on exact-fp32 products
 
 
-def _conv3_geom_ok(x_bhwc):
-    """map sizes the 3x3 64-channel kernels tile: 64-pixel row segments, or (split-bf16 kernels of round 6, on request) 4 x 16-pixel tiles"""
+def _conv3_geom_ok(x_bhwc, any_width=False):
+    """map sizes the 3x3 64-channel kernels tile: 64-pixel row segments, or (split-bf16 kernels of round 6, on request: `any_width` of a
+    caller or the module hook) 4 x 16-pixel tiles -- the generation-4 kernel cuts the last tile column of a ragged map"""
     H, W = x_bhwc.shape[1], x_bhwc.shape[2]
-    return W % 64 == 0 or (CONV3_SB and CONV3_SB_NARROW_MAPS and H % 4 == 0 and W % 16 == 0)
+    return W % 64 == 0 or (CONV3_SB and H % 4 == 0 and ((CONV3_SB_NARROW_MAPS and W % 16 == 0) or (any_width and CONV3_SB_GENERATION == 4)))
 
 
-def _conv3_fast_ok(x_bhwc, Cin, Cout, KH, KW):
+def _conv3_fast_ok(x_bhwc, Cin, Cout, KH, KW, any_width=False):
     return (x_bhwc.is_contiguous() and KH == 3 and KW == 3 and Cin % 64 == 0 and Cout % 64 == 0
-            and _conv3_geom_ok(x_bhwc))
+            and _conv3_geom_ok(x_bhwc, any_width))
 
 
 # exact-fp32 3x3 kernels (used when CONV3_SB is off): weight-stationary ws16 kernel for 64 input channels, filter packings 6 / 7
@@ -447,10 +448,10 @@ def _conv3_sb(x_bhwc, w_oihw, mode, bias, act=ACT_NONE, in_scale=None, in_shift=
     wl = repack_weight(w_oihw, LIB.tatt_conv3_sb_packing(B, H, W, cin, cout, int(act), ACT_NONE) + (mode - 10))
     y = new(x_bhwc, B, H, W, cout)
     nchunk = cin // 64
-    assert nchunk == 1 or (act == ACT_NONE and stats is None)
-    for c in range(nchunk):
+    assert nchunk == 1 or (act in (ACT_NONE, ACT_RELU) and stats is None)
+    for c in range(nchunk):                                  # (an output activation belongs to the last chunk)
         call("tatt_conv3_c64_fwd_sb", P(x_bhwc), cin, 64 * c, P(wl[c * cout * 576:]), P(bias) if c == 0 else None, P(y), B, H, W, cout,
-             act, 0.0 if c == 0 else 1.0, P(in_scale), P(in_shift), int(in_act), P(stats), stream())
+             int(act) if c == nchunk - 1 else ACT_NONE, 0.0 if c == 0 else 1.0, P(in_scale), P(in_shift), int(in_act), P(stats), stream())
     return y
 
 
@@ -467,8 +468,10 @@ def _conv9_mfma_ok(x_bhwc):
     return x_bhwc.is_contiguous() and x_bhwc.shape[1] % 4 == 0 and x_bhwc.shape[2] % 64 == 0 and x_bhwc.shape[3] == 64
 
 
-def conv2d_forward(x_bhwc, weight_oihw, bias, act=ACT_NONE):
-    """y = act(conv(x, W) + b) from the reference-layout (OIHW) filter: picks the kernel and the filter packing it wants."""
+def conv2d_forward(x_bhwc, weight_oihw, bias, act=ACT_NONE, any_width=False):
+    """y = act(conv(x, W) + b) from the reference-layout (OIHW) filter: picks the kernel and the filter packing it wants.
+    any_width: 3x3 convolutions between multiples of 64 channels on maps whose height is a multiple of 4 take the split-bf16 kernel
+    whatever their width (the CRNN's maps; off for the STN head's operator chain, which keeps exact fp32 products)."""
     Cout, Cin, KH, KW = weight_oihw.shape
     if KH == 9 and KW == 9 and Cout == 4 and Cin == 64 and act == ACT_NONE and _conv9_mfma_ok(x_bhwc):
         B, H, W, _ = x_bhwc.shape
@@ -478,9 +481,10 @@ def conv2d_forward(x_bhwc, weight_oihw, bias, act=ACT_NONE):
         else:
             call("tatt_conv9_c64_to_c4_mfma", P(x_bhwc), P(repack_weight(weight_oihw, 8)), P(bias), P(y), B, H, W, stream())
         return y
-    if _conv3_fast_ok(x_bhwc, Cin, Cout, KH, KW):
+    if _conv3_fast_ok(x_bhwc, Cin, Cout, KH, KW, any_width):
         B, H, W, _ = x_bhwc.shape
-        if CONV3_SB and (Cin == 64 or act == ACT_NONE) and (W % 64 == 0 or act == ACT_NONE):
+        gen4 = CONV3_SB_GENERATION == 4 and H % 4 == 0       # (generation 4: any width, ReLU on the output, chunked contractions)
+        if CONV3_SB and ((gen4 and act in (ACT_NONE, ACT_RELU)) or act == ACT_NONE or (Cin == 64 and W % 64 == 0)):
             return _conv3_sb(x_bhwc, weight_oihw, 10, bias, act)
         if W % 64 == 0:                                          # (the exact-fp32 kernels walk 64-pixel row segments)
             y = new(x_bhwc, B, H, W, Cout)
@@ -530,7 +534,7 @@ def bn_stats_finish(part, G, C, M, eps, momentum, gamma, beta, running_mean, run
     return mean, rstd, scale, shift
 
 
-def conv2d_dgrad(dy_bhwc, weight_oihw):
+def conv2d_dgrad(dy_bhwc, weight_oihw, any_width=False):
     """dx = conv(dy, flip(W)^T): the data gradient as a forward convolution with Cout input / Cin output channels."""
     Cout, Cin, KH, KW = weight_oihw.shape
     if KH == 9 and KW == 9 and Cout == 64 and Cin == 4 and _conv9_mfma_ok(dy_bhwc):
@@ -541,7 +545,7 @@ def conv2d_dgrad(dy_bhwc, weight_oihw):
         else:
             call("tatt_conv9_c64_to_c4_mfma", P(dy_bhwc), P(repack_weight(weight_oihw, 9)), None, P(dx), B, H, W, stream())
         return dx
-    if _conv3_fast_ok(dy_bhwc, Cout, Cin, KH, KW):
+    if _conv3_fast_ok(dy_bhwc, Cout, Cin, KH, KW, any_width):
         B, H, W, _ = dy_bhwc.shape
         if CONV3_SB:
             return _conv3_sb(dy_bhwc, weight_oihw, 11, None)
@@ -556,15 +560,15 @@ def conv2d_dgrad(dy_bhwc, weight_oihw):
     return conv_fwd(dy_bhwc, repack_weight(weight_oihw, 1), None, Cin, KH, KW)
 
 
-def conv_wgrad(x_bhwc, dy_bhwc, Cout, KH, KW, want_db=False):
+def conv_wgrad(x_bhwc, dy_bhwc, Cout, KH, KW, want_db=False, any_width=False):
     """-> dw (OIHW), or (dw, db) with want_db: the bias gradient (column sums of dy) comes out of the 3x3 64-channel kernel for
     free (it streams dy anyway); the other paths add a column-sum pass."""
     B, H, W, Cin = x_bhwc.shape
     sn, sh, sw, sc = x_bhwc.stride()
     dw = new(x_bhwc, Cout, Cin, KH, KW)
     contig = x_bhwc.is_contiguous() and dy_bhwc.is_contiguous()
-    if contig and KH == 3 and KW == 3 and Cin % 64 == 0 and Cout % 64 == 0 and (W % 64 == 0 or (CONV3_WGRAD_SB and CONV3_SB_NARROW_MAPS and H % 4 == 0 and W % 16 == 0)):
-        nseg = B * H * W // 64
+    if contig and KH == 3 and KW == 3 and Cin % 64 == 0 and Cout % 64 == 0 and (W % 64 == 0 or (CONV3_WGRAD_SB and H % 4 == 0 and ((CONV3_SB_NARROW_MAPS and W % 16 == 0) or any_width))):
+        nseg = B * (H // 4) * ((W + 15) // 16) if W % 64 else B * H * W // 64
         nblk = (Cin // 64) * (Cout // 64)
         G = min(nseg, max(1, (CONV3_WGRAD_GROUPS if nblk == 1 else 256) // nblk))     # (several channel blocks: one group per CU together)
         n = G * 9 * Cin * Cout

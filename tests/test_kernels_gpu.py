@@ -1101,6 +1101,39 @@ def test_conv3_split_bf16_square_tiles_vs_fp64_and_row_tiles(dev, B, H, W):
         check_close("bwd stats.xhat", got[gen]["dgrad_in2_epbn.stats"][1].float(), (y * xh).reshape(-1, 64).sum(0).float(), rtol=1e-5, atol=1e-3)
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 16, 50), (3, 8, 25), (2, 4, 26), (1, 4, 7)])
+def test_conv3_split_bf16_ragged_width_relu_and_chunked_contractions(dev, B, H, W):
+    """The generation-4 kernel on maps whose width is not a multiple of 16 (the CRNN's 50-, 25-, 26-pixel maps, model/crnn/crnn.py:29-92:
+    the last tile column is cut by the map -- requests beyond it are out of range, its pixels are neither stored nor counted), with the
+    ReLU output activation (on the LAST chunk of a chunked contraction only) and contractions / outputs of several 64-channel blocks,
+    and the ragged weight gradient (tatt_conv3_c64_wgrad_partial_sb, generation 2), against fp64."""
+    from tatt_amd import ops
+    g = torch.Generator().manual_seed(77 + W)
+    for Cin, Cout in ((64, 128), (128, 256), (256, 64)):
+        x = torch.randn(B, H, W, Cin, generator=g)
+        w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+        b = torch.randn(Cout, generator=g)
+        dy = torch.randn(B, H, W, Cout, generator=g)
+        wd = w.double().requires_grad_(True)
+        bd = b.double().requires_grad_(True)
+        xd = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+        ref = F.conv2d(xd, wd, bd, padding=1)
+        ref.backward(dy.double().permute(0, 3, 1, 2))
+        refy = ref.detach().permute(0, 2, 3, 1)
+        for act, want in ((ops.ACT_NONE, refy), (ops.ACT_RELU, torch.relu(refy))):
+            y = ops.conv2d_forward(x.to(dev), w.to(dev), b.to(dev), act, any_width=True)
+            err = float((y.cpu().double() - want).abs().max() / refy.abs().max())
+            assert err < 2e-5, (Cin, Cout, act, err)
+        dx = ops.conv2d_dgrad(dy.to(dev), w.to(dev), any_width=True)
+        err = float((dx.cpu().double() - xd.grad.permute(0, 2, 3, 1)).abs().max() / xd.grad.abs().max())
+        assert err < 2e-5, (Cin, Cout, "dgrad", err)
+        dw, db = ops.conv_wgrad(x.to(dev), dy.to(dev), Cout, 3, 3, want_db=True, any_width=True)
+        err = float((dw.cpu().double() - wd.grad).abs().max() / wd.grad.abs().max())
+        assert err < 2e-5, (Cin, Cout, "wgrad", err)
+        errb = float((db.cpu().double() - bd.grad).abs().max() / bd.grad.abs().max())
+        assert errb < 2e-5, (Cin, Cout, "bias gradient", errb)
+
+
 def _mish_grad64(u):
     u = u.clone().requires_grad_(True)
     F.mish(u).sum().backward()
