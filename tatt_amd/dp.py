@@ -52,6 +52,7 @@ class FlatParams:
                     k = p.numel()
                     self.p[off:off + k].copy_(p.reshape(-1))
                     p.data = self.p[off:off + k].view_as(p)
+                    p._tatt_in_flat = True                   # (raw-pointer kernels update it: its packed filter layouts are refreshed, ops.PACKED)
                     p.grad = None
                     self.offsets[id(p)] = (off, k)
                     off += (k + a - 1) // a * a

@@ -304,7 +304,7 @@ class _PackedFilters:
         h.bufs[mode] = (out, w._version)
         return out
 
-    def _live(self, device=None):
+    def _live(self, device=None, skip_frozen=False):
         """Entries whose filter still lives where the key says.  The weights are read through the raw address in the key (one batched
         launch), so an entry whose owner is gone or has been re-homed since (FlatParams moved `.data`, `.to()`, a `.data =`
         assignment) must NOT be refreshed from that address -- the block may have been freed.  Such entries are dropped: the next
@@ -317,12 +317,16 @@ class _PackedFilters:
                 if h is not None and h.key == key:
                     h.bufs, h.key = {}, None
             elif device is None or key[2] == str(device):
+                if skip_frozen and not w.requires_grad and not getattr(w, "_tatt_in_flat", False):
+                    continue                             # nobody updates it behind torch's back (a frozen teacher recogniser): its layouts stay valid
                 for mode, (out, _) in h.bufs.items():
                     yield key, mode, out
 
     def refresh(self, device=None):
-        """Rebuild every cached layout from the current weights (one launch per 96 entries)."""
-        ent = list(self._live(device))
+        """Rebuild every cached layout from the current weights (one launch per 96 entries).  Filters of parameters that do not require
+        a gradient and do not live in a flat parameter buffer are left alone (in-place updates torch sees bump their version counter and
+        are caught by get())."""
+        ent = list(self._live(device, skip_frozen=True))
         if not ent:
             return
         n = len(ent)
