@@ -106,3 +106,72 @@ def test_world2_product_step_matches_per_shard_oracle(dev, tmp_path):
     k = "block2.bn1.running_mean"
     assert float((r0["sd_end"][k] - stats[0][k]).abs().max()) < 1e-5 and float((r1["sd_end"][k] - stats[1][k]).abs().max()) < 1e-5
     assert float((r0["sd_end"][k] - r1["sd_end"][k]).abs().max()) > 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# no node with more than one GPU has ever run this tree, and an all-reduce of a one-rank RCCL group holds no
+# CUs.  The nearest stand-in for a live collective's channel kernels is tatt_cu_holder (work-groups of 512 threads that sit resident):
+# here they are launched on a stream of their own right where every bucket's all-reduce goes on the wire, while the data-parallel
+# step (staged backward, bucketed all-reduce, the launches that synchronise 256 work-groups in flight -- query-GRU chains, STN head)
+# runs beside them.
+_DP_HOLDER_WORKER = r'''
+import os, sys, torch
+sys.path.insert(0, os.environ["TATT_ROOT"])
+import tatt_amd
+from tatt_amd import ops, functional as Fh
+from tatt_amd.train import Trainer
+from oracle.fixtures import randomize_state_dict, make_inputs
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+STD = dict(scale_factor=2, width=128, height=32, STN=True, mask=True, srb_nums=5, hidden_units=32)
+B, NSTEP = 48, 3
+out = {}
+for groups in (0, 16, 32, 64):
+    torch.manual_seed(1234)
+    m = tatt_amd.TSRN_TL_TRANS(**STD)
+    m.load_state_dict(randomize_state_dict(m.state_dict()))
+    m = m.to(dev).train()
+    m.infoGen.dropout_on = False
+    Fh.set_seed(dev, 99)
+    tr = Trainer(m, use_graph=False, process_group=torch.distributed.group.WORLD)
+    side = torch.cuda.Stream()
+    sink = torch.zeros(4, dtype=torch.int32, device=dev)
+    reduce0 = tr._reduce
+
+    def reduce_with_holders(lo, hi, after_pass, groups=groups):
+        if groups:                                   # resident for ~0.4 ms from the moment the bucket goes on the wire
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                ops.call("tatt_cu_holder", groups, 40000, 65536, ops.P(sink), ops.stream())
+        reduce0(lo, hi, after_pass)
+    tr._reduce = reduce_with_holders
+    losses = []
+    for i in range(NSTEP):
+        x, tp, hr = make_inputs(B, seed=70 + i)
+        losses.append(float(tr.step(x.to(dev), tp.to(dev), hr.to(dev))))
+    torch.cuda.synchronize()
+    tatt_amd.sync_check()
+    out[groups] = {"losses": losses, "p": tr.flat_p.detach().cpu().clone(), "reduces": list(tr.reduce_log)}
+torch.save(out, os.environ["DP_OUT"])
+torch.distributed.destroy_process_group()
+'''
+
+
+def test_dp_step_beside_resident_cu_holders(dev, tmp_path):
+    """Three data-parallel steps (B = 48, one-rank RCCL group: same code path as N ranks -- staged backward, three bucketed all-reduces) with
+    16 / 32 / 64 CU-holder work-groups (64 KB of LDS each) made resident at every all-reduce: no bounded wait may expire
+    (tatt_amd.sync_check) and losses and weights must equal the run without holders bit for bit."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    outf = tmp_path / "holders.pt"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TATT_ROOT=ROOT, DP_OUT=str(outf), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-c", _DP_HOLDER_WORKER], env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                       timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:]
+    res = torch.load(outf, weights_only=False)
+    base = res[0]
+    assert len(base["reduces"]) == 3
+    for groups in (16, 32, 64):
+        assert res[groups]["reduces"] == base["reduces"]
+        assert res[groups]["losses"] == base["losses"], (groups, res[groups]["losses"], base["losses"])
+        assert torch.equal(res[groups]["p"], base["p"]), groups
