@@ -120,8 +120,8 @@ def _timed_ms(run, n=50, warm=5):
 
 
 def _k_conv3_sb(dev, B, H, W):
-    """3x3 convolution 64 -> 64 channels on B x H x W pixels, forward / data-gradient launches of the step (conv3_c64_sb_kernel:
-    split-bf16 operands on the bf16 matrix cores; conv3_c64_ws16_kernel with tatt_amd.ops.CONV3_SB = False: exact fp32 MFMA)."""
+    """3x3 convolution 64 -> 64 channels on B x H x W pixels, forward / data-gradient launches of the step (conv3_c64_sb4_kernel:
+    split-bf16 operands on the bf16 matrix cores, round 6; conv3_c64_ws16_kernel with tatt_amd.ops.CONV3_SB = False: exact fp32 MFMA)."""
     from tatt_amd import ops
     w = torch.randn(64, 64, 3, 3, device=dev) * 0.05
     b = torch.zeros(64, device=dev)
@@ -207,7 +207,8 @@ def _k_gru_wgrad(dev, B, H, W):
 
 
 # kernels bench.py can time live, by the name they carry in the per-step table (prefix match)
-TIMEABLE = [("conv3_c64_sb_kernel", _k_conv3_sb), ("conv3_c64_ws16_kernel", _k_conv3_sb), ("conv3_c64_wgrad_sb_kernel", _k_conv3_wgrad),
+TIMEABLE = [("conv3_c64_sb4_kernel", _k_conv3_sb), ("conv3_c64_sb3_kernel", _k_conv3_sb), ("conv3_c64_sb_kernel", _k_conv3_sb),
+            ("conv3_c64_ws16_kernel", _k_conv3_sb), ("conv3_c64_wgrad_sb2_kernel", _k_conv3_wgrad), ("conv3_c64_wgrad_sb_kernel", _k_conv3_wgrad),
             ("conv3_c64_wgrad_kernel", _k_conv3_wgrad), ("gru32_bwd2_kernel", _k_gru32_bwd), ("gru32_bwd_kernel", _k_gru32_bwd),
             ("gru_wgrad_frag_kernel", _k_gru_wgrad)]
 
@@ -222,7 +223,7 @@ def step_table():
 def pick_kernels(table):
     """-> [(table name, timer, per-step us, launches)] of the timeable kernels, heaviest first.  Without a table: the 3x3 convolution."""
     if not table:
-        return [("conv3_c64_sb_kernel", _k_conv3_sb, None, None)]
+        return [("conv3_c64_sb4_kernel", _k_conv3_sb, None, None)]
     agg = {}
     for name, e in table["kernels"].items():
         for key, fn in TIMEABLE:
@@ -231,7 +232,7 @@ def pick_kernels(table):
                 a[2] += e["us"]
                 a[3] += e["launches"]
                 break
-    return sorted((tuple(v) for v in agg.values()), key=lambda v: -v[2]) or [("conv3_c64_sb_kernel", _k_conv3_sb, None, None)]
+    return sorted((tuple(v) for v in agg.values()), key=lambda v: -v[2]) or [("conv3_c64_sb4_kernel", _k_conv3_sb, None, None)]
 
 
 def roofline_block(name, k, per_step_us, launches, shape_key):

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-end artefacts in ONE gpurun call: bench lines of every configuration, one rocprofv3 kernel trace + step timeline + per-step kernel
 # table, the kernel micro-benchmarks, then the whole -m gpu suite.  usage: tools/final_round.sh <tag>
-tag=${1:-r05}
+tag=${1:-r06}
 mkdir -p gpurun_out; export TMPDIR=/tmp
 b() { name=$1; shift; timeout 300 python bench.py --steps 50 --warmup 10 "$@" > gpurun_out/${tag}_bench_${name}.json 2> gpurun_out/${tag}_bench_${name}.err; echo "bench $name rc=$? $(cut -c1-200 gpurun_out/${tag}_bench_${name}.json)"; }
 b std
