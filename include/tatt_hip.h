@@ -516,6 +516,19 @@ int tatt_sattn_fwd(const float* Q, const float* K, const float* V, float* O, flo
 int tatt_sattn_bwd(const float* Q, const float* K, const float* V, const float* O, const float* lse, const float* dO,
                    float* dQ, float* dK, float* dV, float* Dws, int B, int P, int h, float scale, float pdrop,
                    const unsigned long long* seed, unsigned site, hipStream_t st);
+/* The same pair with the dropout keep decisions handed from the forward to the backward as bits instead of being recomputed in all three
+ * kernels (the counter hash is 19 of the ~30 VALU issue slots a score costs): `bits` = B h P P / 32 words the forward fills (layout:
+ * csrc/sattn2.hip) and the backward of the same call reads; null = recompute (= the entries above).  Only the split-bf16 kernels use
+ * them; whatever runs, a backward must be given what its forward was given.  Same masks, same results as the entries above. */
+int tatt_sattn_fwd_bits(const float* Q, const float* K, const float* V, float* O, float* lse, unsigned* bits, int B, int P, int h,
+                        float scale, float pdrop, const unsigned long long* seed, unsigned site, hipStream_t st);
+int tatt_sattn_bwd_bits(const float* Q, const float* K, const float* V, const float* O, const float* lse, const float* dO,
+                        const unsigned* bits, float* dQ, float* dK, float* dV, float* Dws, int B, int P, int h, float scale,
+                        float pdrop, const unsigned long long* seed, unsigned site, hipStream_t st);
+/* Test / A-B hook: 2 (default) = the split-bf16 kernels (csrc/sattn2.hip: three v_mfma_f32_32x32x16_bf16 products of hi / lo halves per
+ * fp32 product; P % 128 == 0, B h P^2 < 4e9), 1 = the exact-fp32 MFMA kernels (also what other geometries run).  Returns the previous
+ * setting. */
+int tatt_sattn_generation(int gen);
 
 /* ---- one TP-interpreter transformer layer as ONE kernel (csrc/tplayer.hip) --------------------------------- */
 

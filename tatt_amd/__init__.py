@@ -21,7 +21,7 @@ def set_arithmetic(mode: str) -> None:
     either way; INTEGRATION.md "Arithmetic"):
 
       "split_bf16" (default) -- the 64-channel 3x3 convolutions (forward, data and weight gradients), the 9x9 convolutions at the image end (forward, data and weight gradients), the GruBlock projections, the
-          GruBlock weight gradients, the backward of the TP-interpreter layers and the recurrent products and recurrent weight gradient of the query GRU run on the bf16 matrix cores with every fp32 operand split a = hi + lo and
+          GruBlock weight gradients, the backward of the TP-interpreter layers, the recurrent products and recurrent weight gradient of the query GRU and the TBSRN self-attention run on the bf16 matrix cores with every fp32 operand split a = hi + lo and
           a b ~ hi hi + hi lo + lo hi: 2^-16 relative per product, ~16-17 mantissa bits instead of 24
           (profiles/r03_split_bf16_probe.txt: eval SR moves 1.1e-6, gradients ~1e-5 relative);
       "fp32" -- the same operators on v_mfma_f32_* (exact fp32 products), about 2 ms per training step slower at B = 48 (`exact_fp32` in the bench line).
@@ -32,12 +32,12 @@ def set_arithmetic(mode: str) -> None:
         raise ValueError("arithmetic must be 'split_bf16' or 'fp32', got %r" % (mode,))
     on = mode == "split_bf16"
     _ops.CONV3_SB = _ops.CONV3_WGRAD_SB = _ops.TPLAYER_BWD2 = _ops.CONV9_SB = on
-    _F.TOKGEMM_SB = _F.GRU_WGRAD_SB = _F.QGRU_CHAIN_SB = _F.QGRU_WGRAD_SB = on
+    _F.TOKGEMM_SB = _F.GRU_WGRAD_SB = _F.QGRU_CHAIN_SB = _F.QGRU_WGRAD_SB = _F.SATTN_SB = on
 
 
 def get_arithmetic() -> str:
     from . import functional as _F, ops as _ops
-    flags = (_ops.CONV3_SB, _ops.CONV3_WGRAD_SB, _ops.TPLAYER_BWD2, _ops.CONV9_SB, _F.TOKGEMM_SB, _F.GRU_WGRAD_SB, _F.QGRU_CHAIN_SB, _F.QGRU_WGRAD_SB)
+    flags = (_ops.CONV3_SB, _ops.CONV3_WGRAD_SB, _ops.TPLAYER_BWD2, _ops.CONV9_SB, _F.TOKGEMM_SB, _F.GRU_WGRAD_SB, _F.QGRU_CHAIN_SB, _F.QGRU_WGRAD_SB, _F.SATTN_SB)
     return "split_bf16" if all(flags) else ("fp32" if not any(flags) else "mixed")
 
 

@@ -335,25 +335,47 @@ static int sa_check(int B, int P, int h, int E) { return (B < 1 || P < SA_T || P
 
 // O (B,P,E) = dropout(softmax(Q K^T * scale)) V per head of 32 channels (E = 32 h, P a multiple of 64); lse (B,h,P) = log-sum-exp of
 // the scaled scores per query (kept for the backward).
-TATT_API int tatt_sattn_fwd(const float* Q, const float* K, const float* V, float* O, float* lse, int B, int P, int h, float scale,
-                            float pdrop, const unsigned long long* seed, unsigned site, hipStream_t st) {
+// csrc/sattn2.hip: the split-bf16 kernels; -1 = not taken (generation 1 selected, or a geometry they do not cover)
+int sattn2_fwd(const float* Q, const float* K, const float* V, float* O, float* lse, int B, int P, int h, float scale, float pdrop,
+               const unsigned long long* seed, unsigned site, unsigned* bits, hipStream_t st);
+int sattn2_bwd(const float* Q, const float* K, const float* V, const float* lse, const float* dO, const float* Dws, float* dQ, float* dK,
+               float* dV, int B, int P, int h, float scale, float pdrop, const unsigned long long* seed, unsigned site, const unsigned* bits,
+               hipStream_t st);
+// `bits` (null, or B h P P / 32 words): where the forward leaves the keep decisions of the dropout masks for the backward (sattn2.hip);
+// with null -- and in the fp32 kernels always -- every kernel recomputes them from (seed, site).  A backward must be given what its
+// forward was given.
+TATT_API int tatt_sattn_fwd_bits(const float* Q, const float* K, const float* V, float* O, float* lse, unsigned* bits, int B, int P, int h,
+                                 float scale, float pdrop, const unsigned long long* seed, unsigned site, hipStream_t st) {
     const int E = h * SA_D;
     if (sa_check(B, P, h, E)) return 1;
     if (pdrop > 0.f && !seed) return 2;
+    const int r2 = sattn2_fwd(Q, K, V, O, lse, B, P, h, scale, pdrop, seed, site, bits, st);
+    if (r2 >= 0) return r2;
     SAttnP p = {Q, K, V, O, lse, nullptr, nullptr, nullptr, nullptr, nullptr, B, P, h, E, scale, pdrop, seed, site};
     hipLaunchKernelGGL(sattn_fwd_kernel, dim3(P / SA_T, B * h), dim3(256), 0, st, p);
     return LAUNCH_CHECK();
 }
+TATT_API int tatt_sattn_fwd(const float* Q, const float* K, const float* V, float* O, float* lse, int B, int P, int h, float scale,
+                            float pdrop, const unsigned long long* seed, unsigned site, hipStream_t st) {
+    return tatt_sattn_fwd_bits(Q, K, V, O, lse, nullptr, B, P, h, scale, pdrop, seed, site, st);
+}
 // Gradients of the same: Dws = workspace of B*h*P floats.  Three launches (D = rowsum(dO * O); dK, dV; dQ), no atomics.
-TATT_API int tatt_sattn_bwd(const float* Q, const float* K, const float* V, const float* O, const float* lse, const float* dO,
-                            float* dQ, float* dK, float* dV, float* Dws, int B, int P, int h, float scale, float pdrop,
-                            const unsigned long long* seed, unsigned site, hipStream_t st) {
+TATT_API int tatt_sattn_bwd_bits(const float* Q, const float* K, const float* V, const float* O, const float* lse, const float* dO,
+                                 const unsigned* bits, float* dQ, float* dK, float* dV, float* Dws, int B, int P, int h, float scale,
+                                 float pdrop, const unsigned long long* seed, unsigned site, hipStream_t st) {
     const int E = h * SA_D;
     if (sa_check(B, P, h, E)) return 1;
     if (pdrop > 0.f && !seed) return 2;
     SAttnP p = {Q, K, V, const_cast<float*>(O), const_cast<float*>(lse), dO, Dws, dQ, dK, dV, B, P, h, E, scale, pdrop, seed, site};
     hipLaunchKernelGGL(sattn_prep_kernel, dim3(cdiv((long)B * P * h, 256)), dim3(256), 0, st, p);
+    const int r2 = sattn2_bwd(Q, K, V, lse, dO, Dws, dQ, dK, dV, B, P, h, scale, pdrop, seed, site, bits, st);
+    if (r2 >= 0) return r2;
     hipLaunchKernelGGL(sattn_bwd_kv_kernel, dim3(P / SA_T, B * h), dim3(256), 0, st, p);
     hipLaunchKernelGGL(sattn_bwd_q_kernel, dim3(P / SA_T, B * h), dim3(256), 0, st, p);
     return LAUNCH_CHECK();
+}
+TATT_API int tatt_sattn_bwd(const float* Q, const float* K, const float* V, const float* O, const float* lse, const float* dO,
+                            float* dQ, float* dK, float* dV, float* Dws, int B, int P, int h, float scale, float pdrop,
+                            const unsigned long long* seed, unsigned site, hipStream_t st) {
+    return tatt_sattn_bwd_bits(Q, K, V, O, lse, dO, nullptr, dQ, dK, dV, Dws, B, P, h, scale, pdrop, seed, site, st);
 }

@@ -1647,9 +1647,17 @@ class SelfAttnCoreFn(Function):
         return dQ, dK, dV, None, None, None
 
 
+def _sattn_select():
+    want = 2 if SATTN_SB else 1
+    if ops.LIB.tatt_sattn_generation(0) != want:
+        ops.LIB.tatt_sattn_generation(want)
+
+
 class SelfAttnFlashFn(Function):
-    """The same attention as SelfAttnCoreFn without the (B, h, P, P) tensors: csrc/sattn.hip (online softmax forward; backward
-    recomputes the probabilities tile by tile from Q, K and the saved per-query log-sum-exp).  d_k = 32, P a multiple of 64."""
+    """The same attention as SelfAttnCoreFn without the (B, h, P, P) tensors: csrc/sattn2.hip (split bf16; csrc/sattn.hip = the exact
+    fp32 kernels) -- online softmax forward; backward recomputes the probabilities tile by tile from Q, K and the saved per-query
+    log-sum-exp.  With dropout the forward leaves the keep decisions behind as bits (B h P^2 / 8 bytes) so that the two backward kernels
+    do not recompute the counter hash (SATTN_KEEP_BITS).  d_k = 32, P a multiple of 64."""
 
     @staticmethod
     def forward(ctx, Q, K, V, h, pdrop, site):
@@ -1657,22 +1665,25 @@ class SelfAttnFlashFn(Function):
         scale = 1.0 / math.sqrt(E // h)
         seed = current_seed(Q.device) if pdrop > 0.0 else None
         O, lse = torch.empty_like(Q), ops.new(Q, B, h, Pn)
-        ops.call("tatt_sattn_fwd", ops.P(Q), ops.P(K), ops.P(V), ops.P(O), ops.P(lse), B, Pn, h, scale, float(pdrop), ops.P(seed),
-                 int(site), ops.stream())
+        _sattn_select()
+        bits = torch.empty(B * h * Pn * (Pn // 32), device=Q.device, dtype=torch.int32) if (pdrop > 0.0 and SATTN_KEEP_BITS and Pn % 32 == 0) else None
+        ops.call("tatt_sattn_fwd_bits", ops.P(Q), ops.P(K), ops.P(V), ops.P(O), ops.P(lse), ops.P(bits), B, Pn, h, scale, float(pdrop),
+                 ops.P(seed), int(site), ops.stream())
         ctx.save_for_backward(Q, K, V, O, lse)
-        ctx.cfg = (h, float(pdrop), int(site), seed, scale)
+        ctx.cfg = (h, float(pdrop), int(site), seed, scale, bits)
         return O
 
     @staticmethod
     def backward(ctx, dO):
         Q, K, V, O, lse = ctx.saved_tensors
-        h, pdrop, site, seed, scale = ctx.cfg
+        h, pdrop, site, seed, scale, bits = ctx.cfg
         B, Pn, E = Q.shape
         dO = _c(dO)
         dQ, dK, dV = torch.empty_like(Q), torch.empty_like(K), torch.empty_like(V)
         ws = ops.new(Q, B, h, Pn)
-        ops.call("tatt_sattn_bwd", ops.P(Q), ops.P(K), ops.P(V), ops.P(O), ops.P(lse), ops.P(dO), ops.P(dQ), ops.P(dK), ops.P(dV),
-                 ops.P(ws), B, Pn, h, scale, pdrop, ops.P(seed), site, ops.stream())
+        _sattn_select()
+        ops.call("tatt_sattn_bwd_bits", ops.P(Q), ops.P(K), ops.P(V), ops.P(O), ops.P(lse), ops.P(dO), ops.P(bits), ops.P(dQ), ops.P(dK),
+                 ops.P(dV), ops.P(ws), B, Pn, h, scale, pdrop, ops.P(seed), site, ops.stream())
         return dQ, dK, dV, None, None, None
 
 
@@ -1686,6 +1697,8 @@ def self_attention(Q, K, V, h, pdrop, site):
 
 
 SATTN_FLASH = True          # test / A-B hook: False -> materialised scores (SelfAttnCoreFn)
+SATTN_SB = True             # tatt_amd.set_arithmetic: False -> the exact-fp32 kernels of csrc/sattn.hip
+SATTN_KEEP_BITS = True      # test / A-B hook: False -> all three attention kernels recompute the dropout masks
 
 
 class CatPEFn(Function):
