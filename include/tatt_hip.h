@@ -499,6 +499,10 @@ int tatt_softmax_rows_bwd(const float* P, float* dP, long rows, int L, float pdr
  * (128, 192), (64, 192), (64, 64), (64, 128). */
 int tatt_tokgemm_sb(const float* X1, const float* X2, int K1, const float* Wp, const float* bias, float* Y1, float* Y2, int N1,
                     int M, int N, int K, hipStream_t st);
+/* The same with an epilogue: act = 1 (ReLU) after the bias; accum != 0: Y += instead of Y = (sums of data gradients into one map).
+ * Also takes (N, K) = (128, 128) and (128, 64): the TBSRN FeatureEnhancer projections (reference model/tbsrn.py:77-151). */
+int tatt_tokgemm_sb_ex(const float* X1, const float* X2, int K1, const float* Wp, const float* bias, float* Y1, float* Y2, int N1,
+                       int M, int N, int K, int act, int accum, hipStream_t st);
 /* trans = 0: w(n, k) = W[n*ldw + k] (y = x W^T);  trans = 1: w(n, k) = W[k*ldw + n] (dx = dy W).  out: N*K words */
 int tatt_tokgemm_pack(const float* W, float* out, int N, int K, int ldw, int trans, hipStream_t st);
 /* n packs in one launch: ptrs = HOST array of n x 2 device pointers (W, out), dims = HOST array of n x 4 ints (N, K, ldw, trans) */

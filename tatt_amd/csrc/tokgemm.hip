@@ -21,6 +21,7 @@ struct TokGemmP {
     const float* W; const float* bias;               // packed split-bf16 operand (tatt_tokgemm_pack), bias (N) or null
     float* Y1; float* Y2; int N1;                    // destinations: columns [0, N1) to Y1 (row pitch N1), [N1, N) to Y2 (row pitch N - N1)
     int M;
+    int act, accum;                                  // epilogue: ACT_RELU after the bias; accum: Y += (instead of Y =)
 };
 
 __device__ __forceinline__ void tg_split(f32x4 v, uint2& hi, uint2& lo) {
@@ -122,7 +123,13 @@ __global__ __launch_bounds__(512, 1) void tokgemm_sb_kernel(TokGemmP p) {
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) dst[(row0 + 16 * m + r) * ld + c] = (accM[m][cb][r] + accC[m][cb][r]) + bj[cb];
+                    for (int r = 0; r < 4; ++r) {
+                        float* y = dst + (row0 + 16 * m + r) * ld + c;
+                        float v = (accM[m][cb][r] + accC[m][cb][r]) + bj[cb];
+                        if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
+                        if (p.accum) v += *y;
+                        *y = v;
+                    }
             }
         }
         if (!has_next) break;
@@ -210,15 +217,24 @@ static int tg_launch(const TokGemmP& p, hipStream_t st) {
 }
 // Y = [X1 | X2] Wp^T + bias with Wp from tatt_tokgemm_pack; X1 (M, K1), X2 (M, K - K1) (null when K1 == K); the first N1 output columns
 // go to Y1 (M, N1), the rest to Y2 (M, N - N1) (null when N1 == N).  M a multiple of 64; (N, K) in {64,128,192} x {64,128,192}.
-TATT_API int tatt_tokgemm_sb(const float* X1, const float* X2, int K1, const float* Wp, const float* bias, float* Y1, float* Y2, int N1,
-                             int M, int N, int K, hipStream_t st) {
+// _ex: act = ACT_RELU applies max(., 0) after the bias; accum != 0 adds the result to what Y holds (the sum of several data gradients
+// into one map: dx = dq Wq + dk Wk + dv Wv of the TBSRN attention projections).
+TATT_API int tatt_tokgemm_sb_ex(const float* X1, const float* X2, int K1, const float* Wp, const float* bias, float* Y1, float* Y2, int N1,
+                                int M, int N, int K, int act, int accum, hipStream_t st) {
     if (M < 64 || M % 64 || K1 % 4 || (K - K1) % 4 || K1 < 0 || K1 > K || N1 < 0 || N1 > N || (K1 < K && !X2) || (N1 < N && !Y2)) return 1;
-    TokGemmP p = {X1, X2, K1, Wp, bias, Y1, Y2, N1, M};
+    if (act != ACT_NONE && act != ACT_RELU) return 1;
+    TokGemmP p = {X1, X2, K1, Wp, bias, Y1, Y2, N1, M, act, accum};
     if (N == 192 && K == 128) return tg_launch<3, 4>(p, st);
     if (N == 192 && K == 64) return tg_launch<3, 2>(p, st);
     if (N == 128 && K == 192) return tg_launch<2, 6>(p, st);
+    if (N == 128 && K == 128) return tg_launch<2, 4>(p, st);
+    if (N == 128 && K == 64) return tg_launch<2, 2>(p, st);
     if (N == 64 && K == 192) return tg_launch<1, 6>(p, st);
     if (N == 64 && K == 64) return tg_launch<1, 2>(p, st);
     if (N == 64 && K == 128) return tg_launch<1, 4>(p, st);
     return 1;
+}
+TATT_API int tatt_tokgemm_sb(const float* X1, const float* X2, int K1, const float* Wp, const float* bias, float* Y1, float* Y2, int N1,
+                             int M, int N, int K, hipStream_t st) {
+    return tatt_tokgemm_sb_ex(X1, X2, K1, Wp, bias, Y1, Y2, N1, M, N, K, ACT_NONE, 0, st);
 }

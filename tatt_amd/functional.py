@@ -464,18 +464,80 @@ def srb_trunk(x, blk):
 
 
 # --------------------------------------------------------------------------------------------------
+class _PackedLinears:
+    """Split-bf16 operands (tatt_tokgemm_pack) of the nn.Linear weights of the forward in flight, keyed by the weight's storage: a
+    generator packs all of its token projections with one or two launches at the start of its forward (`linear_prepack`: forward
+    operand W (N, K) and data-gradient operand W^T) instead of two tiny launches in front of every GEMM; LinearFn / QKVProjFn look
+    their weight up and carry the data-gradient operand to the backward."""
+
+    def __init__(self):
+        self.table = {}
+
+
+_PKL = _PackedLinears()
+_TOKGEMM_NK = {(192, 128), (192, 64), (128, 192), (128, 128), (128, 64), (64, 192), (64, 64), (64, 128)}      # tatt_tokgemm_sb_ex
+
+
+def linear_prepack(linears):
+    """linears: nn.Linear parameter holders on one device whose (out, in) and (in, out) are shapes of tatt_tokgemm_sb_ex."""
+    import ctypes
+    _PKL.table = {}
+    if not TOKGEMM_SB:
+        return
+    pk_ptrs, pk_dims, outs = [], [], {}
+    for l in linears:
+        W = l.weight
+        N, K = W.shape
+        if not W.is_cuda or (N, K) not in _TOKGEMM_NK or (K, N) not in _TOKGEMM_NK or W.data_ptr() in outs:
+            continue
+        Wfk, Wbk = ops.new(W, N * K), ops.new(W, N * K)
+        pk_ptrs += [W.data_ptr(), Wfk.data_ptr(), W.data_ptr(), Wbk.data_ptr()]
+        pk_dims += [N, K, K, 0, K, N, K, 1]
+        outs[W.data_ptr()] = (Wfk, Wbk, W._version)
+    if pk_ptrs:
+        ops.call("tatt_tokgemm_pack_batch", (ctypes.c_void_p * len(pk_ptrs))(*pk_ptrs), (ctypes.c_int * len(pk_dims))(*pk_dims),
+                 len(pk_ptrs) // 2, ops.stream())
+    _PKL.table = outs
+
+
+def linear_prepack_done():
+    _PKL.table = {}
+
+
+def _packed_linear(weight, M):
+    """(forward operand, data-gradient operand) of a prepacked weight this forward may use on M tokens, else None"""
+    e = _PKL.table.get(weight.data_ptr()) if TOKGEMM_SB else None
+    if e is None or e[2] != weight._version or M % 64 or M < 64:
+        return None
+    return e[0], e[1]
+
+
+def _tokgemm_ex(X, Wpk, bias, N, K, act=ACT_NONE, out=None, accum=False):
+    M = X.shape[0]
+    Y = ops.new(X, M, N) if out is None else out
+    ops.call("tatt_tokgemm_sb_ex", ops.P(X), None, K, ops.P(Wpk), ops.P(bias), ops.P(Y), None, N, M, N, K, int(act), int(bool(accum)),
+             ops.stream())
+    return Y
+
+
 class LinearFn(Function):
-    """y = act(alpha*(x @ W^T + b)); optional second input concatenated along the feature axis."""
+    """y = act(alpha*(x @ W^T + b)); optional second input concatenated along the feature axis.  A weight the forward in flight has
+    prepacked (linear_prepack) runs on the bf16 matrix cores with split operands (csrc/tokgemm.hip), forward and data gradient."""
 
     @staticmethod
     def forward(ctx, x, xb, weight, bias, act, alpha):
         K1 = x.shape[-1]
         x2 = x.reshape(-1, K1)
         xb2 = xb.reshape(-1, xb.shape[-1]) if xb is not None else None
-        y = ops.linear_fwd(x2, weight, bias, act=act, alpha=alpha, x2b=xb2)
+        pk = _packed_linear(weight, x2.shape[0]) if (xb is None and alpha == 1.0 and act in (ACT_NONE, ACT_RELU)) else None
+        if pk is not None:
+            y = _tokgemm_ex(x2, pk[0], bias, weight.shape[0], K1, act)
+        else:
+            y = ops.linear_fwd(x2, weight, bias, act=act, alpha=alpha, x2b=xb2)
         ctx.save_for_backward(x, xb, weight, y if act != ACT_NONE else None)
         ctx.act, ctx.alpha, ctx.has_bias = act, alpha, bias is not None
         ctx.leaves = (weight, bias)
+        ctx.wbk = pk[1] if pk is not None else None
         return y.reshape(*x.shape[:-1], weight.shape[0])
 
     @staticmethod
@@ -489,7 +551,10 @@ class LinearFn(Function):
         x2 = x.reshape(-1, K1)
         dx = dxb = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = ops.linear_bwd_input(dy2, weight, col0=0, ncols=K1, alpha=ctx.alpha).reshape(x.shape)
+            if ctx.wbk is not None:
+                dx = _tokgemm_ex(dy2, ctx.wbk, None, K, N).reshape(x.shape)
+            else:
+                dx = ops.linear_bwd_input(dy2, weight, col0=0, ncols=K1, alpha=ctx.alpha).reshape(x.shape)
         if xb is not None and ctx.needs_input_grad[1]:
             dxb = ops.linear_bwd_input(dy2, weight, col0=K1, ncols=K - K1, alpha=ctx.alpha).reshape(xb.shape)
         want_db = ctx.has_bias and ctx.needs_input_grad[3]
@@ -508,6 +573,60 @@ class LinearFn(Function):
             return dw, db
         dw, db = SIDE.submit(ctx.leaves, param_grads, dy2, x, xb)
         return dx, dxb, dw, db, None, None
+
+
+class QKVProjFn(Function):
+    """The three projections of one token matrix in front of an attention (reference MultiHeadedAttention.forward,
+    model/tbsrn.py:119-128: linears[0..2] applied to the same x) as one operator: q, k, v = x Wq^T + bq, ...; backward
+    dx = dq Wq + dk Wk + dv Wv accumulated by the GEMM epilogues (tatt_tokgemm_sb_ex accum) instead of three maps and two additions.
+    Needs prepacked weights (linear_prepack)."""
+
+    @staticmethod
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv):
+        K = x.shape[-1]
+        x2 = x.reshape(-1, K)
+        pks = [_packed_linear(w, x2.shape[0]) for w in (wq, wk, wv)]
+        N = wq.shape[0]
+        outs = [_tokgemm_ex(x2, pk[0], b, N, K) for pk, b in zip(pks, (bq, bk, bv))]
+        ctx.save_for_backward(x, wq, wk, wv)
+        ctx.wbk = [pk[1] for pk in pks]
+        ctx.has_b = [b is not None for b in (bq, bk, bv)]
+        ctx.leaves = (wq, bq, wk, bk, wv, bv)
+        return tuple(o.reshape(*x.shape[:-1], N) for o in outs)
+
+    @staticmethod
+    def backward(ctx, dq, dk, dv):
+        x, wq, wk, wv = ctx.saved_tensors
+        N, K = wq.shape
+        x2 = x.reshape(-1, K)
+        ds = [_c(d).reshape(-1, N) for d in (dq, dk, dv)]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _tokgemm_ex(ds[0], ctx.wbk[0], None, K, N)
+            _tokgemm_ex(ds[1], ctx.wbk[1], None, K, N, out=dx, accum=True)
+            _tokgemm_ex(ds[2], ctx.wbk[2], None, K, N, out=dx, accum=True)
+            dx = dx.reshape(x.shape)
+        has_b = ctx.has_b
+
+        def param_grads():
+            res = []
+            for d, hb in zip(ds, has_b):
+                dw = ops.new(d, N, K)
+                db = ops.new(d, N) if hb else None
+                ops.linear_bwd_weight(d, x2, out=dw, out_ld=K, rowsum=db)
+                res += [dw, db]
+            return tuple(res)
+        g = SIDE.submit(ctx.leaves, param_grads, x, *ds)
+        return (dx,) + tuple(g)
+
+
+def qkv_projection(x, lq, lk, lv):
+    """lq, lk, lv: nn.Linear holders applied to the same (B, P, K) token matrix"""
+    x = _c(x)
+    M = x.numel() // x.shape[-1]
+    if all(_packed_linear(l.weight, M) is not None for l in (lq, lk, lv)):
+        return QKVProjFn.apply(x, lq.weight, lq.bias, lk.weight, lk.bias, lv.weight, lv.bias)
+    return tuple(linear(x, l.weight, l.bias) for l in (lq, lk, lv))
 
 
 def linear(x, weight, bias=None, act=ACT_NONE, alpha=1.0, xb=None):

@@ -104,6 +104,10 @@ class RecurrentResidualBlock(_Holder):
                 nn.init.xavier_uniform_(p)
 
 
+def _fe_linears(fe: FeatureEnhancer):
+    return list(fe.multihead.linears) + [fe.pff.w_1, fe.pff.w_2, fe.linear]
+
+
 def _feature_enhancer(r, fe: FeatureEnhancer, training, dropout_on, site0):
     """FeatureEnhancer.forward (model/tbsrn.py:77-93) on an NHWC map r (B,H,W,64) -> (B,H,W,64)."""
     B, H, W, C = r.shape
@@ -111,9 +115,7 @@ def _feature_enhancer(r, fe: FeatureEnhancer, training, dropout_on, site0):
     drop = training and dropout_on
     x = Fh.CatPEFn.apply(r.reshape(B, Pn, C), fe.pe_tokens(H, W, r.device))          # (B,P,128)
     mh = fe.multihead
-    q = Fh.linear(x, mh.linears[0].weight, mh.linears[0].bias)
-    k = Fh.linear(x, mh.linears[1].weight, mh.linears[1].bias)
-    v = Fh.linear(x, mh.linears[2].weight, mh.linears[2].bias)
+    q, k, v = Fh.qkv_projection(x, mh.linears[0], mh.linears[1], mh.linears[2])
     a = Fh.self_attention(q, k, v, mh.h, mh.p if drop else 0.0, site0)
     a = Fh.linear(a, mh.linears[3].weight, mh.linears[3].bias)
     ln1, ln3 = fe.mul_layernorm1, fe.mul_layernorm3
@@ -180,6 +182,8 @@ class TBSRN(_TrainPathMixin, nn.Module):
         c1 = self.block1[0]
         b1 = Fh.prelu(Fh.conv2d(xin, c1.weight, c1.bias), self.block1[1].weight)
         b1_in = b1
+        # split-bf16 operands of the 35 FeatureEnhancer projections (forward and data-gradient forms), packed in two launches
+        Fh.linear_prepack([l for i in range(k) for l in _fe_linears(getattr(self, "block%d" % (i + 2)).feature_enhancer)])
         if cuts:                                                  # backward stages: "trunk" (from the loss), "srb4" ... "srb0", "first"
             b1 = cuts.cut("first", b1_in)
         h = b1_in
@@ -187,6 +191,7 @@ class TBSRN(_TrainPathMixin, nn.Module):
             if cuts:
                 h = cuts.cut("first", b1_in) if i == 0 else cuts.cut("srb%d" % (i - 1), h)
             h = _srb(h, getattr(self, "block%d" % (i + 2)), training, self.dropout_on, 100 + 10 * i)
+        Fh.linear_prepack_done()
         if cuts and k > 0:
             h = cuts.cut("srb%d" % (k - 1), h)
         b7 = getattr(self, "block%d" % (k + 2))

@@ -1267,6 +1267,66 @@ def test_tokgemm_split_bf16_vs_fp64(dev, N, K, K1, N1):
         assert err < 1e-5, (trans, err)
 
 
+@pytest.mark.parametrize("N,K", [(128, 128), (128, 64), (64, 128)])
+def test_tokgemm_epilogues_relu_and_accumulate_vs_fp64(dev, N, K):
+    """tatt_tokgemm_sb_ex: the (N, K) of the TBSRN FeatureEnhancer projections; ReLU after the bias; accumulation into the destination
+    (the sum of data gradients dq Wq + dk Wk + dv Wv) -- against fp64."""
+    from tatt_amd import ops
+    from tatt_amd import functional as Fh
+    M = 64 * 21
+    X, W, b, Y0 = R(M, K, seed=21), R(N, K, seed=22) / math.sqrt(K), R(N, seed=23), R(M, N, seed=24)
+    Wpk = torch.empty(N * K, device=dev)
+    ops.call("tatt_tokgemm_pack", ops.P(W.to(dev)), ops.P(Wpk), N, K, K, 0, ops.stream())
+    lin = X.double() @ W.double().t() + b.double()
+    y = Fh._tokgemm_ex(X.to(dev), Wpk, b.to(dev), N, K, act=1)
+    assert float((y.cpu().double() - lin.clamp_min(0)).abs().max() / lin.abs().max()) < 1e-5
+    acc = Y0.clone().to(dev)
+    Fh._tokgemm_ex(X.to(dev), Wpk, b.to(dev), N, K, out=acc, accum=True)
+    assert float((acc.cpu().double() - (Y0.double() + lin)).abs().max() / lin.abs().max()) < 1e-5
+
+
+def test_qkv_projection_operator_vs_three_linears(dev):
+    """QKVProjFn (three prepacked split-bf16 projections of one token matrix; backward accumulates the three data gradients in the
+    GEMM epilogues) against three fp64 linears: values, dx and the six parameter gradients; and LinearFn's prepacked path (ReLU)."""
+    from tatt_amd import functional as Fh
+    g = torch.Generator().manual_seed(4)
+    B, Pn, E = 2, 256, 128
+    x = torch.randn(B, Pn, E, generator=g)
+    lins = [torch.nn.Linear(E, E) for _ in range(3)] + [torch.nn.Linear(E, 64)]
+    ws = [torch.randn(B, Pn, E, generator=g) for _ in range(3)]
+    xd = x.double().requires_grad_(True)
+    ref = [F.linear(xd, l.weight.detach().double(), l.bias.detach().double()) for l in lins[:3]]
+    sum((r * w.double()).sum() for r, w in zip(ref, ws)).backward()
+    ref_dx = xd.grad.clone()
+    dl = [l.to(dev) for l in lins]
+    Fh.linear_prepack(dl)
+    try:
+        xg = x.to(dev).requires_grad_(True)
+        q, k, v = Fh.qkv_projection(xg, dl[0], dl[1], dl[2])
+        assert isinstance(q.grad_fn, Fh.QKVProjFn._backward_cls)
+        sum((o * w.to(dev)).sum() for o, w in zip((q, k, v), ws)).backward()
+        for got, want in zip((q, k, v), ref):
+            assert float((got.detach().cpu().double() - want.detach()).abs().max() / want.detach().abs().max()) < 1e-5
+        assert float((xg.grad.cpu().double() - ref_dx).abs().max() / ref_dx.abs().max()) < 1e-5
+        for l, w in zip(dl[:3], ws):
+            want_w = (w.double().reshape(-1, E).t() @ x.double().reshape(-1, E))
+            want_b = w.double().reshape(-1, E).sum(0)
+            assert float((l.weight.grad.cpu().double() - want_w).abs().max() / want_w.abs().max()) < 1e-5
+            assert float((l.bias.grad.cpu().double() - want_b).abs().max() / want_b.abs().max()) < 1e-5
+        # LinearFn on a prepacked weight: 128 -> 64 with ReLU, forward and data gradient
+        x2 = x.to(dev).requires_grad_(True)
+        y = Fh.linear(x2, dl[3].weight, dl[3].bias, act=1)
+        w4 = torch.randn(B, Pn, 64, generator=g)
+        (y * w4.to(dev)).sum().backward()
+        x2d = x.double().requires_grad_(True)
+        yr = F.relu(F.linear(x2d, lins[3].weight.detach().cpu().double(), lins[3].bias.detach().cpu().double()))
+        (yr * w4.double()).sum().backward()
+        assert float((y.detach().cpu().double() - yr.detach()).abs().max() / yr.detach().abs().max()) < 1e-5
+        assert float((x2.grad.cpu().double() - x2d.grad).abs().max() / x2d.grad.abs().max()) < 1e-5
+    finally:
+        Fh.linear_prepack_done()
+
+
 # ------------------------------------------------------------------------------------------- fused GruBlock weight gradients
 @pytest.mark.parametrize("M,with_xb,groups", [(32 * 200, True, 128), (32 * 200, False, 128), (32, True, 128), (32 * 7, True, 3),
                                                (49152, True, 128), (49152, True, 256)])

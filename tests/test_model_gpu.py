@@ -230,35 +230,44 @@ def test_ptflops_style_probe(dev):
 TBSRN_KW = dict(scale_factor=2, width=512, height=32, STN=True, mask=True, input_channel=4)
 
 
-def test_tbsrn_golden_eval_and_train(dev):
+@pytest.mark.parametrize("arithmetic", ["split_bf16", "fp32"])
+def test_tbsrn_golden_eval_and_train(dev, arithmetic):
     """LR 16x256 (H*W = 4096: the only geometry the unmodified reference executes), B=2: eval SR, train SR, loss and
-    every parameter gradient against the reference-generated vectors and the oracle."""
+    every parameter gradient against the reference-generated vectors and the oracle -- under both arithmetics: exact fp32 products
+    (bound 2e-5 on the images) and the default split-bf16 products (2^-16 per product through 5 attention blocks of 7 projections
+    each: bound 5e-5, measured 2.4e-5)."""
+    import tatt_amd
     from tatt_amd.train import image_loss
     z = np.load("tests/golden/tbsrn_b2.npz")
-    m = build("TBSRN", dev, **TBSRN_KW).eval()
-    sd0 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
-    x, hr = torch.from_numpy(z["x"]), torch.from_numpy(z["hr"])
-    with torch.no_grad():
-        y = m(x.to(dev))
-    e = max_err(y, torch.from_numpy(z["sr_eval"]))
-    assert e < 2e-5, e
-    m.train()
-    m.stn = False                     # see tools/gen_golden.py: the reference cannot train with its STN at this geometry
-    m.dropout_on = False
-    sr = m(x.to(dev))
-    loss = image_loss(sr, hr.to(dev)).mean() * 100
-    loss.backward()
-    assert max_err(sr, torch.from_numpy(z["sr_train"])) < 2e-5
-    assert abs(float(loss.detach()) - float(z["loss"])) < 1e-4 * float(z["loss"])
-    _, o_grads, o_sd1, _, o_out, _ = O.train_step(sd0, x, None, hr, stn=False, tbsrn=True)
-    worst = compare_param_grads(m.named_parameters(), o_grads, rtol=5e-3)
-    print("tbsrn worst relative gradient error vs oracle: %s %.3e" % worst)
-    assert len([k for k, p in m.named_parameters() if p.grad is None]) == len(z["none_keys"])
-    params = dict(m.named_parameters())
-    scale = max(float(r[0]) for r in z["grad_summary"])
-    for k, ref in zip(z["grad_keys"].tolist(), z["grad_summary"]):
-        got = summarize(params[k].grad.cpu())
-        assert abs(got[0] - ref[0]) < 1e-2 * ref[0] + 1e-6 * scale * params[k].numel() ** 0.5, (k, got[0], ref[0])
+    tatt_amd.set_arithmetic(arithmetic)
+    try:
+        tol = 2e-5 if arithmetic == "fp32" else 5e-5
+        m = build("TBSRN", dev, **TBSRN_KW).eval()
+        sd0 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+        x, hr = torch.from_numpy(z["x"]), torch.from_numpy(z["hr"])
+        with torch.no_grad():
+            y = m(x.to(dev))
+        e = max_err(y, torch.from_numpy(z["sr_eval"]))
+        assert e < tol, e
+        m.train()
+        m.stn = False                     # see tools/gen_golden.py: the reference cannot train with its STN at this geometry
+        m.dropout_on = False
+        sr = m(x.to(dev))
+        loss = image_loss(sr, hr.to(dev)).mean() * 100
+        loss.backward()
+        assert max_err(sr, torch.from_numpy(z["sr_train"])) < tol
+        assert abs(float(loss.detach()) - float(z["loss"])) < 1e-4 * float(z["loss"])
+        _, o_grads, o_sd1, _, o_out, _ = O.train_step(sd0, x, None, hr, stn=False, tbsrn=True)
+        worst = compare_param_grads(m.named_parameters(), o_grads, rtol=5e-3)
+        print("tbsrn (%s) worst relative gradient error vs oracle: %s %.3e" % ((arithmetic,) + tuple(worst)))
+        assert len([k for k, p in m.named_parameters() if p.grad is None]) == len(z["none_keys"])
+        params = dict(m.named_parameters())
+        scale = max(float(r[0]) for r in z["grad_summary"])
+        for k, ref in zip(z["grad_keys"].tolist(), z["grad_summary"]):
+            got = summarize(params[k].grad.cpu())
+            assert abs(got[0] - ref[0]) < 1e-2 * ref[0] + 1e-6 * scale * params[k].numel() ** 0.5, (k, got[0], ref[0])
+    finally:
+        tatt_amd.set_arithmetic("split_bf16")
 
 
 def test_tbsrn_train_with_stn_at_16x64(dev):
