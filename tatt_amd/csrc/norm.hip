@@ -667,6 +667,62 @@ __global__ void ln_bwd_kernel(const float* __restrict__ A, const float* __restri
         part[((long)blockIdx.x * 2 + 1) * C + c] = b;
     }
 }
+// C = 128 without dropout (the two LayerNorms of every TBSRN FeatureEnhancer: 10 launches of 49,152 rows per step, 54 us each in the
+// generic kernel -- one row per wave iteration, scalar loads, two 6-step cross-lane sums per row; HBM needs 25 us for the 100 MB).
+// Here a 16-lane group owns a row (lane = channels 4 l .. + 3 and 64 + 4 l .. + 3: two 16-byte loads per tensor), four rows per
+// group in flight, row sums by DPP; the same part[G][2][C] partial layout as ln_bwd_kernel (G = blocks of 64 rows).
+__global__ __launch_bounds__(256) void ln_bwd_c128_kernel(const float* __restrict__ A, const float* __restrict__ Bres, const float* __restrict__ dY,
+                                                          const float* __restrict__ stats, float* __restrict__ dX, int M,
+                                                          const float* __restrict__ gamma, float* __restrict__ part, float eps, int mode) {
+    __shared__ float sh[16][2][128];
+    const int grp = threadIdx.x >> 4, l = threadIdx.x & 15;
+    const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + 4 * l), g1 = *reinterpret_cast<const f32x4*>(gamma + 64 + 4 * l);
+    f32x4 dg0 = {0.f, 0.f, 0.f, 0.f}, dg1 = dg0, db0 = dg0, db1 = dg0;
+    const long r0 = (long)blockIdx.x * LN_BWD_ROWS + 4 * grp;
+    f32x4 x0[4], x1[4], y0[4], y1[4];
+    float mu[4], rs[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long row = r0 + j < M ? r0 + j : M - 1;
+        const float* a = A + row * 128 + 4 * l;
+        x0[j] = *reinterpret_cast<const f32x4*>(a); x1[j] = *reinterpret_cast<const f32x4*>(a + 64);
+        if (Bres) { x0[j] += *reinterpret_cast<const f32x4*>(Bres + row * 128 + 4 * l); x1[j] += *reinterpret_cast<const f32x4*>(Bres + row * 128 + 64 + 4 * l); }
+        y0[j] = *reinterpret_cast<const f32x4*>(dY + row * 128 + 4 * l); y1[j] = *reinterpret_cast<const f32x4*>(dY + row * 128 + 64 + 4 * l);
+        mu[j] = stats[row * 2]; rs[j] = stats[row * 2 + 1];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (r0 + j >= M) break;
+        f32x4 xh0, xh1, dx0, dx1;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            xh0[e] = (x0[j][e] - mu[j]) * rs[j]; xh1[e] = (x1[j][e] - mu[j]) * rs[j];
+            dx0[e] = y0[j][e] * g0[e]; dx1[e] = y1[j][e] * g1[e];
+            dg0[e] += y0[j][e] * xh0[e]; dg1[e] += y1[j][e] * xh1[e];
+            db0[e] += y0[j][e]; db1[e] += y1[j][e];
+            s1 += dx0[e] + dx1[e];
+            s2 += dx0[e] * xh0[e] + dx1[e] * xh1[e];
+        }
+        s1 = row16_sum(s1) * (1.f / 128.f); s2 = row16_sum(s2);
+        const float c2 = mode == 0 ? rs[j] * s2 * (1.f / 128.f) : s2 / (127.f * (1.f / rs[j] - eps));
+        f32x4 o0, o1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o0[e] = rs[j] * (dx0[e] - s1) - xh0[e] * c2; o1[e] = rs[j] * (dx1[e] - s1) - xh1[e] * c2; }
+        float* d = dX + (r0 + j) * 128 + 4 * l;
+        *reinterpret_cast<f32x4*>(d) = o0; *reinterpret_cast<f32x4*>(d + 64) = o1;
+    }
+    *reinterpret_cast<f32x4*>(&sh[grp][0][4 * l]) = dg0; *reinterpret_cast<f32x4*>(&sh[grp][0][64 + 4 * l]) = dg1;
+    *reinterpret_cast<f32x4*>(&sh[grp][1][4 * l]) = db0; *reinterpret_cast<f32x4*>(&sh[grp][1][64 + 4 * l]) = db1;
+    __syncthreads();
+    {
+        const int which = threadIdx.x >> 7, c = threadIdx.x & 127;
+        float v = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) v += sh[g][which][c];
+        part[((long)blockIdx.x * 2 + which) * 128 + c] = v;
+    }
+}
 // part: cdiv(M,64)*2*C floats;  ws: doubles for the colsum (cdiv(G,256)*2*C)
 // dB (with pdrop > 0): the gradient of the residual input in front of its dropout, Dropout'(dX); without dropout it equals dX
 TATT_API int tatt_ln_bwd(const float* A, const float* Bres, const float* dY, const float* stats, float* dX, float* dB, int M,
@@ -676,8 +732,11 @@ TATT_API int tatt_ln_bwd(const float* A, const float* Bres, const float* dY, con
     if (pdrop > 0.f && (!Bres || !seed || !dB)) return 2;
     if (pdrop <= 0.f) dB = nullptr;
     int G = cdiv(M, LN_BWD_ROWS);
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(G), dim3(256), 0, st, A, Bres, dY, stats, dX, dB, M, C, gamma, part, eps, mode, pdrop,
-                       seed, site);
+    if (C == 128 && pdrop <= 0.f)
+        hipLaunchKernelGGL(ln_bwd_c128_kernel, dim3(G), dim3(256), 0, st, A, Bres, dY, stats, dX, M, gamma, part, eps, mode);
+    else
+        hipLaunchKernelGGL(ln_bwd_kernel, dim3(G), dim3(256), 0, st, A, Bres, dY, stats, dX, dB, M, C, gamma, part, eps, mode, pdrop,
+                           seed, site);
     // part viewed as (G, 2C) -> column sums give [dgamma | dbeta]
     int G2 = cs_groups(G);
     int rpb = cdiv(G, G2);

@@ -616,10 +616,12 @@ def test_tps_golden_and_grad(dev):
 
 
 # ---- TBSRN variant kernels -------------------------------------------------------------------------
-def test_tbsrn_layer_norm_mode1(dev):
+@pytest.mark.parametrize("B,Pn", [(3, 50), (4, 1024), (1, 3)])
+def test_tbsrn_layer_norm_mode1(dev, B, Pn):
+    """(backward at C = 128 without dropout = ln_bwd_c128_kernel: 16-lane groups, four rows in flight; ragged row counts included)"""
     from tatt_amd import functional as Fh
     g = torch.Generator().manual_seed(11)
-    a, b = torch.randn(3, 50, 128, generator=g), torch.randn(3, 50, 128, generator=g)
+    a, b = torch.randn(B, Pn, 128, generator=g), torch.randn(B, Pn, 128, generator=g)
     ga, be = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g)
     compare_fn("tbsrn_ln", lambda a, b, g_, be_: Fh.LayerNormFn.apply(a, b, g_, be_, 1e-6, 1, 0.0, 0),
                lambda a, b, g_, be_: O.tbsrn_layer_norm(a + b, g_, be_), [a, b, ga, be], dev)
