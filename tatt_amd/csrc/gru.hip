@@ -590,69 +590,94 @@ struct QStepP {
     float* hnew[2]; float* gsave[2];
     int Wb, HID;
 };
+// RB: 16-row blocks one work-group walks with the SAME weight rows (B operands loaded once per trip, used RB times).  With one row
+// block per work-group (the first version) the Wb / 16 work-groups that share a weight slice are consecutive in dispatch order = on
+// different XCDs: at Wb = 128, HID = 1024 (LR 32x128) every XCD streamed all 25 MB of W_hh through its own L2 each step, 200 MB per
+// step, 39.5 us (5 TB/s) -- profiles/r06_large_kernel_stats.txt.
+template <int RB>
 __global__ __launch_bounds__(256) void qgru_fwd_step_kernel(QStepP p) {
-    __shared__ float red[4][3][16][17];
+    __shared__ float red[RB][4][3][16][17];
     const int d = blockIdx.z;
-    const int m0 = blockIdx.x * 16, j0 = blockIdx.y * 16;
+    const int m0 = blockIdx.x * 16 * RB, j0 = blockIdx.y * 16;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int HID = p.HID;
     const float* hprev = p.hprev[d];
     const float* whh = p.whh[d];
-    f32x4 acc[3];
+    f32x4 acc[RB][3];
 #pragma unroll
-    for (int g = 0; g < 3; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int g = 0; g < 3; ++g) acc[rb][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (hprev) {
         const int i = lane & 15, q = lane >> 4;
         const int kspan = HID / 4;
         const int kbeg = wave * kspan;
-        const int arow = min(m0 + i, p.Wb - 1);
-        // 4 sub-steps (64 k) per trip: 16 independent 16-byte loads are in flight before the first MFMA needs data -- the
+        int arow[RB];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) arow[rb] = min(m0 + 16 * rb + i, p.Wb - 1);
+        // 4 sub-steps (64 k) per trip: 12 + 4 RB independent 16-byte loads are in flight before the first MFMA needs data -- the
         // step is latency-bound (one short wave per SIMD), so load-level parallelism is what matters.
         for (int kb = kbeg; kb < kbeg + kspan; kb += 64) {
-            f32x4 a[4], b[3][4];
+            f32x4 a[RB][4], b[3][4];
 #pragma unroll
             for (int sstep = 0; sstep < 4; ++sstep) {
-                a[sstep] = *reinterpret_cast<const f32x4*>(hprev + (long)arow * HID + kb + 16 * sstep + 4 * q);
 #pragma unroll
                 for (int g = 0; g < 3; ++g)
                     b[g][sstep] = *reinterpret_cast<const f32x4*>(whh + ((long)g * HID + j0 + i) * HID + kb + 16 * sstep + 4 * q);
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb)
+                    a[rb][sstep] = *reinterpret_cast<const f32x4*>(hprev + (long)arow[rb] * HID + kb + 16 * sstep + 4 * q);
             }
 #pragma unroll
             for (int sstep = 0; sstep < 4; ++sstep)
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
-                    for (int g = 0; g < 3; ++g)
-                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[sstep][u], b[g][sstep][u], acc[g], 0, 0, 0);
+                    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                        for (int g = 0; g < 3; ++g)
+                            acc[rb][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rb][sstep][u], b[g][sstep][u], acc[rb][g], 0, 0, 0);
         }
     }
     {
-        const int col = lane & 15, rb = (lane >> 4) * 4;
+        const int col = lane & 15, r4 = (lane >> 4) * 4;
 #pragma unroll
-        for (int g = 0; g < 3; ++g)
+        for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) red[wave][g][rb + r][col] = acc[g][r];
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[rb][wave][g][r4 + r][col] = acc[rb][g][r];
     }
     __syncthreads();
     const int m = t >> 4, j = t & 15;
-    if (m0 + m >= p.Wb) return;
-    float gh[3];
 #pragma unroll
-    for (int g = 0; g < 3; ++g)
-        gh[g] = red[0][g][m][j] + red[1][g][m][j] + red[2][g][m][j] + red[3][g][m][j] + p.bhh[d][g * HID + j0 + j];
-    const long row = m0 + m;
-    const float* gi = p.gi[d] + row * 3 * HID + j0 + j;
-    const float r = sigmoid_fast(gi[0] + gh[0]);
-    const float z = sigmoid_fast(gi[HID] + gh[1]);
-    const float n = tanh_fast(gi[2 * HID] + r * gh[2]);
-    const float hp = hprev ? hprev[row * HID + j0 + j] : 0.f;
-    const float h = (1.f - z) * n + z * hp;
-    p.hnew[d][row * HID + j0 + j] = h;
-    float* gs = p.gsave[d];
-    if (gs) {
-        const long plane = (long)p.Wb * HID, o = row * HID + j0 + j;
-        gs[o] = r; gs[plane + o] = z; gs[2 * plane + o] = n; gs[3 * plane + o] = gh[2];
+    for (int rb = 0; rb < RB; ++rb) {
+        const long row = m0 + 16 * rb + m;
+        if (row >= p.Wb) break;
+        float gh[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+            gh[g] = red[rb][0][g][m][j] + red[rb][1][g][m][j] + red[rb][2][g][m][j] + red[rb][3][g][m][j] + p.bhh[d][g * HID + j0 + j];
+        const float* gi = p.gi[d] + row * 3 * HID + j0 + j;
+        const float r = sigmoid_fast(gi[0] + gh[0]);
+        const float z = sigmoid_fast(gi[HID] + gh[1]);
+        const float n = tanh_fast(gi[2 * HID] + r * gh[2]);
+        const float hp = hprev ? hprev[row * HID + j0 + j] : 0.f;
+        const float h = (1.f - z) * n + z * hp;
+        p.hnew[d][row * HID + j0 + j] = h;
+        float* gs = p.gsave[d];
+        if (gs) {
+            const long plane = (long)p.Wb * HID, o = row * HID + j0 + j;
+            gs[o] = r; gs[plane + o] = z; gs[2 * plane + o] = n; gs[3 * plane + o] = gh[2];
+        }
     }
+}
+// row blocks per work-group of the per-step kernels: as many as keep >= 256 work-groups (at most 4)
+static int qgru_step_rb(int Wb, int HID) {
+    const int nrb = cdiv(Wb, 16), per_rb = (HID / 16) * 2;
+    int rb = 1;
+    while (rb < 4 && nrb % (2 * rb) == 0 && (nrb / (2 * rb)) * per_rb >= 256) rb *= 2;
+    return rb;
 }
 TATT_API int tatt_qgru_fwd_step(const float* gi0, const float* gi1, const float* whh0, const float* whh1,
                                 const float* bhh0, const float* bhh1, const float* hprev0, const float* hprev1,
@@ -660,7 +685,11 @@ TATT_API int tatt_qgru_fwd_step(const float* gi0, const float* gi1, const float*
                                 hipStream_t st) {
     if (HID % 256) return 1;          // each of the 4 waves reduces HID/4 columns in trips of 64
     QStepP p = {{gi0, gi1}, {whh0, whh1}, {bhh0, bhh1}, {hprev0, hprev1}, {hnew0, hnew1}, {gsave0, gsave1}, Wb, HID};
-    hipLaunchKernelGGL(qgru_fwd_step_kernel, dim3(cdiv(Wb, 16), HID / 16, 2), dim3(256), 0, st, p);
+    const int rb = qgru_step_rb(Wb, HID);
+    const dim3 grid(cdiv(cdiv(Wb, 16), rb), HID / 16, 2);
+    if (rb == 4) hipLaunchKernelGGL(qgru_fwd_step_kernel<4>, grid, dim3(256), 0, st, p);
+    else if (rb == 2) hipLaunchKernelGGL(qgru_fwd_step_kernel<2>, grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(qgru_fwd_step_kernel<1>, grid, dim3(256), 0, st, p);
     return LAUNCH_CHECK();
 }
 
@@ -762,63 +791,76 @@ struct QBwdFusedP {
 // 8 waves split the 3*HID contraction and walk it in trips of 96 with 6 + 6 sixteen-byte loads per lane in flight (HID = 512: two
 // trips to L2 instead of the six of a 4-wave / 64-wide walk -- the step is latency, not work: 47 of these follow each other)
 #define QB_WAVES 8
+template <int RB>                                  // row blocks per work-group, see qgru_fwd_step_kernel
 __global__ __launch_bounds__(64 * QB_WAVES) void qgru_bwd_fused_kernel(QBwdFusedP p) {
-    __shared__ float red[QB_WAVES][16][17];
+    __shared__ float red[RB][QB_WAVES][16][17];
     const int d = blockIdx.z;
-    const int m0 = blockIdx.x * 16, j0 = blockIdx.y * 16;
+    const int m0 = blockIdx.x * 16 * RB, j0 = blockIdx.y * 16;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int HID = p.HID, K = 3 * p.HID;
     const float* dgh = p.dgh_cur[d];
     const float* whh = p.whhT[d];
-    f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+    f32x4 acc0[RB], acc1[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) { acc0[rb] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[rb] = acc0[rb]; }
     const int i = lane & 15, q = lane >> 4;
     const int kspan = K / QB_WAVES, kbeg = wave * kspan;               // HID % 256 == 0: kspan is a multiple of 96
-    const int arow = min(m0 + i, p.Wb - 1);
-    const float* ap = dgh + (long)arow * K + kbeg + 4 * q;
+    const float* ap[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) ap[rb] = dgh + (long)min(m0 + 16 * rb + i, p.Wb - 1) * K + kbeg + 4 * q;
     const float* bp = whh + (long)(j0 + i) * K + kbeg + 4 * q;
     for (int kb = 0; kb < kspan; kb += 96) {
-        f32x4 a[6], b[6];
+        f32x4 a[RB][6], b[6];
 #pragma unroll
         for (int sstep = 0; sstep < 6; ++sstep) {
-            a[sstep] = *reinterpret_cast<const f32x4*>(ap + kb + 16 * sstep);
             b[sstep] = *reinterpret_cast<const f32x4*>(bp + kb + 16 * sstep);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) a[rb][sstep] = *reinterpret_cast<const f32x4*>(ap[rb] + kb + 16 * sstep);
         }
 #pragma unroll
         for (int sstep = 0; sstep < 6; ++sstep)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (u & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[sstep][u], b[sstep][u], acc1, 0, 0, 0);
-                else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[sstep][u], b[sstep][u], acc0, 0, 0, 0);
-            }
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) {
+                    if (u & 1) acc1[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rb][sstep][u], b[sstep][u], acc1[rb], 0, 0, 0);
+                    else acc0[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rb][sstep][u], b[sstep][u], acc0[rb], 0, 0, 0);
+                }
     }
     {
-        const int col = lane & 15, rb = (lane >> 4) * 4;
+        const int col = lane & 15, r4 = (lane >> 4) * 4;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[wave][rb + r][col] = acc0[r] + acc1[r];
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[rb][wave][r4 + r][col] = acc0[rb][r] + acc1[rb][r];
     }
     __syncthreads();
     if (t >= 256) return;
     const int m = t >> 4, j = t & 15;
-    if (m0 + m >= p.Wb) return;
-    const long row = m0 + m, e = row * HID + j0 + j;
     const long n_el = (long)p.Wb * HID;
-    float sum = 0.f;
 #pragma unroll
-    for (int w = 0; w < QB_WAVES; ++w) sum += red[w][m][j];
-    const float dh = p.dhseq_next[d][e] + p.dhcarry[d][e] + sum;
-    const float* gs = p.gsave_next[d];
-    const float r = gs[e], z = gs[n_el + e], n = gs[2 * n_el + e], hn = gs[3 * n_el + e];
-    const float hp = p.hprev_next[d] ? p.hprev_next[d][e] : 0.f;
-    const float dn = dh * (1.f - z), dz = dh * (hp - n);
-    const float dnp = dn * (1.f - n * n);
-    const float drp = dnp * hn * r * (1.f - r);
-    const float dzp = dz * z * (1.f - z);
-    const long g3 = row * 3 * HID + j0 + j;
-    float* ga = p.dgi_acc[d];
-    ga[g3] += drp; ga[g3 + HID] += dzp; ga[g3 + 2 * HID] += dnp;
-    float* dg = p.dgh_next[d];
-    dg[g3] = drp; dg[g3 + HID] = dzp; dg[g3 + 2 * HID] = dnp * r;
-    p.dhcarry[d][e] = dh * z;
+    for (int rb = 0; rb < RB; ++rb) {
+        const long row = m0 + 16 * rb + m;
+        if (row >= p.Wb) break;
+        const long e = row * HID + j0 + j;
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < QB_WAVES; ++w) sum += red[rb][w][m][j];
+        const float dh = p.dhseq_next[d][e] + p.dhcarry[d][e] + sum;
+        const float* gs = p.gsave_next[d];
+        const float r = gs[e], z = gs[n_el + e], n = gs[2 * n_el + e], hn = gs[3 * n_el + e];
+        const float hp = p.hprev_next[d] ? p.hprev_next[d][e] : 0.f;
+        const float dn = dh * (1.f - z), dz = dh * (hp - n);
+        const float dnp = dn * (1.f - n * n);
+        const float drp = dnp * hn * r * (1.f - r);
+        const float dzp = dz * z * (1.f - z);
+        const long g3 = row * 3 * HID + j0 + j;
+        float* ga = p.dgi_acc[d];
+        ga[g3] += drp; ga[g3 + HID] += dzp; ga[g3 + 2 * HID] += dnp;
+        float* dg = p.dgh_next[d];
+        dg[g3] = drp; dg[g3 + HID] = dzp; dg[g3 + 2 * HID] = dnp * r;
+        p.dhcarry[d][e] = dh * z;
+    }
 }
 TATT_API int tatt_qgru_bwd_fused(const float* dgh_cur0, const float* dgh_cur1, const float* whhT0, const float* whhT1,
                                  const float* dhseq_next0, const float* dhseq_next1, const float* gsave_next0,
@@ -828,7 +870,11 @@ TATT_API int tatt_qgru_bwd_fused(const float* dgh_cur0, const float* dgh_cur1, c
     if (HID % 256) return 1;
     QBwdFusedP p = {{dgh_cur0, dgh_cur1}, {whhT0, whhT1}, {dhseq_next0, dhseq_next1}, {gsave_next0, gsave_next1},
                     {hprev_next0, hprev_next1}, {dhcarry0, dhcarry1}, {dgi_acc0, dgi_acc1}, {dgh_next0, dgh_next1}, Wb, HID};
-    hipLaunchKernelGGL(qgru_bwd_fused_kernel, dim3(cdiv(Wb, 16), HID / 16, 2), dim3(64 * QB_WAVES), 0, st, p);
+    const int rb = qgru_step_rb(Wb, HID);
+    const dim3 grid(cdiv(cdiv(Wb, 16), rb), HID / 16, 2);
+    if (rb == 4) hipLaunchKernelGGL(qgru_bwd_fused_kernel<4>, grid, dim3(64 * QB_WAVES), 0, st, p);
+    else if (rb == 2) hipLaunchKernelGGL(qgru_bwd_fused_kernel<2>, grid, dim3(64 * QB_WAVES), 0, st, p);
+    else hipLaunchKernelGGL(qgru_bwd_fused_kernel<1>, grid, dim3(64 * QB_WAVES), 0, st, p);
     return LAUNCH_CHECK();
 }
 
