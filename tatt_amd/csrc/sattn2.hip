@@ -101,6 +101,18 @@ __device__ __forceinline__ unsigned s2_writelane2(unsigned w, unsigned long long
     asm("s_nop 3\n\tv_writelane_b32 %0, %1, %3\n\tv_writelane_b32 %0, %2, %4" : "+v"(w) : "s"((unsigned)x), "s"((unsigned)(x >> 32)), "n"(lane), "n"(lane + 1));
     return w;
 }
+// Work-group -> (row block, sample x head).  The gridDim.x row blocks of one (sample, head) read the same K / V (Q / dO) tiles, but
+// consecutive work-groups of a launch go to different XCDs (8 L2 caches): in launch order every XCD would stream every tile.  When the
+// number of (sample, head) pairs is a multiple of 8, XCD c instead owns the pairs c, c + 8, ..: all their row blocks run on it.
+__device__ __forceinline__ void s2_block(int& xb, int& bh) {
+    const unsigned nx = gridDim.x, ny = gridDim.y;
+    xb = blockIdx.x; bh = blockIdx.y;
+    if ((ny & 7) == 0) {
+        const unsigned L = blockIdx.x + nx * blockIdx.y, c = L & 7, r = L >> 3;
+        xb = (int)(r % nx);
+        bh = (int)(c + 8 * (r / nx));
+    }
+}
 // staging: thread tid of 256 moves rows tid >> 3 and (tid >> 3) + 32, channels 4 (tid & 7) .. + 3 of a 64 x 32 tile
 __device__ __forceinline__ void s2_fetch(const float* __restrict__ X, long base_row, int E, int hoff, int tid, f32x4& a, f32x4& b) {
     const int r0 = tid >> 3, c4 = (tid & 7) * 4;
@@ -203,8 +215,10 @@ __global__ __launch_bounds__(256, 2) void sattn2_fwd_kernel(SAttn2P p) {
     __shared__ __attribute__((aligned(16))) char KR[2][2 * S2_RIMG];      // K tile: row image hi | lo
     __shared__ __attribute__((aligned(16))) char VT[2][2 * S2_TIMG];      // V tile: tr image hi | lo
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lj = lane & 31, kb = lane >> 5, a16 = lane & 15, g16 = (lane >> 4) & 1;
-    const int bh = blockIdx.y, b = bh / p.h, head = bh - b * p.h, hoff = head * S2_D;
-    const int q = blockIdx.x * 128 + wave * 32 + lj;
+    int xb, bh;
+    s2_block(xb, bh);
+    const int b = bh / p.h, head = bh - b * p.h, hoff = head * S2_D;
+    const int q = xb * 128 + wave * 32 + lj;
     const long brow = (long)b * p.P;
     s2_u32x4 qh[2], ql[2];
     s2_row_operand(p.Q, brow + q, p.E, hoff, kb, p.scale * S2_LOG2E, qh, ql);
@@ -213,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void sattn2_fwd_kernel(SAttn2P p) {
     const uint32_t k0 = (uint32_t)sd ^ (p.site * 0x9E3779B9u), k1 = (uint32_t)(sd >> 32) + p.site * 0x85EBCA77u;
     const uint32_t rowidx = ((uint32_t)bh * p.P + q) * (uint32_t)p.P + 4 * kb;      // flat index of (b, head, q, key 4 kb)
     const int nb = p.P / 32;
-    unsigned* bits = MODE == 2 ? p.bits + ((size_t)bh * nb + blockIdx.x * 4 + wave) * nb * 32 : nullptr;
+    unsigned* bits = MODE == 2 ? p.bits + ((size_t)bh * nb + xb * 4 + wave) * nb * 32 : nullptr;
     s2_f32x16 o;
 #pragma unroll
     for (int v = 0; v < 16; ++v) o[v] = 0.f;
@@ -291,8 +305,10 @@ template <int MODE>
 __global__ __launch_bounds__(256, 2) void sattn2_bwd_kv_kernel(SAttn2P p) {
     extern __shared__ __attribute__((aligned(16))) char s2_dyn[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lj = lane & 31, kb = lane >> 5, a16 = lane & 15, g16 = (lane >> 4) & 1;
-    const int bh = blockIdx.y, b = bh / p.h, head = bh - b * p.h, hoff = head * S2_D;
-    const int key = blockIdx.x * 128 + wave * 32 + lj;
+    int xb, bh;
+    s2_block(xb, bh);
+    const int b = bh / p.h, head = bh - b * p.h, hoff = head * S2_D;
+    const int key = xb * 128 + wave * 32 + lj;
     const long brow = (long)b * p.P;
     s2_u32x4 kh[2], kl[2], vh[2], vl[2];
     s2_row_operand(p.K, brow + key, p.E, hoff, kb, p.scale * S2_LOG2E, kh, kl);
@@ -304,7 +320,7 @@ __global__ __launch_bounds__(256, 2) void sattn2_bwd_kv_kernel(SAttn2P p) {
     const uint32_t colidx = (uint32_t)bh * p.P * (uint32_t)p.P + (uint32_t)(4 * kb) * p.P + key;   // flat index of (b, head, query 4 kb, key)
     const int nb = p.P / 32;
     // this lane's word of a block's 32: its key is register v = 4 (lj >> 3) + (lj & 3), half (lj >> 2) & 1 of the forward
-    const unsigned* bits = MODE == 2 ? p.bits + (size_t)bh * nb * nb * 32 + (size_t)(blockIdx.x * 4 + wave) * 32 + 2 * (4 * (lj >> 3) + (lj & 3)) + ((lj >> 2) & 1) : nullptr;
+    const unsigned* bits = MODE == 2 ? p.bits + (size_t)bh * nb * nb * 32 + (size_t)(xb * 4 + wave) * 32 + 2 * (4 * (lj >> 3) + (lj & 3)) + ((lj >> 2) & 1) : nullptr;
     s2_f32x16 accK, accV;
 #pragma unroll
     for (int v = 0; v < 16; ++v) { accK[v] = 0.f; accV[v] = 0.f; }
@@ -388,8 +404,10 @@ __global__ __launch_bounds__(256, 2) void sattn2_bwd_q_kernel(SAttn2P p) {
     __shared__ __attribute__((aligned(16))) char VR[2][2 * S2_RIMG];
     __shared__ __attribute__((aligned(16))) char KT[2][2 * S2_TIMG];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lj = lane & 31, kb = lane >> 5, a16 = lane & 15, g16 = (lane >> 4) & 1;
-    const int bh = blockIdx.y, b = bh / p.h, head = bh - b * p.h, hoff = head * S2_D;
-    const int q = blockIdx.x * 128 + wave * 32 + lj;
+    int xb, bh;
+    s2_block(xb, bh);
+    const int b = bh / p.h, head = bh - b * p.h, hoff = head * S2_D;
+    const int q = xb * 128 + wave * 32 + lj;
     const long brow = (long)b * p.P;
     const uint64_t sd = MODE == 1 ? p.seed[0] : 0ull;
     const uint32_t th = dropout_thresh(p.pdrop);
@@ -403,7 +421,7 @@ __global__ __launch_bounds__(256, 2) void sattn2_bwd_q_kernel(SAttn2P p) {
     const int nb = p.P / 32;
     // (constant address space: written by the forward launch, never by this one -- uniform loads from it are scalar loads)
     typedef const __attribute__((address_space(4))) unsigned long long* s2_cmask;
-    const s2_cmask bits = MODE == 2 ? (s2_cmask)(p.bits) + ((size_t)bh * nb + blockIdx.x * 4 + wave) * nb * 16 : (s2_cmask)nullptr;
+    const s2_cmask bits = MODE == 2 ? (s2_cmask)(p.bits) + ((size_t)bh * nb + xb * 4 + wave) * nb * 16 : (s2_cmask)nullptr;
     s2_f32x16 acc;
 #pragma unroll
     for (int v = 0; v < 16; ++v) acc[v] = 0.f;
