@@ -13,6 +13,11 @@ b tssim --tssim --no-cpu-baseline
 b dp_selftest --dp-selftest --no-cpu-baseline
 tools/gpu_quick.sh ${tag}_final none "prof:" > /dev/null 2>&1
 head -3 gpurun_out/${tag}_final_timeline.txt
+for cfg in "tbsrn:--arch tbsrn" "tpg:--arch tatt_tpg" "large:--tile large"; do     # kernel traces of the other configurations
+  tools/gpu_quick.sh ${tag}_${cfg%%:*} none "prof:${cfg#*:}" > /dev/null 2>&1; head -1 gpurun_out/${tag}_${cfg%%:*}_timeline.txt
+done
+bash tools/sattn_prof.sh pmc > gpurun_out/${tag}_sattn_ab.txt 2>&1; grep "^gen" gpurun_out/${tag}_sattn_ab.txt
+[ -x tools/ubench/coissue ] && timeout 60 tools/ubench/coissue > gpurun_out/${tag}_valu_mfma_coissue.txt 2>&1
 timeout 300 python tools/bench_kernels.py > gpurun_out/${tag}_kernel_microbench.txt 2>&1; tail -3 gpurun_out/${tag}_kernel_microbench.txt
 timeout 200 python tools/step_stamps.py > gpurun_out/${tag}_step_stamps.txt 2>&1; tail -2 gpurun_out/${tag}_step_stamps.txt
 timeout 100 python tools/stn_head_bench.py > gpurun_out/${tag}_stn_head_bench.txt 2>&1
