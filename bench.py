@@ -324,9 +324,10 @@ def time_tp_layer(dev, B, L, S=26):
 
 
 def time_tbsrn_attention(dev, B, P=1024, h=4, d=32):
-    """The dominant kernels of the TBSRN step (configs[3]): the score-free self-attention of one FeatureEnhancer (csrc/sattn.hip,
-    fp32 MFMA 16x16x4): forward (QK^T and PV: 4 B h P^2 d FLOPs) and backward (D; dK, dV; dQ: seven P x P x d products = 14 B h P^2 d),
-    dropout on.  -> (ms forward + backward, FLOPs, algorithmic HBM bytes: Q, K, V, O in / out, their gradients)."""
+    """The dominant kernels of the TBSRN step (configs[3]): the score-free self-attention of one FeatureEnhancer (csrc/sattn2.hip: split
+    bf16 on v_mfma_f32_32x32x16_bf16; csrc/sattn.hip under set_arithmetic("fp32")): forward (QK^T and PV: 4 B h P^2 d FLOPs) and backward
+    (D; dK, dV; dQ: seven P x P x d products = 14 B h P^2 d), dropout on, keep bits handed from the forward to the backward as the model
+    does.  -> (ms forward, ms backward, FLOPs, algorithmic HBM bytes: Q, K, V, O in / out, their gradients, the keep bits once out, twice in)."""
     from tatt_amd import ops, functional as Fh
     E = h * d
     Q, K, V, dO = (torch.randn(B, P, E, device=dev) for _ in range(4))
@@ -334,11 +335,14 @@ def time_tbsrn_attention(dev, B, P=1024, h=4, d=32):
     dQ, dK, dV = torch.empty_like(Q), torch.empty_like(Q), torch.empty_like(Q)
     seed = Fh.seed_tensor(dev)
     sc = d ** -0.5
-    fwd = lambda: ops.call("tatt_sattn_fwd", ops.P(Q), ops.P(K), ops.P(V), ops.P(O), ops.P(lse), B, P, h, sc, 0.1, ops.P(seed), 100, ops.stream())
-    bwd = lambda: ops.call("tatt_sattn_bwd", ops.P(Q), ops.P(K), ops.P(V), ops.P(O), ops.P(lse), ops.P(dO), ops.P(dQ), ops.P(dK), ops.P(dV),
-                           ops.P(ws), B, P, h, sc, 0.1, ops.P(seed), 100, ops.stream())
+    bits = torch.empty(B * h * P * (P // 32), device=dev, dtype=torch.int32)
+    Fh._sattn_select()
+    fwd = lambda: ops.call("tatt_sattn_fwd_bits", ops.P(Q), ops.P(K), ops.P(V), ops.P(O), ops.P(lse), ops.P(bits), B, P, h, sc, 0.1,
+                           ops.P(seed), 100, ops.stream())
+    bwd = lambda: ops.call("tatt_sattn_bwd_bits", ops.P(Q), ops.P(K), ops.P(V), ops.P(O), ops.P(lse), ops.P(dO), ops.P(bits), ops.P(dQ),
+                           ops.P(dK), ops.P(dV), ops.P(ws), B, P, h, sc, 0.1, ops.P(seed), 100, ops.stream())
     tf, tb = _timed_ms(fwd, 10, 2), _timed_ms(bwd, 10, 2)
-    return tf, tb, 4.0 * B * h * P * P * d, 14.0 * B * h * P * P * d, 11.0 * B * P * E * 4
+    return tf, tb, 4.0 * B * h * P * P * d, 14.0 * B * h * P * P * d, 11.0 * B * P * E * 4 + 3.0 * B * h * P * P / 8
 
 
 def executed_flop_per_image(tile, B):
@@ -555,13 +559,23 @@ def main():
             tf, tb, ff, fb, kbytes = time_tbsrn_attention(dev, a.batch, tile["H"] * tile["W"])
             kms, kflops = tf + tb, ff + fb
             ach = kflops / (kms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": dominant_kernel_traffic(shape_key, "sattn_fwd_bwd"),
+            from tatt_amd import functional as _Fh
+            sb = _Fh.SATTN_SB
+            peak = PEAK_BF16_MFMA_TFLOPS if sb else PEAK_FP32_MFMA_TFLOPS
+            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "traffic": dominant_kernel_traffic(shape_key, "sattn2_fwd_bwd" if sb else "sattn_fwd_bwd"),
                     "algorithmic_bytes": kbytes,
                     "hbm_gbps": round(kbytes / (kms * 1e-3) / 1e9, 1),
-                    "kernel": "sattn_fwd_kernel + sattn_bwd_kv_kernel + sattn_bwd_q_kernel: score-free self-attention of one FeatureEnhancer "
-                              "(B = %d, P = %d, 4 heads x 32; fp32 MFMA 16x16x4, online softmax, dropout on); 5 per step" % (
-                                  a.batch, tile["H"] * tile["W"]),
+                    "kernel": ("sattn2_fwd_kernel<2> + sattn_prep_kernel + sattn2_bwd_kv_kernel<2> + sattn2_bwd_q_kernel<2>: score-free self-attention "
+                               "of one FeatureEnhancer (B = %d, P = %d, 4 heads x 32; split bf16 on v_mfma_f32_32x32x16_bf16 -- three matrix "
+                               "products per fp32 product: mfma_pipe_util = 3 x frac; online softmax, dropout on with keep bits); 5 per step. "
+                               "`achieved` counts fp32-equivalent FLOPs.  The kernels are bound by VALU + MFMA issue together (the softmax / "
+                               "dropout / operand-split arithmetic is ~4/5 of the issue cycles; the two pipes do not overlap on gfx950: "
+                               "profiles/r06_valu_mfma_coissue.txt), not by the matrix peak" if sb else
+                               "sattn_fwd_kernel + sattn_bwd_kv_kernel + sattn_bwd_q_kernel: score-free self-attention of one FeatureEnhancer "
+                               "(B = %d, P = %d, 4 heads x 32; fp32 MFMA 16x16x4, online softmax, dropout on); 5 per step") % (
+                                   a.batch, tile["H"] * tile["W"]),
+                    "mfma_pipe_util": round((3.0 if sb else 1.0) * ach / peak, 4),
                     "kernel_ms": round(kms, 4), "fwd_ms": round(tf, 4), "bwd_ms": round(tb, 4), "flops_per_launch": kflops,
                     "fwd_tflops": round(ff / (tf * 1e-3) / 1e12, 2), "bwd_tflops": round(fb / (tb * 1e-3) / 1e12, 2)}
         else:
@@ -582,7 +596,8 @@ def main():
             "sustained_steps": a.sustain if sustained is not None else 0, "exact_fp32": exact,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "fp32" + (" (split-bf16 MFMA operands in conv3 / conv3-wgrad / conv9 / tokgemm / gru-wgrad%s)"
-                               % (" / query-GRU recurrence and dW_hh / TP-layer backward" if _Fh.QGRU_CHAIN_SB and a.arch in ("tatt", "tatt_tpg") and a.tile == "std" else "")
+                               % (" / query-GRU recurrence and dW_hh / TP-layer backward" if _Fh.QGRU_CHAIN_SB and a.arch in ("tatt", "tatt_tpg") and a.tile == "std"
+                                  else (" / self-attention / FeatureEnhancer projections" if a.arch == "tbsrn" and _Fh.SATTN_SB else ""))
                                if _ops.CONV3_SB else ""),
             "data": "synthetic",
             "config": {"workload": "TATT (TSRN_TL_TRANS, STN %s, dropout on) train step, batch %d/GPU, %dx%d LR -> %dx%d SR, "

@@ -614,11 +614,11 @@ __global__ __launch_bounds__(512, 1) void conv3_c64_sb_kernel(Conv3SB q) {
 #define S2_DEBUG 0
 #if S2_DEBUG
 __device__ int s2_wrep = 0;
-TATT_API int tatt_conv3_debug_wrep(int r) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(s2_wrep), &r, sizeof(r)); }
+extern "C" __attribute__((visibility("default"))) int tatt_conv3_debug_wrep(int r) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(s2_wrep), &r, sizeof(r)); }
 #endif
 #if S2_STAMP
 __device__ unsigned long long* s2_stamp_buf = nullptr;
-TATT_API int tatt_conv3_debug_stamps(unsigned long long* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(s2_stamp_buf), &buf, sizeof(buf)); }
+extern "C" __attribute__((visibility("default"))) int tatt_conv3_debug_stamps(unsigned long long* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(s2_stamp_buf), &buf, sizeof(buf)); }
 #define S2_STAMP_AT(i) ts[i] = __builtin_amdgcn_s_memtime();
 #else
 #define S2_STAMP_AT(i)

@@ -111,7 +111,8 @@ def test_packed_filter_sizes_come_from_the_library():
     assert LIB.tatt_repack_words(256, 64, 3, 3, 10) == LIB.tatt_repack_words(256, 64, 3, 3, 11) == 256 * 64 * 9
     assert LIB.tatt_repack_words(64, 4, 9, 9, 0) == 64 * 4 * 81
     assert LIB.tatt_repack_words(4, 64, 9, 9, 12) == LIB.tatt_repack_words(64, 4, 9, 9, 13) == 9 * 4 * 6 * 2 * 64 * 4
-    for mode in (-1, 4, 5, 14):
+    assert LIB.tatt_repack_words(128, 64, 3, 3, 14) == LIB.tatt_repack_words(64, 128, 3, 3, 15) == 128 * 64 * 9      # generations 3 / 4
+    for mode in (-1, 4, 5, 16):
         assert LIB.tatt_repack_words(64, 64, 3, 3, mode) == -1
         with pytest.raises(RuntimeError):
             _packed_numel((64, 64, 3, 3), mode)
