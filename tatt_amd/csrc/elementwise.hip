@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256) void gather_grads_kernel(GGTable t) {
     int k = 0;
     while (k + 1 < t.n && (int)blockIdx.x >= t.e[k + 1].block0) ++k;
     const GGEntry& e = t.e[k];
-    const int i = (((int)blockIdx.x - e.block0) * 256 + threadIdx.x) * 4;
+    const long i = ((long)((int)blockIdx.x - e.block0) * 256 + threadIdx.x) * 4;      // (an entry of n < 2^31 elements: 4 i can pass 2^31)
     if (i >= e.n) return;
     float* d = t.dst + e.off + i;
     const bool vec = i + 4 <= e.n && (((uintptr_t)d | (e.src ? (uintptr_t)(e.src + i) : 0)) & 15) == 0;

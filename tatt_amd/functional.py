@@ -1286,8 +1286,11 @@ def _has_gpu():
 def sync_capacity(device=None):
     """Work-groups of each in-flight-synchronising kernel that fit on the device at once (tatt_qgru_chain_capacity, tatt_stn_capacity:
     occupancy per CU x the CUs this process sees), asked once per device.  Those launches are only correct with their whole grid
-    resident: on a partitioned or CU-masked GPU the callers below take the per-step / operator-chain paths instead."""
-    idx = torch.cuda.current_device() if device is None else torch.device(device).index
+    resident: on a partitioned GPU (fewer CUs reported) the callers below take the per-step / operator-chain paths instead.  A CU mask
+    (HSA_CU_MASK) or CUs held by co-running kernels are NOT seen here: the bounded waits + sticky error word cover those."""
+    idx = None if device is None else torch.device(device).index
+    if idx is None:
+        idx = torch.cuda.current_device()
     if idx not in _CAPACITY:
         import ctypes
         q, s = (ctypes.c_int * 4)(), (ctypes.c_int * 2)()
@@ -1313,12 +1316,15 @@ def sticky_word(device):
     return _STICKY[idx]
 
 
-def _qgru_chain_takes(W, HID, bwd=False):
+def _qgru_chain_takes(W, HID, bwd=False, device=None):
+    """Geometry of the persistent chains AND their whole grid resident on `device` (default: the current one).  The capacity is occupancy
+    x the CUs the device reports: it follows partition modes (CPX / a smaller part) but NOT a CU mask (HSA_CU_MASK) nor CUs held by
+    co-running kernels -- there the bounded spin + sticky error word (sync_check) is the protection, not this gate."""
     if not (HID == 512 and W % 16 == 0 and (W // 16) * 2 * (HID // 16) <= 256):
         return False
     if not _has_gpu():                           # (host-only callers: the geometry predicate alone)
         return True
-    cap = sync_capacity()
+    cap = sync_capacity(device)
     return (W // 16) * 2 * (HID // 16) <= cap[(2 if bwd else 0) + (0 if QGRU_CHAIN_SB else 1)]
 
 
@@ -1368,7 +1374,7 @@ class QueryGruFn(Function):
         gsave = ops.new(dev, 2, B, 4, W, HID)
         q = ops.new(dev, B, H, W, C)
         Hh = H // 2
-        chain = QGRU_CHAIN_FWD and _qgru_chain_takes(W, HID) and IN % 1024 == 0
+        chain = QGRU_CHAIN_FWD and _qgru_chain_takes(W, HID, device=dev.device) and IN % 1024 == 0
         if chain:
             # ONE persistent launch: the input projection of each tile, the B time steps of both directions, h written in both layouts
             xch = ops.new(dev, 2, B + 1, W, HID) if QGRU_CHAIN_SB else None      # h in matrix-core operand form (split-bf16 recurrence)
@@ -1391,7 +1397,7 @@ class QueryGruFn(Function):
         # W_hh^T of both directions for the per-step backward kernels (their B operand wants the 3*HID axis contiguous): parameters
         # only, so the two transposes ride on this forked branch.  The persistent backward launch reads W_hh as it is stored.
         whhT = None
-        if any(ctx.needs_input_grad[:9]) and not (QGRU_CHAIN_BWD and _qgru_chain_takes(W, HID, True) and B > 1):
+        if any(ctx.needs_input_grad[:9]) and not (QGRU_CHAIN_BWD and _qgru_chain_takes(W, HID, True, device=dev.device) and B > 1):
             whhT = ops.new(dev, 2, HID, 3 * HID)
             for d, whh in enumerate((whh0, whh1)):                 # (3*HID, HID) -> (HID, 3*HID)
                 ops.copy4d(whh, whhT[d], (1, 1, HID, 3 * HID), (0, 0, 1, HID), (0, 0, 3 * HID, 1))
@@ -1431,7 +1437,7 @@ class QueryGruFn(Function):
         ops.call("tatt_qgru_bwd_gates", ops.P(dhseq[0, B - 1]), ops.P(dhseq[1, 0]), ops.P(gsave[0, B - 1]),
                  ops.P(gsave[1, 0]), ops.P(hp0), ops.P(hp1), ops.P(dhc[0]), ops.P(dhc[1]), ops.P(dgi_acc[0]),
                  ops.P(dgi_acc[1]), ops.P(dgh[0, B - 1]), ops.P(dgh[1, 0]), W, HID, 1, ops.stream())
-        chain = (QGRU_CHAIN_BWD or whhT is None) and _qgru_chain_takes(W, HID, True) and B > 1
+        chain = (QGRU_CHAIN_BWD or whhT is None) and _qgru_chain_takes(W, HID, True, device=dev.device) and B > 1
         if whhT is None and not chain and B > 1:
             raise RuntimeError("tatt_amd: QGRU_CHAIN_BWD was switched off between a forward and its backward")
         if chain:
