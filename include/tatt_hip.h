@@ -503,6 +503,12 @@ int tatt_tokgemm_sb(const float* X1, const float* X2, int K1, const float* Wp, c
  * Also takes (N, K) = (128, 128) and (128, 64): the TBSRN FeatureEnhancer projections (reference model/tbsrn.py:77-151). */
 int tatt_tokgemm_sb_ex(const float* X1, const float* X2, int K1, const float* Wp, const float* bias, float* Y1, float* Y2, int N1,
                        int M, int N, int K, int act, int accum, hipStream_t st);
+/* The epilogues of a position-wise feed-forward w_2(Dropout(relu(w_1 x))) (reference PositionwiseFeedForward, model/tbsrn.py:154-164):
+ * Y = Dropout_pdrop(act(X Wp^T + bias)) with the mask tatt_dropout draws for Y's flat index (forward of w_1), or, with `gate`,
+ * Y = (X Wp^T) * gate_scale where gate > 0, else 0 (data gradient of w_2 gated by the saved forward output F: F > 0 exactly where the
+ * unit was active and kept, gate_scale = 1 / (1 - pdrop)).  One source, one destination; shapes of tatt_tokgemm_sb_ex. */
+int tatt_tokgemm_sb_ffn(const float* X, const float* Wp, const float* bias, float* Y, int M, int N, int K, int act, float pdrop,
+                        const unsigned long long* seed, unsigned site, const float* gate, float gate_scale, hipStream_t st);
 /* trans = 0: w(n, k) = W[n*ldw + k] (y = x W^T);  trans = 1: w(n, k) = W[k*ldw + n] (dx = dy W).  out: N*K words */
 int tatt_tokgemm_pack(const float* W, float* out, int N, int K, int ldw, int trans, hipStream_t st);
 /* n packs in one launch: ptrs = HOST array of n x 2 device pointers (W, out), dims = HOST array of n x 4 ints (N, K, ldw, trans) */

@@ -22,6 +22,10 @@ struct TokGemmP {
     float* Y1; float* Y2; int N1;                    // destinations: columns [0, N1) to Y1 (row pitch N1), [N1, N) to Y2 (row pitch N - N1)
     int M;
     int act, accum;                                  // epilogue: ACT_RELU after the bias; accum: Y += (instead of Y =)
+    // epilogue of the fused feed-forward (tatt_tokgemm_sb_ffn): dropout of the result (mask of tatt_dropout for the same seed word, site
+    // and flat index row * N + col), or a gate -- the result times gate_scale where gate[row * N + col] > 0, else 0
+    float pdrop; const unsigned long long* seed; unsigned site;
+    const float* gate; float gate_scale;
 };
 
 __device__ __forceinline__ void tg_split(f32x4 v, uint2& hi, uint2& lo) {
@@ -33,7 +37,8 @@ __device__ __forceinline__ void tg_split(f32x4 v, uint2& hi, uint2& lo) {
 }
 
 // NCB: 16-column blocks per wave (N = 64 NCB); KS: k-steps of 32 (K = 32 KS)
-template <int NCB, int KS>
+// EPI: the dropout / gate epilogues are compiled in (kept out of the GruBlock instantiations, which sit at the register limit)
+template <int NCB, int KS, bool EPI>
 __global__ __launch_bounds__(512, 1) void tokgemm_sb_kernel(TokGemmP p) {
     constexpr int K = 32 * KS, N = 64 * NCB;
     constexpr int PW = K / 2 + 8;                            // tile pitch in 32-bit words (two bf16 each)
@@ -115,6 +120,10 @@ __global__ __launch_bounds__(512, 1) void tokgemm_sb_kernel(TokGemmP p) {
         {
             const long row0 = (long)tile * 64 + 32 * mh + 4 * kq;
             const int N2 = N - p.N1;
+            const bool drop = EPI && p.pdrop > 0.f;
+            const uint64_t sd = drop ? p.seed[0] : 0ull;
+            const uint32_t th = dropout_thresh(p.pdrop);
+            const float dsc = drop ? 1.f / (1.f - p.pdrop) : 1.f;
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) {
                 const int col = 16 * (nq * NCB + cb) + am;
@@ -127,6 +136,9 @@ __global__ __launch_bounds__(512, 1) void tokgemm_sb_kernel(TokGemmP p) {
                         float* y = dst + (row0 + 16 * m + r) * ld + c;
                         float v = (accM[m][cb][r] + accC[m][cb][r]) + bj[cb];
                         if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
+                        const long flat = (row0 + 16 * m + r) * ld + c;            // (drop / gate: one destination, ld = N)
+                        if (drop) v = dropout_keep(sd, p.site, (uint64_t)flat, th) ? v * dsc : 0.f;
+                        if (EPI && p.gate) v = p.gate[flat] > 0.f ? v * p.gate_scale : 0.f;
                         if (p.accum) v += *y;
                         *y = v;
                     }
@@ -204,17 +216,26 @@ TATT_API int tatt_tokgemm_pack_batch(const float* const* ptrs, const int* dims, 
     return LAUNCH_CHECK();
 }
 
-template <int NCB, int KS>
-static int tg_launch(const TokGemmP& p, hipStream_t st) {
+template <int NCB, int KS, bool EPI>
+static int tg_launch_epi(const TokGemmP& p, hipStream_t st) {
     constexpr int lds = 2 * 2 * 64 * (32 * KS / 2 + 8) * 4;
     static TattPerDevice once;
     tatt_per_device(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tokgemm_sb_kernel<NCB, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tokgemm_sb_kernel<NCB, KS, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     });
     const int ntiles = p.M / 64;
-    hipLaunchKernelGGL((tokgemm_sb_kernel<NCB, KS>), dim3(ntiles < 256 ? ntiles : 256), dim3(512), lds, st, p);
+    hipLaunchKernelGGL((tokgemm_sb_kernel<NCB, KS, EPI>), dim3(ntiles < 256 ? ntiles : 256), dim3(512), lds, st, p);
     return LAUNCH_CHECK();
 }
+template <int NCB, int KS>
+static int tg_launch(const TokGemmP& p, hipStream_t st) {
+    if (p.pdrop > 0.f || p.gate) {
+        if constexpr (NCB <= 2 && KS <= 4) return tg_launch_epi<NCB, KS, true>(p, st);      // (the feed-forward shapes)
+        else return 1;
+    }
+    return tg_launch_epi<NCB, KS, false>(p, st);
+}
+static int tg_dispatch(const TokGemmP& p, int N, int K, hipStream_t st);
 // Y = [X1 | X2] Wp^T + bias with Wp from tatt_tokgemm_pack; X1 (M, K1), X2 (M, K - K1) (null when K1 == K); the first N1 output columns
 // go to Y1 (M, N1), the rest to Y2 (M, N - N1) (null when N1 == N).  M a multiple of 64; (N, K) in {64,128,192} x {64,128,192}.
 // _ex: act = ACT_RELU applies max(., 0) after the bias; accum != 0 adds the result to what Y holds (the sum of several data gradients
@@ -223,7 +244,22 @@ TATT_API int tatt_tokgemm_sb_ex(const float* X1, const float* X2, int K1, const 
                                 int M, int N, int K, int act, int accum, hipStream_t st) {
     if (M < 64 || M % 64 || K1 % 4 || (K - K1) % 4 || K1 < 0 || K1 > K || N1 < 0 || N1 > N || (K1 < K && !X2) || (N1 < N && !Y2)) return 1;
     if (act != ACT_NONE && act != ACT_RELU) return 1;
-    TokGemmP p = {X1, X2, K1, Wp, bias, Y1, Y2, N1, M, act, accum};
+    TokGemmP p = {X1, X2, K1, Wp, bias, Y1, Y2, N1, M, act, accum, 0.f, nullptr, 0u, nullptr, 1.f};
+    return tg_dispatch(p, N, K, st);
+}
+// The two epilogues of a position-wise feed-forward w_2(Dropout(relu(w_1 x))) (reference PositionwiseFeedForward, model/tbsrn.py:154-164)
+// that make the dropout and both element-wise backward passes disappear into GEMMs:
+//   forward  F = Dropout_p(relu(X W1^T + b1)):     act = ACT_RELU, pdrop > 0 (seed, site: the mask tatt_dropout draws for F's flat index)
+//   backward dPre = (dY W2) * [F > 0] / (1 - p):   gate = F, gate_scale = 1 / (1 - p) -- F > 0 exactly where the unit was active AND kept
+// One source, one destination (N1 = N).
+TATT_API int tatt_tokgemm_sb_ffn(const float* X, const float* Wp, const float* bias, float* Y, int M, int N, int K, int act, float pdrop,
+                                 const unsigned long long* seed, unsigned site, const float* gate, float gate_scale, hipStream_t st) {
+    if (M < 64 || M % 64 || (act != ACT_NONE && act != ACT_RELU) || pdrop < 0.f || pdrop >= 1.f || (pdrop > 0.f && !seed)) return 1;
+    if ((double)M * N >= 4.0e18) return 1;
+    TokGemmP p = {X, nullptr, K, Wp, bias, Y, nullptr, N, M, act, 0, pdrop, seed, site, gate, gate_scale};
+    return tg_dispatch(p, N, K, st);
+}
+static int tg_dispatch(const TokGemmP& p, int N, int K, hipStream_t st) {
     if (N == 192 && K == 128) return tg_launch<3, 4>(p, st);
     if (N == 192 && K == 64) return tg_launch<3, 2>(p, st);
     if (N == 128 && K == 192) return tg_launch<2, 6>(p, st);

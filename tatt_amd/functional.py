@@ -620,6 +620,70 @@ class QKVProjFn(Function):
         return (dx,) + tuple(g)
 
 
+class FeedForwardFn(Function):
+    """w_2(Dropout_p(relu(w_1 x))) (reference PositionwiseFeedForward, model/tbsrn.py:154-164) as one operator on prepacked weights
+    (linear_prepack): the dropout rides in the epilogue of the first GEMM, and the backward of dropout and relu in the epilogue of the
+    second GEMM's data gradient (gated by the saved F = Dropout(relu(.)): F > 0 exactly where the unit was active and kept) -- two
+    GEMMs forward, two backward, no element-wise pass.  Masks = tatt_dropout's for the same seed word, site and flat index."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, pdrop, site):
+        K = x.shape[-1]
+        x2 = x.reshape(-1, K)
+        M = x2.shape[0]
+        pk1, pk2 = _packed_linear(w1, M), _packed_linear(w2, M)
+        Nf, No = w1.shape[0], w2.shape[0]
+        seed = current_seed(x.device) if pdrop > 0.0 else None
+        f = ops.new(x2, M, Nf)
+        ops.call("tatt_tokgemm_sb_ffn", ops.P(x2), ops.P(pk1[0]), ops.P(b1), ops.P(f), M, Nf, K, ACT_RELU, float(pdrop), ops.P(seed), int(site),
+                 None, 1.0, ops.stream())
+        y = _tokgemm_ex(f, pk2[0], b2, No, Nf)
+        ctx.save_for_backward(x, f, w1, w2)
+        ctx.wbk = (pk1[1], pk2[1])
+        ctx.pdrop = float(pdrop)
+        ctx.has_b = (b1 is not None, b2 is not None)
+        ctx.leaves = (w1, b1, w2, b2)
+        return y.reshape(*x.shape[:-1], No)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, f, w1, w2 = ctx.saved_tensors
+        Nf, K = w1.shape
+        No = w2.shape[0]
+        x2 = x.reshape(-1, K)
+        M = x2.shape[0]
+        dy2 = _c(dy).reshape(-1, No)
+        dpre = ops.new(dy2, M, Nf)                                   # gradient in front of the relu
+        ops.call("tatt_tokgemm_sb_ffn", ops.P(dy2), ops.P(ctx.wbk[1]), None, ops.P(dpre), M, Nf, No, ACT_NONE, 0.0, None, 0, ops.P(f),
+                 1.0 / (1.0 - ctx.pdrop), ops.stream())
+        dx = _tokgemm_ex(dpre, ctx.wbk[0], None, K, Nf).reshape(x.shape) if ctx.needs_input_grad[0] else None
+        hb1, hb2 = ctx.has_b
+
+        def param_grads():
+            dw2, db2 = ops.new(dy2, No, Nf), (ops.new(dy2, No) if hb2 else None)
+            ops.linear_bwd_weight(dy2, f, out=dw2, out_ld=Nf, rowsum=db2)
+            dw1, db1 = ops.new(dy2, Nf, K), (ops.new(dy2, Nf) if hb1 else None)
+            ops.linear_bwd_weight(dpre, x2, out=dw1, out_ld=K, rowsum=db1)
+            return dw1, db1, dw2, db2
+        g = SIDE.submit(ctx.leaves, param_grads, x, f, dy2, dpre)
+        return (dx,) + tuple(g) + (None, None)
+
+
+def feed_forward(x, w_1, w_2, pdrop, training, site):
+    """w_1, w_2: nn.Linear holders; dropout (site) between them in training"""
+    x = _c(x)
+    M = x.numel() // x.shape[-1]
+    p = float(pdrop) if training else 0.0
+    if _packed_linear(w_1.weight, M) is not None and _packed_linear(w_2.weight, M) is not None and FFN_FUSED:
+        return FeedForwardFn.apply(x, w_1.weight, w_1.bias, w_2.weight, w_2.bias, p, site)
+    f = linear(x, w_1.weight, w_1.bias, act=ACT_RELU)
+    f = dropout(f, pdrop, training, site)
+    return linear(f, w_2.weight, w_2.bias)
+
+
+FFN_FUSED = True            # test / A-B hook: False -> linear + dropout + linear as separate operators
+
+
 def qkv_projection(x, lq, lk, lv):
     """lq, lk, lv: nn.Linear holders applied to the same (B, P, K) token matrix"""
     x = _c(x)

@@ -1329,6 +1329,52 @@ def test_qkv_projection_operator_vs_three_linears(dev):
         Fh.linear_prepack_done()
 
 
+def test_feed_forward_operator_equals_the_operator_chain(dev):
+    """FeedForwardFn (dropout in the first GEMM's epilogue, relu' and dropout' in the epilogue of the second GEMM's data gradient) against
+    linear -> dropout -> linear on the same prepacked weights: the same masks, so values and all gradients agree to round-off; and
+    against fp64 without dropout."""
+    from tatt_amd import functional as Fh
+    g = torch.Generator().manual_seed(6)
+    B, Pn, E = 2, 320, 128
+    x = torch.randn(B, Pn, E, generator=g)
+    w = torch.randn(B, Pn, E, generator=g)
+    l1, l2 = torch.nn.Linear(E, E).to(dev), torch.nn.Linear(E, E).to(dev)
+    res = []
+    for fused in (True, False):
+        Fh.set_seed(dev, 9)
+        Fh.begin_training_forward(dev)
+        Fh.linear_prepack([l1, l2])
+        Fh.FFN_FUSED = fused
+        try:
+            for l in (l1, l2):
+                l.weight.grad = l.bias.grad = None
+            xg = x.to(dev).requires_grad_(True)
+            y = Fh.feed_forward(xg, l1, l2, 0.1, True, 41)
+            assert isinstance(y.grad_fn, Fh.FeedForwardFn._backward_cls) == fused
+            (y * w.to(dev)).sum().backward()
+            res.append([t.detach().cpu().clone() for t in (y, xg.grad, l1.weight.grad, l1.bias.grad, l2.weight.grad, l2.bias.grad)])
+        finally:
+            Fh.FFN_FUSED = True
+            Fh.linear_prepack_done()
+    for name, a, b in zip(("y", "dx", "dw1", "db1", "dw2", "db2"), *res):
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()), (name, float((a - b).abs().max()), float(b.abs().max()))
+    assert float((res[0][0] == 0).float().mean()) < 0.01               # the dropout acts on the hidden layer, not on the output
+    # no dropout (evaluation / p = 0): against fp64
+    Fh.linear_prepack([l1, l2])
+    try:
+        xg = x.to(dev).requires_grad_(True)
+        y = Fh.feed_forward(xg, l1, l2, 0.1, False, 41)
+        (y * w.to(dev)).sum().backward()
+    finally:
+        Fh.linear_prepack_done()
+    xd = x.double().requires_grad_(True)
+    W1, b1, W2, b2 = (t.detach().cpu().double() for t in (l1.weight, l1.bias, l2.weight, l2.bias))
+    yr = F.linear(F.relu(F.linear(xd, W1, b1)), W2, b2)
+    (yr * w.double()).sum().backward()
+    assert float((y.detach().cpu().double() - yr.detach()).abs().max() / yr.detach().abs().max()) < 2e-5
+    assert float((xg.grad.cpu().double() - xd.grad).abs().max() / xd.grad.abs().max()) < 2e-5
+
+
 # ------------------------------------------------------------------------------------------- fused GruBlock weight gradients
 @pytest.mark.parametrize("M,with_xb,groups", [(32 * 200, True, 128), (32 * 200, False, 128), (32, True, 128), (32 * 7, True, 3),
                                                (49152, True, 128), (49152, True, 256)])
