@@ -514,6 +514,13 @@ int tatt_tokgemm_pack(const float* W, float* out, int N, int K, int ldw, int tra
 /* n packs in one launch: ptrs = HOST array of n x 2 device pointers (W, out), dims = HOST array of n x 4 ints (N, K, ldw, trans) */
 int tatt_tokgemm_pack_batch(const float* const* ptrs, const int* dims, int n, hipStream_t st);
 
+/* Weight gradient of a token projection y = x W^T + b on the bf16 matrix cores with split operands (csrc/tokwgrad.hip): per-split
+ * partials of dW (N x K) = A^T B and db (N) = column sums of A for A = dY (M, N), B = X (M, K) contiguous, M % 32 == 0, N, K in
+ * {64, 128}, 1 <= S <= M / 32 (every split owns at least one 32-token chunk); ws >= S*N*K + S*N floats.  Finish with
+ * tatt_splitk_reduce(ws, dW, N, K, S, 0, 0, 0, db, N).  The nn.Linear weight gradients of the TBSRN FeatureEnhancer (reference
+ * model/tbsrn.py:77-164). */
+int tatt_tok_wgrad_sb(const float* A, const float* B, float* ws, int M, int N, int K, int S, hipStream_t st);
+
 /* ---- score-free self-attention of the TBSRN FeatureEnhancer (csrc/sattn.hip) ---------------------------------- */
 
 /* O (B,P,E) = dropout_{pdrop}(softmax(Q K^T * scale)) V per head of 32 channels (E = 32 h, P a multiple of 64): reference

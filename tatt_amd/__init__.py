@@ -32,12 +32,12 @@ def set_arithmetic(mode: str) -> None:
         raise ValueError("arithmetic must be 'split_bf16' or 'fp32', got %r" % (mode,))
     on = mode == "split_bf16"
     _ops.CONV3_SB = _ops.CONV3_WGRAD_SB = _ops.TPLAYER_BWD2 = _ops.CONV9_SB = on
-    _F.TOKGEMM_SB = _F.GRU_WGRAD_SB = _F.QGRU_CHAIN_SB = _F.QGRU_WGRAD_SB = _F.SATTN_SB = on
+    _F.TOKGEMM_SB = _F.GRU_WGRAD_SB = _F.QGRU_CHAIN_SB = _F.QGRU_WGRAD_SB = _F.SATTN_SB = _F.TOK_WGRAD_SB = on
 
 
 def get_arithmetic() -> str:
     from . import functional as _F, ops as _ops
-    flags = (_ops.CONV3_SB, _ops.CONV3_WGRAD_SB, _ops.TPLAYER_BWD2, _ops.CONV9_SB, _F.TOKGEMM_SB, _F.GRU_WGRAD_SB, _F.QGRU_CHAIN_SB, _F.QGRU_WGRAD_SB, _F.SATTN_SB)
+    flags = (_ops.CONV3_SB, _ops.CONV3_WGRAD_SB, _ops.TPLAYER_BWD2, _ops.CONV9_SB, _F.TOKGEMM_SB, _F.GRU_WGRAD_SB, _F.QGRU_CHAIN_SB, _F.QGRU_WGRAD_SB, _F.SATTN_SB, _F.TOK_WGRAD_SB)
     return "split_bf16" if all(flags) else ("fp32" if not any(flags) else "mixed")
 
 

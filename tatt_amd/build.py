@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libtatt_hip.so")
-SOURCES = ["gemm.hip", "conv3.hip", "conv3w.hip", "conv9.hip", "norm.hip", "elementwise.hip", "gru.hip", "attn.hip", "sattn.hip", "sattn2.hip", "tplayer.hip", "tplayer2.hip", "tokgemm.hip", "gruwgrad.hip", "tps.hip", "loss.hip", "lstm.hip", "ssim.hip", "stnhead.hip"]
+SOURCES = ["gemm.hip", "conv3.hip", "conv3w.hip", "conv9.hip", "norm.hip", "elementwise.hip", "gru.hip", "attn.hip", "sattn.hip", "sattn2.hip", "tplayer.hip", "tplayer2.hip", "tokgemm.hip", "tokwgrad.hip", "gruwgrad.hip", "tps.hip", "loss.hip", "lstm.hip", "ssim.hip", "stnhead.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-ffp-contract=fast"]
 # per-source additions.  conv3.hip: the staging waves of the 3x3 kernels run beside MFMA waves on the same SIMD, and packed fp32 VALU forms
 # (what SLP vectorisation makes of adjacent scalar adds / fmas) take issue time from the matrix pipe (profiles/r06_conv3_sb4_roles.txt)

@@ -520,6 +520,17 @@ def _tokgemm_ex(X, Wpk, bias, N, K, act=ACT_NONE, out=None, accum=False):
     return Y
 
 
+def _linear_wgrad(dy2, x2, dw, db):
+    """dw (N, K) = dy2^T x2, db = column sums of dy2 (or None): the split-bf16 token pass when it applies, else the fp32 GEMM"""
+    if TOK_WGRAD_SB and ops.tok_wgrad_takes(dy2, x2) and dw.is_contiguous():
+        ops.tok_wgrad_sb(dy2, x2, dw, db)
+    else:
+        ops.linear_bwd_weight(dy2, x2, out=dw, out_ld=dw.shape[1], rowsum=db)
+
+
+TOK_WGRAD_SB = True         # tatt_amd.set_arithmetic: False -> fp32 GEMMs for the weight gradients of prepacked linears
+
+
 class LinearFn(Function):
     """y = act(alpha*(x @ W^T + b)); optional second input concatenated along the feature axis.  A weight the forward in flight has
     prepacked (linear_prepack) runs on the bf16 matrix cores with split operands (csrc/tokgemm.hip), forward and data gradient."""
@@ -565,7 +576,10 @@ class LinearFn(Function):
             if want_dw:
                 dw = ops.new(dy2, N, K)
                 db = ops.new(dy2, N) if want_db else None             # bias gradient rides along with the weight-gradient GEMM
-                ops.linear_bwd_weight(dy2, x2, alpha=ctx.alpha, out=dw, out_ld=K, rowsum=db)
+                if ctx.wbk is not None and xb is None:
+                    _linear_wgrad(dy2, x2, dw, db)
+                else:
+                    ops.linear_bwd_weight(dy2, x2, alpha=ctx.alpha, out=dw, out_ld=K, rowsum=db)
                 if xb is not None:
                     ops.linear_bwd_weight(dy2, xb.reshape(-1, K - K1), alpha=ctx.alpha, out=dw.reshape(-1)[K1:], out_ld=K)
             elif want_db:
@@ -613,7 +627,7 @@ class QKVProjFn(Function):
             for d, hb in zip(ds, has_b):
                 dw = ops.new(d, N, K)
                 db = ops.new(d, N) if hb else None
-                ops.linear_bwd_weight(d, x2, out=dw, out_ld=K, rowsum=db)
+                _linear_wgrad(d, x2, dw, db)
                 res += [dw, db]
             return tuple(res)
         g = SIDE.submit(ctx.leaves, param_grads, x, *ds)
@@ -661,9 +675,9 @@ class FeedForwardFn(Function):
 
         def param_grads():
             dw2, db2 = ops.new(dy2, No, Nf), (ops.new(dy2, No) if hb2 else None)
-            ops.linear_bwd_weight(dy2, f, out=dw2, out_ld=Nf, rowsum=db2)
+            _linear_wgrad(dy2, f, dw2, db2)
             dw1, db1 = ops.new(dy2, Nf, K), (ops.new(dy2, Nf) if hb1 else None)
-            ops.linear_bwd_weight(dpre, x2, out=dw1, out_ld=K, rowsum=db1)
+            _linear_wgrad(dpre, x2, dw1, db1)
             return dw1, db1, dw2, db2
         g = SIDE.submit(ctx.leaves, param_grads, x, f, dy2, dpre)
         return (dx,) + tuple(g) + (None, None)

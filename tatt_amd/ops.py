@@ -193,6 +193,30 @@ def gru_wgrad_sb(dgi, dgh, x2, xb2, hprev, dWp, dWhh, dbp, dbhh):
     call("tatt_splitk_reduce", P(ws2), P(dWhh), 192, 64, G, 0, 0, 0.0, P(dbhh), 192, stream())
 
 
+TOK_WGRAD_SPLITS = 128        # token splits of tatt_tok_wgrad_sb (one work-group each)
+
+
+def tok_wgrad_takes(dy, x):
+    """tatt_tok_wgrad_sb's geometry: contiguous (M, N) / (M, K), M % 32 == 0, N and K in {64, 128}"""
+    return (dy.dim() == 2 and x.dim() == 2 and dy.shape[0] == x.shape[0] and dy.is_contiguous() and x.is_contiguous()
+            and dy.shape[0] % 32 == 0 and dy.shape[0] > 0 and dy.shape[1] in (64, 128) and x.shape[1] in (64, 128))
+
+
+def tok_wgrad_sb(dy, x, dW, db=None):
+    """dW (N, K) = dy^T x, db = dy.sum(0) (optional) in one split-bf16 pass over the tokens (tatt_tok_wgrad_sb) + a (deferrable)
+    split-K reduction."""
+    _check_dev(dy)
+    M, N = dy.shape
+    K = x.shape[1]
+    chunks = M // 32
+    S = max(1, min(TOK_WGRAD_SPLITS, chunks))
+    while (S - 1) * cdiv(chunks, S) >= chunks:
+        S -= 1
+    ws = _split_ws(new(dy, S * N * K + S * N))
+    call("tatt_tok_wgrad_sb", P(dy), P(x), P(ws), M, N, K, S, stream())
+    call("tatt_splitk_reduce", P(ws), P(dW), N, K, S, 0, 0, 0.0, P(db), N, stream())
+
+
 QGRU_WGRAD_SPLIT = 8          # contraction splits of tatt_qgru_wgrad_sb (96 output tiles x S work-groups for both directions; 4: 81 us, 6: 85, 8: 77, 12: 82)
 
 

@@ -1329,6 +1329,31 @@ def test_qkv_projection_operator_vs_three_linears(dev):
         Fh.linear_prepack_done()
 
 
+@pytest.mark.parametrize("M,N,K,splits", [(64 * 21, 128, 128, 128), (32, 128, 128, 128), (32 * 7, 64, 128, 3), (49152, 128, 128, 128),
+                                            (32 * 50, 128, 64, 128), (32 * 9, 64, 64, 256)])
+def test_tok_wgrad_split_bf16_vs_fp64(dev, M, N, K, splits):
+    """tatt_tok_wgrad_sb + tatt_splitk_reduce: dW = dY^T X and db = column sums of dY in one pass over the tokens on the bf16 matrix
+    cores (operands through the transposing LDS reads), against fp64: every instantiated (N, K), ragged chunk counts over the
+    splits, a single chunk, the full-size token count; twice (bit-identical: the reduction order is fixed)."""
+    from tatt_amd import ops
+    dy, x = R(M, N, seed=31), R(M, K, seed=32)
+    ref_w, ref_b = dy.double().t() @ x.double(), dy.double().sum(0)
+    old = ops.TOK_WGRAD_SPLITS
+    ops.TOK_WGRAD_SPLITS = splits
+    try:
+        outs = []
+        for _ in range(2):
+            dW, db = torch.empty(N, K, device=dev), torch.empty(N, device=dev)
+            assert ops.tok_wgrad_takes(dy.to(dev), x.to(dev))
+            ops.tok_wgrad_sb(dy.to(dev), x.to(dev), dW, db)
+            outs.append((dW.cpu(), db.cpu()))
+    finally:
+        ops.TOK_WGRAD_SPLITS = old
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert float((outs[0][0].double() - ref_w).abs().max() / ref_w.abs().max()) < 1e-5
+    assert float((outs[0][1].double() - ref_b).abs().max() / ref_b.abs().max()) < 2e-6
+
+
 def test_feed_forward_operator_equals_the_operator_chain(dev):
     """FeedForwardFn (dropout in the first GEMM's epilogue, relu' and dropout' in the epilogue of the second GEMM's data gradient) against
     linear -> dropout -> linear on the same prepacked weights: the same masks, so values and all gradients agree to round-off; and
