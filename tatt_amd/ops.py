@@ -194,12 +194,13 @@ def gru_wgrad_sb(dgi, dgh, x2, xb2, hprev, dWp, dWhh, dbp, dbhh):
 
 
 TOK_WGRAD_SPLITS = 128        # token splits of tatt_tok_wgrad_sb (one work-group each)
+TOK_WGRAD_CHUNK = 32          # tokens per staged chunk (TW_TOK of csrc/tokwgrad.hip)
 
 
 def tok_wgrad_takes(dy, x):
     """tatt_tok_wgrad_sb's geometry: contiguous (M, N) / (M, K), M % 32 == 0, N and K in {64, 128}"""
     return (dy.dim() == 2 and x.dim() == 2 and dy.shape[0] == x.shape[0] and dy.is_contiguous() and x.is_contiguous()
-            and dy.shape[0] % 32 == 0 and dy.shape[0] > 0 and dy.shape[1] in (64, 128) and x.shape[1] in (64, 128))
+            and dy.shape[0] % TOK_WGRAD_CHUNK == 0 and dy.shape[0] > 0 and dy.shape[1] in (64, 128) and x.shape[1] in (64, 128))
 
 
 def tok_wgrad_sb(dy, x, dW, db=None):
@@ -208,7 +209,7 @@ def tok_wgrad_sb(dy, x, dW, db=None):
     _check_dev(dy)
     M, N = dy.shape
     K = x.shape[1]
-    chunks = M // 32
+    chunks = M // TOK_WGRAD_CHUNK
     S = max(1, min(TOK_WGRAD_SPLITS, chunks))
     while (S - 1) * cdiv(chunks, S) >= chunks:
         S -= 1
