@@ -74,6 +74,8 @@ class TextPriorSR(torch.nn.Module):
         object.__setattr__(self, "_teacher", teacher)        # frozen: deliberately NOT a registered sub-module / parameter owner
         self._student_probs = None
         self._prior_cache = None                             # detached prior of the last full forward (recipe's second forward)
+        self._gt_ahead = None                                # (stream, teacher prior) of begin_teacher
+        self._teacher_streams = {}
 
     def _apply(self, fn, *args, **kwargs):                 # .to(device) moves the (unregistered) teacher too
         super()._apply(fn, *args, **kwargs)
@@ -132,16 +134,41 @@ class TextPriorSR(torch.nn.Module):
         self._prior_cache = prior.detach()
         return self.sr(x, prior)
 
+    def begin_teacher(self, hr):
+        """Trainer hook, called BEFORE forward(): the frozen teacher's pass over the HR batch depends on nothing the step computes, so
+        with the Trainer's second lane on it is issued at once on a stream of its own and runs beside the generator's forward (some 80
+        small, latency-bound launches: 26 LSTM steps x 2 layers and the chunked convolutions); extra_loss() joins.  Inside the step's
+        hipGraph this is one more parallel branch.  Without the second lane (or on the CPU) extra_loss runs the teacher itself."""
+        self._gt_ahead = None
+        if self._teacher is None or not Fh.FWD_FORK.enabled or not hr.is_cuda or not TEACHER_AHEAD:
+            return
+        k = str(hr.device)
+        if k not in self._teacher_streams:
+            self._teacher_streams[k] = torch.cuda.Stream(device=hr.device)
+        st = self._teacher_streams[k]
+        st.wait_stream(torch.cuda.current_stream(hr.device))
+        with torch.cuda.stream(st), torch.no_grad():
+            gt = self._probs(self._teacher, hr)
+        self._gt_ahead = (st, gt)
+
     def extra_loss(self, hr):
         """Distillation term; None without a teacher.  Call after forward()."""
         if self._teacher is None:
             return None
         assert not self._teacher.training, "the teacher recogniser must stay in eval mode (reference: aster.eval())"
-        with torch.no_grad():
-            gt = self._probs(self._teacher, hr)
+        if self._gt_ahead is not None:
+            st, gt = self._gt_ahead
+            self._gt_ahead = None
+            torch.cuda.current_stream(hr.device).wait_stream(st)
+        else:
+            with torch.no_grad():
+                gt = self._probs(self._teacher, hr)
         loss = semantic_loss(self._student_probs, gt) * 100.0
         self._student_probs = None
         return loss
+
+
+TEACHER_AHEAD = True        # test / A-B hook: False -> the teacher's pass runs inside extra_loss, after the generator's forward
 
 
 class TssimRecipe:
@@ -357,6 +384,8 @@ class Trainer:
                 if self.recipe is not None:
                     loss = self.recipe.loss(self.model, x, tp, hr)
                 else:
+                    if hasattr(self.model, "begin_teacher"):
+                        self.model.begin_teacher(hr)
                     out = self.model(x, tp) if tp is not None else self.model(x)
                     sr = out[0] if isinstance(out, tuple) else out
                     loss = self.loss_fn(sr, hr)

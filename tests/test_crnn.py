@@ -240,6 +240,16 @@ def test_text_prior_sr_with_teacher_through_the_trainer(dev):
     got = float(tr.step(x, None, hr))
     assert abs(got - want) < 1e-6 * abs(want), (got, want)
     assert rel_err(m.tpg.rnn[1].embedding.weight.grad, g_ref) < 1e-5
+    # the teacher's pass ran ahead on its own stream, beside the generator's forward (TextPriorSR.begin_teacher) -- same loss without
+    assert bool(m._teacher_streams) == tr.two_lanes
+    import tatt_amd.train as T
+    T.TEACHER_AHEAD = False
+    try:
+        m2 = build()
+        got2 = float(Trainer(m2, use_graph=False).step(x, None, hr))
+        assert not m2._teacher_streams and got2 == got
+    finally:
+        T.TEACHER_AHEAD = True
     m = build()
     tr = Trainer(m, use_graph=True, warmup_eager=2)
     ls = [float(tr.step(x, None, hr)) for _ in range(5)]
