@@ -220,6 +220,8 @@ class TssimRecipe:
         fwd = (lambda im: model(im, tp)) if tp is not None else model
         # a generator with its own student recogniser: ONE student pass per step, its prior detached and shared by both forwards (:873,911)
         fwd_ret = (lambda im: model(im, reuse_prior=True)) if (tp is None and hasattr(model, "tpg")) else fwd
+        if hasattr(model, "begin_teacher"):
+            model.begin_teacher(hr_rot)                      # the frozen teacher's pass over hr_rot, beside the first generator forward
         out = fwd(x_rot)
         sr = out[0] if isinstance(out, tuple) else out
         # the distillation term belongs to the FIRST forward (student prior on x_rot vs teacher prior on hr_rot, :767,879); it has to be
