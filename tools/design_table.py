@@ -1,0 +1,38 @@
+#!/usr/bin/env python
+"""Regenerates the table of DESIGN.md section 6 from profiles/r06_bench_*.json (run after copying a final-round call's outputs to profiles/)."""
+import json
+import os
+R=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))+'/'
+def b(n): return json.load(open(R+'profiles/r06_bench_%s.json'%n))
+std,large,tsrn,tbsrn,tpg,tssim,dp=(b(n) for n in ("std","large","tsrn","tbsrn","tpg","tssim","dp_selftest"))
+mid=json.load(open(R+'profiles/r06_mid_bench_std.json'))
+roof=std['roofline']; rh=std.get('roofline_hbm') or {}; ra=std.get('roofline_attn') or {}
+col=dp['collectives']
+table='''| | value (the final-round call, one box) | source |
+|---|---|---|
+| `bench.py` (N = 1, the driver's command: 50 timed + 10 warm-up steps) | **%.3f ms/step = %s LR images/s** (sustained over 450 more steps: %.3f ms); the same tree's kernels on the mid-round box: **%.3f ms = %s img/s** (`r06_mid_bench_std.json`; that box ran every configuration ≈ 5 %% faster); round 5: 4.585 ms = 10,469 | `r06_bench_std.json` |
+| the same step with exact fp32 products everywhere (`exact_fp32`, `set_arithmetic("fp32")`) | **%.3f ms/step = %s LR images/s** | same line |
+| large tile (`--tile large`: LR 32×128 → 64×256, B = 16, STN off) | **%.3f ms/step = %s img/s** (round 5: 6.605); exact fp32 %.2f | `r06_bench_large.json` |
+| TSRN / TBSRN (configs[3]) / TATT + CRNN student + teacher | %.3f ms = %s img/s (3.637) / **%.3f ms = %s** (12.287) / **%.3f ms = %s** (11.161) | `r06_bench_tsrn.json`, `r06_bench_tbsrn.json`, `r06_bench_tpg.json` |
+| the shipped recipe (`--tssim`) | %.3f ms/step = %s img/s (9.928) | `r06_bench_tssim.json` |
+| data-parallel step on one GPU (`--dp-selftest`) | %.3f ms/step (+%.1f %% over the single graph of the same call); exposed collectives %.3f ms; pass groups %s ms; collectives %s MB | `r06_bench_dp_selftest.json` |
+| CPU baseline (`cpu_baseline`, kind "port") | %.1f img/s on %d threads (%s) | bench line |
+| `roofline` — %s | %.1f µs per launch with the buffer sets rotated through HBM (14.1 µs on resident data in the kernel trace of the micro-benchmark, `r06_kernel_microbench.txt`) = %.0f TFLOP/s of ALGORITHMIC FLOPs against the 2500 TFLOP/s of the pipe it issues on: **`frac` = %.3f** (`mfma_pipe_util` %.2f: three products per fp32 product), `in_step_frac` %s; HBM %.2f MB (PMC) vs %.2f MB algorithmic | bench line, `conv3_ws_pmc.json` |
+| `roofline_hbm` — %s | %.1f µs, %.1f MB algorithmic → %.2f TB/s = **%.2f** of the 8 TB/s spec peak | bench line |
+| launches per replayed step | **319** (unchanged) | `r06_final_step_timeline.txt` |
+| GPU tests | 293 passed, 2 skipped (`-m gpu`, 8 min 14 s on the box) | `r06_gpu_tests_tail.txt` |
+''' % (std['ms_per_step'], format(round(std['value']),','), std['sustained_ms_per_step'], mid['ms_per_step'], format(round(mid['value']),','),
+       std['exact_fp32']['ms_per_step'], format(round(std['exact_fp32']['value']),','),
+       large['ms_per_step'], format(round(large['value']),','), large['exact_fp32']['ms_per_step'],
+       tsrn['ms_per_step'], format(round(tsrn['value']),','), tbsrn['ms_per_step'], format(round(tbsrn['value']),','), tpg['ms_per_step'], format(round(tpg['value']),','),
+       tssim['ms_per_step'], format(round(tssim['value']),','),
+       dp['ms_per_step'], (dp['ms_per_step']/std['ms_per_step']-1)*100, col['exposed_ms_per_step'], ' / '.join('%.2f'%g['gpu_ms'] for g in col['pass_groups']), ' / '.join('%.1f'%(c['bytes']/1e6) for c in col['per_step']),
+       std['cpu_baseline']['value'], std['cpu_baseline']['cores'], std['cpu_baseline']['sample'].split(';')[0],
+       roof['kernel'].split(' (')[0], roof['kernel_ms']*1e3, roof['achieved'], roof['frac'], roof['mfma_pipe_util'], roof.get('in_step_frac'), roof['traffic']/1e6, roof['algorithmic_bytes']/1e6,
+       rh.get('kernel','').split(' (')[0], rh.get('kernel_ms',0)*1e3, rh.get('algorithmic_bytes',0)/1e6, rh.get('achieved',0)/1e3, rh.get('frac',0))
+s=open(R+'DESIGN.md').read()
+B, E = '<!-- R06_TABLE_BEGIN -->\n', '<!-- R06_TABLE_END -->\n'
+i, j = s.index(B), s.index(E)
+s = s[:i] + B + table + s[j:]
+open(R+'DESIGN.md','w').write(s)
+print(table)
