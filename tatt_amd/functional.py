@@ -204,6 +204,9 @@ class _ForwardFork:
 
 
 FWD_FORK = _ForwardFork()
+# a second, independent branch (own stream): the student recogniser's pass of TextPriorSR, beside the STN head and the first convolution;
+# joined where the generator first reads the text prior (tsrn._trunk_forward)
+FWD_FORK_B = _ForwardFork()
 
 
 def _c(t):

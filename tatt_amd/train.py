@@ -122,7 +122,13 @@ class TextPriorSR(torch.nn.Module):
         if reuse_prior:                  # interfaces/super_resolution.py:911: the first forward's prior, detached; no second student pass
             assert self._prior_cache is not None, "reuse_prior needs a full forward first"
             return self.sr(x, self._prior_cache)
-        probs = self._probs(self.tpg, x)
+        # the student's pass needs only the LR image: with STUDENT_FORK it is a parallel branch (stream of its own) beside the generator's
+        # STN head and first convolution, joined where the generator first reads the prior (tsrn._trunk_forward); its backward (stage
+        # "tpg") runs on that stream too -- the autograd engine orders it against the streams that feed and follow it.  Off by default.
+        if STUDENT_FORK:
+            probs = Fh.FWD_FORK_B.run(x, lambda: self._probs(self.tpg, x))
+        else:
+            probs = self._probs(self.tpg, x)
         cuts = getattr(self.sr, "_grad_cuts", None) if self.training else None
         # staged backward: every consumer of the prior continues on its own detached copy; stage "tpg" adds their gradients up
         self._student_probs = cuts.cut("tpg", probs) if cuts else probs
@@ -132,7 +138,9 @@ class TextPriorSR(torch.nn.Module):
             p_sr = cuts.cut("tpg", probs) if cuts else probs
         prior = p_sr.permute(1, 0, 2).unsqueeze(1).permute(0, 3, 1, 2)            # (B, 37, 1, T)
         self._prior_cache = prior.detach()
-        return self.sr(x, prior)
+        out = self.sr(x, prior)
+        Fh.FWD_FORK_B.join(x.device)                        # (a generator that never read the prior: join before anything else does)
+        return out
 
     def begin_teacher(self, hr):
         """Trainer hook, called BEFORE forward(): the frozen teacher's pass over the HR batch depends on nothing the step computes, so
@@ -168,6 +176,9 @@ class TextPriorSR(torch.nn.Module):
         return loss
 
 
+STUDENT_FORK = False        # True: the student's pass as a parallel branch of the forward (FWD_FORK_B).  Measured, round 6, same call,
+                            # tatt_tpg at B = 48: 8.04 ms in line / 8.15-8.66 ms (bimodal) forked -- a third concurrent branch makes the
+                            # graph executor queue the lanes behind each other (profiles/r05_tail_lane_ab.txt); kept as a tested hook
 TEACHER_AHEAD = True        # test / A-B hook: False -> the teacher's pass runs inside extra_loss, after the generator's forward
 
 
@@ -371,7 +382,7 @@ class Trainer:
     def _main_lane(self, k, x=None, tp=None, hr=None):
         """Stage 0: forward + loss + backward from the loss; stage k > 0: the part of the backward `stages[k]` names."""
         Fh.SIDE.enabled = self.defer
-        Fh.FWD_FORK.enabled = self.two_lanes
+        Fh.FWD_FORK.enabled = Fh.FWD_FORK_B.enabled = self.two_lanes
         Fh.SIDE.stage = k
         Fh.SIDE.due_of = self._due
         Fh.SIDE.immediate = self._immediate
@@ -403,7 +414,7 @@ class Trainer:
         finally:
             Fh.SIDE.enabled = False
             Fh.SIDE.side_stream = None
-            Fh.FWD_FORK.enabled = False
+            Fh.FWD_FORK.enabled = Fh.FWD_FORK_B.enabled = False
             if k == 0 and self.cuts is not None:
                 self.model.set_grad_cuts(None)
         if k == len(self.stages) - 1 and hasattr(self.model, "block"):

@@ -610,6 +610,7 @@ class _GeneratorBase(_TrainPathMixin, nn.Module):
         tp_map = pr_weights = None
         b1_trunk = b1
         if use_tp:
+            Fh.FWD_FORK_B.join(x.device)             # the text prior may have been a parallel branch until here (TextPriorSR's student)
             tp_map, pr_weights = _tp_interpreter(cuts.cut("first", b1) if cuts else b1, text_emb.float(), self.infoGen, training,
                                                  qpos, text_side)
         tp_ret = tp_map

@@ -250,6 +250,14 @@ def test_text_prior_sr_with_teacher_through_the_trainer(dev):
         assert not m2._teacher_streams and got2 == got
     finally:
         T.TEACHER_AHEAD = True
+    # the hook that also forks the student's pass (its backward then runs on that branch's stream): same loss, same gradients
+    T.STUDENT_FORK = True
+    try:
+        m3 = build()
+        got3 = float(Trainer(m3, use_graph=False).step(x, None, hr))
+        assert got3 == got and rel_err(m3.tpg.rnn[1].embedding.weight.grad, m.tpg.rnn[1].embedding.weight.grad) == 0.0
+    finally:
+        T.STUDENT_FORK = False
     m = build()
     tr = Trainer(m, use_graph=True, warmup_eager=2)
     ls = [float(tr.step(x, None, hr)) for _ in range(5)]
