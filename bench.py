@@ -327,7 +327,8 @@ def time_tbsrn_attention(dev, B, P=1024, h=4, d=32):
     """The dominant kernels of the TBSRN step (configs[3]): the score-free self-attention of one FeatureEnhancer (csrc/sattn2.hip: split
     bf16 on v_mfma_f32_32x32x16_bf16; csrc/sattn.hip under set_arithmetic("fp32")): forward (QK^T and PV: 4 B h P^2 d FLOPs) and backward
     (D; dK, dV; dQ: seven P x P x d products = 14 B h P^2 d), dropout on, keep bits handed from the forward to the backward as the model
-    does.  -> (ms forward, ms backward, FLOPs, algorithmic HBM bytes: Q, K, V, O in / out, their gradients, the keep bits once out, twice in)."""
+    does.  -> (ms forward, ms backward, FLOPs, algorithmic HBM bytes = what each of the four launches must read and write: Q K V -> O; dO O -> D;
+    Q K V dO -> dK dV; Q K V dO -> dQ = 17 token tensors, and the keep bits once out, twice in)."""
     from tatt_amd import ops, functional as Fh
     E = h * d
     Q, K, V, dO = (torch.randn(B, P, E, device=dev) for _ in range(4))
@@ -342,7 +343,7 @@ def time_tbsrn_attention(dev, B, P=1024, h=4, d=32):
     bwd = lambda: ops.call("tatt_sattn_bwd_bits", ops.P(Q), ops.P(K), ops.P(V), ops.P(O), ops.P(lse), ops.P(dO), ops.P(bits), ops.P(dQ),
                            ops.P(dK), ops.P(dV), ops.P(ws), B, P, h, sc, 0.1, ops.P(seed), 100, ops.stream())
     tf, tb = _timed_ms(fwd, 10, 2), _timed_ms(bwd, 10, 2)
-    return tf, tb, 4.0 * B * h * P * P * d, 14.0 * B * h * P * P * d, 11.0 * B * P * E * 4 + 3.0 * B * h * P * P / 8
+    return tf, tb, 4.0 * B * h * P * P * d, 14.0 * B * h * P * P * d, 17.0 * B * P * E * 4 + 3.0 * B * h * P * P / 8
 
 
 def executed_flop_per_image(tile, B):
