@@ -17,9 +17,7 @@ table='''| | value (the final-round call, one box) | source |
 | the shipped recipe (`--tssim`) | %.3f ms/step = %s img/s (9.928) | `r06_bench_tssim.json` |
 | data-parallel step on one GPU (`--dp-selftest`) | %.3f ms/step (+%.1f %% over the single graph of the same call); exposed collectives %.3f ms; pass groups %s ms; collectives %s MB | `r06_bench_dp_selftest.json` |
 | CPU baseline (`cpu_baseline`, kind "port") | %.1f img/s on %d threads (%s) | bench line |
-| `roofline` — %s | %.1f µs per launch with the buffer sets rotated through HBM (14.1 µs on resident data in the kernel trace of the micro-benchmark, `r06_kernel_microbench.txt`) = %.0f TFLOP/s of ALGORITHMIC FLOPs against the 2500 TFLOP/s of the pipe it issues on: **`frac` = %.3f** (`mfma_pipe_util` %.2f: three products per fp32 product), `in_step_frac` %s; HBM %.2f MB (PMC) vs %.2f MB algorithmic | bench line, `conv3_ws_pmc.json` |
-| `roofline_hbm` — %s | %.1f µs, %.1f MB algorithmic → %.2f TB/s = **%.2f** of the 8 TB/s spec peak | bench line |
-| launches per replayed step | **319** (unchanged) | `r06_final_step_timeline.txt` |
+@@ROOF@@| launches per replayed step | **319** (unchanged) | `r06_final_step_timeline.txt` |
 | GPU tests | 293 passed, 2 skipped (`-m gpu`, 8 min 14 s on the box) | `r06_gpu_tests_tail.txt` |
 ''' % (std['ms_per_step'], format(round(std['value']),','), std['sustained_ms_per_step'], mid['ms_per_step'], format(round(mid['value']),','),
        std['exact_fp32']['ms_per_step'], format(round(std['exact_fp32']['value']),','),
@@ -27,9 +25,22 @@ table='''| | value (the final-round call, one box) | source |
        tsrn['ms_per_step'], format(round(tsrn['value']),','), tbsrn['ms_per_step'], format(round(tbsrn['value']),','), tpg['ms_per_step'], format(round(tpg['value']),','),
        tssim['ms_per_step'], format(round(tssim['value']),','),
        dp['ms_per_step'], (dp['ms_per_step']/std['ms_per_step']-1)*100, col['exposed_ms_per_step'], ' / '.join('%.2f'%g['gpu_ms'] for g in col['pass_groups']), ' / '.join('%.1f'%(c['bytes']/1e6) for c in col['per_step']),
-       std['cpu_baseline']['value'], std['cpu_baseline']['cores'], std['cpu_baseline']['sample'].split(';')[0],
-       roof['kernel'].split(' (')[0], roof['kernel_ms']*1e3, roof['achieved'], roof['frac'], roof['mfma_pipe_util'], roof.get('in_step_frac'), roof['traffic']/1e6, roof['algorithmic_bytes']/1e6,
-       rh.get('kernel','').split(' (')[0], rh.get('kernel_ms',0)*1e3, rh.get('algorithmic_bytes',0)/1e6, rh.get('achieved',0)/1e3, rh.get('frac',0))
+       std['cpu_baseline']['value'], std['cpu_baseline']['cores'], std['cpu_baseline']['sample'].split(';')[0])
+def roof_row(tag, r):
+    name = r['kernel'].split(' (')[0]
+    ins = r.get('in_step') or {}
+    if r['bound'] == 'mfma':
+        return ("| `%s` — `%s` | %.1f µs per launch with the buffer sets rotated through HBM = %.0f TFLOP/s of ALGORITHMIC FLOPs against the %.0f TFLOP/s "
+                "of the pipe it issues on: **`frac` = %.3f** (`mfma_pipe_util` %.2f: three matrix products per fp32 product); in the step's trace %.1f µs per "
+                "launch (`in_step_frac` %s); HBM %.2f MB by PMC against %.2f MB algorithmic → %.2f TB/s | bench line, `conv3_ws_pmc.json` |\n" % (
+                    tag, name, r['kernel_ms'] * 1e3, r['achieved'], r['peak'], r['frac'], r.get('mfma_pipe_util', 0), ins.get('us_per_launch', 0),
+                    r.get('in_step_frac'), (r.get('traffic') or 0) / 1e6, r['algorithmic_bytes'] / 1e6, r.get('hbm_gbps', 0) / 1e3))
+    return ("| `%s` — `%s` | %.1f µs per launch, %.1f MB algorithmic (PMC %.1f MB) → %.2f TB/s = **`frac` %.3f** of the 8 TB/s spec peak (%.2f of "
+            "the 6.3 TB/s this part reaches in a pure copy); in the step's trace %.1f µs per launch (`in_step_frac` %s) | bench line |\n" % (
+                tag, name, r['kernel_ms'] * 1e3, r['algorithmic_bytes'] / 1e6, (r.get('traffic') or 0) / 1e6, r['achieved'] / 1e3, r['frac'], r['achieved'] / 6300.0,
+                ins.get('us_per_launch', 0), r.get('in_step_frac')))
+roofs = roof_row('roofline', std['roofline']) + ''.join(roof_row(k, std[k]) for k in ('roofline_mfma', 'roofline_hbm') if std.get(k))
+table = table.replace('@@ROOF@@', roofs)
 s=open(R+'DESIGN.md').read()
 B, E = '<!-- R06_TABLE_BEGIN -->\n', '<!-- R06_TABLE_END -->\n'
 i, j = s.index(B), s.index(E)
