@@ -349,6 +349,7 @@ OUTCONV_BUCKET = "srb0"
 # their work-groups to leave the CUs (156 us in the step, 15 alone) on a side lane that is the longer one of that pass; filed with its
 # own stage it runs in a pass whose side lane has room
 OUTCONV_BIAS_BUCKET = "trunk"
+PRECOMPOSE_ON_FORK = True    # test / A-B hook: False -> the GruBlock compose / pack launches run on the main lane, in front of the STN head
 TP_FUSED = True          # test hook: False walks the operator-by-operator path for every geometry (tests compare the two)
 
 
@@ -581,7 +582,14 @@ class _GeneratorBase(_TrainPathMixin, nn.Module):
         k = self.srb_nums
         cuts = self._grad_cuts if training else None
         qpos = None
+        pre_forked = False
         if use_tp:
+            if PRECOMPOSE_ON_FORK and k > 0 and isinstance(getattr(self, "block2").gru1, GruBlock):
+                # the composed / packed GruBlock projections are parameters-only work as well, first needed by the first residual
+                # block: they lead the forked branch instead of standing in front of the STN head on the main lane (25 us)
+                Fh.FWD_FORK.run(x, lambda: Fh.gru_precompose([g for i in range(k) for g in (getattr(self, "block%d" % (i + 2)).gru1,
+                                                                                         getattr(self, "block%d" % (i + 2)).gru2)]))
+                pre_forked = True
             # first of all: the query embedding depends on parameters only (no dropout in it) and is the longest dependent chain of
             # the forward's head -- its forked branch starts before anything else is issued
             qpos = _query_pos(self.infoGen, x.shape[0], x.shape[2], x.shape[3])
@@ -591,7 +599,7 @@ class _GeneratorBase(_TrainPathMixin, nn.Module):
         if use_tp and text_emb is None:
             text_emb = torch.zeros(1, 37, 1, 26, device=x.device)         # reference :653-654
         text_side = None
-        if k > 0 and isinstance(getattr(self, "block2").gru1, GruBlock):
+        if not pre_forked and k > 0 and isinstance(getattr(self, "block2").gru1, GruBlock):
             # the composed 1x1-conv x GRU-input projections of every residual block: parameters only, one launch for all of them
             Fh.gru_precompose([g for i in range(k) for g in (getattr(self, "block%d" % (i + 2)).gru1,
                                                              getattr(self, "block%d" % (i + 2)).gru2)])
