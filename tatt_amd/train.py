@@ -366,8 +366,6 @@ class Trainer:
         self._graphs = None
         self._one = None
         self._static = None
-        self._static_flat = None
-        self._static_offs = None
         self._nsteps = 0
         self._works = []
         self.last_loss = None
@@ -566,15 +564,10 @@ class Trainer:
                 self._capture(x, tp, hr)
             graphs = self._graphs
             sx, stp, shr = self._static
-            ins = [t for t in (x, tp, hr) if t is not None]
-            if (self._static_flat is not None and self.cuda
-                    and all(t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda for t in ins)):
-                ops.gather_grads(self._static_flat, [(t, o, t.numel()) for t, o in zip(ins, self._static_offs)])     # one launch
-            else:
-                sx.copy_(x)
-                shr.copy_(hr)
-                if stp is not None:
-                    stp.copy_(tp)
+            sx.copy_(x)
+            shr.copy_(hr)
+            if stp is not None:
+                stp.copy_(tp)
         if graphs is not None and "step" in graphs:
             graphs["step"].replay()                  # single GPU: the whole step is one graph
             return self.last_loss.clone()            # (the captured tensor is overwritten by the next replay)
@@ -608,21 +601,7 @@ class Trainer:
 
     def _capture(self, x, tp, hr):
         """Capturing executes nothing: step() replays right away, so the step that captured is a real step."""
-        # the step's static inputs are views of ONE flat buffer: a step refreshes them with one multi-tensor copy launch
-        ins = [t for t in (x, tp, hr) if t is not None]
-        offs, total = [], 0
-        for t in ins:
-            offs.append(total)
-            total += (t.numel() + 3) // 4 * 4                # 16-byte aligned views
-        self._static_flat = torch.zeros(total, device=x.device, dtype=torch.float32) if all(t.dtype == torch.float32 for t in ins) else None
-        if self._static_flat is not None:
-            views = [self._static_flat[o:o + t.numel()].view(t.shape) for o, t in zip(offs, ins)]
-            for v, t in zip(views, ins):
-                v.copy_(t)
-            self._static_offs = offs
-            self._static = (views[0], None if tp is None else views[1], views[-1])
-        else:
-            self._static = (x.clone(), None if tp is None else tp.clone(), hr.clone())
+        self._static = (x.clone(), None if tp is None else tp.clone(), hr.clone())
         sx, stp, shr = self._static
         torch.cuda.synchronize()
         nst = len(self.stages)
