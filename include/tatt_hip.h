@@ -509,6 +509,10 @@ int tatt_tokgemm_sb_ex(const float* X1, const float* X2, int K1, const float* Wp
  * unit was active and kept, gate_scale = 1 / (1 - pdrop)).  One source, one destination; shapes of tatt_tokgemm_sb_ex. */
 int tatt_tokgemm_sb_ffn(const float* X, const float* Wp, const float* bias, float* Y, int M, int N, int K, int act, float pdrop,
                         const unsigned long long* seed, unsigned site, const float* gate, float gate_scale, hipStream_t st);
+/* Y = X Wp^T + bias + addend: addend (M, N) contiguous and left intact, Y must not alias it; (N, K) within 128 x 128.  The sum of a
+ * data gradient and the gradient a residual connection carries (TBSRN FeatureEnhancer sub-layers) without an element-wise launch. */
+int tatt_tokgemm_sb_add(const float* X, const float* Wp, const float* bias, const float* addend, float* Y, int M, int N, int K,
+                        hipStream_t st);
 /* trans = 0: w(n, k) = W[n*ldw + k] (y = x W^T);  trans = 1: w(n, k) = W[k*ldw + n] (dx = dy W).  out: N*K words */
 int tatt_tokgemm_pack(const float* W, float* out, int N, int K, int ldw, int trans, hipStream_t st);
 /* n packs in one launch: ptrs = HOST array of n x 2 device pointers (W, out), dims = HOST array of n x 4 ints (N, K, ldw, trans) */

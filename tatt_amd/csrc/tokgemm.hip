@@ -26,6 +26,7 @@ struct TokGemmP {
     // and flat index row * N + col), or a gate -- the result times gate_scale where gate[row * N + col] > 0, else 0
     float pdrop; const unsigned long long* seed; unsigned site;
     const float* gate; float gate_scale;
+    const float* addend;                             // Y = ... + addend (same shape as Y, one destination): a sum that leaves its operand intact
 };
 
 __device__ __forceinline__ void tg_split(f32x4 v, uint2& hi, uint2& lo) {
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(512, 1) void tokgemm_sb_kernel(TokGemmP p) {
                     for (int r = 0; r < 4; ++r) {
                         const long flat = (row0 + 16 * m + r) * p.N1 + col;
                         gv[PRE ? cb : 0][m][r] = (EPI && p.gate) ? p.gate[flat] : 1.f;
-                        yv[PRE ? cb : 0][m][r] = (p.accum && col < p.N1) ? p.Y1[flat] : 0.f;
+                        yv[PRE ? cb : 0][m][r] = p.addend ? p.addend[flat] : ((p.accum && col < p.N1) ? p.Y1[flat] : 0.f);
                     }
             }
         }
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(512, 1) void tokgemm_sb_kernel(TokGemmP p) {
                         const long flat = (row0 + 16 * m + r) * ld + c;            // (drop / gate / accum: one destination, ld = N)
                         if (drop) v = dropout_keep(sd, p.site, (uint64_t)flat, th) ? v * dsc : 0.f;
                         if (EPI && p.gate) v = (PRE ? gv[PRE ? cb : 0][m][r] : p.gate[flat]) > 0.f ? v * p.gate_scale : 0.f;
-                        if (p.accum) v += PRE ? yv[PRE ? cb : 0][m][r] : *y;
+                        if (p.accum || (PRE && p.addend)) v += PRE ? yv[PRE ? cb : 0][m][r] : *y;
                         *y = v;
                     }
             }
@@ -263,7 +264,7 @@ TATT_API int tatt_tokgemm_sb_ex(const float* X1, const float* X2, int K1, const 
                                 int M, int N, int K, int act, int accum, hipStream_t st) {
     if (M < 64 || M % 64 || K1 % 4 || (K - K1) % 4 || K1 < 0 || K1 > K || N1 < 0 || N1 > N || (K1 < K && !X2) || (N1 < N && !Y2)) return 1;
     if ((act != ACT_NONE && act != ACT_RELU) || (accum && N1 != N)) return 1;
-    TokGemmP p = {X1, X2, K1, Wp, bias, Y1, Y2, N1, M, act, accum, 0.f, nullptr, 0u, nullptr, 1.f};
+    TokGemmP p = {X1, X2, K1, Wp, bias, Y1, Y2, N1, M, act, accum, 0.f, nullptr, 0u, nullptr, 1.f, nullptr};
     return tg_dispatch(p, N, K, st);
 }
 // The two epilogues of a position-wise feed-forward w_2(Dropout(relu(w_1 x))) (reference PositionwiseFeedForward, model/tbsrn.py:154-164)
@@ -275,7 +276,15 @@ TATT_API int tatt_tokgemm_sb_ffn(const float* X, const float* Wp, const float* b
                                  const unsigned long long* seed, unsigned site, const float* gate, float gate_scale, hipStream_t st) {
     if (M < 64 || M % 64 || (act != ACT_NONE && act != ACT_RELU) || pdrop < 0.f || pdrop >= 1.f || (pdrop > 0.f && !seed)) return 1;
     if ((double)M * N >= 4.0e18) return 1;
-    TokGemmP p = {X, nullptr, K, Wp, bias, Y, nullptr, N, M, act, 0, pdrop, seed, site, gate, gate_scale};
+    TokGemmP p = {X, nullptr, K, Wp, bias, Y, nullptr, N, M, act, 0, pdrop, seed, site, gate, gate_scale, nullptr};
+    return tg_dispatch(p, N, K, st);
+}
+// Y = X Wp^T + bias + addend (addend (M, N) contiguous, left intact; Y may not alias it): the sum of a data gradient and the gradient a
+// residual connection carries, without an element-wise launch and without overwriting either.  (N, K) with N <= 128, K <= 128.
+TATT_API int tatt_tokgemm_sb_add(const float* X, const float* Wp, const float* bias, const float* addend, float* Y, int M, int N, int K,
+                                 hipStream_t st) {
+    if (M < 64 || M % 64 || !addend || addend == Y || N > 128 || K > 128) return 1;
+    TokGemmP p = {X, nullptr, K, Wp, bias, Y, nullptr, N, M, ACT_NONE, 0, 0.f, nullptr, 0u, nullptr, 1.f, addend};
     return tg_dispatch(p, N, K, st);
 }
 static int tg_dispatch(const TokGemmP& p, int N, int K, hipStream_t st) {

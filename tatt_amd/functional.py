@@ -686,6 +686,63 @@ class FeedForwardFn(Function):
         return (dx,) + tuple(g) + (None, None)
 
 
+class FeedForwardLnFn(Function):
+    """LayerNorm(x + w_2(Dropout_p(relu(w_1 x)))) -- the feed-forward sub-layer of the TBSRN FeatureEnhancer with its residual LayerNorm
+    (reference model/tbsrn.py:87-90) as ONE operator.  The forward is FeedForwardFn's two GEMMs and the LayerNorm launch; what the
+    composition buys is the backward: x has two consumers (the feed-forward and the residual), and as separate operators autograd adds
+    their two gradients with an element-wise launch (25 MB read twice, written once, per block).  Here the LayerNorm backward writes the
+    residual's gradient and w_1's data-gradient GEMM ACCUMULATES into it (tatt_tokgemm_sb_ex accum).  Prepacked weights (linear_prepack)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, gamma, beta, eps, mode, pdrop, site):
+        K = x.shape[-1]
+        x2 = x.reshape(-1, K)
+        M = x2.shape[0]
+        pk1, pk2 = _packed_linear(w1, M), _packed_linear(w2, M)
+        Nf, No = w1.shape[0], w2.shape[0]
+        seed = current_seed(x.device) if pdrop > 0.0 else None
+        f = ops.new(x2, M, Nf)
+        ops.call("tatt_tokgemm_sb_ffn", ops.P(x2), ops.P(pk1[0]), ops.P(b1), ops.P(f), M, Nf, K, ACT_RELU, float(pdrop), ops.P(seed), int(site),
+                 None, 1.0, ops.stream())
+        y = _tokgemm_ex(f, pk2[0], b2, No, Nf)
+        out, stats = ops.ln_fwd(x2, y, gamma, beta, eps, mode)
+        ctx.save_for_backward(x, f, y, stats, w1, w2, gamma)
+        ctx.wbk = (pk1[1], pk2[1])
+        ctx.pdrop, ctx.eps, ctx.mode = float(pdrop), eps, mode
+        ctx.has_b = (b1 is not None, b2 is not None)
+        ctx.leaves = (w1, b1, w2, b2)
+        return out.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, f, y, stats, w1, w2, gamma = ctx.saved_tensors
+        Nf, K = w1.shape
+        No = w2.shape[0]
+        x2 = x.reshape(-1, K)
+        M = x2.shape[0]
+        # d(x + y): the residual's gradient and the feed-forward output's gradient are the same tensor
+        dxy, _, dg, db = ops.ln_bwd(x2, y, _c(dout).reshape(-1, K), stats, gamma, ctx.eps, ctx.mode)
+        dpre = ops.new(dxy, M, Nf)                                   # gradient in front of the relu
+        ops.call("tatt_tokgemm_sb_ffn", ops.P(dxy), ops.P(ctx.wbk[1]), None, ops.P(dpre), M, Nf, No, ACT_NONE, 0.0, None, 0, ops.P(f),
+                 1.0 / (1.0 - ctx.pdrop), ops.stream())
+        hb1, hb2 = ctx.has_b
+
+        def param_grads():
+            dw2, db2 = ops.new(dyc, No, Nf), (ops.new(dyc, No) if hb2 else None)
+            _linear_wgrad(dyc, f, dw2, db2)
+            dw1, db1 = ops.new(dyc, Nf, K), (ops.new(dyc, Nf) if hb1 else None)
+            _linear_wgrad(dpre, x2, dw1, db1)
+            return dw1, db1, dw2, db2
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.new(dxy, M, K)                                  # = dxy (residual) + dpre W1; dxy stays what w_2's weight gradient reads
+            ops.call("tatt_tokgemm_sb_add", ops.P(dpre), ops.P(ctx.wbk[0]), None, ops.P(dxy), ops.P(dx), M, K, Nf, ops.stream())
+            dx = dx.reshape(x.shape)
+        dyc = dxy
+        g = SIDE.submit(ctx.leaves, param_grads, x, f, dyc, dpre)
+        return (dx,) + tuple(g) + (dg, db, None, None, None, None)
+
+
 def feed_forward(x, w_1, w_2, pdrop, training, site):
     """w_1, w_2: nn.Linear holders; dropout (site) between them in training"""
     x = _c(x)
@@ -698,6 +755,19 @@ def feed_forward(x, w_1, w_2, pdrop, training, site):
     return linear(f, w_2.weight, w_2.bias)
 
 
+def feed_forward_ln(x, w_1, w_2, gamma, beta, eps, mode, pdrop, training, site):
+    """LayerNorm_mode(x + w_2(Dropout(relu(w_1 x)))): one operator when the weights are prepacked, else the operator chain"""
+    x = _c(x)
+    M = x.numel() // x.shape[-1]
+    p = float(pdrop) if training else 0.0
+    if (FFN_LN_FUSED and FFN_FUSED and _packed_linear(w_1.weight, M) is not None and _packed_linear(w_2.weight, M) is not None
+            and w_2.weight.shape[0] == x.shape[-1] and x.shape[-1] <= 128 and w_1.weight.shape[0] <= 128):
+        return FeedForwardLnFn.apply(x, w_1.weight, w_1.bias, w_2.weight, w_2.bias, gamma, beta, eps, mode, p, site)
+    f = feed_forward(x, w_1, w_2, pdrop, training, site)
+    return LayerNormFn.apply(x, f, gamma, beta, eps, mode, 0.0, 0)
+
+
+FFN_LN_FUSED = True         # test / A-B hook: False -> feed-forward and LayerNorm as two operators (autograd adds x's two gradients)
 FFN_FUSED = True            # test / A-B hook: False -> linear + dropout + linear as separate operators
 
 

@@ -120,8 +120,7 @@ def _feature_enhancer(r, fe: FeatureEnhancer, training, dropout_on, site0):
     a = Fh.linear(a, mh.linears[3].weight, mh.linears[3].bias)
     ln1, ln3 = fe.mul_layernorm1, fe.mul_layernorm3
     x = Fh.LayerNormFn.apply(x, a, ln1.a_2, ln1.b_2, ln1.eps, 1, 0.0, 0)
-    f = Fh.feed_forward(x, fe.pff.w_1, fe.pff.w_2, fe.pff.p, drop, site0 + 1)
-    x = Fh.LayerNormFn.apply(x, f, ln3.a_2, ln3.b_2, ln3.eps, 1, 0.0, 0)
+    x = Fh.feed_forward_ln(x, fe.pff.w_1, fe.pff.w_2, ln3.a_2, ln3.b_2, ln3.eps, 1, fe.pff.p, drop, site0 + 1)
     x = Fh.linear(x, fe.linear.weight, fe.linear.bias)
     return x.reshape(B, H, W, C)
 

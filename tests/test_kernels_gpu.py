@@ -1400,6 +1400,38 @@ def test_feed_forward_operator_equals_the_operator_chain(dev):
     assert float((xg.grad.cpu().double() - xd.grad).abs().max() / xd.grad.abs().max()) < 2e-5
 
 
+def test_feed_forward_layer_norm_operator_equals_the_two_operators(dev):
+    """FeedForwardLnFn (the residual's gradient and w_1's data gradient summed in the GEMM epilogue, tatt_tokgemm_sb_add) against
+    FeedForwardFn followed by LayerNormFn (autograd adds the two gradients of x): same masks and kernels, so values, dx and all six
+    parameter gradients agree to the order of one addition."""
+    from tatt_amd import functional as Fh
+    g = torch.Generator().manual_seed(16)
+    B, Pn, E = 2, 320, 128
+    x = torch.randn(B, Pn, E, generator=g)
+    w = torch.randn(B, Pn, E, generator=g)
+    l1, l2 = torch.nn.Linear(E, E).to(dev), torch.nn.Linear(E, E).to(dev)
+    ga, be = (torch.rand(E, generator=g) + 0.5).to(dev).requires_grad_(True), torch.randn(E, generator=g).to(dev).requires_grad_(True)
+    res = []
+    for fused in (True, False):
+        Fh.set_seed(dev, 9)
+        Fh.begin_training_forward(dev)
+        Fh.linear_prepack([l1, l2])
+        Fh.FFN_LN_FUSED = fused
+        try:
+            for t in (l1.weight, l1.bias, l2.weight, l2.bias, ga, be):
+                t.grad = None
+            xg = x.to(dev).requires_grad_(True)
+            y = Fh.feed_forward_ln(xg, l1, l2, ga, be, 1e-6, 1, 0.1, True, 43)
+            assert isinstance(y.grad_fn, Fh.FeedForwardLnFn._backward_cls) == fused
+            (y * w.to(dev)).sum().backward()
+            res.append([t.detach().cpu().clone() for t in (y, xg.grad, l1.weight.grad, l1.bias.grad, l2.weight.grad, l2.bias.grad, ga.grad, be.grad)])
+        finally:
+            Fh.FFN_LN_FUSED = True
+            Fh.linear_prepack_done()
+    for name, a, b in zip(("y", "dx", "dw1", "db1", "dw2", "db2", "dgamma", "dbeta"), *res):
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()), (name, float((a - b).abs().max()), float(b.abs().max()))
+
+
 # ------------------------------------------------------------------------------------------- fused GruBlock weight gradients
 @pytest.mark.parametrize("M,with_xb,groups", [(32 * 200, True, 128), (32 * 200, False, 128), (32, True, 128), (32 * 7, True, 3),
                                                (49152, True, 128), (49152, True, 256)])
