@@ -1963,6 +1963,91 @@ class SelfAttnFlashFn(Function):
         return dQ, dK, dV, None, None, None
 
 
+class AttnLnFn(Function):
+    """LayerNorm(x + W_o attention(W_q x, W_k x, W_v x)) -- the attention sub-layer of the TBSRN FeatureEnhancer with its residual
+    LayerNorm (reference model/tbsrn.py:80-86, 119-151) as ONE operator: QKVProjFn, SelfAttnFlashFn, the output projection and
+    LayerNormFn back to back, with the same launches.  As with FeedForwardLnFn the composition is for the backward: the gradient the
+    residual carries is the addend of the first of the three data-gradient GEMMs into x (tatt_tokgemm_sb_add) instead of an element-wise
+    launch by autograd.  Prepacked weights (linear_prepack); d_k = 32, a token count the score-free kernels take."""
+
+    @staticmethod
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, wo, bo, gamma, beta, eps, mode, h, pdrop, site):
+        B, Pn, E = x.shape
+        x2 = x.reshape(-1, E)
+        M = x2.shape[0]
+        pks = [_packed_linear(w, M) for w in (wq, wk, wv, wo)]
+        q, k, v = (_tokgemm_ex(x2, pk[0], b, E, E).reshape(B, Pn, E) for pk, b in zip(pks[:3], (bq, bk, bv)))
+        scale = 1.0 / math.sqrt(E // h)
+        seed = current_seed(x.device) if pdrop > 0.0 else None
+        O, lse = torch.empty_like(q), ops.new(q, B, h, Pn)
+        _sattn_select()
+        bits = torch.empty(B * h * Pn * (Pn // 32), device=x.device, dtype=torch.int32) if (pdrop > 0.0 and SATTN_KEEP_BITS and Pn % 32 == 0) else None
+        ops.call("tatt_sattn_fwd_bits", ops.P(q), ops.P(k), ops.P(v), ops.P(O), ops.P(lse), ops.P(bits), B, Pn, h, scale, float(pdrop),
+                 ops.P(seed), int(site), ops.stream())
+        a = _tokgemm_ex(O.reshape(-1, E), pks[3][0], bo, E, E)
+        out, stats = ops.ln_fwd(x2, a, gamma, beta, eps, mode)
+        ctx.save_for_backward(x, q, k, v, O, lse, a, stats, wq, wk, wv, wo, gamma)
+        ctx.wbk = [pk[1] for pk in pks]
+        ctx.cfg = (h, float(pdrop), int(site), seed, scale, bits, eps, mode)
+        ctx.has_b = [b is not None for b in (bq, bk, bv, bo)]
+        ctx.leaves = (wq, bq, wk, bk, wv, bv, wo, bo)
+        return out.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, q, k, v, O, lse, a, stats, wq, wk, wv, wo, gamma = ctx.saved_tensors
+        h, pdrop, site, seed, scale, bits, eps, mode = ctx.cfg
+        B, Pn, E = x.shape
+        x2, O2 = x.reshape(-1, E), O.reshape(-1, E)
+        M = x2.shape[0]
+        dxa, _, dg, db = ops.ln_bwd(x2, a, _c(dout).reshape(-1, E), stats, gamma, eps, mode)      # d(x + a)
+        dO = _tokgemm_ex(dxa, ctx.wbk[3], None, E, E).reshape(B, Pn, E)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        ws = ops.new(q, B, h, Pn)
+        _sattn_select()
+        ops.call("tatt_sattn_bwd_bits", ops.P(q), ops.P(k), ops.P(v), ops.P(O), ops.P(lse), ops.P(dO), ops.P(bits), ops.P(dq), ops.P(dk),
+                 ops.P(dv), ops.P(ws), B, Pn, h, scale, pdrop, ops.P(seed), site, ops.stream())
+        dq2, dk2, dv2 = dq.reshape(-1, E), dk.reshape(-1, E), dv.reshape(-1, E)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.new(dxa, M, E)                                  # = dxa (residual) + dq Wq + dk Wk + dv Wv; dxa stays for W_o's gradient
+            ops.call("tatt_tokgemm_sb_add", ops.P(dq2), ops.P(ctx.wbk[0]), None, ops.P(dxa), ops.P(dx), M, E, E, ops.stream())
+            _tokgemm_ex(dk2, ctx.wbk[1], None, E, E, out=dx, accum=True)
+            _tokgemm_ex(dv2, ctx.wbk[2], None, E, E, out=dx, accum=True)
+            dx = dx.reshape(x.shape)
+        has_b = ctx.has_b
+
+        def param_grads():
+            res = []
+            for d, src, hb in ((dq2, x2, has_b[0]), (dk2, x2, has_b[1]), (dv2, x2, has_b[2]), (dxa, O2, has_b[3])):
+                dw = ops.new(d, E, E)
+                dbias = ops.new(d, E) if hb else None
+                _linear_wgrad(d, src, dw, dbias)
+                res += [dw, dbias]
+            return tuple(res)
+        g = SIDE.submit(ctx.leaves, param_grads, x, O, dq, dk, dv, dxa)
+        return (dx,) + tuple(g) + (dg, db, None, None, None, None, None)
+
+
+def attention_ln(x, mh, gamma, beta, eps, mode, pdrop, site):
+    """LayerNorm_mode(x + linears[3](attention(linears[0..2](x)))) of a MultiHeadedAttention holder `mh`: one operator when the weights
+    are prepacked and the score-free kernels take the geometry, else the operator chain"""
+    x = _c(x)
+    B, Pn, E = x.shape
+    lq, lk, lv, lo = mh.linears[0], mh.linears[1], mh.linears[2], mh.linears[3]
+    if (ATTN_LN_FUSED and SATTN_FLASH and E == 32 * mh.h and E <= 128 and Pn % 64 == 0
+            and all(_packed_linear(l.weight, B * Pn) is not None and tuple(l.weight.shape) == (E, E) for l in (lq, lk, lv, lo))):
+        return AttnLnFn.apply(x, lq.weight, lq.bias, lk.weight, lk.bias, lv.weight, lv.bias, lo.weight, lo.bias, gamma, beta, eps, mode,
+                              mh.h, float(pdrop), site)
+    q, k, v = qkv_projection(x, lq, lk, lv)
+    a = self_attention(q, k, v, mh.h, pdrop, site)
+    a = linear(a, lo.weight, lo.bias)
+    return LayerNormFn.apply(x, a, gamma, beta, eps, mode, 0.0, 0)
+
+
+ATTN_LN_FUSED = True        # test / A-B hook: False -> projections, attention, output projection and LayerNorm as separate operators
+
+
 def self_attention(Q, K, V, h, pdrop, site):
     """Multi-head self-attention core over (B, P, E) projected tensors: the score-free kernels when they apply, else the
     materialised path (any head width / ragged P)."""

@@ -115,11 +115,8 @@ def _feature_enhancer(r, fe: FeatureEnhancer, training, dropout_on, site0):
     drop = training and dropout_on
     x = Fh.CatPEFn.apply(r.reshape(B, Pn, C), fe.pe_tokens(H, W, r.device))          # (B,P,128)
     mh = fe.multihead
-    q, k, v = Fh.qkv_projection(x, mh.linears[0], mh.linears[1], mh.linears[2])
-    a = Fh.self_attention(q, k, v, mh.h, mh.p if drop else 0.0, site0)
-    a = Fh.linear(a, mh.linears[3].weight, mh.linears[3].bias)
     ln1, ln3 = fe.mul_layernorm1, fe.mul_layernorm3
-    x = Fh.LayerNormFn.apply(x, a, ln1.a_2, ln1.b_2, ln1.eps, 1, 0.0, 0)
+    x = Fh.attention_ln(x, mh, ln1.a_2, ln1.b_2, ln1.eps, 1, mh.p if drop else 0.0, site0)
     x = Fh.feed_forward_ln(x, fe.pff.w_1, fe.pff.w_2, ln3.a_2, ln3.b_2, ln3.eps, 1, fe.pff.p, drop, site0 + 1)
     x = Fh.linear(x, fe.linear.weight, fe.linear.bias)
     return x.reshape(B, H, W, C)

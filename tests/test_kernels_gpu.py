@@ -1432,6 +1432,43 @@ def test_feed_forward_layer_norm_operator_equals_the_two_operators(dev):
         assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()), (name, float((a - b).abs().max()), float(b.abs().max()))
 
 
+def test_attention_layer_norm_operator_equals_the_operator_chain(dev):
+    """AttnLnFn (projections, score-free attention with dropout, output projection, residual LayerNorm; the residual's gradient is the
+    addend of the first data-gradient GEMM into x) against the same launches as separate operators: values, dx and all ten parameter
+    gradients to the order of one addition."""
+    from tatt_amd import functional as Fh
+    from tatt_amd.tbsrn import MultiHeadedAttention
+    g = torch.Generator().manual_seed(26)
+    B, Pn, E = 2, 256, 128
+    x = torch.randn(B, Pn, E, generator=g)
+    w = torch.randn(B, Pn, E, generator=g)
+    torch.manual_seed(3)
+    mh = MultiHeadedAttention(4, E).to(dev)
+    for l in mh.linears:
+        torch.nn.init.normal_(l.weight, std=0.08)
+    ga, be = (torch.rand(E, generator=g) + 0.5).to(dev).requires_grad_(True), torch.randn(E, generator=g).to(dev).requires_grad_(True)
+    leaves = [t for l in mh.linears for t in (l.weight, l.bias)] + [ga, be]
+    res = []
+    for fused in (True, False):
+        Fh.set_seed(dev, 19)
+        Fh.begin_training_forward(dev)
+        Fh.linear_prepack(list(mh.linears))
+        Fh.ATTN_LN_FUSED = fused
+        try:
+            for t in leaves:
+                t.grad = None
+            xg = x.to(dev).requires_grad_(True)
+            y = Fh.attention_ln(xg, mh, ga, be, 1e-6, 1, 0.1, 57)
+            assert isinstance(y.grad_fn, Fh.AttnLnFn._backward_cls) == fused
+            (y * w.to(dev)).sum().backward()
+            res.append([t.detach().cpu().clone() for t in [y, xg.grad] + [t.grad for t in leaves]])
+        finally:
+            Fh.ATTN_LN_FUSED = True
+            Fh.linear_prepack_done()
+    for i, (a, b) in enumerate(zip(*res)):
+        assert float((a - b).abs().max()) <= 3e-6 * float(b.abs().max()), (i, float((a - b).abs().max()), float(b.abs().max()))
+
+
 # ------------------------------------------------------------------------------------------- fused GruBlock weight gradients
 @pytest.mark.parametrize("M,with_xb,groups", [(32 * 200, True, 128), (32 * 200, False, 128), (32, True, 128), (32 * 7, True, 3),
                                                (49152, True, 128), (49152, True, 256)])
