@@ -18,7 +18,7 @@ table='''| | value (the final-round call, one box) | source |
 | data-parallel step on one GPU (`--dp-selftest`) | %.3f ms/step (+%.1f %% over the single graph of the same call); exposed collectives %.3f ms; pass groups %s ms; collectives %s MB | `r06_bench_dp_selftest.json` |
 | CPU baseline (`cpu_baseline`, kind "port") | %.1f img/s on %d threads (%s) | bench line |
 @@ROOF@@| launches per replayed step | **319** (unchanged) | `r06_final_step_timeline.txt` |
-| GPU tests | 293 passed, 2 skipped (`-m gpu`, 8 min 14 s on the box) | `r06_gpu_tests_tail.txt` |
+| GPU tests | 295 passed, 2 skipped (`-m gpu`, about 8 minutes on the box) | `r06_gpu_tests_tail.txt` |
 ''' % (std['ms_per_step'], format(round(std['value']),','), std['sustained_ms_per_step'], mid['ms_per_step'], format(round(mid['value']),','),
        std['exact_fp32']['ms_per_step'], format(round(std['exact_fp32']['value']),','),
        large['ms_per_step'], format(round(large['value']),','), large['exact_fp32']['ms_per_step'],
