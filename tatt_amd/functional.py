@@ -516,6 +516,7 @@ def _packed_linear(weight, M):
 
 
 def _tokgemm_ex(X, Wpk, bias, N, K, act=ACT_NONE, out=None, accum=False):
+    ops._check_dev(X)
     M = X.shape[0]
     Y = ops.new(X, M, N) if out is None else out
     ops.call("tatt_tokgemm_sb_ex", ops.P(X), None, K, ops.P(Wpk), ops.P(bias), ops.P(Y), None, N, M, N, K, int(act), int(bool(accum)),
@@ -1937,6 +1938,7 @@ class SelfAttnFlashFn(Function):
 
     @staticmethod
     def forward(ctx, Q, K, V, h, pdrop, site):
+        ops._check_dev(Q)
         B, Pn, E = Q.shape
         scale = 1.0 / math.sqrt(E // h)
         seed = current_seed(Q.device) if pdrop > 0.0 else None
@@ -1972,6 +1974,7 @@ class AttnLnFn(Function):
 
     @staticmethod
     def forward(ctx, x, wq, bq, wk, bk, wv, bv, wo, bo, gamma, beta, eps, mode, h, pdrop, site):
+        ops._check_dev(x)
         B, Pn, E = x.shape
         x2 = x.reshape(-1, E)
         M = x2.shape[0]

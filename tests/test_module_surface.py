@@ -76,6 +76,31 @@ def test_product_path_has_no_cpu_fallback():
         tatt_amd.TSRN(**STD).eval()(torch.rand(1, 4, 16, 64))
 
 
+def test_round6_operators_have_no_cpu_fallback():
+    """The operators added in round 6 (TBSRN's composite sub-layers, the score-free attention, the token weight gradient) refuse CPU
+    tensors like everything else on the path: nothing silently computes on the host."""
+    import tatt_amd
+    from tatt_amd import functional as Fh, ops
+    from tatt_amd.tbsrn import MultiHeadedAttention, PositionwiseFeedForward
+    x = torch.randn(1, 128, 128)
+    ga, be = torch.ones(128), torch.zeros(128)
+    pff, mh = PositionwiseFeedForward(128, 128), MultiHeadedAttention(4, 128)
+    Fh.linear_prepack([pff.w_1, pff.w_2] + list(mh.linears))              # CPU weights: nothing is packed, the table stays empty
+    assert not Fh._PKL.table
+    with pytest.raises(RuntimeError, match="GPU"):
+        Fh.feed_forward_ln(x, pff.w_1, pff.w_2, ga, be, 1e-6, 1, 0.1, True, 1)
+    with pytest.raises(RuntimeError, match="GPU"):
+        Fh.attention_ln(x, mh, ga, be, 1e-6, 1, 0.0, 2)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        Fh.SelfAttnFlashFn.apply(x, x, x, 4, 0.0, 0)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        Fh._tokgemm_ex(torch.randn(64, 128), torch.randn(128 * 128), None, 128, 128)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.tok_wgrad_sb(torch.randn(64, 128), torch.randn(64, 128), torch.empty(128, 128))
+    with pytest.raises(RuntimeError):
+        tatt_amd.TBSRN(scale_factor=2, width=128, height=32, STN=False, mask=True).eval()(torch.rand(1, 4, 16, 64))
+
+
 def test_product_does_not_import_oracle():
     for root, _, files in os.walk(os.path.join(ROOT, "tatt_amd")):
         for f in files:
